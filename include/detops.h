@@ -1,0 +1,212 @@
+/*
+ * detops.h — C ABI of libdetops_gfx950.so, the MI355X (gfx950 / CDNA4) detection-head
+ * operator library.
+ *
+ * This is the drop-in boundary for the hot path of facebookresearch/maskrcnn-benchmark:
+ * every entry point below replaces one function of the reference's pybind module
+ * `maskrcnn_benchmark._C` (reference: maskrcnn_benchmark/csrc/vision.cpp:9-25), which the
+ * reference's `maskrcnn_benchmark.layers` package binds.  The host side that re-exports the
+ * exact 14-name `_C` surface on top of this ABI is
+ * `maskrcnn-benchmark_amd/maskrcnn_benchmark/_C.py` (ctypes).
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (HBM) unless the name ends in `_host`.
+ *   - Tensors are dense, contiguous, NCHW, fp32 unless the function name says otherwise.
+ *   - `stream` is a `hipStream_t` passed as `void*` (0 = the null stream).  Every launch goes
+ *     to that stream; no entry point synchronises the host, allocates or frees device memory
+ *     (scratch comes from caller-provided workspaces sized by the *_workspace_bytes queries),
+ *     so every call is hipGraph-capturable and re-entrant per stream.
+ *   - Return value: 0 on success, a positive hipError_t if a HIP call failed, or one of the
+ *     negative DETOPS_E* codes for argument errors.  Nothing is written on error.
+ *   - ROI rows are (batch_index, x1, y1, x2, y2) in image coordinates, batch index stored as
+ *     float (reference: maskrcnn_benchmark/modeling/poolers.py:78-89).
+ */
+#ifndef DETOPS_H_
+#define DETOPS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DETOPS_ABI_VERSION 1
+
+#define DETOPS_EINVAL   (-1) /* bad shape / null pointer / negative size            */
+#define DETOPS_EWORKSPACE (-2) /* workspace too small (see *_workspace_bytes)       */
+#define DETOPS_EUNSUPPORTED (-3) /* configuration outside what the kernels implement */
+
+typedef void* detops_stream_t; /* hipStream_t */
+
+/* Library identification: returns DETOPS_ABI_VERSION; `arch` (may be NULL) receives a static
+ * string naming the ISA the device code was built for ("gfx950"). */
+int detops_version(const char** arch);
+
+/* ------------------------------------------------------------------------------------------
+ * ROIAlign  — replaces _C.roi_align_forward / _C.roi_align_backward
+ *   reference: csrc/ROIAlign.h:11-25 (forward), :27-45 (backward);
+ *              csrc/cpu/ROIAlign_cpu.cpp:113-257, csrc/cuda/ROIAlign_cuda.cu:64-122,177-346.
+ *   input  [N,C,H,W]   rois [K,5]   output / grad_out [K,C,PH,PW]   grad_in [N,C,H,W]
+ *   sampling_ratio <= 0 selects the adaptive grid ceil(roi_h/PH) x ceil(roi_w/PW).
+ *   backward: `zero_grad_in` != 0 makes the call zero-fill grad_in first (the reference
+ *   allocates it with at::zeros, ROIAlign_cuda.cu:316); 0 accumulates into the caller's buffer
+ *   (used by the multi-level pooler to fuse several ROI sets into one gradient map).
+ * ---------------------------------------------------------------------------------------- */
+int detops_roi_align_forward_f32(const float* input, const float* rois, float* output,
+                                 int N, int C, int H, int W, int K, int PH, int PW,
+                                 float spatial_scale, int sampling_ratio,
+                                 detops_stream_t stream);
+
+int detops_roi_align_backward_f32(const float* grad_out, const float* rois, float* grad_in,
+                                  int N, int C, int H, int W, int K, int PH, int PW,
+                                  float spatial_scale, int sampling_ratio, int zero_grad_in,
+                                  detops_stream_t stream);
+
+/* Multi-level (FPN) ROIAlign in ONE launch — the sync-free form of
+ * modeling/poolers.py:91-121 (LevelMapper :11-42 + per-level ROIAlign :116-119).
+ *   inputs[l] : device pointer to level l's feature map [N,C,H[l],W[l]], scale[l] its stride^-1
+ *   rois [K,5]; the FPN level of each ROI is computed on device with the reference's formula
+ *   lvl = clamp(floor(canonical_level + log2(sqrt(area)/canonical_scale + eps)), k_min, k_max)
+ *   with area = (x2-x1+1)*(y2-y1+1)  (structures/bounding_box.py:212-216, TO_REMOVE = 1).
+ *   `levels_out` (may be NULL) receives the 0-based level index per ROI as int32.
+ *   num_levels <= DETOPS_MAX_LEVELS.  The pointer/shape arrays are HOST arrays (copied into
+ *   the kernel argument block).
+ */
+#define DETOPS_MAX_LEVELS 8
+int detops_roi_align_fpn_forward_f32(const float* const* inputs_host, const int* H_host,
+                                     const int* W_host, const float* scale_host,
+                                     int num_levels, const float* rois, float* output,
+                                     int32_t* levels_out, int N, int C, int K, int PH, int PW,
+                                     int sampling_ratio, int k_min, int k_max,
+                                     float canonical_scale, float canonical_level, float eps,
+                                     detops_stream_t stream);
+
+int detops_roi_align_fpn_backward_f32(const float* grad_out, const float* rois,
+                                      const int32_t* levels, float* const* grad_inputs_host,
+                                      const int* H_host, const int* W_host,
+                                      const float* scale_host, int num_levels, int N, int C,
+                                      int K, int PH, int PW, int sampling_ratio,
+                                      int zero_grad_in, detops_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ROIPool — replaces _C.roi_pool_forward / _C.roi_pool_backward
+ *   reference: csrc/ROIPool.h:11-45, csrc/cuda/ROIPool_cuda.cu:16-108 (CUDA-only there).
+ *   argmax [K,C,PH,PW] int32: index h*W+w inside the channel plane, -1 for an empty bin.
+ * ---------------------------------------------------------------------------------------- */
+int detops_roi_pool_forward_f32(const float* input, const float* rois, float* output,
+                                int32_t* argmax, int N, int C, int H, int W, int K, int PH,
+                                int PW, float spatial_scale, detops_stream_t stream);
+
+int detops_roi_pool_backward_f32(const float* grad_out, const float* rois,
+                                 const int32_t* argmax, float* grad_in, int N, int C, int H,
+                                 int W, int K, int PH, int PW, int zero_grad_in,
+                                 detops_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * NMS — replaces _C.nms
+ *   reference: csrc/nms.h:10-28, csrc/cpu/nms_cpu.cpp:5-75 (the CPU semantics are the
+ *   contract: suppress j iff IoU(i,j) >= threshold, +1 pixel convention, result = kept
+ *   ORIGINAL indices in ascending order, int64).
+ *   boxes [n,4] xyxy fp32, scores [n] fp32.  Sort order: score descending, ties broken by
+ *   ascending original index (stable).
+ *   keep      [n]  int64, first *num_keep entries valid (ascending original indices)
+ *   num_keep  [1]  int32 on device (the caller decides when/if to read it back)
+ *   Entirely device-side: no host round trip (the reference's CUDA path copies the n x n/64
+ *   bitmask to the host and scans it there, csrc/cuda/nms.cu:100-123).
+ * ---------------------------------------------------------------------------------------- */
+size_t detops_nms_workspace_bytes(int n);
+
+int detops_nms_f32(const float* boxes, const float* scores, int n, float threshold,
+                   int64_t* keep, int32_t* num_keep, void* workspace, size_t workspace_bytes,
+                   detops_stream_t stream);
+
+/* Batched / segmented NMS: S independent problems in one launch sequence (the RPN's
+ * per-(image, level) loop, modeling/rpn/inference.py:111-121, and the per-class loop of
+ * modeling/roi_heads/box_head/inference.py:122-135).
+ *   seg_offsets [S+1] int32 on device: segment s owns rows seg_offsets[s] .. seg_offsets[s+1]-1
+ *   of boxes/scores; max_n >= the longest segment (host-known upper bound).
+ *   keep [total] int64: segment s writes its kept indices (LOCAL to the segment, ascending)
+ *   at keep[seg_offsets[s] ...]; num_keep [S] int32.
+ */
+size_t detops_nms_batched_workspace_bytes(int num_segments, int max_n);
+
+int detops_nms_batched_f32(const float* boxes, const float* scores,
+                           const int32_t* seg_offsets, int num_segments, int max_n,
+                           float threshold, int64_t* keep, int32_t* num_keep, void* workspace,
+                           size_t workspace_bytes, detops_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SigmoidFocalLoss — replaces _C.sigmoid_focalloss_forward / _backward
+ *   reference: csrc/SigmoidFocalLoss.h:10-41, csrc/cuda/SigmoidFocalLoss_cuda.cu:20-101.
+ *   logits [R,C] fp32, targets [R] int32 in {-1 ignore, 0 background, 1..C}, losses [R,C].
+ *   `_sum` additionally (or only, if losses == NULL) accumulates sum(losses) into *loss_sum
+ *   (fp32, device; must be zeroed by the caller) — what layers/sigmoid_focal_loss.py:66-67
+ *   does with a separate .sum().
+ * ---------------------------------------------------------------------------------------- */
+int detops_sigmoid_focal_loss_forward_f32(const float* logits, const int32_t* targets,
+                                          float* losses, int R, int C, float gamma,
+                                          float alpha, detops_stream_t stream);
+
+int detops_sigmoid_focal_loss_backward_f32(const float* logits, const int32_t* targets,
+                                           const float* d_losses, float* d_logits, int R,
+                                           int C, float gamma, float alpha,
+                                           detops_stream_t stream);
+
+int detops_sigmoid_focal_loss_forward_sum_f32(const float* logits, const int32_t* targets,
+                                              float* losses /* nullable */, float* loss_sum,
+                                              int R, int C, float gamma, float alpha,
+                                              detops_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Deformable convolution building blocks — the kernels behind _C.deform_conv_forward,
+ * _backward_input, _backward_parameters, _C.modulated_deform_conv_forward/_backward
+ *   reference: csrc/deform_conv.h:11-191, csrc/cuda/deform_conv_kernel_cuda.cu:197-874,
+ *              host orchestration csrc/cuda/deform_conv_cuda.cu:158-691.
+ *   dtype: 0 = fp32, 1 = fp16, 2 = bf16 (all buffers share it; interpolation runs in fp32).
+ *   im       [B, C, H, W]
+ *   offset   [B, dg*2*kh*kw, Ho, Wo]   channel 2*(i*kw+j) = dh, +1 = dw
+ *   mask     [B, dg*kh*kw,   Ho, Wo]   NULL selects the v1 (un-modulated) operator
+ *   col      [C*kh*kw, B*Ho*Wo]        row (c*kh+i)*kw+j, column (b*Ho+ho)*Wo+wo
+ *   col2im accumulates into grad_im (caller zero-fills, as deform_conv_func.py:88 does);
+ *   col2im_coord overwrites grad_offset (and grad_mask when mask != NULL).
+ * ---------------------------------------------------------------------------------------- */
+#define DETOPS_F32 0
+#define DETOPS_F16 1
+#define DETOPS_BF16 2
+
+int detops_deformable_im2col(const void* im, const void* offset, const void* mask, void* col,
+                             int dtype, int B, int C, int H, int W, int kh, int kw, int pad_h,
+                             int pad_w, int stride_h, int stride_w, int dil_h, int dil_w,
+                             int deformable_group, detops_stream_t stream);
+
+int detops_deformable_col2im(const void* col, const void* offset, const void* mask,
+                             void* grad_im, int dtype, int B, int C, int H, int W, int kh,
+                             int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                             int dil_h, int dil_w, int deformable_group,
+                             detops_stream_t stream);
+
+int detops_deformable_col2im_coord(const void* col, const void* im, const void* offset,
+                                   const void* mask, void* grad_offset, void* grad_mask,
+                                   int dtype, int B, int C, int H, int W, int kh, int kw,
+                                   int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                                   int dil_w, int deformable_group, detops_stream_t stream);
+
+/* Fused deformable convolution forward (implicit GEMM on MFMA, never materialising `col`):
+ *   out[b, co, ho, wo] = sum_{c,i,j} weight[co, c, i, j] * sample(im[b, c], offset, i, j) (* mask)
+ *   (+ bias[co] if bias != NULL).  group == 1 only.  dtype fp16/bf16 inputs use
+ *   v_mfma_f32_32x32x16_{f16,bf16} with fp32 accumulation; fp32 uses v_mfma_f32_32x32x2_f32.
+ *   Equivalent to deform_conv_forward_cuda (deform_conv_cuda.cu:158-266) /
+ *   modulated_deform_conv_cuda_forward (:496-575) end to end.
+ */
+int detops_deform_conv_forward_fused(const void* im, const void* offset, const void* mask,
+                                     const void* weight, const void* bias, void* out, int dtype,
+                                     int B, int C, int H, int W, int Cout, int kh, int kw,
+                                     int pad_h, int pad_w, int stride_h, int stride_w,
+                                     int dil_h, int dil_w, int deformable_group,
+                                     detops_stream_t stream);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* DETOPS_H_ */
