@@ -153,6 +153,13 @@ int detops_sigmoid_focal_loss_backward_f32(const float* logits, const int32_t* t
                                            int C, float gamma, float alpha,
                                            detops_stream_t stream);
 
+/* backward of the summed loss: every element shares ONE upstream gradient, read from the device
+ * scalar *d_loss_scalar (no [R,C] broadcast buffer). */
+int detops_sigmoid_focal_loss_backward_scalar_f32(const float* logits, const int32_t* targets,
+                                                  const float* d_loss_scalar, float* d_logits,
+                                                  int R, int C, float gamma, float alpha,
+                                                  detops_stream_t stream);
+
 int detops_sigmoid_focal_loss_forward_sum_f32(const float* logits, const int32_t* targets,
                                               float* losses /* nullable */, float* loss_sum,
                                               int R, int C, float gamma, float alpha,
@@ -191,20 +198,6 @@ int detops_deformable_col2im_coord(const void* col, const void* im, const void* 
                                    int dtype, int B, int C, int H, int W, int kh, int kw,
                                    int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
                                    int dil_w, int deformable_group, detops_stream_t stream);
-
-/* Fused deformable convolution forward (implicit GEMM on MFMA, never materialising `col`):
- *   out[b, co, ho, wo] = sum_{c,i,j} weight[co, c, i, j] * sample(im[b, c], offset, i, j) (* mask)
- *   (+ bias[co] if bias != NULL).  group == 1 only.  dtype fp16/bf16 inputs use
- *   v_mfma_f32_32x32x16_{f16,bf16} with fp32 accumulation; fp32 uses v_mfma_f32_32x32x2_f32.
- *   Equivalent to deform_conv_forward_cuda (deform_conv_cuda.cu:158-266) /
- *   modulated_deform_conv_cuda_forward (:496-575) end to end.
- */
-int detops_deform_conv_forward_fused(const void* im, const void* offset, const void* mask,
-                                     const void* weight, const void* bias, void* out, int dtype,
-                                     int B, int C, int H, int W, int Cout, int kh, int kw,
-                                     int pad_h, int pad_w, int stride_h, int stride_w,
-                                     int dil_h, int dil_w, int deformable_group,
-                                     detops_stream_t stream);
 
 #ifdef __cplusplus
 } /* extern "C" */

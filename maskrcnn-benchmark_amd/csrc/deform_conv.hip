@@ -1,0 +1,363 @@
+// deform_conv.hip — deformable convolution (v1 / modulated v2) building blocks for gfx950.
+//
+// Replaces deformable_im2col / col2im / col2im_coord and their modulated twins
+// (reference csrc/cuda/deform_conv_kernel_cuda.cu:197-250, :286-342, :380-443, :577-774) behind
+// detops_deformable_{im2col,col2im,col2im_coord}.  fp32 / fp16 / bf16 storage, fp32 arithmetic.
+//
+// Thread mapping differs from the reference on purpose.  There, every (channel, pixel) thread
+// re-reads the 2*kh*kw offsets and re-derives the bilinear weights, i.e. C times per sampling
+// point.  Here one thread owns a SAMPLING POINT (b, ho, wo, tap): it reads its offset pair (and
+// mask) once, computes the 4 tap indices + weights once, and then walks a chunk of channels.
+// Lanes run along wo, so offset loads, column stores/loads and gradient stores are coalesced and
+// the 4 gathers of neighbouring lanes fall into neighbouring addresses.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "detops_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <typename T> __device__ __forceinline__ float ld(const T* p) { return static_cast<float>(*p); }
+template <> __device__ __forceinline__ float ld<__half>(const __half* p) { return __half2float(*p); }
+template <> __device__ __forceinline__ float ld<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, float v) { *p = static_cast<T>(v); }
+template <> __device__ __forceinline__ void st<__half>(__half* p, float v) { *p = __float2half(v); }
+template <> __device__ __forceinline__ void st<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+
+__device__ __forceinline__ void atomic_add_t(float* p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_t(__half* p, float v) {
+  // 16-bit atomics: CAS on the containing dword
+  unsigned* base = reinterpret_cast<unsigned*>(reinterpret_cast<uintptr_t>(p) & ~uintptr_t(3));
+  const bool hi = reinterpret_cast<uintptr_t>(p) & 2;
+  unsigned old = *base, assumed;
+  do {
+    assumed = old;
+    const unsigned short cur = hi ? (assumed >> 16) : (assumed & 0xffffu);
+    const __half nh = __float2half(__half2float(__ushort_as_half(cur)) + v);
+    const unsigned short nb = __half_as_ushort(nh);
+    const unsigned repl = hi ? ((assumed & 0xffffu) | (static_cast<unsigned>(nb) << 16))
+                             : ((assumed & 0xffff0000u) | nb);
+    old = atomicCAS(base, assumed, repl);
+  } while (old != assumed);
+}
+__device__ __forceinline__ void atomic_add_t(__hip_bfloat16* p, float v) {
+  unsigned* base = reinterpret_cast<unsigned*>(reinterpret_cast<uintptr_t>(p) & ~uintptr_t(3));
+  const bool hi = reinterpret_cast<uintptr_t>(p) & 2;
+  unsigned old = *base, assumed;
+  do {
+    assumed = old;
+    const unsigned short cur = hi ? (assumed >> 16) : (assumed & 0xffffu);
+    const float f = __uint_as_float(static_cast<unsigned>(cur) << 16) + v;
+    const __hip_bfloat16 nbf = __float2bfloat16(f);
+    const unsigned short nb = *reinterpret_cast<const unsigned short*>(&nbf);
+    const unsigned repl = hi ? ((assumed & 0xffffu) | (static_cast<unsigned>(nb) << 16))
+                             : ((assumed & 0xffff0000u) | nb);
+    old = atomicCAS(base, assumed, repl);
+  } while (old != assumed);
+}
+
+struct Geom {
+  int B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dg, Ho, Wo;
+};
+
+// The 4 bilinear taps of one sampling point (zero padding outside the map):
+// deformable_im2col_bilinear, deform_conv_kernel_cuda.cu:91-122.
+struct Sample {
+  int i1, i2, i3, i4;      // flat indices h*W+w, -1 when that tap is outside
+  float w1, w2, w3, w4;    // hh*hw, hh*lw, lh*hw, lh*lw
+  float lh, lw;
+  bool inside;             // h_im > -1 && w_im > -1 && h_im < H && w_im < W   (:236)
+};
+
+__device__ __forceinline__ Sample make_sample(float h_im, float w_im, int H, int W) {
+  Sample s;
+  s.inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < static_cast<float>(H)) &&
+             (w_im < static_cast<float>(W));
+  const int h_low = static_cast<int>(floorf(h_im)), w_low = static_cast<int>(floorf(w_im));
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  s.lh = h_im - static_cast<float>(h_low);
+  s.lw = w_im - static_cast<float>(w_low);
+  const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+  s.w1 = hh * hw; s.w2 = hh * s.lw; s.w3 = s.lh * hw; s.w4 = s.lh * s.lw;
+  const bool t = h_low >= 0, b = h_high <= H - 1, l = w_low >= 0, r = w_high <= W - 1;
+  s.i1 = (s.inside && t && l) ? h_low * W + w_low : -1;
+  s.i2 = (s.inside && t && r) ? h_low * W + w_high : -1;
+  s.i3 = (s.inside && b && l) ? h_high * W + w_low : -1;
+  s.i4 = (s.inside && b && r) ? h_high * W + w_high : -1;
+  return s;
+}
+
+// Decode a sampling-point id: p = ((b*K + tap)*Ho + ho)*Wo + wo   (wo fastest -> coalescing)
+struct Point {
+  int b, tap, ho, wo, pix;  // pix = ho*Wo + wo
+};
+__device__ __forceinline__ Point decode(int64_t p, const Geom& g) {
+  Point q;
+  const int K = g.kh * g.kw;
+  q.wo = static_cast<int>(p % g.Wo);
+  int64_t r = p / g.Wo;
+  q.ho = static_cast<int>(r % g.Ho);
+  r /= g.Ho;
+  q.tap = static_cast<int>(r % K);
+  q.b = static_cast<int>(r / K);
+  q.pix = q.ho * g.Wo + q.wo;
+  return q;
+}
+
+template <typename T>
+__device__ __forceinline__ Sample point_sample(const Point& q, const Geom& g, int dgi,
+                                               const T* __restrict__ offset) {
+  const int K = g.kh * g.kw;
+  const int i = q.tap / g.kw, j = q.tap - i * g.kw;
+  const size_t HWo = static_cast<size_t>(g.Ho) * g.Wo;
+  const T* op = offset + (static_cast<size_t>(q.b) * g.dg + dgi) * 2 * K * HWo;
+  const float off_h = ld(op + (2 * q.tap) * HWo + q.pix);
+  const float off_w = ld(op + (2 * q.tap + 1) * HWo + q.pix);
+  const float h_im = static_cast<float>(q.ho * g.stride_h - g.pad_h + i * g.dil_h) + off_h;
+  const float w_im = static_cast<float>(q.wo * g.stride_w - g.pad_w + j * g.dil_w) + off_w;
+  return make_sample(h_im, w_im, g.H, g.W);
+}
+
+// ------------------------------------------------------------------------------------ im2col
+// grid.x over sampling points, grid.y over (deformable group, channel chunk)
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+im2col_kernel(const T* __restrict__ im, const T* __restrict__ offset, const T* __restrict__ mask,
+              T* __restrict__ col, Geom g, int cchunk, int64_t npoints) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= npoints) return;
+  const int cpg = g.C / g.dg;
+  const int chunks_per_g = (cpg + cchunk - 1) / cchunk;
+  const int dgi = blockIdx.y / chunks_per_g;
+  const int c0 = dgi * cpg + (blockIdx.y - dgi * chunks_per_g) * cchunk;
+  const int c1 = min(c0 + cchunk, (dgi + 1) * cpg);
+  const Point q = decode(p, g);
+  const int K = g.kh * g.kw;
+  const Sample s = point_sample(q, g, dgi, offset);
+  float m = 1.f;
+  if (mask)
+    m = ld(mask + ((static_cast<size_t>(q.b) * g.dg + dgi) * K + q.tap) * g.Ho * g.Wo + q.pix);
+  const size_t plane = static_cast<size_t>(g.H) * g.W;
+  const size_t ncol = static_cast<size_t>(g.B) * g.Ho * g.Wo;
+  const T* ip = im + (static_cast<size_t>(q.b) * g.C + c0) * plane;
+  T* cp = col + (static_cast<size_t>(c0) * K + q.tap) * ncol + static_cast<size_t>(q.b) * g.Ho * g.Wo + q.pix;
+  for (int c = c0; c < c1; ++c) {
+    float v = 0.f;
+    if (s.inside) {
+      const float v1 = s.i1 >= 0 ? ld(ip + s.i1) : 0.f;
+      const float v2 = s.i2 >= 0 ? ld(ip + s.i2) : 0.f;
+      const float v3 = s.i3 >= 0 ? ld(ip + s.i3) : 0.f;
+      const float v4 = s.i4 >= 0 ? ld(ip + s.i4) : 0.f;
+      v = (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4);
+    }
+    st(cp, mask ? v * m : v);
+    ip += plane;
+    cp += static_cast<size_t>(K) * ncol;
+  }
+}
+
+// ------------------------------------------------------------------------------------ col2im
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+col2im_kernel(const T* __restrict__ col, const T* __restrict__ offset, const T* __restrict__ mask,
+              T* __restrict__ grad_im, Geom g, int cchunk, int64_t npoints) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= npoints) return;
+  const int cpg = g.C / g.dg;
+  const int chunks_per_g = (cpg + cchunk - 1) / cchunk;
+  const int dgi = blockIdx.y / chunks_per_g;
+  const int c0 = dgi * cpg + (blockIdx.y - dgi * chunks_per_g) * cchunk;
+  const int c1 = min(c0 + cchunk, (dgi + 1) * cpg);
+  const Point q = decode(p, g);
+  const int K = g.kh * g.kw;
+  const Sample s = point_sample(q, g, dgi, offset);
+  if (!s.inside) return;  // get_gradient_weight returns 0 outside (:127-131)
+  float m = 1.f;
+  if (mask)
+    m = ld(mask + ((static_cast<size_t>(q.b) * g.dg + dgi) * K + q.tap) * g.Ho * g.Wo + q.pix);
+  const size_t plane = static_cast<size_t>(g.H) * g.W;
+  const size_t ncol = static_cast<size_t>(g.B) * g.Ho * g.Wo;
+  T* gp = grad_im + (static_cast<size_t>(q.b) * g.C + c0) * plane;
+  const T* cp = col + (static_cast<size_t>(c0) * K + q.tap) * ncol + static_cast<size_t>(q.b) * g.Ho * g.Wo + q.pix;
+  for (int c = c0; c < c1; ++c) {
+    const float gv = ld(cp) * m;  // cur_top_grad (:322 / :681)
+    if (s.i1 >= 0) atomic_add_t(gp + s.i1, s.w1 * gv);
+    if (s.i2 >= 0) atomic_add_t(gp + s.i2, s.w2 * gv);
+    if (s.i3 >= 0) atomic_add_t(gp + s.i3, s.w3 * gv);
+    if (s.i4 >= 0) atomic_add_t(gp + s.i4, s.w4 * gv);
+    gp += plane;
+    cp += static_cast<size_t>(K) * ncol;
+  }
+}
+
+// ------------------------------------------------------------------------------------ col2im_coord
+// One thread per sampling point produces BOTH offset gradients (d/dh, d/dw) and the mask gradient,
+// looping over the channels of its deformable group in ascending order (the reference's
+// accumulation order, :413-439 / :738-766).
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+col2im_coord_kernel(const T* __restrict__ col, const T* __restrict__ im, const T* __restrict__ offset,
+                    const T* __restrict__ mask, T* __restrict__ grad_offset, T* __restrict__ grad_mask,
+                    Geom g, int64_t npoints_per_dg) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= npoints_per_dg) return;
+  const int dgi = blockIdx.y;
+  const int cpg = g.C / g.dg;
+  const Point q = decode(p, g);
+  const int K = g.kh * g.kw;
+  const Sample s = point_sample(q, g, dgi, offset);
+  const size_t HWo = static_cast<size_t>(g.Ho) * g.Wo;
+  float m = 1.f;
+  if (mask) m = ld(mask + ((static_cast<size_t>(q.b) * g.dg + dgi) * K + q.tap) * HWo + q.pix);
+  float gh = 0.f, gw = 0.f, gm = 0.f;
+  if (s.inside) {
+    const size_t plane = static_cast<size_t>(g.H) * g.W;
+    const size_t ncol = static_cast<size_t>(g.B) * HWo;
+    const int c0 = dgi * cpg;
+    const T* ip = im + (static_cast<size_t>(q.b) * g.C + c0) * plane;
+    const T* cp = col + (static_cast<size_t>(c0) * K + q.tap) * ncol + static_cast<size_t>(q.b) * HWo + q.pix;
+    const float hw = 1.f - s.lw, hh = 1.f - s.lh;
+    for (int c = 0; c < cpg; ++c) {
+      const float gv = ld(cp);
+      const float v1 = s.i1 >= 0 ? ld(ip + s.i1) : 0.f;
+      const float v2 = s.i2 >= 0 ? ld(ip + s.i2) : 0.f;
+      const float v3 = s.i3 >= 0 ? ld(ip + s.i3) : 0.f;
+      const float v4 = s.i4 >= 0 ? ld(ip + s.i4) : 0.f;
+      // get_coordinate_weight, bp_dir 0 (:170-180) and 1 (:181-191)
+      const float wh = -hw * v1 - s.lw * v2 + hw * v3 + s.lw * v4;
+      const float ww = -hh * v1 + hh * v2 - s.lh * v3 + s.lh * v4;
+      gh += wh * gv * m;
+      gw += ww * gv * m;
+      gm += gv * (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4);  // :760
+      ip += plane;
+      cp += static_cast<size_t>(K) * ncol;
+    }
+  }
+  T* gop = grad_offset + (static_cast<size_t>(q.b) * g.dg + dgi) * 2 * K * HWo;
+  st(gop + (2 * q.tap) * HWo + q.pix, gh);
+  st(gop + (2 * q.tap + 1) * HWo + q.pix, gw);
+  if (mask && grad_mask)
+    st(grad_mask + ((static_cast<size_t>(q.b) * g.dg + dgi) * K + q.tap) * HWo + q.pix, gm);
+}
+
+inline int make_geom(Geom& g, int B, int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
+                     int stride_h, int stride_w, int dil_h, int dil_w, int dg) {
+  if (B < 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || stride_h <= 0 || stride_w <= 0 ||
+      dil_h <= 0 || dil_w <= 0 || dg <= 0 || C % dg != 0 || pad_h < 0 || pad_w < 0)
+    return DETOPS_EINVAL;
+  g = Geom{B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dg, 0, 0};
+  g.Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  g.Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  if (g.Ho < 1 || g.Wo < 1) return DETOPS_EINVAL;
+  return 0;
+}
+
+inline int pick_cchunk(int cpg, int64_t npoints) {
+  // enough workgroups to fill the chip, but keep >= 16 channels per thread to amortise the setup
+  int cc = cpg;
+  while (cc > 16 && ceil_div64(npoints, kBlock) * ceil_div64(cpg, cc) < 8 * kNumCU) cc = (cc + 1) / 2;
+  return cc;
+}
+
+template <typename T>
+int im2col_t(const void* im, const void* offset, const void* mask, void* col, const Geom& g,
+             hipStream_t st_) {
+  const int64_t np = static_cast<int64_t>(g.B) * g.kh * g.kw * g.Ho * g.Wo;
+  if (np == 0) return 0;
+  const int cpg = g.C / g.dg;
+  const int cc = pick_cchunk(cpg, np);
+  const dim3 grid(static_cast<unsigned>(ceil_div64(np, kBlock)),
+                  static_cast<unsigned>(g.dg * ceil_div64(cpg, cc)));
+  hipLaunchKernelGGL(im2col_kernel<T>, grid, dim3(kBlock), 0, st_, static_cast<const T*>(im),
+                     static_cast<const T*>(offset), static_cast<const T*>(mask), static_cast<T*>(col),
+                     g, cc, np);
+  return launch_status();
+}
+
+template <typename T>
+int col2im_t(const void* col, const void* offset, const void* mask, void* grad_im, const Geom& g,
+             hipStream_t st_) {
+  const int64_t np = static_cast<int64_t>(g.B) * g.kh * g.kw * g.Ho * g.Wo;
+  if (np == 0) return 0;
+  const int cpg = g.C / g.dg;
+  const int cc = pick_cchunk(cpg, np);
+  const dim3 grid(static_cast<unsigned>(ceil_div64(np, kBlock)),
+                  static_cast<unsigned>(g.dg * ceil_div64(cpg, cc)));
+  hipLaunchKernelGGL(col2im_kernel<T>, grid, dim3(kBlock), 0, st_, static_cast<const T*>(col),
+                     static_cast<const T*>(offset), static_cast<const T*>(mask),
+                     static_cast<T*>(grad_im), g, cc, np);
+  return launch_status();
+}
+
+template <typename T>
+int coord_t(const void* col, const void* im, const void* offset, const void* mask, void* goff,
+            void* gmask, const Geom& g, hipStream_t st_) {
+  const int64_t np = static_cast<int64_t>(g.B) * g.kh * g.kw * g.Ho * g.Wo;
+  if (np == 0) return 0;
+  const dim3 grid(static_cast<unsigned>(ceil_div64(np, kBlock)), static_cast<unsigned>(g.dg));
+  hipLaunchKernelGGL(col2im_coord_kernel<T>, grid, dim3(kBlock), 0, st_, static_cast<const T*>(col),
+                     static_cast<const T*>(im), static_cast<const T*>(offset),
+                     static_cast<const T*>(mask), static_cast<T*>(goff), static_cast<T*>(gmask), g, np);
+  return launch_status();
+}
+
+}  // namespace
+
+#define DETOPS_DTYPE_SWITCH(dtype, CALL)                              \
+  switch (dtype) {                                                    \
+    case DETOPS_F32: return CALL(float);                              \
+    case DETOPS_F16: return CALL(__half);                             \
+    case DETOPS_BF16: return CALL(__hip_bfloat16);                    \
+    default: return DETOPS_EUNSUPPORTED;                              \
+  }
+
+DETOPS_API int detops_deformable_im2col(const void* im, const void* offset, const void* mask,
+                                        void* col, int dtype, int B, int C, int H, int W, int kh,
+                                        int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                                        int dil_h, int dil_w, int deformable_group,
+                                        detops_stream_t stream) {
+  Geom g;
+  if (int rc = make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w,
+                         deformable_group))
+    return rc;
+  if (B == 0) return 0;
+  if (!im || !offset || !col) return DETOPS_EINVAL;
+#define CALL(T) im2col_t<T>(im, offset, mask, col, g, as_stream(stream))
+  DETOPS_DTYPE_SWITCH(dtype, CALL)
+#undef CALL
+}
+
+DETOPS_API int detops_deformable_col2im(const void* col, const void* offset, const void* mask,
+                                        void* grad_im, int dtype, int B, int C, int H, int W,
+                                        int kh, int kw, int pad_h, int pad_w, int stride_h,
+                                        int stride_w, int dil_h, int dil_w, int deformable_group,
+                                        detops_stream_t stream) {
+  Geom g;
+  if (int rc = make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w,
+                         deformable_group))
+    return rc;
+  if (B == 0) return 0;
+  if (!col || !offset || !grad_im) return DETOPS_EINVAL;
+#define CALL(T) col2im_t<T>(col, offset, mask, grad_im, g, as_stream(stream))
+  DETOPS_DTYPE_SWITCH(dtype, CALL)
+#undef CALL
+}
+
+DETOPS_API int detops_deformable_col2im_coord(const void* col, const void* im, const void* offset,
+                                              const void* mask, void* grad_offset, void* grad_mask,
+                                              int dtype, int B, int C, int H, int W, int kh, int kw,
+                                              int pad_h, int pad_w, int stride_h, int stride_w,
+                                              int dil_h, int dil_w, int deformable_group,
+                                              detops_stream_t stream) {
+  Geom g;
+  if (int rc = make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w,
+                         deformable_group))
+    return rc;
+  if (B == 0) return 0;
+  if (!col || !im || !offset || !grad_offset || (mask && !grad_mask)) return DETOPS_EINVAL;
+#define CALL(T) coord_t<T>(col, im, offset, mask, grad_offset, grad_mask, g, as_stream(stream))
+  DETOPS_DTYPE_SWITCH(dtype, CALL)
+#undef CALL
+}

@@ -1,0 +1,198 @@
+// focal_loss.hip — SigmoidFocalLoss forward / backward for gfx950 (MI355X), fp32.
+//
+// Replaces SigmoidFocalLossForward / SigmoidFocalLossBackward
+// (reference csrc/cuda/SigmoidFocalLoss_cuda.cu:20-58, :61-101) behind
+// detops_sigmoid_focal_loss_{forward,backward,forward_sum}_f32.
+//
+// A pure HBM stream ([R,C] logits in, [R,C] out, one int32 target per row): 16-byte loads and
+// stores per lane, grid-stride over float4 groups.  The reference evaluates expf twice, logf twice
+// and powf twice per element; here one e = exp(-|x|) and one L = log(1 + e) feed every term:
+//     p      = sigmoid(x)        = x>=0 ? 1/(1+e) : e/(1+e)
+//     1 - p                      = x>=0 ? e/(1+e) : 1/(1+e)      (no cancellation)
+//     log p                      = min(x,0) - L, clamped at log(FLT_MIN) like max(p, FLT_MIN)
+//     -x*(x>=0) - log(1+exp(x-2x*(x>=0)))  = -max(x,0) - L      (the reference's own stable form)
+// which keeps the VALU work (~60 instr/element) well under the HBM time.  Results agree with the
+// reference formula to ~1e-7 absolute (tests: rtol 1e-4, atol 1e-6 vs the oracle restatement).
+#include <float.h>
+
+#include "detops_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr float kLogFltMin = -87.33654475f;  // logf(FLT_MIN)
+
+__device__ __forceinline__ float pow_gamma(float v, float gamma) {
+  if (gamma == 2.f) return v * v;
+  if (gamma == 1.f) return v;
+  if (gamma == 0.f) return 1.f;
+  return powf(v, gamma);
+}
+
+struct Terms {
+  float p, q, logp, nsp;  // sigmoid, 1-sigmoid, log p (clamped), -max(x,0) - L = log(1-p)
+};
+
+__device__ __forceinline__ Terms terms(float x) {
+  Terms t;
+  const float e = expf(-fabsf(x));
+  const float L = logf(1.f + e);
+  const float inv = __builtin_amdgcn_rcpf(1.f + e);
+  const float ei = e * inv;
+  const bool pos = x >= 0.f;
+  t.p = pos ? inv : ei;
+  t.q = pos ? ei : inv;
+  t.logp = fmaxf(fminf(x, 0.f) - L, kLogFltMin);
+  t.nsp = -fmaxf(x, 0.f) - L;
+  return t;
+}
+
+__device__ __forceinline__ float fwd_elem(float x, int t, int d, float gamma, float alpha) {
+  const float c1 = (t == d + 1) ? 1.f : 0.f;
+  const float c2 = (t >= 0 && t != d + 1) ? 1.f : 0.f;
+  const Terms k = terms(x);
+  const float term1 = pow_gamma(k.q, gamma) * k.logp;
+  const float term2 = pow_gamma(k.p, gamma) * k.nsp;
+  return -c1 * term1 * alpha - c2 * term2 * (1.f - alpha);
+}
+
+__device__ __forceinline__ float bwd_elem(float x, int t, int d, float gamma, float alpha, float dl) {
+  const float c1 = (t == d + 1) ? 1.f : 0.f;
+  const float c2 = (t >= 0 && t != d + 1) ? 1.f : 0.f;
+  const Terms k = terms(x);
+  const float term1 = pow_gamma(k.q, gamma) * (k.q - k.p * gamma * k.logp);
+  const float term2 = pow_gamma(k.p, gamma) * (k.nsp * k.q * gamma - k.p);
+  return (-c1 * term1 * alpha - c2 * term2 * (1.f - alpha)) * dl;
+}
+
+// MODE 0: forward, 1: backward, 2: forward + sum (losses may be null),
+//      3: backward with ONE upstream gradient for all elements (dloss points to a device scalar)
+template <int MODE, bool VEC4>
+__global__ void __launch_bounds__(kBlock)
+focal_kernel(const float* __restrict__ logits, const int32_t* __restrict__ targets,
+             const float* __restrict__ dloss, float* __restrict__ out, float* __restrict__ sum_out,
+             int64_t total, int C, float gamma, float alpha) {
+  float lsum = 0.f;
+  const float gscalar = (MODE == 3) ? dloss[0] : 0.f;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  if (VEC4) {
+    const int64_t total4 = total >> 2;
+    const int C4 = C >> 2;
+    for (int64_t v = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; v < total4; v += stride) {
+      const int n = static_cast<int>(v / C4);
+      const int d = static_cast<int>(v - static_cast<int64_t>(n) * C4) << 2;
+      const int t = targets[n];
+      const float4 x = reinterpret_cast<const float4*>(logits)[v];
+      float4 r;
+      if (MODE == 3) {
+        r.x = bwd_elem(x.x, t, d, gamma, alpha, gscalar);
+        r.y = bwd_elem(x.y, t, d + 1, gamma, alpha, gscalar);
+        r.z = bwd_elem(x.z, t, d + 2, gamma, alpha, gscalar);
+        r.w = bwd_elem(x.w, t, d + 3, gamma, alpha, gscalar);
+      } else if (MODE == 1) {
+        const float4 g = reinterpret_cast<const float4*>(dloss)[v];
+        r.x = bwd_elem(x.x, t, d, gamma, alpha, g.x);
+        r.y = bwd_elem(x.y, t, d + 1, gamma, alpha, g.y);
+        r.z = bwd_elem(x.z, t, d + 2, gamma, alpha, g.z);
+        r.w = bwd_elem(x.w, t, d + 3, gamma, alpha, g.w);
+      } else {
+        r.x = fwd_elem(x.x, t, d, gamma, alpha);
+        r.y = fwd_elem(x.y, t, d + 1, gamma, alpha);
+        r.z = fwd_elem(x.z, t, d + 2, gamma, alpha);
+        r.w = fwd_elem(x.w, t, d + 3, gamma, alpha);
+        if (MODE == 2) lsum += (r.x + r.y) + (r.z + r.w);
+      }
+      if (MODE != 2 || out) reinterpret_cast<float4*>(out)[v] = r;
+    }
+  } else {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += stride) {
+      const int n = static_cast<int>(i / C);
+      const int d = static_cast<int>(i - static_cast<int64_t>(n) * C);
+      const int t = targets[n];
+      float r;
+      if (MODE == 3) r = bwd_elem(logits[i], t, d, gamma, alpha, gscalar);
+      else if (MODE == 1) r = bwd_elem(logits[i], t, d, gamma, alpha, dloss[i]);
+      else r = fwd_elem(logits[i], t, d, gamma, alpha);
+      if (MODE == 2) lsum += r;
+      if (MODE != 2 || out) out[i] = r;
+    }
+  }
+  if (MODE == 2) {
+    __shared__ float wsum[kBlock / kWave];
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) lsum += __shfl_down(lsum, off);
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+      for (int j = 0; j < kBlock / kWave; ++j) s += wsum[j];
+      atomicAdd(sum_out, s);
+    }
+  }
+}
+
+template <int MODE>
+int launch(const float* logits, const int32_t* targets, const float* dloss, float* out,
+           float* sum_out, int R, int C, float gamma, float alpha, hipStream_t st) {
+  const int64_t total = static_cast<int64_t>(R) * C;
+  if (total == 0) return 0;
+  const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                   (MODE == 3 || (reinterpret_cast<uintptr_t>(dloss) & 15) == 0);
+  const int64_t work = vec ? (total >> 2) : total;
+  const int blocks = static_cast<int>(std::min<int64_t>(ceil_div64(work, kBlock), kNumCU * 8));
+  if (vec)
+    hipLaunchKernelGGL((focal_kernel<MODE, true>), dim3(blocks), dim3(kBlock), 0, st, logits, targets,
+                       dloss, out, sum_out, total, C, gamma, alpha);
+  else
+    hipLaunchKernelGGL((focal_kernel<MODE, false>), dim3(blocks), dim3(kBlock), 0, st, logits,
+                       targets, dloss, out, sum_out, total, C, gamma, alpha);
+  return launch_status();
+}
+
+}  // namespace
+
+DETOPS_API int detops_sigmoid_focal_loss_forward_f32(const float* logits, const int32_t* targets,
+                                                     float* losses, int R, int C, float gamma,
+                                                     float alpha, detops_stream_t stream) {
+  if (R < 0 || C < 0) return DETOPS_EINVAL;
+  if (static_cast<int64_t>(R) * C == 0) return 0;
+  if (!logits || !targets || !losses) return DETOPS_EINVAL;
+  return launch<0>(logits, targets, nullptr, losses, nullptr, R, C, gamma, alpha, as_stream(stream));
+}
+
+DETOPS_API int detops_sigmoid_focal_loss_backward_f32(const float* logits, const int32_t* targets,
+                                                      const float* d_losses, float* d_logits,
+                                                      int R, int C, float gamma, float alpha,
+                                                      detops_stream_t stream) {
+  if (R < 0 || C < 0) return DETOPS_EINVAL;
+  if (static_cast<int64_t>(R) * C == 0) return 0;
+  if (!logits || !targets || !d_losses || !d_logits) return DETOPS_EINVAL;
+  return launch<1>(logits, targets, d_losses, d_logits, nullptr, R, C, gamma, alpha,
+                   as_stream(stream));
+}
+
+DETOPS_API int detops_sigmoid_focal_loss_forward_sum_f32(const float* logits,
+                                                         const int32_t* targets, float* losses,
+                                                         float* loss_sum, int R, int C,
+                                                         float gamma, float alpha,
+                                                         detops_stream_t stream) {
+  if (R < 0 || C < 0 || !loss_sum) return DETOPS_EINVAL;
+  if (static_cast<int64_t>(R) * C == 0) return 0;
+  if (!logits || !targets) return DETOPS_EINVAL;
+  return launch<2>(logits, targets, nullptr, losses, loss_sum, R, C, gamma, alpha,
+                   as_stream(stream));
+}
+
+DETOPS_API int detops_sigmoid_focal_loss_backward_scalar_f32(const float* logits,
+                                                             const int32_t* targets,
+                                                             const float* d_loss_scalar,
+                                                             float* d_logits, int R, int C,
+                                                             float gamma, float alpha,
+                                                             detops_stream_t stream) {
+  if (R < 0 || C < 0) return DETOPS_EINVAL;
+  if (static_cast<int64_t>(R) * C == 0) return 0;
+  if (!logits || !targets || !d_loss_scalar || !d_logits) return DETOPS_EINVAL;
+  return launch<3>(logits, targets, d_loss_scalar, d_logits, nullptr, R, C, gamma, alpha,
+                   as_stream(stream));
+}

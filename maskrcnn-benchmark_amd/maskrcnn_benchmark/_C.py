@@ -1,0 +1,554 @@
+"""`maskrcnn_benchmark._C` — the reference's native-operator module, re-exported over the C ABI of
+libdetops_gfx950.so (include/detops.h).
+
+Same names, argument order and ownership rules as the reference's pybind module
+(reference: maskrcnn_benchmark/csrc/vision.cpp:9-25 and the dispatch headers csrc/*.h):
+
+    nms, roi_align_forward, roi_align_backward, roi_pool_forward, roi_pool_backward,
+    sigmoid_focalloss_forward, sigmoid_focalloss_backward,
+    deform_conv_forward, deform_conv_backward_input, deform_conv_backward_parameters,
+    modulated_deform_conv_forward, modulated_deform_conv_backward
+
+(the two deform_psroi_pooling_* names are exported and raise NotImplementedError — see
+DESIGN.md "out of scope").  PyTorch is plumbing here: it owns device memory and the current HIP
+stream; every computation happens in the hand-written gfx950 kernels (GEMMs of the deformable
+convolution go through torch.addmm -> hipBLASLt/rocBLAS, as the reference's go through cuBLAS).
+
+There is no CPU path: CPU tensors raise "Not implemented on the CPU" (the reference's own message
+for its CUDA-only operators, e.g. csrc/ROIAlign.h:44).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_of
+
+# ------------------------------------------------------------------------------------------ helpers
+
+
+def _need_cuda(name, *tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("%s: Not implemented on the CPU (HIP-only build, no fallback)" % name)
+
+
+def _f32c(name, t):
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s: expected a float32 tensor, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+class _on_device:
+    """Make `t`'s device current for the launch (no-op in the single-device case)."""
+
+    def __init__(self, t):
+        self.idx = t.device.index
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if self.idx is not None and self.idx != cur:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *a):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+# ------------------------------------------------------------------------------------------ NMS
+def nms(dets, scores, threshold):
+    """reference csrc/nms.h:10-28: dets [n,4] xyxy, scores [n] -> int64 kept indices, ascending.
+    CPU semantics (IoU >= threshold suppresses; csrc/cpu/nms_cpu.cpp:60)."""
+    _need_cuda("nms", dets, scores)
+    if dets.numel() == 0:  # nms.h:17-18 returns an empty CPU long tensor
+        return torch.empty((0,), dtype=torch.long, device="cpu")
+    dets = _f32c("nms", dets)
+    scores = _f32c("nms", scores)
+    n = dets.size(0)
+    if dets.dim() != 2 or dets.size(1) != 4 or scores.numel() != n:
+        raise RuntimeError("nms: expected dets [n,4] and scores [n]")
+    keep = torch.empty((n,), dtype=torch.long, device=dets.device)
+    num = torch.empty((1,), dtype=torch.int32, device=dets.device)
+    ws_bytes = lib.detops_nms_workspace_bytes(n)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dets.device)
+    with _on_device(dets):
+        check(lib.detops_nms_f32(ptr(dets), ptr(scores), n, float(threshold), ptr(keep), ptr(num),
+                                 ptr(ws), ws_bytes, stream_of(dets)), "nms")
+    return keep[: int(num.item())]  # the variable-length return value forces one readback
+
+
+def nms_batched(boxes, scores, seg_offsets, max_n, threshold):
+    """Sync-free segmented NMS (extension; not in the reference `_C`).
+    boxes [T,4], scores [T], seg_offsets int32 [S+1] (device).  Returns (keep [T] int64 with each
+    segment's LOCAL kept indices packed at its offset, num_keep [S] int32) — all on device."""
+    _need_cuda("nms_batched", boxes, scores, seg_offsets)
+    boxes = _f32c("nms_batched", boxes)
+    scores = _f32c("nms_batched", scores)
+    S = seg_offsets.numel() - 1
+    keep = torch.empty((boxes.size(0),), dtype=torch.long, device=boxes.device)
+    num = torch.zeros((max(S, 0),), dtype=torch.int32, device=boxes.device)
+    if S <= 0 or boxes.size(0) == 0:
+        return keep, num
+    seg_offsets = seg_offsets.to(torch.int32).contiguous()
+    ws_bytes = lib.detops_nms_batched_workspace_bytes(S, int(max_n))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=boxes.device)
+    with _on_device(boxes):
+        check(lib.detops_nms_batched_f32(ptr(boxes), ptr(scores), ptr(seg_offsets), S, int(max_n),
+                                         float(threshold), ptr(keep), ptr(num), ptr(ws), ws_bytes,
+                                         stream_of(boxes)), "nms_batched")
+    return keep, num
+
+
+# ------------------------------------------------------------------------------------------ ROIAlign
+def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
+    """reference csrc/ROIAlign.h:11-25 -> [K,C,PH,PW]."""
+    _need_cuda("roi_align_forward", input, rois)
+    input = _f32c("roi_align_forward", input)
+    rois = _f32c("roi_align_forward", rois)
+    N, C, H, W = input.shape
+    K = rois.size(0)
+    out = torch.empty((K, C, pooled_height, pooled_width), dtype=input.dtype, device=input.device)
+    if out.numel() == 0:
+        return out
+    with _on_device(input):
+        check(lib.detops_roi_align_forward_f32(ptr(input), ptr(rois), ptr(out), N, C, H, W, K,
+                                               pooled_height, pooled_width, float(spatial_scale),
+                                               int(sampling_ratio), stream_of(input)),
+              "roi_align_forward")
+    return out
+
+
+def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
+                       height, width, sampling_ratio):
+    """reference csrc/ROIAlign.h:27-45 -> zero-initialised [bs,ch,h,w] with the scattered grads."""
+    _need_cuda("roi_align_backward", grad, rois)
+    grad = _f32c("roi_align_backward", grad)
+    rois = _f32c("roi_align_backward", rois)
+    K = rois.size(0)
+    gin = torch.empty((batch_size, channels, height, width), dtype=grad.dtype, device=grad.device)
+    with _on_device(grad):
+        check(lib.detops_roi_align_backward_f32(ptr(grad), ptr(rois), ptr(gin), batch_size, channels,
+                                                height, width, K, pooled_height, pooled_width,
+                                                float(spatial_scale), int(sampling_ratio), 1,
+                                                stream_of(grad)), "roi_align_backward")
+    return gin
+
+
+def _host_arrays(tensors, scales):
+    L = len(tensors)
+    ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in tensors])
+    Hs = (ctypes.c_int * L)(*[t.size(2) for t in tensors])
+    Ws = (ctypes.c_int * L)(*[t.size(3) for t in tensors])
+    sc = (ctypes.c_float * L)(*[float(s) for s in scales])
+    return ptrs, Hs, Ws, sc
+
+
+def roi_align_fpn_forward(inputs, rois, scales, pooled_height, pooled_width, sampling_ratio, k_min,
+                          k_max, canonical_scale=224.0, canonical_level=4.0, eps=1e-6):
+    """Multi-level ROIAlign in one launch (extension): the device-side form of
+    modeling/poolers.py:91-121.  Returns (out [K,C,PH,PW], levels int32 [K])."""
+    _need_cuda("roi_align_fpn_forward", rois, *inputs)
+    inputs = [_f32c("roi_align_fpn_forward", t) for t in inputs]
+    rois = _f32c("roi_align_fpn_forward", rois)
+    N, C = inputs[0].shape[:2]
+    K = rois.size(0)
+    out = torch.empty((K, C, pooled_height, pooled_width), dtype=torch.float32, device=rois.device)
+    levels = torch.empty((K,), dtype=torch.int32, device=rois.device)
+    if K == 0:
+        return out, levels
+    ptrs, Hs, Ws, sc = _host_arrays(inputs, scales)
+    with _on_device(rois):
+        check(lib.detops_roi_align_fpn_forward_f32(
+            ptrs, Hs, Ws, sc, len(inputs), ptr(rois), ptr(out), ptr(levels), N, C, K, pooled_height,
+            pooled_width, int(sampling_ratio), int(k_min), int(k_max), float(canonical_scale),
+            float(canonical_level), float(eps), stream_of(rois)), "roi_align_fpn_forward")
+    return out, levels
+
+
+def roi_align_fpn_backward(grad, rois, levels, shapes, scales, pooled_height, pooled_width,
+                           sampling_ratio):
+    """Backward of roi_align_fpn_forward: returns one zero-initialised gradient map per level."""
+    _need_cuda("roi_align_fpn_backward", grad, rois, levels)
+    grad = _f32c("roi_align_fpn_backward", grad)
+    K = rois.size(0)
+    gins = [torch.empty(tuple(s), dtype=torch.float32, device=grad.device) for s in shapes]
+    N, C = shapes[0][:2]
+    ptrs, Hs, Ws, sc = _host_arrays(gins, scales)
+    with _on_device(grad):
+        check(lib.detops_roi_align_fpn_backward_f32(
+            ptr(grad), ptr(rois), ptr(levels), ptrs, Hs, Ws, sc, len(gins), N, C, K, pooled_height,
+            pooled_width, int(sampling_ratio), 1, stream_of(grad)), "roi_align_fpn_backward")
+    return gins
+
+
+# ------------------------------------------------------------------------------------------ ROIPool
+def roi_pool_forward(input, rois, spatial_scale, pooled_height, pooled_width):
+    """reference csrc/ROIPool.h:11-24 -> (output, argmax int32)."""
+    _need_cuda("roi_pool_forward", input, rois)
+    input = _f32c("roi_pool_forward", input)
+    rois = _f32c("roi_pool_forward", rois)
+    N, C, H, W = input.shape
+    K = rois.size(0)
+    out = torch.empty((K, C, pooled_height, pooled_width), dtype=input.dtype, device=input.device)
+    argmax = torch.zeros((K, C, pooled_height, pooled_width), dtype=torch.int32, device=input.device)
+    if out.numel() == 0:
+        return out, argmax
+    with _on_device(input):
+        check(lib.detops_roi_pool_forward_f32(ptr(input), ptr(rois), ptr(out), ptr(argmax), N, C, H,
+                                              W, K, pooled_height, pooled_width,
+                                              float(spatial_scale), stream_of(input)),
+              "roi_pool_forward")
+    return out, argmax
+
+
+def roi_pool_backward(grad, input, rois, argmax, spatial_scale, pooled_height, pooled_width,
+                      batch_size, channels, height, width):
+    """reference csrc/ROIPool.h:26-45 (`input` is unused there too)."""
+    _need_cuda("roi_pool_backward", grad, rois, argmax)
+    grad = _f32c("roi_pool_backward", grad)
+    rois = _f32c("roi_pool_backward", rois)
+    argmax = argmax.contiguous()
+    K = rois.size(0)
+    gin = torch.empty((batch_size, channels, height, width), dtype=grad.dtype, device=grad.device)
+    with _on_device(grad):
+        check(lib.detops_roi_pool_backward_f32(ptr(grad), ptr(rois), ptr(argmax), ptr(gin),
+                                               batch_size, channels, height, width, K, pooled_height,
+                                               pooled_width, 1, stream_of(grad)), "roi_pool_backward")
+    return gin
+
+
+# ------------------------------------------------------------------------------------------ focal
+def _focal_args(name, logits, targets, num_classes):
+    _need_cuda(name, logits, targets)
+    if logits.dim() != 2:
+        raise RuntimeError("logits should be NxClass")  # SigmoidFocalLoss_cuda.cu:112
+    logits = _f32c(name, logits)
+    if targets.dtype != torch.int32:
+        raise RuntimeError("%s: targets must be int32 (reference kernel reads `const int*`)" % name)
+    targets = targets.contiguous()
+    if targets.numel() != logits.size(0) or logits.size(1) != num_classes:
+        raise RuntimeError("%s: shape mismatch" % name)
+    return logits, targets
+
+
+def sigmoid_focalloss_forward(logits, targets, num_classes, gamma, alpha):
+    """reference csrc/SigmoidFocalLoss.h:10-24 -> losses [R,C]."""
+    logits, targets = _focal_args("sigmoid_focalloss_forward", logits, targets, num_classes)
+    losses = torch.empty_like(logits)
+    with _on_device(logits):
+        check(lib.detops_sigmoid_focal_loss_forward_f32(ptr(logits), ptr(targets), ptr(losses),
+                                                        logits.size(0), num_classes, float(gamma),
+                                                        float(alpha), stream_of(logits)),
+              "sigmoid_focalloss_forward")
+    return losses
+
+
+def sigmoid_focalloss_backward(logits, targets, d_losses, num_classes, gamma, alpha):
+    """reference csrc/SigmoidFocalLoss.h:26-41 -> d_logits [R,C]."""
+    logits, targets = _focal_args("sigmoid_focalloss_backward", logits, targets, num_classes)
+    _need_cuda("sigmoid_focalloss_backward", d_losses)
+    d_losses = _f32c("sigmoid_focalloss_backward", d_losses)
+    if d_losses.shape != logits.shape:
+        raise RuntimeError("sigmoid_focalloss_backward: d_losses must be [R,C]")
+    d_logits = torch.empty_like(logits)
+    with _on_device(logits):
+        check(lib.detops_sigmoid_focal_loss_backward_f32(ptr(logits), ptr(targets), ptr(d_losses),
+                                                         ptr(d_logits), logits.size(0), num_classes,
+                                                         float(gamma), float(alpha),
+                                                         stream_of(logits)),
+              "sigmoid_focalloss_backward")
+    return d_logits
+
+
+def sigmoid_focalloss_forward_sum(logits, targets, num_classes, gamma, alpha):
+    """Extension: sum(losses) without materialising [R,C] (what SigmoidFocalLoss.forward needs)."""
+    logits, targets = _focal_args("sigmoid_focalloss_forward_sum", logits, targets, num_classes)
+    total = torch.zeros((), dtype=torch.float32, device=logits.device)
+    with _on_device(logits):
+        check(lib.detops_sigmoid_focal_loss_forward_sum_f32(ptr(logits), ptr(targets), None,
+                                                            ptr(total), logits.size(0), num_classes,
+                                                            float(gamma), float(alpha),
+                                                            stream_of(logits)),
+              "sigmoid_focalloss_forward_sum")
+    return total
+
+
+def sigmoid_focalloss_backward_scalar(logits, targets, d_loss, num_classes, gamma, alpha):
+    """Extension: backward of the summed loss; d_loss is a 0-dim / 1-element device tensor."""
+    logits, targets = _focal_args("sigmoid_focalloss_backward_scalar", logits, targets, num_classes)
+    _need_cuda("sigmoid_focalloss_backward_scalar", d_loss)
+    d_loss = d_loss.reshape(1).to(torch.float32).contiguous()
+    d_logits = torch.empty_like(logits)
+    with _on_device(logits):
+        check(lib.detops_sigmoid_focal_loss_backward_scalar_f32(
+            ptr(logits), ptr(targets), ptr(d_loss), ptr(d_logits), logits.size(0), num_classes,
+            float(gamma), float(alpha), stream_of(logits)), "sigmoid_focalloss_backward_scalar")
+    return d_logits
+
+
+# ------------------------------------------------------------------------------------------ deformable conv
+def _dcn_check(name, *tensors):
+    _need_cuda(name, *tensors)
+    dt = tensors[0].dtype
+    if dt not in _lib.DTYPE_CODE:
+        raise RuntimeError("%s: unsupported dtype %s" % (name, dt))
+    for t in tensors:
+        if t is not None and t.dtype != dt:
+            raise RuntimeError("%s: all tensors must share one dtype" % name)
+    return _lib.DTYPE_CODE[dt]
+
+
+def _out_hw(H, W, kH, kW, padH, padW, dH, dW, dilH, dilW):
+    return ((H + 2 * padH - (dilH * (kH - 1) + 1)) // dH + 1,
+            (W + 2 * padW - (dilW * (kW - 1) + 1)) // dW + 1)
+
+
+def _shape_check(input, offset, grad_output, weight, kH, kW, dH, dW, padH, padW, dilH, dilW, group,
+                 deformable_group):
+    """reference csrc/cuda/deform_conv_cuda.cu:67-156 (same conditions, RuntimeError)."""
+    if weight.dim() != 4:
+        raise RuntimeError("4D weight tensor (nOutputPlane,nInputPlane,kH,kW) expected, but got: %d" % weight.dim())
+    if not weight.is_contiguous():
+        raise RuntimeError("weight tensor has to be contiguous")
+    if kW <= 0 or kH <= 0:
+        raise RuntimeError("kernel size should be greater than zero, but got kH: %d kW: %d" % (kH, kW))
+    if weight.size(2) != kH or weight.size(3) != kW:
+        raise RuntimeError("kernel size should be consistent with weight")
+    if dW <= 0 or dH <= 0:
+        raise RuntimeError("stride should be greater than zero, but got dH: %d dW: %d" % (dH, dW))
+    if dilW <= 0 or dilH <= 0:
+        raise RuntimeError("dilation should be greater than 0")
+    if input.dim() != 4:
+        raise RuntimeError("3D or 4D input tensor expected but got: %d" % input.dim())
+    nIn = weight.size(1) * group
+    H, W = input.size(2), input.size(3)
+    Ho, Wo = _out_hw(H, W, kH, kW, padH, padW, dH, dW, dilH, dilW)
+    if nIn % deformable_group != 0:
+        raise RuntimeError("input channels must divide deformable group size")
+    if Wo < 1 or Ho < 1:
+        raise RuntimeError("Given input size: (%d x %d x %d). Calculated output size: (%d x %d x %d). "
+                           "Output size is too small" % (nIn, H, W, weight.size(0), Ho, Wo))
+    if input.size(1) != nIn:
+        raise RuntimeError("invalid number of input planes, expected: %d, but got: %d" % (nIn, input.size(1)))
+    if H < kH or W < kW:
+        raise RuntimeError("input image is smaller than kernel")
+    if offset.size(2) != Ho or offset.size(3) != Wo:
+        raise RuntimeError("invalid spatial size of offset, expected height: %d width: %d, but got "
+                           "height: %d width: %d" % (Ho, Wo, offset.size(2), offset.size(3)))
+    if offset.size(1) != deformable_group * 2 * kH * kW:
+        raise RuntimeError("invalid number of channels of offset")
+    if offset.size(0) != input.size(0):
+        raise RuntimeError("invalid batch size of offset")
+    if grad_output is not None:
+        if grad_output.size(1) != weight.size(0):
+            raise RuntimeError("invalid number of gradOutput planes, expected: %d, but got: %d"
+                               % (weight.size(0), grad_output.size(1)))
+        if grad_output.size(2) != Ho or grad_output.size(3) != Wo:
+            raise RuntimeError("invalid size of gradOutput")
+    return Ho, Wo
+
+
+def _geom_args(B, C, H, W, kH, kW, padH, padW, dH, dW, dilH, dilW, dg):
+    return (B, C, H, W, kH, kW, padH, padW, dH, dW, dilH, dilW, dg)
+
+
+def deformable_im2col(im, offset, mask, kH, kW, padH, padW, dH, dW, dilH, dilW, dg):
+    """col [C*kH*kW, B*Ho*Wo] (deform_conv_kernel_cuda.cu:197-250 / :577-640)."""
+    code = _dcn_check("deformable_im2col", im, offset, mask)
+    B, C, H, W = im.shape
+    Ho, Wo = _out_hw(H, W, kH, kW, padH, padW, dH, dW, dilH, dilW)
+    col = torch.empty((C * kH * kW, B * Ho * Wo), dtype=im.dtype, device=im.device)
+    with _on_device(im):
+        check(lib.detops_deformable_im2col(ptr(im), ptr(offset), ptr(mask), ptr(col), code,
+                                           *_geom_args(B, C, H, W, kH, kW, padH, padW, dH, dW, dilH,
+                                                       dilW, dg), stream_of(im)), "deformable_im2col")
+    return col
+
+
+def deformable_col2im(col, offset, mask, grad_im, kH, kW, padH, padW, dH, dW, dilH, dilW, dg):
+    """accumulates into grad_im [B,C,H,W] (deform_conv_kernel_cuda.cu:286-342 / :642-700)."""
+    code = _dcn_check("deformable_col2im", col, offset, mask, grad_im)
+    B, C, H, W = grad_im.shape
+    with _on_device(col):
+        check(lib.detops_deformable_col2im(ptr(col), ptr(offset), ptr(mask), ptr(grad_im), code,
+                                           *_geom_args(B, C, H, W, kH, kW, padH, padW, dH, dW, dilH,
+                                                       dilW, dg), stream_of(col)), "deformable_col2im")
+
+
+def deformable_col2im_coord(col, im, offset, mask, grad_offset, grad_mask, kH, kW, padH, padW, dH,
+                            dW, dilH, dilW, dg):
+    """overwrites grad_offset (and grad_mask) (deform_conv_kernel_cuda.cu:380-443 / :702-774)."""
+    code = _dcn_check("deformable_col2im_coord", col, im, offset, mask, grad_offset, grad_mask)
+    B, C, H, W = im.shape
+    with _on_device(col):
+        check(lib.detops_deformable_col2im_coord(ptr(col), ptr(im), ptr(offset), ptr(mask),
+                                                 ptr(grad_offset), ptr(grad_mask), code,
+                                                 *_geom_args(B, C, H, W, kH, kW, padH, padW, dH, dW,
+                                                             dilH, dilW, dg), stream_of(col)),
+              "deformable_col2im_coord")
+
+
+def _grouped_weight_times_cols(weight, col, group, out):
+    """out[g] (+)= W[g] @ col[g]; out is [Cout, ncol] (written), fp32/half via rocBLAS/hipBLASLt."""
+    Cout = weight.size(0)
+    Mg = Cout // group
+    Kg = col.size(0) // group
+    w2 = weight.reshape(group, Mg, Kg)
+    for g in range(group):
+        torch.mm(w2[g], col[g * Kg:(g + 1) * Kg], out=out[g * Mg:(g + 1) * Mg])
+
+
+def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH,
+                        dilationW, dilationH, group, deformable_group, im2col_step):
+    """reference csrc/deform_conv.h:11-42 / csrc/cuda/deform_conv_cuda.cu:158-266.
+    Writes `output` in place; note the W-before-H argument order.  Returns 1."""
+    _dcn_check("deform_conv_forward", input, weight, offset, output)
+    input, offset, weight = input.contiguous(), offset.contiguous(), weight.contiguous()
+    Ho, Wo = _shape_check(input, offset, None, weight, kH, kW, dH, dW, padH, padW, dilationH,
+                          dilationW, group, deformable_group)
+    B, C = input.shape[:2]
+    Cout = weight.size(0)
+    if B % im2col_step != 0:
+        raise RuntimeError("im2col step must divide batchsize")
+    out = output.view(B, Cout, Ho, Wo)
+    for b0 in range(0, B, im2col_step):
+        sl = slice(b0, b0 + im2col_step)
+        col = deformable_im2col(input[sl], offset[sl], None, kH, kW, padH, padW, dH, dW, dilationH,
+                                dilationW, deformable_group)
+        buf = torch.empty((Cout, im2col_step * Ho * Wo), dtype=input.dtype, device=input.device)
+        _grouped_weight_times_cols(weight, col, group, buf)
+        out[sl].copy_(buf.view(Cout, im2col_step, Ho, Wo).transpose(0, 1))
+    return 1
+
+
+def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW,
+                               kH, dW, dH, padW, padH, dilationW, dilationH, group, deformable_group,
+                               im2col_step):
+    """reference csrc/deform_conv.h:45-77 / deform_conv_cuda.cu:268-380: accumulates into the
+    caller-zeroed gradInput, overwrites gradOffset.  Returns 1."""
+    _dcn_check("deform_conv_backward_input", input, offset, gradOutput, gradInput, gradOffset, weight)
+    input, offset = input.contiguous(), offset.contiguous()
+    gradOutput, weight = gradOutput.contiguous(), weight.contiguous()
+    Ho, Wo = _shape_check(input, offset, gradOutput, weight, kH, kW, dH, dW, padH, padW, dilationH,
+                          dilationW, group, deformable_group)
+    B, C = input.shape[:2]
+    Cout = weight.size(0)
+    Mg, Kg = Cout // group, (C // group) * kH * kW
+    w2 = weight.reshape(group, Mg, Kg)
+    for b0 in range(0, B, im2col_step):
+        sl = slice(b0, b0 + im2col_step)
+        go = gradOutput[sl].transpose(0, 1).reshape(Cout, im2col_step * Ho * Wo)
+        col = torch.empty((C * kH * kW, im2col_step * Ho * Wo), dtype=input.dtype, device=input.device)
+        for g in range(group):  # columns = W^T * gradOut  (:338-341)
+            torch.mm(w2[g].t(), go[g * Mg:(g + 1) * Mg], out=col[g * Kg:(g + 1) * Kg])
+        deformable_col2im_coord(col, input[sl], offset[sl], None, gradOffset[sl], None, kH, kW, padH,
+                                padW, dH, dW, dilationH, dilationW, deformable_group)
+        deformable_col2im(col, offset[sl], None, gradInput[sl], kH, kW, padH, padW, dH, dW, dilationH,
+                          dilationW, deformable_group)
+    return 1
+
+
+def deform_conv_backward_parameters(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW,
+                                    dH, padW, padH, dilationW, dilationH, group, deformable_group,
+                                    scale, im2col_step):
+    """reference csrc/deform_conv.h:80-112 / deform_conv_cuda.cu:382-494:
+    gradWeight += scale * gradOut * cols^T.  Returns 1."""
+    _dcn_check("deform_conv_backward_parameters", input, offset, gradOutput, gradWeight)
+    input, offset, gradOutput = input.contiguous(), offset.contiguous(), gradOutput.contiguous()
+    Ho, Wo = _shape_check(input, offset, gradOutput, gradWeight, kH, kW, dH, dW, padH, padW,
+                          dilationH, dilationW, group, deformable_group)
+    B, C = input.shape[:2]
+    Cout = gradWeight.size(0)
+    Mg, Kg = Cout // group, (C // group) * kH * kW
+    gw = gradWeight.view(group, Mg, Kg)
+    for b0 in range(0, B, im2col_step):
+        sl = slice(b0, b0 + im2col_step)
+        col = deformable_im2col(input[sl], offset[sl], None, kH, kW, padH, padW, dH, dW, dilationH,
+                                dilationW, deformable_group)
+        go = gradOutput[sl].transpose(0, 1).reshape(Cout, im2col_step * Ho * Wo)
+        for g in range(group):  # :466-472
+            gw[g].addmm_(go[g * Mg:(g + 1) * Mg], col[g * Kg:(g + 1) * Kg].t(), beta=1.0,
+                         alpha=float(scale))
+    return 1
+
+
+def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, output, columns, kernel_h,
+                                  kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                                  group, deformable_group, with_bias):
+    """reference csrc/deform_conv.h:115-149 / deform_conv_cuda.cu:496-575 (H-before-W order).
+    The reference loops per image; one im2col + one GEMM per group over the whole batch gives the
+    same sums."""
+    _dcn_check("modulated_deform_conv_forward", input, weight, offset, mask, output)
+    if not input.is_contiguous():
+        raise RuntimeError("input tensor has to be contiguous")
+    if not weight.is_contiguous():
+        raise RuntimeError("weight tensor has to be contiguous")
+    B, C, H, W = input.shape
+    Cout, Cker, kh_, kw_ = weight.shape
+    if kh_ != kernel_h or kw_ != kernel_w:
+        raise RuntimeError("Input shape and kernel shape wont match: (%d x %d vs %d x %d)."
+                           % (kernel_h, kernel_w, kh_, kw_))
+    if C != Cker * group:
+        raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (C, Cker * group))
+    Ho, Wo = _out_hw(H, W, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w)
+    offset, mask = offset.contiguous(), mask.contiguous()
+    col = deformable_im2col(input, offset, mask, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w,
+                            dilation_h, dilation_w, deformable_group)
+    buf = torch.empty((Cout, B * Ho * Wo), dtype=input.dtype, device=input.device)
+    _grouped_weight_times_cols(weight, col, group, buf)
+    out = output.view(B, Cout, Ho, Wo)
+    out.copy_(buf.view(Cout, B, Ho, Wo).transpose(0, 1))
+    if with_bias:
+        out += bias.view(1, -1, 1, 1)
+
+
+def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, columns, grad_input,
+                                   grad_weight, grad_bias, grad_offset, grad_mask, grad_output,
+                                   kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h,
+                                   dilation_w, group, deformable_group, with_bias):
+    """reference csrc/deform_conv.h:152-191 / deform_conv_cuda.cu:577-691.  grad_input /
+    grad_weight / grad_bias are accumulated into (caller passes zeros); grad_offset / grad_mask are
+    overwritten."""
+    _dcn_check("modulated_deform_conv_backward", input, weight, offset, mask, grad_input, grad_weight,
+               grad_offset, grad_mask, grad_output)
+    if not input.is_contiguous():
+        raise RuntimeError("input tensor has to be contiguous")
+    if not weight.is_contiguous():
+        raise RuntimeError("weight tensor has to be contiguous")
+    B, C, H, W = input.shape
+    Cout, Cker, kh_, kw_ = weight.shape
+    if kh_ != kernel_h or kw_ != kernel_w:
+        raise RuntimeError("Input shape and kernel shape wont match: (%d x %d vs %d x %d)."
+                           % (kernel_h, kernel_w, kh_, kw_))
+    if C != Cker * group:
+        raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (C, Cker * group))
+    Ho, Wo = _out_hw(H, W, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w)
+    offset, mask, grad_output = offset.contiguous(), mask.contiguous(), grad_output.contiguous()
+    geom = (kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w,
+            deformable_group)
+    Mg, Kg = Cout // group, Cker * kernel_h * kernel_w
+    w2 = weight.reshape(group, Mg, Kg)
+    go = grad_output.transpose(0, 1).reshape(Cout, B * Ho * Wo)
+    col = torch.empty((C * kernel_h * kernel_w, B * Ho * Wo), dtype=input.dtype, device=input.device)
+    for g in range(group):  # columns = W^T * gradOut (:628-631)
+        torch.mm(w2[g].t(), go[g * Mg:(g + 1) * Mg], out=col[g * Kg:(g + 1) * Kg])
+    deformable_col2im_coord(col, input, offset, mask, grad_offset, grad_mask, *geom)
+    deformable_col2im(col, offset, mask, grad_input, *geom)
+    col = deformable_im2col(input, offset, mask, *geom)
+    gw = grad_weight.view(group, Mg, Kg)
+    for g in range(group):  # :666-670
+        gw[g].addmm_(go[g * Mg:(g + 1) * Mg], col[g * Kg:(g + 1) * Kg].t())
+    if with_bias:  # :671-676 gradOut * ones
+        grad_bias += go.sum(1)
+
+
+def deform_psroi_pooling_forward(*args, **kwargs):
+    """reference csrc/deform_pool.h:11-38.  No model config of the reference uses deformable
+    PS-ROI pooling; it is outside the hot path and not built yet."""
+    raise NotImplementedError("deform_psroi_pooling_forward is not built in this HIP-only library")
+
+
+def deform_psroi_pooling_backward(*args, **kwargs):
+    raise NotImplementedError("deform_psroi_pooling_backward is not built in this HIP-only library")

@@ -1,0 +1,84 @@
+"""ctypes binding of libdetops_gfx950.so (C ABI declared in include/detops.h).
+
+The library is built in-tree by `make -C maskrcnn-benchmark_amd/csrc` (hipcc, gfx950) into
+maskrcnn_benchmark/lib/.  There is NO fallback: if the shared object is missing or does not export
+a symbol the import fails loudly — the detection-head operators exist only as HIP kernels.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  — loads the HIP runtime (libamdhip64) this library links against
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdetops_gfx950.so")
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/detops.h one to one
+_P = c_void_p
+SIGNATURES = {
+    "detops_version": (c_int, [_P]),
+    "detops_roi_align_forward_f32": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, _P]),
+    "detops_roi_align_backward_f32": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P]),
+    "detops_roi_align_fpn_forward_f32": (
+        c_int, [_P, _P, _P, _P, c_int, _P, _P, _P] + [c_int] * 8 + [c_float, c_float, c_float, _P]),
+    "detops_roi_align_fpn_backward_f32": (
+        c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P]),
+    "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),
+    "detops_roi_pool_backward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
+    "detops_nms_workspace_bytes": (c_size_t, [c_int]),
+    "detops_nms_f32": (c_int, [_P, _P, c_int, c_float, _P, _P, _P, c_size_t, _P]),
+    "detops_nms_batched_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "detops_nms_batched_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
+    "detops_sigmoid_focal_loss_forward_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_sigmoid_focal_loss_backward_f32": (
+        c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_sigmoid_focal_loss_backward_scalar_f32": (
+        c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_sigmoid_focal_loss_forward_sum_f32": (
+        c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_deformable_im2col": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),
+    "detops_deformable_col2im": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),
+    "detops_deformable_col2im_coord": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 14 + [_P]),
+}
+
+_ERRORS = {-1: "DETOPS_EINVAL (bad shape / null pointer)", -2: "DETOPS_EWORKSPACE (workspace too small)",
+           -3: "DETOPS_EUNSUPPORTED (configuration not implemented)"}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libdetops_gfx950.so not found at %s — build it with `make -C maskrcnn-benchmark_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). The detection-head operators "
+            "have no CPU / PyTorch fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.detops_version(None) != 1:
+        raise ImportError("libdetops_gfx950.so: ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = _ERRORS.get(rc, "hipError_t %d" % rc)
+        raise RuntimeError("%s failed: %s" % (what, msg))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t):
+    """The current HIP stream of the tensor's device, as an integer handle."""
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}

@@ -1,0 +1,456 @@
+"""Parity tests of the HIP operators against the oracle — run with `-m gpu` on an MI355X.
+
+Every call goes through `maskrcnn_benchmark._C` / `maskrcnn_benchmark.layers`, i.e. through the
+C ABI of libdetops_gfx950.so.  Tolerances are the ones BASELINE.json's north_star states:
+NMS kept indices bit-exact; ROIAlign / focal loss within 1e-4 (fp32); DCN fp32 1e-4, half 2e-2.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _C():
+    from maskrcnn_benchmark import _C as C
+
+    return C
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+# ============================================================================ ROIAlign forward
+@pytest.mark.parametrize("ph,pw,sr", [(7, 7, 2), (14, 14, 2), (7, 7, 0), (3, 5, 3), (1, 1, 1)])
+def test_roi_align_forward_cfg1_bit_exact(ph, pw, sr):
+    """BASELINE configs[0]: 256x14x14 map, 512 ROIs — bit-identical to the reference CPU kernel
+    (the oracle is pinned bit-exact to it)."""
+    inp, rois, scale = synth.cfg1_roi_align()
+    ref = oracle.roi_align_forward(inp, rois, scale, ph, pw, sr)
+    out = _C().roi_align_forward(_t(inp), _t(rois), scale, ph, pw, sr).cpu().numpy()
+    assert np.abs(out - ref).max() <= 1e-4  # the stated tolerance
+    assert np.array_equal(out, ref), "max abs diff %g" % np.abs(out - ref).max()
+
+
+def test_roi_align_forward_golden_reference_vectors(golden_dir):
+    g = _load(golden_dir, "ref_cpu_vectors.npz")
+    for i in range(4):
+        ph, pw, sr = [int(v) for v in g[f"ra_cfg_{i}"]]
+        out = _C().roi_align_forward(_t(g["ra_input"]), _t(g["ra_rois"]), float(g["ra_scale"]), ph, pw, sr)
+        assert np.array_equal(out.cpu().numpy(), g[f"ra_out_{i}"])
+    for i in range(2):
+        ph, pw, sr = [int(v) for v in g[f"ra2_cfg_{i}"]]
+        out = _C().roi_align_forward(_t(g["ra2_input"]), _t(g["ra2_rois"]), 1.0 / 32, ph, pw, sr)
+        assert np.array_equal(out.cpu().numpy(), g[f"ra2_out_{i}"])
+
+
+def test_roi_align_forward_fpn_full_size_and_fused():
+    """cfg-2: 1024 ROIs on the 2-image 800x1344 pyramid, per level and in the fused launch."""
+    feats = synth.fpn_features()
+    rois = synth.fpn_rois()
+    lv = synth.level_map(rois)
+    scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
+    tf = [_t(f) for f in feats]
+    expected = np.zeros((rois.shape[0], 256, 7, 7), np.float32)
+    for l in range(4):
+        idx = np.nonzero(lv == l)[0]
+        assert len(idx) > 0
+        ref = oracle.roi_align_forward(feats[l], rois[idx], scales[l], 7, 7, 2)
+        out = _C().roi_align_forward(tf[l], _t(rois[idx]), scales[l], 7, 7, 2).cpu().numpy()
+        assert np.array_equal(out, ref)
+        expected[idx] = ref
+    out, levels = _C().roi_align_fpn_forward(tf, _t(rois), scales, 7, 7, 2, 2, 5)
+    np.testing.assert_array_equal(levels.cpu().numpy(), lv)
+    assert np.array_equal(out.cpu().numpy(), expected)
+
+
+def test_roi_align_forward_edge_cases():
+    C = _C()
+    x = torch.randn(2, 3, 10, 12, device=DEV)
+    assert C.roi_align_forward(x, torch.zeros(0, 5, device=DEV), 0.5, 7, 7, 2).shape == (0, 3, 7, 7)
+    rois = np.array([[0, -500, -500, -400, -400],     # entirely outside -> zeros
+                     [1, 0, 0, 5000, 4000],           # huge adaptive grid -> on-the-fly path
+                     [1, 3, 3, 3, 3],                 # degenerate -> forced 1x1
+                     [0, 5.5, 2.25, 20.75, 17.5]], np.float32)
+    xn = x.cpu().numpy()
+    for sr in (0, 2):
+        ref = oracle.roi_align_forward(xn, rois, 1.0, 4, 6, sr)
+        out = C.roi_align_forward(x, _t(rois), 1.0, 4, 6, sr).cpu().numpy()
+        assert np.array_equal(out, ref), sr
+        assert not out[0].any()
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        C.roi_align_forward(x.cpu(), _t(rois).cpu(), 1.0, 4, 6, 2)
+
+
+# ============================================================================ ROIAlign backward
+@pytest.mark.parametrize("ph,pw,sr", [(7, 7, 2), (14, 14, 2), (7, 7, 0), (3, 5, 3)])
+def test_roi_align_backward_cfg1(ph, pw, sr):
+    inp, rois, scale = synth.cfg1_roi_align()
+    g = np.random.RandomState(1).randn(rois.shape[0], 256, ph, pw).astype(np.float32)
+    ref = oracle.roi_align_backward(g, rois, scale, ph, pw, *inp.shape, sr, acc64=True)
+    out = _C().roi_align_backward(_t(g), _t(rois), scale, ph, pw, *inp.shape, sr).cpu().numpy()
+    # 512 ROIs pile onto a 14x14 map: |grad_in| ~ 1e2; 1e-4 relative to the result's scale
+    assert np.abs(out - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+def test_roi_align_backward_fpn_full_size_and_fused():
+    feats_shapes = [(2, 256, h, w) for (h, w) in synth.fpn_shapes()[:4]]
+    rois = synth.fpn_rois()
+    lv = synth.level_map(rois)
+    scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
+    g = np.random.RandomState(2).randn(rois.shape[0], 256, 7, 7).astype(np.float32)
+    refs = []
+    for l in (1, 2, 3):  # P3..P5 against the oracle (P2 is 138 MB; covered by the fused run below)
+        idx = np.nonzero(lv == l)[0]
+        ref = oracle.roi_align_backward(g[idx], rois[idx], scales[l], 7, 7, *feats_shapes[l], 2, acc64=True)
+        out = _C().roi_align_backward(_t(g[idx]), _t(rois[idx]), scales[l], 7, 7, *feats_shapes[l], 2)
+        _close(out, ref, rtol=1e-4, atol=1e-4)
+        refs.append(ref)
+    gins = _C().roi_align_fpn_backward(_t(g), _t(rois), _t(lv), feats_shapes, scales, 7, 7, 2)
+    for l in (1, 2, 3):
+        _close(gins[l], refs[l - 1], rtol=1e-4, atol=1e-4)
+    idx = np.nonzero(lv == 0)[0]
+    p2 = _C().roi_align_backward(_t(g[idx]), _t(rois[idx]), scales[0], 7, 7, *feats_shapes[0], 2)
+    torch.testing.assert_close(gins[0], p2, rtol=1e-4, atol=1e-4)
+
+
+def test_roi_align_adjoint_and_linearity_full_size():
+    """<fwd(x), g> == <x, bwd(g)> and bwd is linear — size-independent properties at cfg-2 scale."""
+    C = _C()
+    x = torch.randn(2, 256, 100, 168, device=DEV)
+    rois_np = synth.fpn_rois(seed=9)
+    rois = _t(rois_np[synth.level_map(rois_np) == 1])
+    K = rois.size(0)
+    g1 = torch.randn(K, 256, 7, 7, device=DEV)
+    g2 = torch.randn(K, 256, 7, 7, device=DEV)
+    y = C.roi_align_forward(x, rois, 1 / 8, 7, 7, 2)
+    b1 = C.roi_align_backward(g1, rois, 1 / 8, 7, 7, 2, 256, 100, 168, 2)
+    lhs = (y.double() * g1.double()).sum().item()
+    rhs = (x.double() * b1.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+    b2 = C.roi_align_backward(g2, rois, 1 / 8, 7, 7, 2, 256, 100, 168, 2)
+    b12 = C.roi_align_backward(0.5 * g1 + g2, rois, 1 / 8, 7, 7, 2, 256, 100, 168, 2)
+    torch.testing.assert_close(b12, 0.5 * b1 + b2, rtol=1e-4, atol=1e-4)
+
+
+def test_roi_align_backward_edge_cases():
+    C = _C()
+    gin = C.roi_align_backward(torch.zeros(0, 3, 7, 7, device=DEV), torch.zeros(0, 5, device=DEV), 0.5,
+                               7, 7, 2, 3, 10, 12, 2)
+    assert gin.shape == (2, 3, 10, 12) and not gin.any()
+    rois = np.array([[0, -500, -500, -400, -400], [1, 0, 0, 5000, 4000], [1, 3, 3, 3, 3],
+                     [0, 5.5, 2.25, 20.75, 17.5], [1, 0, 0, 200, 150]], np.float32)
+    g = np.random.RandomState(3).randn(5, 3, 4, 6).astype(np.float32)
+    for sr in (0, 2):
+        ref = oracle.roi_align_backward(g, rois, 1.0, 4, 6, 2, 3, 10, 12, sr, acc64=True)
+        out = C.roi_align_backward(_t(g), _t(rois), 1.0, 4, 6, 2, 3, 10, 12, sr)
+        _close(out, ref, rtol=1e-4, atol=1e-5)
+    # a patch larger than the LDS budget (100x100 px) takes the direct-atomics path
+    rois = np.array([[0, 2, 3, 118, 109]], np.float32)
+    g = np.random.RandomState(4).randn(1, 2, 7, 7).astype(np.float32)
+    ref = oracle.roi_align_backward(g, rois, 1.0, 7, 7, 1, 2, 128, 128, 0, acc64=True)
+    out = C.roi_align_backward(_t(g), _t(rois), 1.0, 7, 7, 1, 2, 128, 128, 0)
+    _close(out, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_roi_align_layer_autograd_and_amp():
+    from maskrcnn_benchmark.layers import ROIAlign
+
+    inp, rois, scale = synth.cfg1_roi_align(K=64, C=16)
+    layer = ROIAlign((7, 7), scale, 2)
+    assert repr(layer) == "ROIAlign(output_size=(7, 7), spatial_scale=0.0625, sampling_ratio=2)"
+    x = _t(inp).requires_grad_(True)
+    y = layer(x, _t(rois))
+    g = torch.randn_like(y)
+    y.backward(g)
+    ref = oracle.roi_align_backward(g.cpu().numpy(), rois, scale, 7, 7, *inp.shape, 2, acc64=True)
+    _close(x.grad, ref, rtol=1e-4, atol=1e-4)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y16 = layer(_t(inp).half(), _t(rois).half())
+    assert y16.dtype == torch.float32  # amp.float_function semantics (reference roi_align.py:57)
+
+
+# ============================================================================ ROIPool
+def test_roi_pool_forward_backward():
+    C = _C()
+    inp, rois, scale = synth.cfg1_roi_align(K=200, C=32)
+    out, amax = C.roi_pool_forward(_t(inp), _t(rois), scale, 7, 7)
+    ref, ramax = oracle.roi_pool_forward(inp, rois, scale, 7, 7)
+    assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(amax.cpu().numpy(), ramax)
+    assert amax.dtype == torch.int32 and (ramax == -1).any()
+    g = np.random.RandomState(5).randn(*ref.shape).astype(np.float32)
+    gin = C.roi_pool_backward(_t(g), _t(inp), _t(rois), amax, scale, 7, 7, *inp.shape)
+    _close(gin, oracle.roi_pool_backward(g, rois, ramax, *inp.shape), rtol=1e-4, atol=1e-4)
+    # FPN-sized map, two images
+    feats = synth.fpn_features(levels=4)[2]
+    r = synth.fpn_rois(seed=6, per_image=64)
+    out, amax = C.roi_pool_forward(_t(feats), _t(r), 1 / 16, 7, 7)
+    ref, ramax = oracle.roi_pool_forward(feats, r, 1 / 16, 7, 7)
+    assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(amax.cpu().numpy(), ramax)
+    from maskrcnn_benchmark.layers import ROIPool
+
+    assert repr(ROIPool((7, 7), 0.25)) == "ROIPool(output_size=(7, 7), spatial_scale=0.25)"
+
+
+# ============================================================================ NMS
+def _nms(b, s, thr):
+    return _C().nms(_t(b), _t(s), thr).cpu().numpy()
+
+
+def test_nms_reference_known_answers(golden_dir):
+    g = _load(golden_dir, "nms_reference_tests.npz")
+    for i in range(int(g["num_cases"])):
+        keep = _nms(g[f"boxes_{i}"], g[f"scores_{i}"], float(g[f"thresh_{i}"]))
+        np.testing.assert_array_equal(keep, g[f"expected_{i}"])
+
+
+def test_nms_matches_compiled_reference_vectors(golden_dir):
+    g = _load(golden_dir, "ref_cpu_vectors.npz")
+    for key in g["nms_cases"]:
+        _, n, uniform, seed, thr = str(key).split("_")
+        b, s = synth.nms_boxes(int(n), seed=int(seed), uniform=bool(int(uniform)))
+        np.testing.assert_array_equal(_nms(b, s, int(thr) / 100.0), g[str(key)], err_msg=str(key))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 128, 129, 1000, 2000, 6000, 8192, 8193, 12000])
+def test_nms_bit_exact_vs_oracle(n):
+    for uniform in (False, True):
+        b, s = synth.nms_boxes(n, seed=40 + n % 7, uniform=uniform)
+        for thr in (0.5, 0.7):
+            keep = _nms(b, s, thr)
+            assert keep.dtype == np.int64
+            np.testing.assert_array_equal(keep, oracle.nms(b, s, thr))
+
+
+def test_nms_edge_cases():
+    C = _C()
+    e = C.nms(torch.zeros(0, 4, device=DEV), torch.zeros(0, device=DEV), 0.5)
+    assert e.shape == (0,) and e.dtype == torch.long and e.device.type == "cpu"  # nms.h:17-18
+    b = np.array([[0, 0, 9, 9], [0, 0, 9, 4]], np.float32)  # IoU exactly 0.5
+    s = np.array([0.9, 0.8], np.float32)
+    np.testing.assert_array_equal(_nms(b, s, 0.5), [0])  # >= (CPU semantics), not > (nms.cu:60)
+    np.testing.assert_array_equal(_nms(b, s, 0.5000001), [0, 1])
+    # ties and duplicates: stable order, identical boxes collapse to the first of the best score
+    b = np.array([[0, 0, 10, 10]] * 5 + [[50, 50, 60, 60]] * 3, np.float32)
+    s = np.array([0.3, 0.9, 0.9, 0.1, 0.9, 0.5, 0.5, 0.5], np.float32)
+    np.testing.assert_array_equal(_nms(b, s, 0.7), oracle.nms(b, s, 0.7))
+    np.testing.assert_array_equal(_nms(b, s, 0.7), [1, 5])
+    # non-distinct random scores
+    b, s = synth.nms_boxes(3000, seed=3, distinct_scores=False)
+    s = np.round(s, 2)
+    np.testing.assert_array_equal(_nms(b, s, 0.6), oracle.nms(b, s, 0.6))
+    # threshold 0 and > 1
+    b, s = synth.nms_boxes(500, seed=4)
+    for thr in (0.0, 1.5):
+        np.testing.assert_array_equal(_nms(b, s, thr), oracle.nms(b, s, thr))
+
+
+def test_nms_idempotent_and_sorted_full_size():
+    b, s = synth.nms_boxes(2000, seed=8)
+    keep = _nms(b, s, 0.7)
+    assert np.all(np.diff(keep) > 0)
+    again = _nms(b[keep], s[keep], 0.7)
+    np.testing.assert_array_equal(again, np.arange(len(keep)))
+
+
+def test_nms_batched_rpn_segments():
+    segs = synth.rpn_nms_segments()
+    segs.insert(3, (np.zeros((0, 4), np.float32), np.zeros((0,), np.float32)))  # an empty segment
+    boxes = np.concatenate([b for b, _ in segs])
+    scores = np.concatenate([s for _, s in segs])
+    offs = np.cumsum([0] + [len(s) for _, s in segs]).astype(np.int32)
+    keep, num = _C().nms_batched(_t(boxes), _t(scores), _t(offs), 2000, 0.7)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    for i, (b, s) in enumerate(segs):
+        ref = oracle.nms(b, s, 0.7)
+        assert num[i] == len(ref)
+        np.testing.assert_array_equal(keep[offs[i]:offs[i] + num[i]], ref)
+
+
+def test_nms_layer_amp_hint():
+    from maskrcnn_benchmark.layers import nms
+
+    b, s = synth.nms_boxes(300, seed=5)
+    with torch.autocast("cuda", dtype=torch.float16):
+        keep = nms(_t(b), _t(s), 0.5)
+    np.testing.assert_array_equal(keep.cpu().numpy(), oracle.nms(b, s, 0.5))
+
+
+# ============================================================================ SigmoidFocalLoss
+def test_focal_vs_oracle_and_golden(golden_dir):
+    C = _C()
+    logits, targets = synth.focal_inputs(20000, 80)
+    tl, tt = _t(logits), _t(targets)
+    f = C.sigmoid_focalloss_forward(tl, tt, 80, 2.0, 0.25)
+    _close(f, oracle.sigmoid_focal_loss_forward(logits, targets, 2.0, 0.25), rtol=1e-4, atol=1e-6)
+    d = np.random.RandomState(6).rand(*logits.shape).astype(np.float32)
+    b = C.sigmoid_focalloss_backward(tl, tt, _t(d), 80, 2.0, 0.25)
+    _close(b, oracle.sigmoid_focal_loss_backward(logits, targets, d, 2.0, 0.25), rtol=1e-4, atol=1e-6)
+    # the reference's own Python CPU composite (layers/sigmoid_focal_loss.py:40-50)
+    g = _load(golden_dir, "focal_python_composite.npz")
+    f = C.sigmoid_focalloss_forward(_t(g["logits"]), _t(g["targets"]), 80, float(g["gamma"]), float(g["alpha"]))
+    _close(f, g["losses"], rtol=1e-4, atol=1e-6)
+    b = C.sigmoid_focalloss_backward(_t(g["logits"]), _t(g["targets"]), _t(g["d_losses"]), 80,
+                                     float(g["gamma"]), float(g["alpha"]))
+    _close(b, g["d_logits"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("gamma,alpha,C", [(2.0, 0.25, 80), (1.5, 0.4, 80), (0.0, 0.5, 7), (1.0, 0.25, 3)])
+def test_focal_parameters_and_odd_class_counts(gamma, alpha, C):
+    logits, targets = synth.focal_inputs(999, C, seed=7)
+    logits[0, :] = [-100, -90, -20, 0, 20, 90, 100][:C] + [0.5] * max(0, C - 7)
+    targets[:5] = [1, min(2, C), -1, 0, C]
+    f = _C().sigmoid_focalloss_forward(_t(logits), _t(targets), C, gamma, alpha)
+    _close(f, oracle.sigmoid_focal_loss_forward(logits, targets, gamma, alpha), rtol=1e-4, atol=1e-6)
+    d = np.random.RandomState(8).rand(*logits.shape).astype(np.float32)
+    b = _C().sigmoid_focalloss_backward(_t(logits), _t(targets), _t(d), C, gamma, alpha)
+    _close(b, oracle.sigmoid_focal_loss_backward(logits, targets, d, gamma, alpha), rtol=1e-4, atol=1e-6)
+    assert torch.isfinite(f).all() and torch.isfinite(b).all()
+
+
+def test_focal_full_size_properties_and_module():
+    """cfg-4: R = 2 x 201,600 anchors x 80 classes.  sum kernel == sum of elementwise kernel ==
+    torch composite; module backward == explicit backward with a constant upstream gradient."""
+    from maskrcnn_benchmark.layers import SigmoidFocalLoss
+
+    C = _C()
+    logits, targets = synth.focal_inputs(403200, 80)
+    tl, tt = _t(logits), _t(targets)
+    losses = C.sigmoid_focalloss_forward(tl, tt, 80, 2.0, 0.25)
+    total = C.sigmoid_focalloss_forward_sum(tl, tt, 80, 2.0, 0.25)
+    ref_sum = losses.double().sum().item()
+    assert abs(total.item() - ref_sum) <= 1e-4 * abs(ref_sum)
+    # torch composite of the reference's CPU formula, evaluated on the GPU in fp64
+    x = tl.double()
+    p = torch.sigmoid(x)
+    cls = torch.arange(1, 81, device=DEV).unsqueeze(0)
+    t = tt.unsqueeze(1)
+    comp = -(t == cls).double() * (1 - p) ** 2 * torch.log(p) * 0.25 \
+        - ((t != cls) & (t >= 0)).double() * p ** 2 * torch.log1p(-p) * 0.75
+    torch.testing.assert_close(losses.double(), comp, rtol=1e-4, atol=1e-6)
+    rows_ignored = (tt == -1)
+    assert not losses[rows_ignored].any()
+    # module: sum + backward
+    mod = SigmoidFocalLoss(2.0, 0.25)
+    assert repr(mod) == "SigmoidFocalLoss(gamma=2.0, alpha=0.25)"
+    xg = tl.clone().requires_grad_(True)
+    loss = mod(xg, tt) / 1234.0
+    loss.backward()
+    explicit = C.sigmoid_focalloss_backward(tl, tt, torch.full_like(tl, 1 / 1234.0), 80, 2.0, 0.25)
+    torch.testing.assert_close(xg.grad, explicit, rtol=1e-5, atol=1e-9)
+
+
+# ============================================================================ deformable conv
+GEOMS = [dict(B=2, C=8, H=13, W=17, Cout=6, k=3, stride=1, pad=1, dil=1, dg=1, group=1),
+         dict(B=2, C=8, H=14, W=15, Cout=8, k=3, stride=2, pad=2, dil=2, dg=2, group=2),
+         dict(B=2, C=64, H=50, W=84, Cout=64, k=3, stride=1, pad=1, dil=1, dg=1, group=1)]
+
+
+def _dcn_case(g, modulated, seed=3):
+    x, off, mask, wgt = synth.dcn_inputs(g["B"], g["C"], g["H"], g["W"], g["Cout"], g["k"], g["dg"],
+                                         modulated, seed=seed)
+    Ho = (g["H"] + 2 * g["pad"] - (g["dil"] * (g["k"] - 1) + 1)) // g["stride"] + 1
+    Wo = (g["W"] + 2 * g["pad"] - (g["dil"] * (g["k"] - 1) + 1)) // g["stride"] + 1
+    off = np.ascontiguousarray(off[:, :, :Ho, :Wo])
+    mask = None if mask is None else np.ascontiguousarray(mask[:, :, :Ho, :Wo])
+    wgt = np.ascontiguousarray(wgt[:, : g["C"] // g["group"]])
+    return x, off, mask, wgt
+
+
+@pytest.mark.parametrize("gi", range(len(GEOMS)))
+@pytest.mark.parametrize("modulated", [False, True])
+def test_deformable_kernels_vs_oracle_fp32(gi, modulated):
+    C = _C()
+    g = GEOMS[gi]
+    x, off, mask, _ = _dcn_case(g, modulated)
+    k, p, s, d, dg = g["k"], g["pad"], g["stride"], g["dil"], g["dg"]
+    geo = (k, k, p, p, s, s, d, d, dg)
+    ogeo = dict(kh=k, kw=k, pad=(p, p), stride=(s, s), dil=(d, d), dg=dg)
+    tm = None if mask is None else _t(mask)
+    col = C.deformable_im2col(_t(x), _t(off), tm, *geo)
+    ref_col = oracle.deformable_im2col(x, off, mask, **ogeo)
+    _close(col, ref_col, rtol=1e-5, atol=1e-5)
+    gcol = np.random.RandomState(9).randn(*ref_col.shape).astype(np.float32)
+    gim = torch.zeros(*x.shape, device=DEV)
+    C.deformable_col2im(_t(gcol), _t(off), tm, gim, *geo)
+    _close(gim, oracle.deformable_col2im(gcol, off, mask, *x.shape, **ogeo), rtol=1e-4, atol=1e-4)
+    goff = torch.empty(*off.shape, device=DEV)
+    gmask = None if mask is None else torch.empty(*mask.shape, device=DEV)
+    C.deformable_col2im_coord(_t(gcol), _t(x), _t(off), tm, goff, gmask, *geo)
+    rgoff, rgmask = oracle.deformable_col2im_coord(gcol, x, off, mask, **ogeo)
+    scale = max(1.0, np.abs(rgoff).max())
+    _close(goff, rgoff, rtol=1e-4, atol=1e-4 * scale)
+    if modulated:
+        _close(gmask, rgmask, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(rgmask).max()))
+
+
+@pytest.mark.parametrize("gi", [0, 1])
+@pytest.mark.parametrize("modulated", [False, True])
+def test_deform_conv_layers_end_to_end_fp32(gi, modulated):
+    from maskrcnn_benchmark.layers import deform_conv, modulated_deform_conv
+
+    g = GEOMS[gi]
+    if modulated and g["stride"] != 1:
+        pass  # modulated API takes scalar stride/pad/dil (reference deform_conv_func.py:150-160)
+    x, off, mask, wgt = _dcn_case(g, modulated)
+    bias = np.random.RandomState(4).randn(g["Cout"]).astype(np.float32) if modulated else None
+    tx, toff, tw = (_t(a).requires_grad_(True) for a in (x, off, wgt))
+    og = dict(pad=(g["pad"],) * 2, stride=(g["stride"],) * 2, dil=(g["dil"],) * 2, group=g["group"], dg=g["dg"])
+    if modulated:
+        tmask, tb = _t(mask).requires_grad_(True), _t(bias).requires_grad_(True)
+        y = modulated_deform_conv(tx, toff, tmask, tw, tb, g["stride"], g["pad"], g["dil"], g["group"], g["dg"])
+    else:
+        y = deform_conv(tx, toff, tw, g["stride"], g["pad"], g["dil"], g["group"], g["dg"])
+    ref = oracle.deform_conv_forward(x, off, mask, wgt, bias, **og)
+    _close(y, ref, rtol=1e-4, atol=1e-4)
+    go = np.random.RandomState(7).randn(*ref.shape).astype(np.float32)
+    y.backward(_t(go))
+    gin, goff, gmask, gw, gb = oracle.deform_conv_backward(x, off, mask, wgt, go, bias is not None, **og)
+    _close(tx.grad, gin, rtol=1e-4, atol=1e-4)
+    _close(toff.grad, goff, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(goff).max()))
+    _close(tw.grad, gw, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(gw).max()))
+    if modulated:
+        _close(tmask.grad, gmask, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(gmask).max()))
+        _close(tb.grad, gb, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(gb).max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_deform_conv_half_precision(dtype):
+    """cfg-5: fp16 / bf16 storage, fp32 sampling arithmetic: <= 2e-2 relative to the fp32 oracle
+    evaluated on the same (rounded) inputs."""
+    from maskrcnn_benchmark.layers import DFConv2d, deform_conv
+
+    g = GEOMS[2]
+    x, off, _, wgt = _dcn_case(g, False)
+    hx, hoff, hw = (_t(a).to(dtype) for a in (x, off, wgt))
+    ref = oracle.deform_conv_forward(hx.float().cpu().numpy(), hoff.float().cpu().numpy(), None,
+                                     hw.float().cpu().numpy(), None, pad=(1, 1), stride=(1, 1),
+                                     dil=(1, 1), group=1, dg=1)
+    y = deform_conv(hx, hoff, hw, 1, 1, 1, 1, 1)
+    assert y.dtype == dtype
+    err = (y.float().cpu().numpy() - ref)
+    assert np.abs(err).max() <= 2e-2 * np.abs(ref).max()
+    layer = DFConv2d(16, 16, with_modulated_dcn=True).to(DEV).to(dtype)
+    out = layer(torch.randn(2, 16, 20, 24, device=DEV, dtype=dtype))
+    assert out.shape == (2, 16, 20, 24) and torch.isfinite(out).all()
+    out.float().sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())

@@ -1,0 +1,197 @@
+"""Per-operator micro-benchmarks of the HIP detection-head kernels (HIP-event timed on the stream
+the kernels are launched on) with the ALGORITHMIC byte counts of SURVEY.md §8(d).
+
+    python tools/opbench.py [--iters 50] [--json out.json] [--only roi_align_fwd,...]
+
+Used by bench.py for the `roofline` object and by the profiling recipes in profiles/README.md.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "maskrcnn-benchmark_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+
+
+def dev_time_us(fn, iters=50, warmup=5):
+    """Average device time of fn() in microseconds, HIP events on the current stream."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) * 1000.0 / iters
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _entry(name, us, alg_bytes, extra=None):
+    e = {"op": name, "us": round(us, 2), "alg_bytes": int(alg_bytes),
+         "gbs": round(alg_bytes / us / 1e3, 1), "frac_of_8TBs": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+    if extra:
+        e.update(extra)
+    return e
+
+
+def bench_roi_align(C, iters, which=("fwd", "bwd")):
+    out = []
+    # cfg-1 (BASELINE configs[0]) ---------------------------------------------------------
+    inp, rois, scale = synth.cfg1_roi_align()
+    ti, tr = _t(inp), _t(rois)
+    for ph, pw, sr in [(7, 7, 2), (14, 14, 2), (7, 7, 0)]:
+        K, Cc = rois.shape[0], inp.shape[1]
+        alg = 4 * K * Cc * ph * pw + 4 * inp.size + 20 * K
+        if "fwd" in which:
+            us = dev_time_us(lambda: C.roi_align_forward(ti, tr, scale, ph, pw, sr), iters)
+            out.append(_entry(f"roi_align_fwd cfg1 {ph}x{pw} sr{sr}", us, alg))
+        if "bwd" in which:
+            g = torch.randn(K, Cc, ph, pw, device="cuda")
+            us = dev_time_us(lambda: C.roi_align_backward(g, tr, scale, ph, pw, 1, Cc, 14, 14, sr), iters)
+            out.append(_entry(f"roi_align_bwd cfg1 {ph}x{pw} sr{sr}", us, alg))
+    # cfg-2 box head: 1024 ROIs over P2..P5, 7x7 sr2; cfg-3 mask head: 256 ROIs, 14x14 sr2 ----
+    feats = [torch.randn(2, 256, h, w, device="cuda") for (h, w) in synth.fpn_shapes()[:4]]
+    scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
+    shapes = [tuple(f.shape) for f in feats]
+    feat_bytes = sum(f.numel() * 4 for f in feats)
+    for tag, K, ph in (("box-head 1024x7x7", 1024, 7), ("mask-head 256x14x14", 256, 14)):
+        rois = synth.fpn_rois(per_image=K // 2)
+        tr = _t(rois)
+        alg = 4 * K * 256 * ph * ph + feat_bytes + 20 * K
+        lv = synth.level_map(rois)
+        per = [(l, _t(rois[lv == l])) for l in range(4)]
+
+        def per_level_fwd():
+            for l, r in per:
+                C.roi_align_forward(feats[l], r, scales[l], ph, ph, 2)
+
+        if "fwd" in which:
+            us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
+            out.append(_entry(f"roi_align_fwd fpn-fused {tag}", us, alg))
+            us = dev_time_us(per_level_fwd, iters)
+            out.append(_entry(f"roi_align_fwd fpn-per-level(4 launches) {tag}", us, alg))
+        if "bwd" in which:
+            g = torch.randn(K, 256, ph, ph, device="cuda")
+            tl = _t(lv)
+            us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
+            out.append(_entry(f"roi_align_bwd fpn-fused (incl. zero-fill) {tag}", us, alg))
+    return out
+
+
+def bench_nms(C, iters):
+    out = []
+    for n, uniform in [(819, False), (2000, False), (2000, True), (6000, False)]:
+        b, s = synth.nms_boxes(n, seed=2, uniform=uniform)
+        tb, ts = _t(b), _t(s)
+        us = dev_time_us(lambda: C.nms(tb, ts, 0.7), iters)  # includes the count readback
+        k = int(C.nms(tb, ts, 0.7).numel())
+        out.append(_entry(f"nms n={n} {'uniform' if uniform else 'clustered'} (with .item())", us,
+                          20 * n + 8 * k, {"kept": k, "pairs_per_us": round(n * (n - 1) / 2 / us, 1)}))
+    segs = synth.rpn_nms_segments()
+    boxes = _t(np.concatenate([b for b, _ in segs]))
+    scores = _t(np.concatenate([s for _, s in segs]))
+    offs = _t(np.cumsum([0] + [len(s) for _, s in segs]).astype(np.int32))
+    us = dev_time_us(lambda: C.nms_batched(boxes, scores, offs, 2000, 0.7), iters)
+    tot = int(boxes.size(0))
+    pairs = sum(len(s) * (len(s) - 1) // 2 for _, s in segs)
+    out.append(_entry("nms batched 10 RPN segments (no sync)", us, 20 * tot,
+                      {"pairs_per_us": round(pairs / us, 1)}))
+    return out
+
+
+def bench_focal(C, iters):
+    out = []
+    for R in (200000, 403200):
+        logits, targets = synth.focal_inputs(R, 80)
+        tl, tt = _t(logits), _t(targets)
+        d = torch.rand_like(tl)
+        one = torch.ones((), device="cuda")
+        us = dev_time_us(lambda: C.sigmoid_focalloss_forward(tl, tt, 80, 2.0, 0.25), iters)
+        out.append(_entry(f"focal_fwd R={R}", us, 2 * 4 * R * 80 + 4 * R))
+        us = dev_time_us(lambda: C.sigmoid_focalloss_backward(tl, tt, d, 80, 2.0, 0.25), iters)
+        out.append(_entry(f"focal_bwd R={R}", us, 3 * 4 * R * 80 + 4 * R))
+        us = dev_time_us(lambda: C.sigmoid_focalloss_forward_sum(tl, tt, 80, 2.0, 0.25), iters)
+        out.append(_entry(f"focal_fwd_sum R={R}", us, 4 * R * 80 + 4 * R))
+        us = dev_time_us(lambda: C.sigmoid_focalloss_backward_scalar(tl, tt, one, 80, 2.0, 0.25), iters)
+        out.append(_entry(f"focal_bwd_scalar R={R}", us, 2 * 4 * R * 80 + 4 * R))
+    return out
+
+
+def bench_dcn(C, iters):
+    out = []
+    for (Cc, H, W) in [(128, 100, 168), (256, 50, 84), (512, 25, 42)]:
+        for dt, e in ((torch.float32, 4), (torch.float16, 2)):
+            x = torch.randn(2, Cc, H, W, device="cuda").to(dt)
+            off = (torch.randn(2, 18, H, W, device="cuda") * 2).to(dt)
+            geo = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+            ncol = 2 * H * W
+            alg = e * (x.numel() + off.numel() + Cc * 9 * ncol)
+            us = dev_time_us(lambda: C.deformable_im2col(x, off, None, *geo), iters)
+            out.append(_entry(f"dcn_im2col C={Cc} {H}x{W} {str(dt)[6:]}", us, alg))
+            col = torch.randn(Cc * 9, ncol, device="cuda").to(dt)
+            gim = torch.zeros_like(x)
+            us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), iters)
+            out.append(_entry(f"dcn_col2im C={Cc} {H}x{W} {str(dt)[6:]}", us, alg))
+            goff = torch.empty_like(off)
+            us = dev_time_us(lambda: C.deformable_col2im_coord(col, x, off, None, goff, None, *geo), iters)
+            out.append(_entry(f"dcn_col2im_coord C={Cc} {H}x{W} {str(dt)[6:]}", us, alg))
+    return out
+
+
+def copy_ceiling(iters):
+    a = torch.empty(256 * 1024 * 1024 // 4, device="cuda")
+    b = torch.empty_like(a)
+    us = dev_time_us(lambda: b.copy_(a), iters)
+    return _entry("hbm copy 256MiB (torch copy_, ceiling reference)", us, 2 * a.numel() * 4)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    from maskrcnn_benchmark import _C as C
+
+    only = set(filter(None, args.only.split(",")))
+    res = []
+    t0 = time.time()
+    if not only or "copy" in only:
+        res.append(copy_ceiling(args.iters))
+    if not only or "roi_align" in only:
+        res += bench_roi_align(C, args.iters)
+    if not only or "nms" in only:
+        res += bench_nms(C, args.iters)
+    if not only or "focal" in only:
+        res += bench_focal(C, args.iters)
+    if not only or "dcn" in only:
+        res += bench_dcn(C, args.iters)
+    for r in res:
+        print("%-70s %10.2f us  %9.1f GB/s  (%.1f%% of 8 TB/s) %s" % (
+            r["op"], r["us"], r["gbs"], 100 * r["frac_of_8TBs"],
+            {k: v for k, v in r.items() if k not in ("op", "us", "gbs", "frac_of_8TBs", "alg_bytes")} or ""))
+    print("total %.1f s" % (time.time() - t0))
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
