@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py — the driver's measurement contract.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config FILE] [--dtype float32|bfloat16|float16]
+
+A "step" is one training iteration (forward + backward + gradient all-reduce + SGD update) of
+`e2e_mask_rcnn_R_50_FPN_1x` (BASELINE.json's metric config) on one batch of 2 synthetic
+1333x800 COCO-shaped images per GPU (padded to 800x1344), random-init weights, batches resident in
+HBM before the timed region.  N > 1 is launched by the driver with torch.distributed.run, one rank
+per GPU over RCCL; per-GPU work is fixed (weak scaling), value = total images / max-over-ranks time.
+
+Besides the contract line, rank 0 reports
+  * "roofline": the dominant hand-written kernel of the step (largest total time among the HIP
+    entry points), timed live with HIP events on its launch stream inside the timed region;
+    achieved = algorithmic bytes per launch / mean launch time, vs the 8 TB/s HBM peak;
+  * "kernels": the same figures for every hand-written entry point seen in the timed region;
+  * "cpu_baseline": the reference's own CPU ROIAlign kernel (oracle/_ref, built from the reference
+    sources) — or the C restatement if that library is absent — timed on this host on a bounded
+    sample of the box-head ROIAlign workload (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "maskrcnn-benchmark_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="e2e_mask_rcnn_R_50_FPN_1x.yaml")
+    ap.add_argument("--dtype", default=None, help="override cfg.DTYPE (float32 | bfloat16 | float16)")
+    ap.add_argument("--images-per-gpu", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("opts", nargs=argparse.REMAINDER, default=[])
+    return ap.parse_args()
+
+
+def algorithmic_bytes(name, feat_bytes):
+    """ROIAlign fwd/bwd = pooled tensor + every pooled feature map once + rois;
+    focal fwd(sum) = logits + targets (+ nothing written), bwd = logits + targets + d_logits."""
+    import re
+    m = re.match(r"roi_align_fpn_(fwd|bwd)\[K=(\d+),C=(\d+),(\d+)x(\d+)\]", name)
+    if m:
+        K, C, ph, pw = (int(m.group(i)) for i in (2, 3, 4, 5))
+        return 4 * K * C * ph * pw + feat_bytes + 20 * K
+    m = re.match(r"focal_(fwd_sum|bwd_scalar)\[R=(\d+),C=(\d+)\]", name)
+    if m:
+        R, C = int(m.group(2)), int(m.group(3))
+        return (4 * R * C + 4 * R) if m.group(1) == "fwd_sum" else (8 * R * C + 4 * R)
+    return None
+
+
+def cpu_baseline(sample_rois=1024, min_seconds=8.0):
+    """reference CPU ROIAlign forward on a bounded sample of the box-head workload (1 thread)."""
+    import numpy as np
+    import torch
+
+    import oracle
+    import synth
+
+    rng_feats = [np.random.RandomState(10 + i).randn(2, 256, h, w).astype(np.float32)
+                 for i, (h, w) in enumerate(synth.fpn_shapes()[:4])]
+    rois = synth.fpn_rois(seed=3, per_image=512, n_images=2)
+    lv = synth.level_map(rois)
+    pick = np.random.RandomState(0).permutation(len(rois))[:sample_rois]
+    ref = oracle.ref()
+    torch.set_num_threads(1)
+    feats_t = [torch.from_numpy(f) for f in rng_feats]
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        for l in range(4):
+            sel = pick[lv[pick] == l]
+            if sel.size == 0:
+                continue
+            if ref is not None:
+                ref.roi_align_forward(feats_t[l], torch.from_numpy(rois[sel]), 1.0 / (4 << l), 7, 7, 2)
+            else:
+                oracle.roi_align_forward(rng_feats[l], rois[sel], 1.0 / (4 << l), 7, 7, 2)
+        reps += 1
+        if time.perf_counter() - t0 >= min_seconds or reps >= 50:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    # scale the sample to the full launch: per-ROI cost dominates; bytes per §8d for the full launch
+    full_bytes = 4 * 1024 * 256 * 49 + sum(f.nbytes for f in rng_feats) + 20 * 1024
+    est_full_s = dt * 1024.0 / sample_rois
+    return {"value": round(full_bytes / est_full_s / 1e9, 4), "unit": "GB/s", "cores": 1,
+            "kind": "reference" if ref is not None else "port",
+            "sample": "ROIAlign fwd box-head (1024 ROIs x 256 ch x 7x7 sr2 over P2-P5 of 2x800x1344): %d of the 1024 "
+                      "ROIs per pass, %d passes, %.3f s per pass on 1 thread (scaled x%.1f to the full launch); %s" % (
+                          sample_rois, reps, dt, 1024.0 / sample_rois,
+                          "reference csrc/cpu/ROIAlign_cpu.cpp compiled in oracle/_ref" if ref is not None
+                          else "C restatement oracle/detops_oracle.c"),
+            "roi_align_fwd_ms_est": round(est_full_s * 1e3, 2)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the detection-head operators are HIP-only)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    from maskrcnn_benchmark import _C
+    from maskrcnn_benchmark.engine.bench_step import build_training, load_cfg, make_device_batches
+
+    opts = list(args.opts)
+    if opts and opts[0] == "--":
+        opts = opts[1:]
+    if args.dtype:
+        opts += ["DTYPE", args.dtype]
+    cfg = load_cfg(args.config, opts)
+    torch.manual_seed(1234 + rank)
+    torch.backends.cudnn.benchmark = True  # MIOpen: search the conv algorithm once per (fixed) shape
+    model, optimizer, scheduler, step = build_training(cfg, device, distributed, local_rank)
+    if args.channels_last:
+        model.to(memory_format=torch.channels_last)
+    batches = make_device_batches(cfg, device, images_per_gpu=args.images_per_gpu, num_batches=2, seed=rank)
+    feat_bytes = 0
+    H, W = batches[0][0].tensors.shape[-2:]
+    for s in (4, 8, 16, 32):
+        feat_bytes += 4 * args.images_per_gpu * 256 * ((H + s - 1) // s) * ((W + s - 1) // s)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    losses = None
+    for i in range(args.warmup):
+        losses = step(*batches[i % len(batches)])
+    sync()
+    timer = None
+    if rank == 0 and not args.no_kernel_timing:
+        timer = _C.KernelTimer()
+        _C.KERNEL_TIMER = timer
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = step(*batches[i % len(batches)])
+    sync()
+    elapsed = time.perf_counter() - t0
+    _C.KERNEL_TIMER = None
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_vals = {k: float(v) for k, v in losses.items()} if losses else {}
+
+    if rank == 0:
+        images = args.images_per_gpu * world * args.steps
+        line = {
+            "metric": "training images/sec %s" % os.path.splitext(os.path.basename(args.config))[0],
+            "value": round(images / elapsed, 3),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[cfg.DTYPE],
+            "data": "synthetic",
+            "config": {"workload": "%s: fwd+bwd+allreduce+SGD, %d img/GPU of synthetic 1333x800 (padded %dx%d), "
+                                   "random-init weights" % (os.path.basename(args.config), args.images_per_gpu, H, W),
+                       "global_batch": args.images_per_gpu * world, "parallelism": "dp%d" % world},
+            "loss_finite": all(v == v and abs(v) != float("inf") for v in loss_vals.values()),
+            "losses": {k: round(v, 4) for k, v in loss_vals.items()},
+            "max_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+        }
+        if timer is not None:
+            kernels, dominant = {}, None
+            for name, (count, total_ms) in sorted(timer.results().items()):
+                b = algorithmic_bytes(name, feat_bytes)
+                mean_us = total_ms / max(count, 1) * 1e3
+                entry = {"launches": count, "mean_us": round(mean_us, 2), "ms_per_step": round(total_ms / args.steps, 4)}
+                if b is not None:
+                    entry["alg_bytes"] = b
+                    entry["achieved_GBs"] = round(b / (mean_us * 1e-6) / 1e9, 1)
+                    if dominant is None or total_ms > dominant[1]:
+                        dominant = (name, total_ms, entry)
+                kernels[name] = entry
+            line["kernels"] = kernels
+            if dominant is not None:
+                name, _, e = dominant
+                line["roofline"] = {"kernel": name, "bound": "hbm", "achieved": e["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": round(e["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                                    "alg_bytes_per_launch": e["alg_bytes"], "mean_us": e["mean_us"]}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline is a reported extra; never lose the bench line
+                line["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

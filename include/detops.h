@@ -136,6 +136,15 @@ int detops_nms_batched_f32(const float* boxes, const float* scores,
                            float threshold, int64_t* keep, int32_t* num_keep, void* workspace,
                            size_t workspace_bytes, detops_stream_t stream);
 
+/* Same computation, dense result: keep_mask [total] uint8, keep_mask[seg_offsets[s] + i] = 1 iff
+ * box i of segment s survives.  Fixed-shape output for callers that never read a count back
+ * (the padded RPN proposal path; replaces the `keep` index list + nonzero of
+ * modeling/rpn/inference.py:111-121). */
+int detops_nms_batched_mask_f32(const float* boxes, const float* scores,
+                                const int32_t* seg_offsets, int num_segments, int max_n,
+                                float threshold, uint8_t* keep_mask, int32_t* num_keep,
+                                void* workspace, size_t workspace_bytes, detops_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * SigmoidFocalLoss — replaces _C.sigmoid_focalloss_forward / _backward
  *   reference: csrc/SigmoidFocalLoss.h:10-41, csrc/cuda/SigmoidFocalLoss_cuda.cu:20-101.

@@ -184,7 +184,8 @@ __device__ __forceinline__ u64 uniform64(u64 v) {  // value known to be wave-uni
 
 __global__ void __launch_bounds__(kScanThreads)
 nms_scan_kernel(const int32_t* __restrict__ seg_offsets, int n_single, Work w,
-                int64_t* __restrict__ keep, int32_t* __restrict__ num_keep) {
+                int64_t* __restrict__ keep, int32_t* __restrict__ num_keep,
+                uint8_t* __restrict__ keep_mask) {
   __shared__ u64 remv[kMaxWords];    // pending "removed" bits per column block (sorted positions)
   __shared__ u64 keptw[kMaxWords];   // kept bits per row block (sorted positions)
   __shared__ u64 flags[kMaxWords];   // kept bits in ORIGINAL index space
@@ -266,6 +267,10 @@ nms_scan_kernel(const int32_t* __restrict__ seg_offsets, int n_single, Work w,
     }
   }
   __syncthreads();
+  if (keep_mask) {  // dense 0/1 form (original index space) for fixed-shape, sync-free callers
+    uint8_t* km = keep_mask + sv.begin;
+    for (int p = tid; p < n; p += kScanThreads) km[p] = static_cast<uint8_t>((flags[p >> 6] >> (p & 63)) & 1ull);
+  }
   // workgroup exclusive prefix sum over popcounts of the flag words
   const int wpt = (nb + kScanThreads - 1) / kScanThreads;  // words per thread (<= 2)
   const int w0 = tid * wpt;
@@ -288,7 +293,7 @@ nms_scan_kernel(const int32_t* __restrict__ seg_offsets, int n_single, Work w,
   }
   int pos = base + incl - local;
   int64_t* kout = keep + sv.begin;
-  for (int j = 0; j < wpt; ++j) {
+  for (int j = 0; keep && j < wpt; ++j) {
     if (w0 + j >= nb) break;
     u64 f = flags[w0 + j];
     while (f) {
@@ -333,8 +338,8 @@ Layout make_layout(int S, int max_n, bool big) {
 }
 
 int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets, int S, int max_n,
-            float thr, int64_t* keep, int32_t* num_keep, void* ws, size_t ws_bytes,
-            hipStream_t st) {
+            float thr, int64_t* keep, int32_t* num_keep, uint8_t* keep_mask, void* ws,
+            size_t ws_bytes, hipStream_t st) {
   const bool big = max_n > kSortLdsMax;
   const Layout l = make_layout(S, max_n, big);
   if (ws_bytes < l.total || !ws) return DETOPS_EWORKSPACE;
@@ -370,7 +375,7 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nbm, nbm, S), dim3(kWave), 0, st, seg_offsets, max_n, thr,
                      w);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(S), dim3(kScanThreads), 0, st, seg_offsets, max_n, w, keep,
-                     num_keep);
+                     num_keep, keep_mask);
   return launch_status();
 }
 
@@ -389,7 +394,7 @@ DETOPS_API int detops_nms_f32(const float* boxes, const float* scores, int n, fl
   if (n == 0) return static_cast<int>(hipMemsetAsync(num_keep, 0, sizeof(int32_t), st));
   if (!boxes || !scores || !keep) return DETOPS_EINVAL;
   if (n > kScanMaxN) return DETOPS_EUNSUPPORTED;
-  return run_nms(boxes, scores, nullptr, 1, n, threshold, keep, num_keep, workspace,
+  return run_nms(boxes, scores, nullptr, 1, n, threshold, keep, num_keep, nullptr, workspace,
                  workspace_bytes, st);
 }
 
@@ -412,5 +417,22 @@ DETOPS_API int detops_nms_batched_f32(const float* boxes, const float* scores,
   if (!boxes || !scores || !keep) return DETOPS_EINVAL;
   if (max_n > kSortLdsMax) return DETOPS_EUNSUPPORTED;
   return run_nms(boxes, scores, seg_offsets, num_segments, max_n, threshold, keep, num_keep,
-                 workspace, workspace_bytes, st);
+                 nullptr, workspace, workspace_bytes, st);
+}
+
+DETOPS_API int detops_nms_batched_mask_f32(const float* boxes, const float* scores,
+                                           const int32_t* seg_offsets, int num_segments, int max_n,
+                                           float threshold, uint8_t* keep_mask, int32_t* num_keep,
+                                           void* workspace, size_t workspace_bytes,
+                                           detops_stream_t stream) {
+  if (num_segments < 0 || max_n < 0) return DETOPS_EINVAL;
+  if (num_segments == 0) return 0;
+  if (!seg_offsets || !num_keep) return DETOPS_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (max_n == 0)
+    return static_cast<int>(hipMemsetAsync(num_keep, 0, sizeof(int32_t) * num_segments, st));
+  if (!boxes || !scores || !keep_mask) return DETOPS_EINVAL;
+  if (max_n > kSortLdsMax) return DETOPS_EUNSUPPORTED;
+  return run_nms(boxes, scores, seg_offsets, num_segments, max_n, threshold, nullptr, num_keep,
+                 keep_mask, workspace, workspace_bytes, st);
 }

@@ -57,6 +57,55 @@ class _on_device:
             torch.cuda.set_device(self.prev)
 
 
+class KernelTimer(object):
+    """Optional per-entry-point timing with HIP events recorded on the launch stream (the current
+    torch stream of the tensor's device).  bench.py installs one to measure the hand-written
+    kernels live inside the timed region; `results()` must be called after a device sync."""
+
+    def __init__(self):
+        self.pairs = {}
+
+    def span(self, name, t):
+        return _Span(self, name, t)
+
+    def results(self):
+        """name -> (launches, total_ms)"""
+        out = {}
+        for name, pairs in self.pairs.items():
+            out[name] = (len(pairs), sum(a.elapsed_time(b) for a, b in pairs))
+        return out
+
+
+class _Span(object):
+    def __init__(self, timer, name, t):
+        self.timer, self.name, self.t = timer, name, t
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record(torch.cuda.current_stream(self.t.device))
+
+    def __exit__(self, *exc):
+        self.b.record(torch.cuda.current_stream(self.t.device))
+        self.timer.pairs.setdefault(self.name, []).append((self.a, self.b))
+
+
+class _NoSpan(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOSPAN = _NoSpan()
+KERNEL_TIMER = None  # set to a KernelTimer to collect timings
+
+
+def _timed(name, t):
+    return _NOSPAN if KERNEL_TIMER is None else KERNEL_TIMER.span(name, t)
+
+
 # ------------------------------------------------------------------------------------------ NMS
 def nms(dets, scores, threshold):
     """reference csrc/nms.h:10-28: dets [n,4] xyxy, scores [n] -> int64 kept indices, ascending.
@@ -99,6 +148,29 @@ def nms_batched(boxes, scores, seg_offsets, max_n, threshold):
                                          float(threshold), ptr(keep), ptr(num), ptr(ws), ws_bytes,
                                          stream_of(boxes)), "nms_batched")
     return keep, num
+
+
+def nms_batched_mask(boxes, scores, seg_offsets, max_n, threshold):
+    """Sync-free segmented NMS, dense form (extension): returns (keep_mask [T] bool,
+    num_keep [S] int32), keep_mask in the ORIGINAL row order of `boxes`."""
+    _need_cuda("nms_batched_mask", boxes, scores, seg_offsets)
+    boxes = _f32c("nms_batched_mask", boxes)
+    scores = _f32c("nms_batched_mask", scores)
+    S = seg_offsets.numel() - 1
+    mask = torch.zeros((boxes.size(0),), dtype=torch.uint8, device=boxes.device)
+    num = torch.zeros((max(S, 0),), dtype=torch.int32, device=boxes.device)
+    if S <= 0 or boxes.size(0) == 0:
+        return mask.bool(), num
+    if seg_offsets.dtype != torch.int32:
+        seg_offsets = seg_offsets.to(torch.int32)
+    seg_offsets = seg_offsets.contiguous()
+    ws_bytes = lib.detops_nms_batched_workspace_bytes(S, int(max_n))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=boxes.device)
+    with _on_device(boxes), _timed("nms_batched[S=%d,max_n=%d]" % (S, int(max_n)), boxes):
+        check(lib.detops_nms_batched_mask_f32(ptr(boxes), ptr(scores), ptr(seg_offsets), S, int(max_n),
+                                              float(threshold), ptr(mask), ptr(num), ptr(ws), ws_bytes,
+                                              stream_of(boxes)), "nms_batched_mask")
+    return mask.view(torch.bool), num
 
 
 # ------------------------------------------------------------------------------------------ ROIAlign
@@ -159,7 +231,7 @@ def roi_align_fpn_forward(inputs, rois, scales, pooled_height, pooled_width, sam
     if K == 0:
         return out, levels
     ptrs, Hs, Ws, sc = _host_arrays(inputs, scales)
-    with _on_device(rois):
+    with _on_device(rois), _timed("roi_align_fpn_fwd[K=%d,C=%d,%dx%d]" % (K, C, pooled_height, pooled_width), rois):
         check(lib.detops_roi_align_fpn_forward_f32(
             ptrs, Hs, Ws, sc, len(inputs), ptr(rois), ptr(out), ptr(levels), N, C, K, pooled_height,
             pooled_width, int(sampling_ratio), int(k_min), int(k_max), float(canonical_scale),
@@ -176,7 +248,7 @@ def roi_align_fpn_backward(grad, rois, levels, shapes, scales, pooled_height, po
     gins = [torch.empty(tuple(s), dtype=torch.float32, device=grad.device) for s in shapes]
     N, C = shapes[0][:2]
     ptrs, Hs, Ws, sc = _host_arrays(gins, scales)
-    with _on_device(grad):
+    with _on_device(grad), _timed("roi_align_fpn_bwd[K=%d,C=%d,%dx%d]" % (K, C, pooled_height, pooled_width), grad):
         check(lib.detops_roi_align_fpn_backward_f32(
             ptr(grad), ptr(rois), ptr(levels), ptrs, Hs, Ws, sc, len(gins), N, C, K, pooled_height,
             pooled_width, int(sampling_ratio), 1, stream_of(grad)), "roi_align_fpn_backward")
@@ -266,7 +338,7 @@ def sigmoid_focalloss_forward_sum(logits, targets, num_classes, gamma, alpha):
     """Extension: sum(losses) without materialising [R,C] (what SigmoidFocalLoss.forward needs)."""
     logits, targets = _focal_args("sigmoid_focalloss_forward_sum", logits, targets, num_classes)
     total = torch.zeros((), dtype=torch.float32, device=logits.device)
-    with _on_device(logits):
+    with _on_device(logits), _timed("focal_fwd_sum[R=%d,C=%d]" % (logits.size(0), num_classes), logits):
         check(lib.detops_sigmoid_focal_loss_forward_sum_f32(ptr(logits), ptr(targets), None,
                                                             ptr(total), logits.size(0), num_classes,
                                                             float(gamma), float(alpha),
@@ -281,7 +353,7 @@ def sigmoid_focalloss_backward_scalar(logits, targets, d_loss, num_classes, gamm
     _need_cuda("sigmoid_focalloss_backward_scalar", d_loss)
     d_loss = d_loss.reshape(1).to(torch.float32).contiguous()
     d_logits = torch.empty_like(logits)
-    with _on_device(logits):
+    with _on_device(logits), _timed("focal_bwd_scalar[R=%d,C=%d]" % (logits.size(0), num_classes), logits):
         check(lib.detops_sigmoid_focal_loss_backward_scalar_f32(
             ptr(logits), ptr(targets), ptr(d_loss), ptr(d_logits), logits.size(0), num_classes,
             float(gamma), float(alpha), stream_of(logits)), "sigmoid_focalloss_backward_scalar")

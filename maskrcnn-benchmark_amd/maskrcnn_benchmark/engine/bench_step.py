@@ -1,0 +1,70 @@
+"""Builders shared by bench.py, tools/train_net.py and __graft_entry__.smoke(): config -> model +
+overlapped SGD + schedule (+ DDP) and device-resident synthetic batches."""
+import os
+
+import torch
+
+from maskrcnn_benchmark.config import cfg as _default_cfg
+from maskrcnn_benchmark.data.synthetic import BatchCollator, SyntheticCOCODataset
+from maskrcnn_benchmark.modeling.detector import build_detection_model
+from maskrcnn_benchmark.solver import make_lr_scheduler
+
+from .ddp_step import TrainStep, make_overlapped_sgd, wrap_data_parallel
+
+CONFIG_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "configs")
+
+
+def load_cfg(config_file, opts=()):
+    cfg = _default_cfg.clone()
+    if config_file:
+        if not os.path.isabs(config_file) and not os.path.exists(config_file):
+            config_file = os.path.join(CONFIG_DIR, config_file)
+        cfg.merge_from_file(config_file)
+    cfg.merge_from_list(list(opts))
+    cfg.freeze()
+    return cfg
+
+
+def build_training(cfg, device, distributed=False, local_rank=0, overlap_optimizer=True):
+    """-> (model (DDP-wrapped when distributed), optimizer, scheduler, TrainStep)."""
+    model = build_detection_model(cfg).to(device)
+    model.train()
+    optimizer = make_overlapped_sgd(cfg, model)
+    scheduler = make_lr_scheduler(cfg, optimizer)
+    fp16 = cfg.DTYPE == "float16"
+    if distributed:
+        ids = [local_rank] if torch.device(device).type == "cuda" else None
+        model = wrap_data_parallel(model, optimizer, device_ids=ids, overlap_optimizer=overlap_optimizer and not fp16)
+    step = TrainStep(model, optimizer, scheduler, dtype=cfg.DTYPE, device_type=torch.device(device).type)
+    return model, optimizer, scheduler, step
+
+
+def make_device_batches(cfg, device, images_per_gpu=2, num_batches=2, seed=0, height=None, width=None):
+    """`num_batches` synthetic (ImageList, targets) pairs resident on `device`."""
+    H = height or cfg.INPUT.MIN_SIZE_TRAIN[0]
+    W = width or cfg.INPUT.MAX_SIZE_TRAIN
+    ds = SyntheticCOCODataset(length=num_batches * images_per_gpu, height=H, width=W,
+                              num_classes=cfg.MODEL.ROI_BOX_HEAD.NUM_CLASSES, with_masks=cfg.MODEL.MASK_ON, seed=seed)
+    collate = BatchCollator(cfg.DATALOADER.SIZE_DIVISIBILITY)
+    out = []
+    for b in range(num_batches):
+        images, targets, _ = collate([ds[b * images_per_gpu + i] for i in range(images_per_gpu)])
+        out.append((images.to(device), [t.to(device) for t in targets]))
+    return out
+
+
+def smoke_train_step(device, config_file="e2e_mask_rcnn_R_50_FPN_1x.yaml", steps=2):
+    """tiny forward + backward + update of the flagship detector (small image, full architecture)."""
+    cfg = load_cfg(config_file, ["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 500, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 500,
+                                 "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 128])
+    torch.manual_seed(0)
+    model, optimizer, scheduler, step = build_training(cfg, device)
+    (images, targets), = make_device_batches(cfg, device, images_per_gpu=1, num_batches=1, height=256, width=320)
+    losses = None
+    for _ in range(steps):
+        losses = step(images, targets)
+    vals = {k: float(v) for k, v in losses.items()}
+    assert all(v == v and abs(v) != float("inf") for v in vals.values()), "non-finite loss: %r" % vals
+    print("smoke: one %s training step on %s ->" % (os.path.basename(config_file), device),
+          {k: round(v, 4) for k, v in vals.items()})
+    return vals

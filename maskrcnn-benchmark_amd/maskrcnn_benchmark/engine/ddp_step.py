@@ -1,0 +1,158 @@
+"""The data-parallel training step (reference tools/train_net.py:45-54 + engine/trainer.py:66-99:
+DistributedDataParallel wrap, `losses.backward()`, `optimizer.step()`).
+
+MI355X design.  One process per GPU; gradients are all-reduced by RCCL over xGMI in ~25 MB fp32
+buckets while the backward pass is still running (torch DDP, `gradient_as_bucket_view=True`, no
+buffer broadcast — every BatchNorm is frozen).  Instead of running the optimizer after the whole
+backward, each bucket's SGD update is chained to that bucket's all-reduce as a future callback:
+it executes on the communication side stream as soon as the bucket's averaged gradient exists,
+overlapping the remaining backward compute; the main stream joins the side stream only when DDP
+finalises the backward.  With one process there is no communication and the same multi-tensor
+update runs on the main stream after backward.
+
+The update is SGD with momentum exactly as torch.optim.SGD computes it (dampening 0, no Nesterov):
+    g <- g + wd * p ;  buf <- momentum * buf + g (buf <- g on the first step) ;  p <- p - lr * buf
+with the reference's per-parameter hyper-parameters (biases: lr x BIAS_LR_FACTOR, WEIGHT_DECAY_BIAS;
+solver/build.py:7-20), held in the optimizer's param groups so LR schedulers keep working.
+"""
+import torch
+import torch.distributed as dist
+
+
+class OverlappedSGD(torch.optim.Optimizer):
+    """SGD(momentum) whose update can be applied to an arbitrary subset of its parameters
+    (`step_params`) — the unit the DDP bucket callback works on — using multi-tensor kernels."""
+
+    def __init__(self, params, lr, momentum=0.0):
+        super(OverlappedSGD, self).__init__(params, dict(lr=lr, momentum=momentum, weight_decay=0.0))
+        self._group_of = {}
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                self._group_of[p] = gi
+        self.deferred = False  # True while a DDP hook applies the updates during backward
+
+    @torch.no_grad()
+    def step_params(self, params):
+        by_group = {}
+        for p in params:
+            if p.grad is None:
+                continue
+            by_group.setdefault(self._group_of[p], []).append(p)
+        for gi, ps in by_group.items():
+            g = self.param_groups[gi]
+            lr, mom, wd = g["lr"], g["momentum"], g["weight_decay"]
+            grads = [p.grad for p in ps]
+            if wd != 0:
+                grads = torch._foreach_add(grads, ps, alpha=wd)
+            if mom != 0:
+                bufs, fresh = [], []
+                for p, gr in zip(ps, grads):
+                    st = self.state[p]
+                    if "momentum_buffer" not in st:
+                        st["momentum_buffer"] = torch.clone(gr).detach()
+                        fresh.append(True)
+                    else:
+                        fresh.append(False)
+                    bufs.append(st["momentum_buffer"])
+                old = [b for b, f in zip(bufs, fresh) if not f]
+                if old:
+                    torch._foreach_mul_(old, mom)
+                    torch._foreach_add_(old, [gr for gr, f in zip(grads, fresh) if not f])
+                grads = bufs
+            torch._foreach_add_(ps, grads, alpha=-lr)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        if not self.deferred:
+            self.step_params([p for g in self.param_groups for p in g["params"]])
+        return loss
+
+
+def make_overlapped_sgd(cfg, model):
+    """reference solver/build.py:7-20 hyper-parameters, two param groups (weights / biases)."""
+    S = cfg.SOLVER
+    weights, biases = [], []
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            (biases if "bias" in name else weights).append(p)
+    groups = []
+    if weights:
+        groups.append({"params": weights, "lr": S.BASE_LR, "weight_decay": S.WEIGHT_DECAY})
+    if biases:
+        groups.append({"params": biases, "lr": S.BASE_LR * S.BIAS_LR_FACTOR, "weight_decay": S.WEIGHT_DECAY_BIAS})
+    return OverlappedSGD(groups, S.BASE_LR, momentum=S.MOMENTUM)
+
+
+def _allreduce_then_step(optimizer, process_group):
+    """DDP communication hook: average the bucket over the ranks, then update the bucket's
+    parameters in the all-reduce's completion callback (side stream)."""
+    def hook(state, bucket):
+        group = process_group if process_group is not None else dist.group.WORLD
+        world = dist.get_world_size(group)
+        buf = bucket.buffer()
+        buf.div_(world)
+        fut = dist.all_reduce(buf, group=group, async_op=True).get_future()
+
+        def apply(f):
+            if optimizer.deferred:
+                optimizer.step_params(bucket.parameters())
+            return bucket.buffer()
+
+        return fut.then(apply)
+
+    return hook
+
+
+def wrap_data_parallel(model, optimizer=None, device_ids=None, bucket_cap_mb=25, process_group=None,
+                       overlap_optimizer=True):
+    """DistributedDataParallel over RCCL (or gloo in tests) with the optimizer overlapped into the
+    gradient all-reduce.  Returns the wrapped model (the bare model for a single process)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return model
+    ddp = torch.nn.parallel.DistributedDataParallel(
+        model, device_ids=device_ids, output_device=None if device_ids is None else device_ids[0],
+        broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
+        process_group=process_group)
+    if optimizer is not None and overlap_optimizer and isinstance(optimizer, OverlappedSGD):
+        optimizer.deferred = True
+        ddp.register_comm_hook(None, _allreduce_then_step(optimizer, process_group))
+    return ddp
+
+
+class TrainStep(object):
+    """One training iteration: forward (optionally under autocast) -> sum of losses -> backward
+    (+ overlapped all-reduce/optimizer) -> optimizer.  Returns the loss dict (device tensors; no
+    host sync)."""
+
+    def __init__(self, model, optimizer, scheduler=None, dtype="float32", device_type="cuda"):
+        self.model = model
+        self.optimizer = optimizer
+        self.scheduler = scheduler
+        self.amp_dtype = {"float32": None, "float16": torch.float16, "bfloat16": torch.bfloat16}[dtype]
+        self.device_type = device_type
+        self.scaler = None
+        if self.amp_dtype is torch.float16:
+            if getattr(optimizer, "deferred", False):
+                raise ValueError("fp16 loss scaling needs the classic optimizer step (overlap_optimizer=False)")
+            self.scaler = torch.amp.GradScaler(device_type)
+
+    def __call__(self, images, targets):
+        if self.amp_dtype is None:
+            loss_dict = self.model(images, targets)
+        else:
+            with torch.autocast(device_type=self.device_type, dtype=self.amp_dtype):
+                loss_dict = self.model(images, targets)
+        losses = sum(loss for loss in loss_dict.values())
+        self.optimizer.zero_grad(set_to_none=False) if getattr(self.optimizer, "deferred", False) \
+            else self.optimizer.zero_grad(set_to_none=True)
+        if self.scaler is not None:
+            self.scaler.scale(losses).backward()
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
+        else:
+            losses.backward()
+            self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return loss_dict

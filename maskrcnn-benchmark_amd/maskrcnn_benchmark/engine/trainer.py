@@ -1,0 +1,61 @@
+"""do_train (reference engine/trainer.py:43-150): the training loop around TrainStep with the
+reference's logging cadence (every 20 iterations) and loss reduction across ranks for the log."""
+import datetime
+import logging
+import time
+
+import torch
+
+from maskrcnn_benchmark.utils.comm import get_world_size, reduce_dict
+from maskrcnn_benchmark.utils.metric_logger import MetricLogger
+
+from .ddp_step import TrainStep
+
+
+def reduce_loss_dict(loss_dict):
+    """losses averaged over ranks on rank 0 (reference :18-40); a no-op for one process."""
+    return reduce_dict(loss_dict, average=True) if get_world_size() > 1 else loss_dict
+
+
+def do_train(cfg, model, data_loader, optimizer, scheduler, checkpointer, device, checkpoint_period, arguments,
+             log_period=20):
+    logger = logging.getLogger("maskrcnn_benchmark.trainer")
+    logger.info("Start training")
+    meters = MetricLogger(delimiter="  ")
+    max_iter = len(data_loader)
+    start_iter = arguments["iteration"]
+    model.train()
+    step = TrainStep(model, optimizer, scheduler, dtype=cfg.DTYPE, device_type=torch.device(device).type)
+    start_training_time = time.time()
+    end = time.time()
+    for iteration, (images, targets, _) in enumerate(data_loader, start_iter):
+        if any(len(t) < 1 for t in targets):
+            logger.error("Iteration=%d || an image has no ground-truth box; skipped", iteration + 1)
+            continue
+        data_time = time.time() - end
+        iteration = iteration + 1
+        arguments["iteration"] = iteration
+        images = images.to(device)
+        targets = [t.to(device) for t in targets]
+        loss_dict = step(images, targets)
+        if iteration % log_period == 0 or iteration == max_iter:
+            reduced = reduce_loss_dict(loss_dict)
+            meters.update(loss=sum(v for v in reduced.values()), **reduced)
+        batch_time = time.time() - end
+        end = time.time()
+        meters.update(time=batch_time, data=data_time)
+        if iteration % log_period == 0 or iteration == max_iter:
+            eta = str(datetime.timedelta(seconds=int(meters.time.global_avg * (max_iter - iteration))))
+            mem = torch.cuda.max_memory_allocated() / 1024.0 / 1024.0 if torch.cuda.is_available() else 0.0
+            logger.info(meters.delimiter.join(["eta: {}".format(eta), "iter: {}".format(iteration), str(meters),
+                                               "lr: {:.6f}".format(optimizer.param_groups[0]["lr"]),
+                                               "max mem: {:.0f}".format(mem)]))
+        if checkpointer is not None and checkpoint_period > 0 and iteration % checkpoint_period == 0:
+            checkpointer.save("model_{:07d}".format(iteration), **arguments)
+        if iteration == max_iter:
+            if checkpointer is not None:
+                checkpointer.save("model_final", **arguments)
+            break
+    total = time.time() - start_training_time
+    logger.info("Total training time: {} ({:.4f} s / it)".format(str(datetime.timedelta(seconds=total)),
+                                                                 total / max(max_iter, 1)))

@@ -1,0 +1,106 @@
+"""Pooler: ROIAlign over a feature pyramid (reference modeling/poolers.py:11-121).
+
+The reference assigns every ROI to a pyramid level on the host side of a `nonzero` per level, runs
+one ROIAlign launch per level and scatters the results back (4 syncs + 4 launches + 4 index_puts
+per call).  Here the whole thing is ONE kernel launch: `_C.roi_align_fpn_forward` evaluates the
+LevelMapper formula per ROI on the device and reads from the right level's feature map
+(include/detops.h: detops_roi_align_fpn_forward_f32).  The backward is likewise one launch that
+produces every level's gradient map.
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from maskrcnn_benchmark import _C
+from maskrcnn_benchmark.layers import ROIAlign
+from maskrcnn_benchmark.layers._amp import float_function
+
+from .utils import cat
+
+
+class LevelMapper(object):
+    """FPN paper eq. 1: target level of each ROI from its scale (reference :11-42).  Kept as a
+    host/torch-side helper (tests, tooling); the training path uses the in-kernel version."""
+
+    def __init__(self, k_min, k_max, canonical_scale=224, canonical_level=4, eps=1e-6):
+        self.k_min = k_min
+        self.k_max = k_max
+        self.s0 = canonical_scale
+        self.lvl0 = canonical_level
+        self.eps = eps
+
+    def __call__(self, boxlists):
+        s = torch.sqrt(cat([b.area() for b in boxlists]))
+        lvl = torch.floor(self.lvl0 + torch.log2(s / self.s0 + self.eps))
+        lvl = torch.clamp(lvl, min=self.k_min, max=self.k_max)
+        return lvl.to(torch.int64) - self.k_min
+
+
+class _ROIAlignFPN(Function):
+    """autograd glue of the fused multi-level ROIAlign."""
+
+    @staticmethod
+    def forward(ctx, rois, output_size, scales, sampling_ratio, k_min, k_max, *features):
+        out, levels = _C.roi_align_fpn_forward(features, rois, scales, output_size[0], output_size[1],
+                                               sampling_ratio, k_min, k_max)
+        ctx.save_for_backward(rois, levels)
+        ctx.cfg = (output_size, scales, sampling_ratio)
+        ctx.shapes = [tuple(f.shape) for f in features]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad):
+        rois, levels = ctx.saved_tensors
+        output_size, scales, sampling_ratio = ctx.cfg
+        grads = _C.roi_align_fpn_backward(grad, rois, levels, ctx.shapes, scales, output_size[0],
+                                          output_size[1], sampling_ratio)
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+@float_function
+def roi_align_fpn(features, rois, output_size, scales, sampling_ratio, k_min, k_max):
+    return _ROIAlignFPN.apply(rois, tuple(output_size), tuple(scales), sampling_ratio, k_min, k_max,
+                              *features)
+
+
+class Pooler(nn.Module):
+    """`Pooler(output_size, scales, sampling_ratio)`; `forward(x: list[Tensor], boxes: list[BoxList])
+    -> Tensor [K, C, output_size...]` with K = total number of boxes, ordered image by image."""
+
+    def __init__(self, output_size, scales, sampling_ratio):
+        super(Pooler, self).__init__()
+        self.poolers = nn.ModuleList(
+            [ROIAlign(output_size, spatial_scale=s, sampling_ratio=sampling_ratio) for s in scales])
+        self.output_size = output_size if isinstance(output_size, (tuple, list)) else (output_size, output_size)
+        self.scales = tuple(float(s) for s in scales)
+        self.sampling_ratio = sampling_ratio
+        # scales are 1/2^k: recover k of the first / last level
+        self.k_min = int(round(-torch.log2(torch.tensor(scales[0], dtype=torch.float32)).item()))
+        self.k_max = int(round(-torch.log2(torch.tensor(scales[-1], dtype=torch.float32)).item()))
+        self.map_levels = LevelMapper(self.k_min, self.k_max)
+
+    @staticmethod
+    def convert_to_roi_format(boxes):
+        """list[BoxList] -> [K,5] rows (image index, x1, y1, x2, y2); the index is stored as float
+        like the reference (:78-89)."""
+        rows = []
+        for i, b in enumerate(boxes):
+            bb = b.bbox
+            rows.append(torch.cat([bb.new_full((bb.shape[0], 1), float(i)), bb], dim=1))
+        return cat(rows, dim=0)
+
+    def forward(self, x, boxes):
+        rois = boxes if isinstance(boxes, torch.Tensor) else self.convert_to_roi_format(boxes)
+        x = list(x)[:len(self.poolers)]  # extra pyramid levels (P6) are not pooled from (reference zip)
+        if len(self.poolers) == 1:
+            return self.poolers[0](x[0], rois)
+        return roi_align_fpn(x, rois, self.output_size, self.scales, self.sampling_ratio,
+                             self.k_min, self.k_max)
+
+
+def make_pooler(cfg, head_name):
+    head = cfg.MODEL[head_name]
+    r = head.POOLER_RESOLUTION
+    return Pooler(output_size=(r, r), scales=head.POOLER_SCALES, sampling_ratio=head.POOLER_SAMPLING_RATIO)

@@ -1,0 +1,99 @@
+"""Fast R-CNN head loss + proposal sampling (reference roi_heads/box_head/loss.py:16-193).
+
+`subsample`: label every proposal by IoU with the ground truth (fg >= 0.5, else bg; Matcher
+without low-quality matches), draw 512 per image with <= 25 % foreground, attach class labels and
+box-regression targets.  `__call__`: softmax cross-entropy over the sampled ROIs (mean) and
+smooth-L1 (beta 1) on the positives' class-specific deltas, summed / #sampled.
+
+The sampled set has a FIXED length (BATCH_SIZE_PER_IMAGE slots per image, positives first,
+unfilled slots flagged invalid and label -1) so the head runs with static shapes and no `nonzero`.
+"""
+import torch
+from torch.nn import functional as F
+
+from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+from maskrcnn_benchmark.modeling.matcher import Matcher
+from maskrcnn_benchmark.modeling.rpn.loss import match_batched, pad_targets, smooth_l1_elementwise
+from maskrcnn_benchmark.modeling.utils import cat
+from maskrcnn_benchmark.structures.bounding_box import BoxList
+
+
+def stack_proposals(proposals):
+    """list[BoxList] (possibly different lengths, optional "valid" field) -> boxes [N,K,4],
+    valid [N,K]."""
+    K = max(len(p) for p in proposals)
+    dev = proposals[0].bbox.device
+    boxes = torch.zeros((len(proposals), K, 4), dtype=torch.float32, device=dev)
+    valid = torch.zeros((len(proposals), K), dtype=torch.bool, device=dev)
+    for i, p in enumerate(proposals):
+        n = len(p)
+        boxes[i, :n] = p.convert("xyxy").bbox
+        valid[i, :n] = p.get_field("valid") if p.has_field("valid") else True
+    return boxes, valid
+
+
+class FastRCNNLossComputation(object):
+    def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, cls_agnostic_bbox_reg=False):
+        self.proposal_matcher = proposal_matcher
+        self.fg_bg_sampler = fg_bg_sampler
+        self.box_coder = box_coder
+        self.cls_agnostic_bbox_reg = cls_agnostic_bbox_reg
+
+    def prepare_targets(self, boxes, valid, targets):
+        """-> labels [N,K] int64 (class, 0 bg, -1 ignored/invalid), regression_targets [N,K,4],
+        matched_idxs [N,K]."""
+        gt, row_valid, extra = pad_targets(targets, boxes.device, ("labels",))
+        matched = match_batched(self.proposal_matcher, gt, row_valid, boxes)
+        labels = torch.gather(extra["labels"], 1, matched.clamp(min=0))
+        labels = torch.where(matched == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(labels), labels)
+        labels = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, torch.full_like(labels, -1), labels)
+        labels = torch.where(valid, labels, torch.full_like(labels, -1))
+        matched_gt = torch.gather(gt, 1, matched.clamp(min=0)[:, :, None].expand(-1, -1, 4))
+        return labels, self.box_coder.encode(matched_gt, boxes), matched
+
+    def subsample(self, proposals, targets):
+        boxes, valid = stack_proposals(proposals)
+        labels, regression_targets, matched = self.prepare_targets(boxes, valid, targets)
+        idx, slot_valid = self.fg_bg_sampler.sample_fixed(labels)
+        out = []
+        for i, p in enumerate(proposals):
+            sel = idx[i]
+            bl = BoxList(boxes[i][sel], p.size, mode="xyxy")
+            bl.add_field("labels", torch.where(slot_valid[i], labels[i][sel], torch.full_like(sel, -1)))
+            bl.add_field("regression_targets", regression_targets[i][sel])
+            bl.add_field("matched_idxs", matched[i][sel])
+            bl.add_field("valid", slot_valid[i])
+            if p.has_field("objectness"):
+                bl.add_field("objectness", p.get_field("objectness")[sel])
+            out.append(bl)
+        self._proposals = out
+        return out
+
+    def __call__(self, class_logits, box_regression):
+        class_logits = cat(class_logits, dim=0).float()
+        box_regression = cat(box_regression, dim=0).float()
+        if not hasattr(self, "_proposals"):
+            raise RuntimeError("subsample needs to be called before")
+        proposals = self._proposals
+        labels = cat([p.get_field("labels") for p in proposals], dim=0)
+        regression_targets = cat([p.get_field("regression_targets") for p in proposals], dim=0)
+        num_sampled = (labels >= 0).sum().clamp(min=1).to(torch.float32)
+        classification_loss = F.cross_entropy(class_logits, labels, ignore_index=-1, reduction="sum") / num_sampled
+        pos = labels > 0
+        if self.cls_agnostic_bbox_reg:
+            deltas = box_regression[:, 4:8]
+        else:
+            cols = 4 * labels.clamp(min=0)[:, None] + torch.arange(4, device=labels.device)
+            deltas = torch.gather(box_regression, 1, cols)
+        l1 = smooth_l1_elementwise(deltas, regression_targets, beta=1.0).sum(dim=1)
+        box_loss = torch.where(pos, l1, torch.zeros_like(l1)).sum() / num_sampled
+        return classification_loss, box_loss
+
+
+def make_roi_box_loss_evaluator(cfg):
+    H = cfg.MODEL.ROI_HEADS
+    matcher = Matcher(H.FG_IOU_THRESHOLD, H.BG_IOU_THRESHOLD, allow_low_quality_matches=False)
+    sampler = BalancedPositiveNegativeSampler(H.BATCH_SIZE_PER_IMAGE, H.POSITIVE_FRACTION)
+    return FastRCNNLossComputation(matcher, sampler, BoxCoder(weights=H.BBOX_REG_WEIGHTS),
+                                   cfg.MODEL.CLS_AGNOSTIC_BBOX_REG)

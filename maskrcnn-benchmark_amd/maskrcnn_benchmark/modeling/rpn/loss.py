@@ -1,0 +1,108 @@
+"""RPN loss (reference modeling/rpn/loss.py:21-158).
+
+Per image: IoU(gt, anchors) -> Matcher (0.7 / 0.3, low-quality matches allowed) -> labels
+{1 fg, 0 bg, -1 ignored: between thresholds or anchor outside the image} and box-regression
+targets; sample 256 anchors per image (<= 50 % fg); objectness = BCE-with-logits (mean over the
+sampled anchors), box = smooth-L1(beta 1/9) summed over sampled positives / #sampled.
+
+Batched over images (ground truth padded to the largest count with a row mask) and free of
+`nonzero`: sampled subsets are boolean masks and the losses are masked sums, so the values equal
+the reference's indexed forms while nothing is synchronised with the host.
+"""
+import torch
+from torch.nn import functional as F
+
+from maskrcnn_benchmark.modeling.matcher import Matcher
+from maskrcnn_benchmark.structures.boxlist_ops import box_iou_matrix
+
+from ..balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+from .utils import concat_box_prediction_layers
+
+
+def pad_targets(targets, device, fields=()):
+    """list[BoxList] -> (boxes [N,M,4] (padding rows = a far-away unit box), row_valid [N,M] bool,
+    {field: [N,M]}) with M = max number of ground-truth boxes; host-side sizes only, no sync."""
+    N = len(targets)
+    M = max(max(len(t) for t in targets), 1)
+    boxes = torch.full((N, M, 4), -1e5, dtype=torch.float32, device=device)
+    boxes[:, :, 2:] = -1e5 + 1
+    row_valid = torch.zeros((N, M), dtype=torch.bool, device=device)
+    extra = {f: torch.zeros((N, M), dtype=torch.int64, device=device) for f in fields}
+    for i, t in enumerate(targets):
+        m = len(t)
+        if m == 0:
+            continue
+        boxes[i, :m] = t.convert("xyxy").bbox.to(device)
+        row_valid[i, :m] = True
+        for f in fields:
+            extra[f][i, :m] = t.get_field(f).to(device=device, dtype=torch.int64)
+    return boxes, row_valid, extra
+
+
+def match_batched(matcher, gt_boxes, row_valid, boxes):
+    """IoU + Matcher for a batch: gt_boxes [N,M,4], boxes [N,K,4] (or [K,4] shared) -> matched_idxs
+    [N,K] int64 (>= 0 index into the image's gt rows, -1 / -2 as in Matcher)."""
+    if boxes.dim() == 2:
+        boxes = boxes.unsqueeze(0).expand(gt_boxes.shape[0], -1, -1)
+    iou = box_iou_matrix(gt_boxes, boxes)
+    iou = torch.where(row_valid[:, :, None], iou, iou.new_full((), -1.0))
+    return matcher(iou, row_valid)
+
+
+def smooth_l1_elementwise(pred, target, beta):
+    n = torch.abs(pred - target)
+    return torch.where(n < beta, 0.5 * n * n / beta, n - 0.5 * beta)
+
+
+class RPNLossComputation(object):
+    def __init__(self, proposal_matcher, fg_bg_sampler, box_coder, generate_labels_func):
+        self.proposal_matcher = proposal_matcher
+        self.fg_bg_sampler = fg_bg_sampler
+        self.box_coder = box_coder
+        self.copied_fields = []
+        self.generate_labels_func = generate_labels_func
+        self.discard_cases = ["not_visibility", "between_thresholds"]
+
+    def prepare_targets(self, anchors, targets):
+        """anchors: list (image) of list (level) of BoxList.  -> labels [N,A] float (1/0/-1),
+        regression_targets [N,A,4]."""
+        all_anchors = torch.cat([b.bbox for b in anchors[0]], dim=0)
+        dev = all_anchors.device
+        gt, row_valid, extra = pad_targets(targets, dev, self.copied_fields)
+        matched = match_batched(self.proposal_matcher, gt, row_valid, all_anchors)
+        labels = self.generate_labels_func(matched, extra).to(torch.float32)
+        labels = torch.where(matched == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(labels), labels)
+        if "not_visibility" in self.discard_cases:
+            vis = torch.stack([torch.cat([b.get_field("visibility") for b in per_image], dim=0)
+                               for per_image in anchors], dim=0)
+            labels = torch.where(vis, labels, labels.new_full((), -1.0))
+        if "between_thresholds" in self.discard_cases:
+            labels = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, labels.new_full((), -1.0), labels)
+        matched_gt = torch.gather(gt, 1, matched.clamp(min=0)[:, :, None].expand(-1, -1, 4))
+        regression_targets = self.box_coder.encode(matched_gt, all_anchors.unsqueeze(0))
+        return labels, regression_targets
+
+    def __call__(self, anchors, objectness, box_regression, targets):
+        labels, regression_targets = self.prepare_targets(anchors, targets)
+        pos, neg = self.fg_bg_sampler._masks(labels)
+        sampled = pos | neg
+        num_sampled = sampled.sum().clamp(min=1).to(torch.float32)
+        objectness, box_regression = concat_box_prediction_layers(objectness, box_regression, keep_batch=True)
+        objectness = objectness.squeeze(-1).float()
+        box_regression = box_regression.float()
+        box_l = smooth_l1_elementwise(box_regression, regression_targets, beta=1.0 / 9).sum(dim=-1)
+        box_loss = torch.where(pos, box_l, torch.zeros_like(box_l)).sum() / num_sampled
+        bce = F.binary_cross_entropy_with_logits(objectness, labels.clamp(min=0), reduction="none")
+        objectness_loss = torch.where(sampled, bce, torch.zeros_like(bce)).sum() / num_sampled
+        return objectness_loss, box_loss
+
+
+def generate_rpn_labels(matched_idxs, extra=None):
+    return matched_idxs >= 0
+
+
+def make_rpn_loss_evaluator(cfg, box_coder):
+    R = cfg.MODEL.RPN
+    matcher = Matcher(R.FG_IOU_THRESHOLD, R.BG_IOU_THRESHOLD, allow_low_quality_matches=True)
+    sampler = BalancedPositiveNegativeSampler(R.BATCH_SIZE_PER_IMAGE, R.POSITIVE_FRACTION)
+    return RPNLossComputation(matcher, sampler, box_coder, generate_rpn_labels)

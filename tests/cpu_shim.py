@@ -1,0 +1,106 @@
+"""TEST-ONLY stand-ins for the HIP operators, backed by the CPU oracle.
+
+The product package has no CPU path (its `_C` raises on CPU tensors).  To exercise the *host logic*
+of the model surface (proposal selection, target assignment, samplers, losses, the DDP step) in the
+`-m "not gpu"` suite, `install()` monkeypatches the handful of `_C` entry points the model calls
+with implementations that run the oracle (oracle/detops_oracle.c) on numpy copies.  Nothing outside
+tests/ imports this module.
+"""
+import contextlib
+
+import numpy as np
+import torch
+
+import oracle
+from maskrcnn_benchmark import _C
+
+
+def _np(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy())
+
+
+def _roi_align_forward(input, rois, scale, ph, pw, sr):
+    return torch.from_numpy(oracle.roi_align_forward(_np(input.float()), _np(rois.float()), float(scale), ph, pw, sr))
+
+
+def _roi_align_backward(grad, rois, scale, ph, pw, N, C, H, W, sr):
+    return torch.from_numpy(oracle.roi_align_backward(_np(grad.float()), _np(rois.float()), float(scale), ph, pw,
+                                                      N, C, H, W, sr))
+
+
+def _fpn_forward(inputs, rois, scales, ph, pw, sr, k_min, k_max, canonical_scale=224.0, canonical_level=4.0,
+                 eps=1e-6):
+    r = _np(rois.float())
+    lv = oracle.fpn_level(r, k_min, k_max, canonical_scale, canonical_level, eps)
+    K, C = r.shape[0], inputs[0].shape[1]
+    out = np.zeros((K, C, ph, pw), np.float32)
+    for l, (f, s) in enumerate(zip(inputs, scales)):
+        sel = np.nonzero(lv == l)[0]
+        if sel.size:
+            out[sel] = oracle.roi_align_forward(_np(f.float()), r[sel], float(s), ph, pw, sr)
+    return torch.from_numpy(out), torch.from_numpy(lv.astype(np.int32))
+
+
+def _fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr):
+    r, g, lv = _np(rois.float()), _np(grad.float()), _np(levels)
+    outs = []
+    for l, (shp, s) in enumerate(zip(shapes, scales)):
+        sel = np.nonzero(lv == l)[0]
+        N, C, H, W = shp
+        if sel.size:
+            outs.append(torch.from_numpy(oracle.roi_align_backward(g[sel], r[sel], float(s), ph, pw, N, C, H, W, sr)))
+        else:
+            outs.append(torch.zeros(shp))
+    return outs
+
+
+def _nms(dets, scores, thr):
+    if dets.numel() == 0:
+        return torch.empty((0,), dtype=torch.long)
+    return torch.from_numpy(oracle.nms(_np(dets.float()), _np(scores.float()), float(thr)).astype(np.int64))
+
+
+def _nms_batched_mask(boxes, scores, seg_offsets, max_n, thr):
+    b, s, seg = _np(boxes.float()), _np(scores.float()), _np(seg_offsets)
+    mask = np.zeros(b.shape[0], bool)
+    num = np.zeros(len(seg) - 1, np.int32)
+    for i in range(len(seg) - 1):
+        lo, hi = int(seg[i]), int(seg[i + 1])
+        if hi > lo:
+            k = oracle.nms(b[lo:hi], s[lo:hi], float(thr))
+            mask[lo + k] = True
+            num[i] = len(k)
+    return torch.from_numpy(mask), torch.from_numpy(num)
+
+
+def _focal_sum(logits, targets, num_classes, gamma, alpha):
+    return torch.from_numpy(oracle.sigmoid_focal_loss_forward(_np(logits.float()), _np(targets), gamma, alpha)).sum()
+
+
+def _focal_bwd_scalar(logits, targets, d_loss, num_classes, gamma, alpha):
+    d = np.full(tuple(logits.shape), float(d_loss), np.float32)
+    return torch.from_numpy(oracle.sigmoid_focal_loss_backward(_np(logits.float()), _np(targets), d, gamma, alpha))
+
+
+_PATCHES = {
+    "roi_align_forward": _roi_align_forward,
+    "roi_align_backward": _roi_align_backward,
+    "roi_align_fpn_forward": _fpn_forward,
+    "roi_align_fpn_backward": _fpn_backward,
+    "nms": _nms,
+    "nms_batched_mask": _nms_batched_mask,
+    "sigmoid_focalloss_forward_sum": _focal_sum,
+    "sigmoid_focalloss_backward_scalar": _focal_bwd_scalar,
+}
+
+
+@contextlib.contextmanager
+def install():
+    saved = {k: getattr(_C, k) for k in _PATCHES}
+    try:
+        for k, v in _PATCHES.items():
+            setattr(_C, k, v)
+        yield
+    finally:
+        for k, v in saved.items():
+            setattr(_C, k, v)
