@@ -20,7 +20,9 @@ def _axis_taps(lo, size, M):
     indices, frac [P,M] float32) of torch's bilinear resize to M samples."""
     scale = size.to(torch.float32) / M
     dst = torch.arange(M, device=lo.device, dtype=torch.float32)
-    src = (scale[:, None] * (dst[None, :] + 0.5) - 0.5).clamp(min=0)
+    # ATen's CPU kernel evaluates scale*(dst+0.5)-0.5 as ONE fused multiply-add; the fp64 product of
+    # two fp32 numbers is exact, so rounding the fp64 expression once to fp32 reproduces the FMA
+    src = (scale.double()[:, None] * (dst.double()[None, :] + 0.5) - 0.5).to(torch.float32).clamp(min=0)
     i0 = src.floor().to(torch.int64)
     i0 = torch.minimum(i0, (size - 1)[:, None])
     i1 = torch.minimum(i0 + 1, (size - 1)[:, None])
@@ -47,9 +49,12 @@ def project_masks_on_boxes(masks, mask_index, boxes, discretization_size):
         return flat[base, yy[:, :, None] * W + xx[:, None, :]].to(torch.float32)
 
     hy, hx = 1.0 - ly, 1.0 - lx
-    top = hx[:, None, :] * tap(y0, x0) + lx[:, None, :] * tap(y0, x1)
-    bot = hx[:, None, :] * tap(y1, x0) + lx[:, None, :] * tap(y1, x1)
-    val = hy[:, :, None] * top + ly[:, :, None] * bot
+    # operation order of ATen's CPU bilinear kernel (the reference resizes masks on the CPU):
+    # ((h0*w0)*p00 + (h0*w1)*p01) + (h1*w0)*p10 + (h1*w1)*p11, every product rounded to fp32 —
+    # matters because integer masks truncate a sum that may land one ulp below 1.0
+    val = (hy[:, :, None] * hx[:, None, :]) * tap(y0, x0) + (hy[:, :, None] * lx[:, None, :]) * tap(y0, x1)
+    val = val + (ly[:, :, None] * hx[:, None, :]) * tap(y1, x0)
+    val = val + (ly[:, :, None] * lx[:, None, :]) * tap(y1, x1)
     if not masks.dtype.is_floating_point:
         val = val.to(masks.dtype).to(torch.float32)  # `.type_as(self.masks)`: integer masks truncate
     return val

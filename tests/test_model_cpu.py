@@ -1,0 +1,328 @@
+"""Host-logic parity of the model surface against fixtures produced by the REFERENCE's own Python
+modules (tests/golden/make_golden_model.py): anchors, Matcher, BoxList ops, IoU, LevelMapper, target
+assignment (RPN / RetinaNet / Fast R-CNN), RPN loss, mask targets, proposal selection, LR schedule.
+Operators that only exist as HIP kernels are replaced by the oracle through tests/cpu_shim.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cpu_shim
+from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+from maskrcnn_benchmark.modeling.matcher import Matcher
+from maskrcnn_benchmark.modeling.poolers import LevelMapper
+from maskrcnn_benchmark.modeling.rpn.anchor_generator import AnchorGenerator, generate_anchors
+from maskrcnn_benchmark.structures.bounding_box import BoxList
+from maskrcnn_benchmark.structures.boxlist_ops import boxlist_iou
+from maskrcnn_benchmark.structures.image_list import ImageList, to_image_list
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+# ------------------------------------------------------------------ config
+def test_config_files_load_and_reject_unknown_keys(tmp_path):
+    from maskrcnn_benchmark.config import cfg
+    from maskrcnn_benchmark.engine.bench_step import CONFIG_DIR, load_cfg
+    for f in ("e2e_mask_rcnn_R_50_FPN_1x.yaml", "e2e_faster_rcnn_R_50_FPN_1x.yaml", "e2e_mask_rcnn_R_101_FPN_1x.yaml",
+              "retinanet/retinanet_R-50-FPN_1x.yaml"):
+        c = load_cfg(f)
+        assert c.MODEL.RPN.ANCHOR_STRIDE == (4, 8, 16, 32, 64)
+        assert c.is_frozen()
+    c = load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml", ["MODEL.RESNETS.STAGE_WITH_DCN", "(False,True,True,True)",
+                                                   "SOLVER.BASE_LR", "0.01", "DTYPE", "float16"])
+    assert c.MODEL.RESNETS.STAGE_WITH_DCN == (False, True, True, True) and c.SOLVER.BASE_LR == 0.01
+    assert c.MODEL.ROI_MASK_HEAD.RESOLUTION == 28 and c.MODEL.MASK_ON is True
+    assert cfg.MODEL.MASK_ON is False  # the global default tree is untouched
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("MODEL:\n  NO_SUCH_KEY: 1\n")
+    with pytest.raises(KeyError):
+        load_cfg(str(bad))
+    with pytest.raises(AttributeError):
+        c.SOLVER.BASE_LR = 1.0
+    assert os.path.isdir(CONFIG_DIR)
+
+
+# ------------------------------------------------------------------ anchors
+def test_anchors_match_reference():
+    g = load("model_anchors.npz")
+    for i, (stride, size) in enumerate(zip((4, 8, 16, 32, 64), (32, 64, 128, 256, 512))):
+        np.testing.assert_array_equal(generate_anchors(stride, (size,), (0.5, 1.0, 2.0)).float().numpy(), g["rpn_cell_%d" % i])
+    for i, (stride, size) in enumerate(zip((8, 16, 32, 64, 128), (32, 64, 128, 256, 512))):
+        sizes = tuple(size * 2 ** (k / 3.0) for k in range(3))
+        np.testing.assert_array_equal(generate_anchors(stride, sizes, (0.5, 1.0, 2.0)).float().numpy(), g["retina_cell_%d" % i])
+    ag = AnchorGenerator(sizes=((32,), (64,), (128,)), anchor_strides=(4, 8, 16), straddle_thresh=0)
+    feats = [torch.zeros(1, 1, h, w) for h, w in g["grids"]]
+    il = ImageList(torch.zeros(2, 3, 20, 28), [tuple(s) for s in g["image_sizes"]])
+    anchors = ag(il, feats)
+    for l in range(3):
+        np.testing.assert_array_equal(anchors[0][l].bbox.numpy(), g["grid_%d" % l])
+        for i in range(2):
+            np.testing.assert_array_equal(anchors[i][l].get_field("visibility").numpy(), g["vis_%d_%d" % (i, l)])
+
+
+# ------------------------------------------------------------------ matcher
+def test_matcher_matches_reference_including_ties_and_batched():
+    g = load("model_matcher.npz")
+    for c, (hi, lo, lq) in enumerate(g["cfgs"]):
+        m = Matcher(float(hi), float(lo), allow_low_quality_matches=bool(lq))
+        for k in range(4):
+            q = T(g["q_%d_%d" % (c, k)])
+            np.testing.assert_array_equal(m(q).numpy(), g["m_%d_%d" % (c, k)])
+            # batched + padded rows give the same answer
+            pad = torch.full((3, q.shape[1]), -1.0)
+            qb = torch.stack([torch.cat([q, pad]), torch.cat([q, pad])])
+            rv = torch.zeros(2, q.shape[0] + 3, dtype=torch.bool)
+            rv[:, :q.shape[0]] = True
+            out = m(qb, rv)
+            np.testing.assert_array_equal(out[0].numpy(), g["m_%d_%d" % (c, k)])
+            np.testing.assert_array_equal(out[1].numpy(), g["m_%d_%d" % (c, k)])
+    with pytest.raises(ValueError):
+        Matcher(0.5, 0.5)(torch.zeros(0, 4))
+
+
+# ------------------------------------------------------------------ BoxList
+def test_boxlist_ops_match_reference():
+    g = load("model_boxlist.npz")
+    W, H = (int(v) for v in g["size"])
+    bl = BoxList(T(g["boxes"]), (W, H), "xyxy")
+    tol = dict(rtol=0, atol=1e-4)
+    np.testing.assert_allclose(bl.convert("xywh").bbox.numpy(), g["xywh"], **tol)
+    np.testing.assert_allclose(bl.convert("xywh").convert("xyxy").bbox.numpy(), g["xywh_back"], **tol)
+    np.testing.assert_allclose(bl.resize((W * 2, H * 2)).bbox.numpy(), g["resize_same"], **tol)
+    np.testing.assert_allclose(bl.resize((480, 250)).bbox.numpy(), g["resize_diff"], **tol)
+    np.testing.assert_allclose(bl.transpose(0).bbox.numpy(), g["flip_lr"], **tol)
+    np.testing.assert_allclose(bl.transpose(1).bbox.numpy(), g["flip_tb"], **tol)
+    np.testing.assert_allclose(bl.crop((30, 20, 250, 160)).bbox.numpy(), g["crop"], **tol)
+    np.testing.assert_allclose(bl.area().numpy(), g["area"], rtol=1e-6)
+    np.testing.assert_allclose(bl.convert("xywh").area().numpy(), g["area_xywh"], rtol=1e-5)
+    np.testing.assert_allclose(BoxList(T(g["clip_in"]).clone(), (W, H)).clip_to_image(False).bbox.numpy(), g["clip_out"], **tol)
+    np.testing.assert_allclose(BoxList(T(g["clip_in"]).clone(), (W, H)).clip_to_image(True).bbox.numpy(), g["clip_kept"], **tol)
+    np.testing.assert_allclose(boxlist_iou(bl, BoxList(T(g["boxes2"]), (W, H))).numpy(), g["iou"], rtol=1e-5, atol=1e-7)
+    lv = LevelMapper(2, 5)([BoxList(T(g["lm_boxes"]), (1344, 800))])
+    np.testing.assert_array_equal(lv.numpy(), g["lm_levels"])
+    with pytest.raises(ValueError):
+        BoxList(torch.zeros(3, 5), (10, 10))
+    f = bl.copy_with_fields([])
+    f.add_field("labels", torch.arange(len(f)))
+    assert f[torch.tensor([3, 1])].get_field("labels").tolist() == [3, 1]
+
+
+def test_to_image_list_pads_to_divisor():
+    il = to_image_list([torch.ones(3, 30, 50), torch.ones(3, 41, 33)], 32)
+    assert tuple(il.tensors.shape) == (2, 3, 64, 64)
+    assert [tuple(s) for s in il.image_sizes] == [(30, 50), (41, 33)]
+    assert float(il.tensors[0, :, 30:].abs().sum()) == 0 and float(il.tensors[1, :, :, 33:].abs().sum()) == 0
+
+
+# ------------------------------------------------------------------ target assignment + RPN loss
+def _targets_setup(g):
+    H, W = (int(v) for v in g["canvas"])
+    ag = AnchorGenerator(sizes=((32,), (64,), (128,)), anchor_strides=(8, 16, 32), straddle_thresh=0)
+    feats = [torch.zeros(2, 1, H // s, W // s) for s in (8, 16, 32)]
+    il = ImageList(torch.zeros(2, 3, H, W), [tuple(int(v) for v in s) for s in g["image_sizes"]])
+    anchors = ag(il, feats)
+    targets = []
+    for i, (h, w) in enumerate(il.image_sizes):
+        t = BoxList(T(g["gt_%d" % i]), (w, h))
+        t.add_field("labels", T(g["gt_labels_%d" % i]))
+        targets.append(t)
+    return anchors, targets
+
+
+class _FixedSampler(object):
+    def __init__(self, n_pos, n_neg):
+        self.n_pos, self.n_neg = n_pos, n_neg
+
+    def _masks(self, labels):
+        pos, neg = labels >= 1, labels == 0
+        return pos & (pos.cumsum(-1) <= self.n_pos), neg & (neg.cumsum(-1) <= self.n_neg)
+
+
+def test_rpn_and_retinanet_target_assignment_and_rpn_loss_match_reference():
+    from maskrcnn_benchmark.modeling.rpn.loss import RPNLossComputation, generate_rpn_labels
+    from maskrcnn_benchmark.modeling.rpn.retinanet.loss import generate_retinanet_labels
+    g = load("model_targets.npz")
+    anchors, targets = _targets_setup(g)
+    rpn = RPNLossComputation(Matcher(0.7, 0.3, True), _FixedSampler(16, 48), BoxCoder((1., 1., 1., 1.)), generate_rpn_labels)
+    lab, reg = rpn.prepare_targets(anchors, targets)
+    for i in range(2):
+        np.testing.assert_array_equal(lab[i].numpy(), g["rpn_labels_%d" % i])
+        sel = g["rpn_labels_%d" % i] > 0  # regression targets only matter on positives; all are compared anyway
+        np.testing.assert_allclose(reg[i].numpy(), g["rpn_reg_%d" % i], rtol=1e-4, atol=1e-5)
+        assert sel.sum() > 0
+    obj = [T(g["objectness_%d" % l]) for l in range(3)]
+    breg = [T(g["box_reg_%d" % l]) for l in range(3)]
+    lo, lb = rpn(anchors, obj, breg, targets)
+    np.testing.assert_allclose([float(lo), float(lb)], g["rpn_loss"], rtol=1e-5)
+    ret = RPNLossComputation(Matcher(0.5, 0.4, True), None, BoxCoder((10., 10., 5., 5.)), generate_retinanet_labels)
+    ret.copied_fields, ret.discard_cases = ["labels"], ["between_thresholds"]
+    lab, reg = ret.prepare_targets(anchors, targets)
+    for i in range(2):
+        np.testing.assert_array_equal(lab[i].numpy(), g["ret_labels_%d" % i])
+        np.testing.assert_allclose(reg[i].numpy(), g["ret_reg_%d" % i], rtol=1e-4, atol=1e-5)
+
+
+def test_fast_rcnn_target_assignment_matches_reference():
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.loss import FastRCNNLossComputation, stack_proposals
+    g = load("model_targets.npz")
+    _, targets = _targets_setup(g)
+    sizes = [(int(w), int(h)) for h, w in g["image_sizes"]]
+    props = [BoxList(T(g["props_%d" % i]), sizes[i]) for i in range(2)]
+    frc = FastRCNNLossComputation(Matcher(0.5, 0.5, False), BalancedPositiveNegativeSampler(32, 0.25), BoxCoder((10., 10., 5., 5.)))
+    boxes, valid = stack_proposals(props)
+    lab, reg, _ = frc.prepare_targets(boxes, valid, targets)
+    for i in range(2):
+        n = len(props[i])
+        np.testing.assert_array_equal(lab[i, :n].numpy(), g["frc_labels_%d" % i])
+        np.testing.assert_allclose(reg[i, :n].numpy(), g["frc_reg_%d" % i], rtol=1e-4, atol=1e-5)
+        assert (lab[i, n:] == -1).all()
+    # fixed-length sampling: positives first, <= 25 % positives, invalid slots flagged
+    out = frc.subsample(props, targets)
+    for i, s in enumerate(out):
+        l, v = s.get_field("labels"), s.get_field("valid")
+        assert len(s) == 32 and int((l > 0).sum()) <= 8
+        npos = int((l > 0).sum())
+        assert (l[:npos] > 0).all() and (l[npos:] <= 0).all()
+        assert (l[~v] == -1).all() and (l[v] >= 0).all()
+        # every sampled row is a real proposal with the label the assignment gave it
+        for j in torch.nonzero(v).flatten().tolist():
+            d = (boxes[i] - s.bbox[j]).abs().sum(1)
+            k = int(d.argmin())
+            assert float(d[k]) == 0 and int(lab[i, k]) == int(l[j])
+
+
+# ------------------------------------------------------------------ samplers
+def test_balanced_sampler_counts_and_uniformity():
+    torch.manual_seed(0)
+    s = BalancedPositiveNegativeSampler(64, 0.25)
+    labels = torch.zeros(2, 500, dtype=torch.int64)
+    labels[0, :40] = 3
+    labels[0, 400:] = -1
+    labels[1, :5] = 1
+    pos, neg = s([labels[0], labels[1]])
+    assert int(pos[0].sum()) == 16 and int(neg[0].sum()) == 48
+    assert int(pos[1].sum()) == 5 and int(neg[1].sum()) == 59
+    assert not (pos[0] & (labels[0] < 1)).any() and not (neg[0] & (labels[0] != 0)).any()
+    hits = torch.zeros(40)
+    for _ in range(300):
+        p, _ = s([labels[0]])
+        hits += p[0][:40].float()
+    assert hits.min() > 60 and hits.max() < 180  # each positive chosen ~ 300*16/40 = 120 times
+    idx, valid = s.sample_fixed(labels)
+    assert idx.shape == (2, 64) and valid.all()
+    few = torch.full((1, 100), -1, dtype=torch.int64)
+    few[0, :10] = 0
+    idx, valid = s.sample_fixed(few)
+    assert int(valid.sum()) == 10 and (few[0][idx[0][valid[0]]] == 0).all()
+
+
+# ------------------------------------------------------------------ mask targets
+def test_mask_targets_match_reference_binary_mask_path():
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head.loss import project_masks_on_boxes
+    from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
+    g = load("model_masks.npz")
+    masks, props, which = T(g["masks"]), T(g["props"]), T(g["which"])
+    out_u8 = project_masks_on_boxes(masks, which, props, 28).numpy()
+    out_f32 = project_masks_on_boxes(masks.float(), which, props, 28).numpy()
+    np.testing.assert_allclose(out_f32, g["targets_f32"], atol=2e-6)
+    # integer masks truncate the interpolated value (a sum one ulp below 1.0 becomes 0): the
+    # projection follows the CPU kernel operation by operation, so this is exact
+    np.testing.assert_array_equal(out_u8, g["targets_u8"])
+    # and the structures-level crop+resize (what the reference's loss calls per ROI) agrees too
+    W, H = (int(v) for v in g["size"])
+    seg = SegmentationMask(masks.float(), (W, H))
+    for j in (0, 7, 39):
+        r = seg[int(which[j])].crop(props[j]).resize((28, 28)).get_mask_tensor().numpy()
+        np.testing.assert_allclose(r, g["targets_f32"][j], atol=2e-6)
+
+
+# ------------------------------------------------------------------ proposal selection
+@pytest.mark.parametrize("tag", ["train", "train_perimg", "test"])
+def test_rpn_proposal_selection_matches_reference(tag):
+    from maskrcnn_benchmark.modeling.rpn.inference import RPNPostProcessor
+    g = load("model_proposals.npz")
+    H, W = (int(v) for v in g["canvas"])
+    ag = AnchorGenerator(sizes=((32,), (64,), (128,)), anchor_strides=(8, 16, 32), straddle_thresh=0)
+    feats = [torch.zeros(2, 1, H // s, W // s) for s in (8, 16, 32)]
+    il = ImageList(torch.zeros(2, 3, H, W), [tuple(int(v) for v in s) for s in g["image_sizes"]])
+    anchors = ag(il, feats)
+    obj = [T(g["objectness_%d" % l]) for l in range(3)]
+    breg = [T(g["box_reg_%d" % l]) for l in range(3)]
+    pre, post, min_size, fpn_post, per_batch = (int(v) for v in g["%s_cfg" % tag])
+    pp = RPNPostProcessor(pre, post, 0.7, min_size, BoxCoder((1., 1., 1., 1.)), fpn_post, bool(per_batch))
+    pp.train(tag.startswith("train"))
+    with cpu_shim.install():
+        res = pp(anchors, obj, breg, None)
+    for i, r in enumerate(res):
+        s = r.get_field("objectness")
+        b = r.bbox
+        if r.has_field("valid"):
+            v = r.get_field("valid")
+            s, b = s[v], b[v]
+        order = torch.argsort(s, descending=True, stable=True)
+        np.testing.assert_allclose(s[order].numpy(), g["%s_scores_%d" % (tag, i)], rtol=1e-6)
+        np.testing.assert_allclose(b[order].numpy(), g["%s_boxes_%d" % (tag, i)], rtol=1e-5, atol=1e-4)
+
+
+# ------------------------------------------------------------------ solver
+def test_lr_schedule_and_smooth_l1_match_reference():
+    from maskrcnn_benchmark.layers import smooth_l1_loss
+    from maskrcnn_benchmark.solver import WarmupMultiStepLR
+    g = load("model_solver.npz")
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=0.02)
+    sched = WarmupMultiStepLR(opt, (30, 40), 0.1, warmup_factor=1.0 / 3, warmup_iters=10, warmup_method="linear")
+    lrs = []
+    for _ in range(50):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()
+    np.testing.assert_allclose(lrs, g["lrs"], rtol=1e-12)
+    a, b = T(g["sl1_a"]), T(g["sl1_b"])
+    got = [float(smooth_l1_loss(a, b, beta=1.0 / 9, size_average=False)), float(smooth_l1_loss(a, b, beta=1.0, size_average=True)),
+           float(smooth_l1_loss(a, b, beta=0.11, size_average=False))]
+    np.testing.assert_allclose(got, g["sl1"], rtol=1e-6)
+    with pytest.raises(ValueError):
+        WarmupMultiStepLR(opt, (40, 30))
+
+
+# ------------------------------------------------------------------ whole model on the CPU shim
+@pytest.mark.parametrize("config", ["e2e_mask_rcnn_R_50_FPN_1x.yaml", "retinanet/retinanet_R-50-FPN_1x.yaml"])
+def test_tiny_model_trains_on_cpu_shim(config, monkeypatch):
+    import maskrcnn_benchmark.layers.sigmoid_focal_loss as sfl
+    from maskrcnn_benchmark.data.synthetic import BatchCollator, SyntheticCOCODataset
+    from maskrcnn_benchmark.engine.bench_step import load_cfg
+    from maskrcnn_benchmark.engine.ddp_step import TrainStep, make_overlapped_sgd
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    cfg = load_cfg(config, ["MODEL.DEVICE", "cpu", "MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 100, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 150,
+                            "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 32, "MODEL.RESNETS.RES2_OUT_CHANNELS", 16,
+                            "MODEL.RESNETS.WIDTH_PER_GROUP", 4, "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 16,
+                            "MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM", 32, "MODEL.ROI_MASK_HEAD.CONV_LAYERS", (16, 16),
+                            "SOLVER.BASE_LR", 0.002])
+    torch.manual_seed(0)
+    model = build_detection_model(cfg).train()
+    ds = SyntheticCOCODataset(length=2, height=96, width=128, with_masks=cfg.MODEL.MASK_ON, min_objects=2, max_objects=4)
+    images, targets, _ = BatchCollator(32)([ds[0], ds[1]])
+    step = TrainStep(model, make_overlapped_sgd(cfg, model), None, "float32", "cpu")
+    monkeypatch.setattr(sfl.SigmoidFocalLoss, "forward",
+                        lambda self, l, t: sfl.sigmoid_focal_loss_sum(l.float(), t, self.gamma, self.alpha))
+    with cpu_shim.install():
+        first = {k: float(v) for k, v in step(images, list(targets)).items()}
+        for _ in range(3):
+            last = {k: float(v) for k, v in step(images, list(targets)).items()}
+        assert all(np.isfinite(v) for v in last.values())
+        assert sum(last.values()) < sum(first.values())
+        model.eval()
+        with torch.no_grad():
+            det = model(images)
+        assert len(det) == 2 and det[0].has_field("scores") and det[0].has_field("labels")
