@@ -17,9 +17,10 @@
 //   * lanes run over (channel, bin) with bin fastest: stores are fully coalesced (the output of a
 //     (ROI, chunk) is one contiguous run), gathers hit a <= ~30x30 px patch per channel that
 //     stays L1/L2 resident.
-//   * backward: the ROI's footprint patch [channels x py x px] is accumulated in LDS with
-//     ds_add_f32 (no global atomics inside a ROI), then flushed with row-contiguous
-//     global_atomic_add_f32 — one atomic per touched input pixel per ROI instead of 4 per sample.
+//   * forward fast path (fixed 1x1 / 2x2 sampling): the ROI footprint is staged in LDS, a thread
+//     keeps its bin's sample offsets + weights in registers across the channel loop (see below).
+//   * backward: tile-centric — a workgroup owns a pixel tile of one gradient map and accumulates
+//     every overlapping ROI in LDS; no global atomics, no separate zero-fill (see below).
 #include <type_traits>
 
 #include "detops_common.h"
@@ -29,7 +30,6 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kTabBig = 512;    // axis-table entries per axis kept in LDS (adaptive grids);
 constexpr int kTabSmall = 32;   // fixed sampling_ratio: PH*sr, PW*sr <= 32 covers 7x7..14x14 @ sr 2
-constexpr int kPatchFloats = 8192;  // backward LDS patch budget (32 KiB)
 
 struct __align__(16) Tap {
   int lo, hi;   // y axis: pre-multiplied by W
@@ -187,151 +187,322 @@ roi_align_fwd_kernel(Levels L, const float* __restrict__ rois, const int32_t* __
 }
 
 // ------------------------------------------------------------------------------------------
-// backward
+// forward, fast path: fixed sampling grid (SR x SR, SR in {1,2}), compile-time bin counts.
+//
+//   * the ROI's footprint [channels x (py+1) x (px+1)] is staged into LDS with row-contiguous
+//     global loads (each feature byte under the ROI crosses the memory system once per workgroup,
+//     coalesced, instead of 4*SR*SR times as scattered 4-byte gathers that each cost the texture
+//     path a cache-line lookup);
+//   * a thread owns ONE output bin for a strided set of channels: its SR*SR samples' patch offsets
+//     and 4 bilinear weights live in registers for the whole channel loop, so the inner loop is
+//     4 LDS reads + 7 fp32 ops per sample and nothing else;
+//   * taps are addressed as (lo, lo+1): the patch carries one extra row/column that replicates the
+//     clamped border pixel, which is exactly what the reference reads when x_high == x_low
+//     (weight 0 on that tap) — so the two taps of a row are adjacent and fetched as one
+//     ds_read2_b32;
+//   * the arithmetic keeps the reference's order with FP contraction off: bit-identical to the
+//     reference CPU kernel for finite inputs.
+// Footprints that do not fit the LDS budget fall through to the generic gather loop.
 // ------------------------------------------------------------------------------------------
-template <int PH_, int PW_, int kTabCap>
-__global__ void __launch_bounds__(kBlock)
-roi_align_bwd_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
-                     const float* __restrict__ gout, int C, int K, int PHr, int PWr, int sr, int CT,
-                     int chunks) {
-  const int PH = PH_ ? PH_ : PHr;
-  const int PW = PW_ ? PW_ : PWr;
-  const int bins = PH * PW;
-  __shared__ Tap tabY[kTabCap];
-  __shared__ Tap tabX[kTabCap];
-  __shared__ float patch[kPatchFloats];
-  __shared__ int s_bounds[4];  // ymin, ymax, xmin, xmax over valid taps (tabY holds RAW rows here)
+constexpr int kLdsPatchFloats = 8192 - 64;  // ~32 KiB dynamic LDS per workgroup -> 4-5 workgroups / CU
 
+template <int PH, int PW, int SR, int G>
+__global__ void __launch_bounds__(((PH * PW * G + 63) / 64) * 64)
+roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
+                         int32_t* __restrict__ levels_out, float* __restrict__ out, int C, int K, int CT,
+                         int chunks) {
+  constexpr int BINS = PH * PW;
+  constexpr int NS = SR * SR;
+  constexpr int NT = ((BINS * G + 63) / 64) * 64;
+  extern __shared__ float patch[];
+  __shared__ Tap tabY[PH * SR];
+  __shared__ Tap tabX[PW * SR];
+  __shared__ int s_bounds[4];
+
+  const int tid = threadIdx.x;
   const int k = blockIdx.x / chunks;
   const int chunk = blockIdx.x - k * chunks;
   const float* roi = rois + static_cast<size_t>(k) * 5;
   int lvl = 0;
   if (L.num > 1) lvl = levels_in ? levels_in[k] : fpn_level(roi, L);
-  float* gin = L.lv[0].gin; int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
+  if (levels_out && chunk == 0 && tid == 0) levels_out[k] = lvl;
+  const float* in = L.lv[0].in; int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
 #pragma unroll
   for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
-    if (i == lvl) { gin = L.lv[i].gin; H = L.lv[i].H; W = L.lv[i].W; scale = L.lv[i].scale; }
+    if (i == lvl) { in = L.lv[i].in; H = L.lv[i].H; W = L.lv[i].W; scale = L.lv[i].scale; }
 
-  const RoiGeom g = roi_geometry(roi, scale, PH, PW, sr);
-  const int ny = PH * g.gh, nx = PW * g.gw;
-  const bool use_tab = (ny <= kTabCap) && (nx <= kTabCap);
+  const RoiGeom g = roi_geometry(roi, scale, PH, PW, SR);
+  if (tid == 0) { s_bounds[0] = 0x7fffffff; s_bounds[1] = -1; s_bounds[2] = 0x7fffffff; s_bounds[3] = -1; }
+  __syncthreads();
+  if (tid < PH * SR + PW * SR) {
+    if (tid < PH * SR) {
+      const Tap e = axis_entry(g.start_h, g.bin_h, tid / SR, tid % SR, SR, H, 1);
+      tabY[tid] = e;
+      if (e.l != 0.f || e.h != 0.f) { atomicMin(&s_bounds[0], e.lo); atomicMax(&s_bounds[1], e.lo); }
+    } else {
+      const int u = tid - PH * SR;
+      const Tap e = axis_entry(g.start_w, g.bin_w, u / SR, u % SR, SR, W, 1);
+      tabX[u] = e;
+      if (e.l != 0.f || e.h != 0.f) { atomicMin(&s_bounds[2], e.lo); atomicMax(&s_bounds[3], e.lo); }
+    }
+  }
+  __syncthreads();
   const int c0 = chunk * CT;
   const int cend = min(C, c0 + CT);
+  float* obase = out + (static_cast<size_t>(k) * C + c0) * BINS;
+  if (s_bounds[1] < 0 || s_bounds[3] < 0) {  // every sample falls outside the map: all-zero output
+    for (int o = tid; o < (cend - c0) * BINS; o += NT) obase[o] = 0.f;
+    return;
+  }
+  const int ymin = s_bounds[0], xmin = s_bounds[2];
+  const int rows = s_bounds[1] - ymin + 2;   // (lo range) + the lo+1 row
+  const int ps = s_bounds[3] - xmin + 2;     // row stride incl. the lo+1 column
+  const int area = rows * ps;
   const size_t plane = static_cast<size_t>(H) * W;
-  float* gbase = gin + (static_cast<size_t>(g.b) * C + c0) * plane;
-  const float* gobase = gout + (static_cast<size_t>(k) * C + c0) * bins;
-  // (g*w)/count in the reference; for power-of-two counts the reciprocal multiply is exact
-  const int icount = g.gh * g.gw;
-  const bool pow2 = (icount & (icount - 1)) == 0;
-  const float inv_count = 1.f / g.count;
+  const float* base = in + (static_cast<size_t>(g.b) * C + c0) * plane;
 
-  int py = 0, px = 0, ymin = 0, xmin = 0;
-  bool lds_path = false;
-  if (use_tab) {
-    if (threadIdx.x == 0) {
-      s_bounds[0] = 0x7fffffff; s_bounds[1] = -1; s_bounds[2] = 0x7fffffff; s_bounds[3] = -1;
+  if (area > kLdsPatchFloats) {  // footprint too large for LDS: gather straight from the map
+    for (int o = tid; o < (cend - c0) * BINS; o += NT) {
+#pragma clang fp contract(off)
+      const int cl = o / BINS;
+      const int bin = o - cl * BINS;
+      const int ph = bin / PW, pw = bin - ph * PW;
+      const float* d = base + static_cast<size_t>(cl) * plane;
+      float acc = 0.f;
+      for (int iy = 0; iy < SR; ++iy) {
+        const Tap ty = tabY[ph * SR + iy];
+        const float* r0 = d + ty.lo * W;
+        const float* r1 = d + ty.hi * W;
+        for (int ix = 0; ix < SR; ++ix) {
+          const Tap tx = tabX[pw * SR + ix];
+          const float w1 = ty.h * tx.h, w2 = ty.h * tx.l, w3 = ty.l * tx.h, w4 = ty.l * tx.l;
+          acc += w1 * r0[tx.lo] + w2 * r0[tx.hi] + w3 * r1[tx.lo] + w4 * r1[tx.hi];
+        }
+      }
+      obase[o] = acc / g.count;
+    }
+    return;
+  }
+
+  // per-thread sample geometry (registers)
+  const int bin = tid % BINS;
+  const int csub = tid / BINS;  // >= G: idle lane of the last wave
+  const int ph = bin / PW, pw = bin - ph * PW;
+  int off[NS];
+  float w1[NS], w2[NS], w3[NS], w4[NS];
+#pragma unroll
+  for (int iy = 0; iy < SR; ++iy) {
+    const Tap ty = tabY[ph * SR + iy];
+    const bool vy = (ty.l != 0.f || ty.h != 0.f);
+#pragma unroll
+    for (int ix = 0; ix < SR; ++ix) {
+#pragma clang fp contract(off)
+      const Tap tx = tabX[pw * SR + ix];
+      const bool v = vy && (tx.l != 0.f || tx.h != 0.f);
+      const int s = iy * SR + ix;
+      off[s] = v ? (ty.lo - ymin) * ps + (tx.lo - xmin) : 0;
+      w1[s] = v ? ty.h * tx.h : 0.f;
+      w2[s] = v ? ty.h * tx.l : 0.f;
+      w3[s] = v ? ty.l * tx.h : 0.f;
+      w4[s] = v ? ty.l * tx.l : 0.f;
+    }
+  }
+  const float inv_count = 1.f / static_cast<float>(NS);  // NS in {1,4}: exact reciprocal
+
+  // staging lanes: RS lanes walk one patch row, NT/RS rows in flight
+  const int RS = ps <= 16 ? 16 : (ps <= 32 ? 32 : 64);
+  const int lx = tid & (RS - 1);
+  const int lrow = tid / RS;
+  const int rstep = NT / RS;
+  const int ctb = min(cend - c0, kLdsPatchFloats / area);
+  for (int cs = c0; cs < cend; cs += ctb) {
+    const int cn = min(ctb, cend - cs);
+    const float* src = base + static_cast<size_t>(cs - c0) * plane;
+    const int total_rows = cn * rows;
+    for (int r = lrow; r < total_rows; r += rstep) {
+      const int c = r / rows;
+      const int y = r - c * rows;
+      const float* srow = src + static_cast<size_t>(c) * plane + static_cast<size_t>(min(ymin + y, H - 1)) * W;
+      float* drow = patch + r * ps;
+      for (int x = lx; x < ps; x += RS) drow[x] = srow[min(xmin + x, W - 1)];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < ny + nx; t += kBlock) {
-      if (t < ny) {
-        const Tap e = axis_entry(g.start_h, g.bin_h, t / g.gh, t % g.gh, g.gh, H, 1);
-        tabY[t] = e;
-        if (e.l != 0.f || e.h != 0.f) { atomicMin(&s_bounds[0], e.lo); atomicMax(&s_bounds[1], e.hi); }
-      } else {
-        const int u = t - ny;
-        const Tap e = axis_entry(g.start_w, g.bin_w, u / g.gw, u % g.gw, g.gw, W, 1);
-        tabX[u] = e;
-        if (e.l != 0.f || e.h != 0.f) { atomicMin(&s_bounds[2], e.lo); atomicMax(&s_bounds[3], e.hi); }
+    if (csub < G) {
+      float* o = obase + static_cast<size_t>(cs - c0) * BINS + bin;
+      for (int c = csub; c < cn; c += G) {
+#pragma clang fp contract(off)
+        const float* p = patch + c * area;
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const float* q = p + off[s];
+          acc += w1[s] * q[0] + w2[s] * q[1] + w3[s] * q[ps] + w4[s] * q[ps + 1];
+        }
+        o[static_cast<size_t>(c) * BINS] = acc * inv_count;
       }
     }
     __syncthreads();
-    if (s_bounds[1] < 0 || s_bounds[3] < 0) return;  // ROI entirely outside the map (uniform)
-    ymin = s_bounds[0];
-    py = s_bounds[1] - ymin + 1;
-    xmin = s_bounds[2];
-    px = s_bounds[3] - xmin + 1;
-    lds_path = (py * px) <= kPatchFloats;
   }
+}
 
-  if (lds_path) {
-    const int area = py * px;
-    const int ctb = min(cend - c0, kPatchFloats / area);
-    for (int cs = c0; cs < cend; cs += ctb) {
-      const int cn = min(ctb, cend - cs);
-      for (int e = threadIdx.x; e < cn * area; e += kBlock) patch[e] = 0.f;
-      __syncthreads();
-      const int total = cn * bins;
-      const float* go = gobase + static_cast<size_t>(cs - c0) * bins;
-      for (int o = threadIdx.x; o < total; o += kBlock) {
+// ------------------------------------------------------------------------------------------
+// backward, tile-centric: no global atomics, no separate zero-fill.
+//
+// The gradient maps are cut into TH x TW pixel tiles; one workgroup owns (level, image, tile,
+// CT channels), accumulates the contribution of EVERY ROI that touches its tile into an LDS
+// accumulator (ds_add_f32), and finally stores the tile with plain row-contiguous stores.  Each
+// gradient-map element is therefore written exactly once (tiles no ROI touches store zeros — the
+// zero-fill the reference gets from at::zeros, ROIAlign_cuda.cu:316, comes for free), and the
+// ~130 M global atomics / launch of the ROI-centric formulation (16 per gradient element in the
+// reference, ROIAlign_cuda.cu:246-249) disappear.  The price is redundant tap evaluation for ROIs
+// that straddle tiles (~2.3x at 32 x 64 tiles for box-head ROIs), paid in LDS/VALU cycles that are
+// not the bottleneck.  ROIs are visited in ascending index order (ballot compaction).
+// ------------------------------------------------------------------------------------------
+constexpr int kAccFloats = 8192;  // 32 KiB LDS accumulator: CT * TH * TW <= kAccFloats
+constexpr int kBwdList = 256;     // ROIs tested per scan round (one per thread)
+
+struct BwdPlan {
+  int first_item[DETOPS_MAX_LEVELS + 1];  // workgroup-id prefix per level
+  int tiles_x[DETOPS_MAX_LEVELS], tiles_y[DETOPS_MAX_LEVELS];
+  int TH, TW, CT, chunks, accumulate;
+};
+
+template <int PH_, int PW_, int kTabCap>
+__global__ void __launch_bounds__(kBlock)
+roi_align_bwd_tile_kernel(Levels L, BwdPlan P, const float* __restrict__ rois,
+                          const int32_t* __restrict__ levels_in, const float* __restrict__ gout, int C,
+                          int K, int PHr, int PWr, int sr) {
+  const int PH = PH_ ? PH_ : PHr;
+  const int PW = PW_ ? PW_ : PWr;
+  const int bins = PH * PW;
+  extern __shared__ float acc[];
+  __shared__ Tap tabY[kTabCap];
+  __shared__ Tap tabX[kTabCap];
+  __shared__ int s_list[kBwdList];
+  __shared__ int s_wcount[kBlock / kWave];
+
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  // ---- decode the work item
+  int lvl = 0;
+#pragma unroll
+  for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+    if (i < L.num && static_cast<int>(blockIdx.x) >= P.first_item[i]) lvl = i;
+  float* gin = L.lv[0].gin; int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
+  int ntx = P.tiles_x[0], nty = P.tiles_y[0];
+#pragma unroll
+  for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+    if (i == lvl) { gin = L.lv[i].gin; H = L.lv[i].H; W = L.lv[i].W; scale = L.lv[i].scale;
+                    ntx = P.tiles_x[i]; nty = P.tiles_y[i]; }
+  int rem = static_cast<int>(blockIdx.x) - P.first_item[lvl];
+  const int chunk = rem % P.chunks; rem /= P.chunks;
+  const int tix = rem % ntx; rem /= ntx;
+  const int tiy = rem % nty;
+  const int b = rem / nty;
+  const int TH = P.TH, TW = P.TW;
+  const int y0 = tiy * TH, x0 = tix * TW;
+  const int y1 = min(H, y0 + TH) - 1, x1 = min(W, x0 + TW) - 1;  // inclusive
+  const int c0 = chunk * P.CT;
+  const int cn = min(P.CT, C - c0);
+  const int tarea = TH * TW;
+
+  for (int e = tid; e < cn * tarea; e += kBlock) acc[e] = 0.f;
+  // (the first __syncthreads below orders the clear before any accumulation)
+
+  for (int kb = 0; kb < K; kb += kBwdList) {
+    // ---- which of ROIs [kb, kb+256) touch this tile?  ordered compaction
+    const int r = kb + tid;
+    bool hit = false;
+    if (r < K) {
+      const float* roi = rois + static_cast<size_t>(r) * 5;
+      const int rl = (L.num > 1) ? levels_in[r] : 0;
+      if (rl == lvl && static_cast<int>(roi[0]) == b) {
+#pragma clang fp contract(off)
+        const float sw = roi[1] * scale, sh = roi[2] * scale;
+        const float rw = fmaxf(roi[3] * scale - sw, 1.f), rh = fmaxf(roi[4] * scale - sh, 1.f);
+        // rows/cols any tap of this ROI can touch (conservative): floor(first) .. floor(last)+1
+        const float fy0 = floorf(fmaxf(sh, 0.f)), fy1 = floorf(sh + rh) + 1.f;
+        const float fx0 = floorf(fmaxf(sw, 0.f)), fx1 = floorf(sw + rw) + 1.f;
+        hit = fy0 <= static_cast<float>(y1) && fy1 >= static_cast<float>(y0) &&
+              fx0 <= static_cast<float>(x1) && fx1 >= static_cast<float>(x0);
+      }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_wcount[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < kBlock / kWave; ++j) {
+      const int v = s_wcount[j];
+      if (j < wave) before += v;
+      total += v;
+    }
+    if (hit) s_list[before + __popcll(m & ((1ull << lane) - 1ull))] = r;
+    __syncthreads();
+
+    for (int li = 0; li < total; ++li) {
+      const int k = s_list[li];
+      const float* roi = rois + static_cast<size_t>(k) * 5;
+      const RoiGeom g = roi_geometry(roi, scale, PH, PW, sr);
+      const int ny = PH * g.gh, nx = PW * g.gw;
+      const bool use_tab = (ny <= kTabCap) && (nx <= kTabCap);
+      if (use_tab) {
+        for (int t = tid; t < ny + nx; t += kBlock) {
+          if (t < ny) tabY[t] = axis_entry(g.start_h, g.bin_h, t / g.gh, t % g.gh, g.gh, H, 1);
+          else { const int u = t - ny; tabX[u] = axis_entry(g.start_w, g.bin_w, u / g.gw, u % g.gw, g.gw, W, 1); }
+        }
+        __syncthreads();
+      }
+      const int icount = g.gh * g.gw;
+      const bool pow2 = (icount & (icount - 1)) == 0;
+      const float inv_count = 1.f / g.count;
+      const float* go = gout + (static_cast<size_t>(k) * C + c0) * bins;
+      for (int o = tid; o < cn * bins; o += kBlock) {
 #pragma clang fp contract(off)
         const int cl = o / bins;
         const int bin = o - cl * bins;
         const int ph = bin / PW;
         const int pw = bin - ph * PW;
         const float gval = go[o];
-        float* pp = patch + cl * area;
+        float* a = acc + cl * tarea;
         for (int iy = 0; iy < g.gh; ++iy) {
-          const Tap ty = tabY[ph * g.gh + iy];
-          if (ty.l == 0.f && ty.h == 0.f) continue;
-          const int r0 = (ty.lo - ymin) * px - xmin;
-          const int r1 = (ty.hi - ymin) * px - xmin;
+          const Tap ty = use_tab ? tabY[ph * g.gh + iy] : axis_entry(g.start_h, g.bin_h, ph, iy, g.gh, H, 1);
+          if ((ty.l == 0.f && ty.h == 0.f) || ty.hi < y0 || ty.lo > y1) continue;
+          const bool in0 = ty.lo >= y0, in1 = ty.hi <= y1;
+          const int r0 = (ty.lo - y0) * TW - x0, r1 = (ty.hi - y0) * TW - x0;
           for (int ix = 0; ix < g.gw; ++ix) {
-            const Tap tx = tabX[pw * g.gw + ix];
-            if (tx.l == 0.f && tx.h == 0.f) continue;
+            const Tap tx = use_tab ? tabX[pw * g.gw + ix] : axis_entry(g.start_w, g.bin_w, pw, ix, g.gw, W, 1);
+            if ((tx.l == 0.f && tx.h == 0.f) || tx.hi < x0 || tx.lo > x1) continue;
+            const bool jn0 = tx.lo >= x0, jn1 = tx.hi <= x1;
             const float w1 = ty.h * tx.h, w2 = ty.h * tx.l, w3 = ty.l * tx.h, w4 = ty.l * tx.l;
             float g1 = gval * w1, g2 = gval * w2, g3 = gval * w3, g4 = gval * w4;
             if (pow2) { g1 *= inv_count; g2 *= inv_count; g3 *= inv_count; g4 *= inv_count; }
             else { g1 /= g.count; g2 /= g.count; g3 /= g.count; g4 /= g.count; }
-            atomicAdd(pp + r0 + tx.lo, g1);
-            atomicAdd(pp + r0 + tx.hi, g2);
-            atomicAdd(pp + r1 + tx.lo, g3);
-            atomicAdd(pp + r1 + tx.hi, g4);
+            if (in0 && jn0) atomicAdd(a + r0 + tx.lo, g1);
+            if (in0 && jn1) atomicAdd(a + r0 + tx.hi, g2);
+            if (in1 && jn0) atomicAdd(a + r1 + tx.lo, g3);
+            if (in1 && jn1) atomicAdd(a + r1 + tx.hi, g4);
           }
         }
       }
-      __syncthreads();
-      float* gb = gbase + static_cast<size_t>(cs - c0) * plane + static_cast<size_t>(ymin) * W + xmin;
-      for (int e = threadIdx.x; e < cn * area; e += kBlock) {
-        const float v = patch[e];
-        if (v != 0.f) {
-          const int cl = e / area;
-          const int r = e - cl * area;
-          const int y = r / px;
-          const int x = r - y * px;
-          atomicAdd(gb + static_cast<size_t>(cl) * plane + y * W + x, v);
-        }
-      }
-      __syncthreads();
+      __syncthreads();  // tables are rebuilt for the next ROI
     }
-    return;
   }
+  __syncthreads();
 
-  // Fallback (huge adaptive grids or patches): direct global atomics, reference-style scatter.
-  const int total = (cend - c0) * bins;
-  for (int o = threadIdx.x; o < total; o += kBlock) {
-#pragma clang fp contract(off)
-    const int cl = o / bins;
-    const int bin = o - cl * bins;
-    const int ph = bin / PW;
-    const int pw = bin - ph * PW;
-    const float gval = gobase[o];
-    float* d = gbase + static_cast<size_t>(cl) * plane;
-    for (int iy = 0; iy < g.gh; ++iy) {
-      const Tap ty = use_tab ? tabY[ph * g.gh + iy]
-                             : axis_entry(g.start_h, g.bin_h, ph, iy, g.gh, H, 1);
-      if (ty.l == 0.f && ty.h == 0.f) continue;
-      float* d0 = d + static_cast<size_t>(ty.lo) * W;
-      float* d1 = d + static_cast<size_t>(ty.hi) * W;
-      for (int ix = 0; ix < g.gw; ++ix) {
-        const Tap tx = use_tab ? tabX[pw * g.gw + ix]
-                               : axis_entry(g.start_w, g.bin_w, pw, ix, g.gw, W, 1);
-        if (tx.l == 0.f && tx.h == 0.f) continue;
-        const float w1 = ty.h * tx.h, w2 = ty.h * tx.l, w3 = ty.l * tx.h, w4 = ty.l * tx.l;
-        atomicAdd(d0 + tx.lo, gval * w1 / g.count);
-        atomicAdd(d0 + tx.hi, gval * w2 / g.count);
-        atomicAdd(d1 + tx.lo, gval * w3 / g.count);
-        atomicAdd(d1 + tx.hi, gval * w4 / g.count);
-      }
+  // ---- store the tile (row-contiguous); every in-map element of the tile is written exactly once
+  const size_t plane = static_cast<size_t>(H) * W;
+  float* gb = gin + (static_cast<size_t>(b) * C + c0) * plane;
+  const int tw_valid = x1 - x0 + 1, th_valid = y1 - y0 + 1;
+  for (int e = tid; e < cn * tarea; e += kBlock) {
+    const int cl = e / tarea;
+    const int rr = e - cl * tarea;
+    const int y = rr / TW;
+    const int x = rr - y * TW;
+    if (y < th_valid && x < tw_valid) {
+      float* dst = gb + static_cast<size_t>(cl) * plane + static_cast<size_t>(y0 + y) * W + (x0 + x);
+      float v = acc[e];
+      if (P.accumulate) v += *dst;
+      *dst = v;
     }
   }
 }
@@ -358,9 +529,34 @@ inline void dispatch_shape(int PH, int PW, int sr, F&& f) {
   else f(IC<0>{}, IC<0>{}, IC<kTabBig>{});
 }
 
+template <int PH, int PW, int SR, int G>
+void launch_fwd_lds(const Levels& L, const float* rois, const int32_t* levels_in, int32_t* levels_out,
+                    float* out, int C, int K, hipStream_t st) {
+  constexpr int NT = ((PH * PW * G + 63) / 64) * 64;
+  int CT = 64;  // channels per workgroup: >= 4 x 256 workgroups when the problem allows it
+  while (CT > 16 && static_cast<int64_t>(K) * ceil_div64(C, CT) < 4 * kNumCU) CT >>= 1;
+  if (CT > C) CT = C;
+  const int chunks = static_cast<int>(ceil_div64(C, CT));
+  hipLaunchKernelGGL((roi_align_fwd_lds_kernel<PH, PW, SR, G>), dim3(static_cast<unsigned>(K) * chunks),
+                     dim3(NT), (kLdsPatchFloats + 64) * sizeof(float), st, L, rois, levels_in, levels_out,
+                     out, C, K, CT, chunks);
+}
+
 int run_forward(const Levels& L, const float* rois, const int32_t* levels_in, int32_t* levels_out,
                 float* out, int C, int K, int PH, int PW, int sr, hipStream_t st) {
   if (K == 0 || C == 0) return 0;
+  if (PH == 7 && PW == 7 && sr == 2) {
+    launch_fwd_lds<7, 7, 2, 5>(L, rois, levels_in, levels_out, out, C, K, st);
+    return launch_status();
+  }
+  if (PH == 14 && PW == 14 && sr == 2) {
+    launch_fwd_lds<14, 14, 2, 2>(L, rois, levels_in, levels_out, out, C, K, st);
+    return launch_status();
+  }
+  if (PH == 7 && PW == 7 && sr == 1) {
+    launch_fwd_lds<7, 7, 1, 5>(L, rois, levels_in, levels_out, out, C, K, st);
+    return launch_status();
+  }
   const int CT = pick_chunk(C, K);
   const int chunks = static_cast<int>(ceil_div64(C, CT));
   const dim3 grid(static_cast<unsigned>(K) * chunks);
@@ -372,15 +568,46 @@ int run_forward(const Levels& L, const float* rois, const int32_t* levels_in, in
   return launch_status();
 }
 
-int run_backward(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
-                 int C, int K, int PH, int PW, int sr, hipStream_t st) {
-  if (K == 0 || C == 0) return 0;
-  const int CT = pick_chunk(C, K);
-  const int chunks = static_cast<int>(ceil_div64(C, CT));
-  const dim3 grid(static_cast<unsigned>(K) * chunks);
+inline int pow2_at_least(int v, int cap) {
+  int p = 1;
+  while (p < v && p < cap) p <<= 1;
+  return p;
+}
+
+int run_backward_tiles(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
+                       int N, int C, int K, int PH, int PW, int sr, int accumulate, hipStream_t st) {
+  if (C == 0 || N == 0) return 0;
+  int Hmax = 0, Wmax = 0;
+  for (int i = 0; i < L.num; ++i) { Hmax = max(Hmax, L.lv[i].H); Wmax = max(Wmax, L.lv[i].W); }
+  BwdPlan P{};
+  P.TW = pow2_at_least(Wmax, 64);
+  P.TH = pow2_at_least(Hmax, 32);
+  P.accumulate = accumulate;
+  int CT = min(4, max(1, kAccFloats / (P.TH * P.TW)));
+  CT = min(CT, C);
+  auto count_items = [&](int ct) {
+    int64_t items = 0;
+    for (int i = 0; i < L.num; ++i)
+      items += static_cast<int64_t>(N) * ceil_div64(L.lv[i].H, P.TH) * ceil_div64(L.lv[i].W, P.TW) * ceil_div64(C, ct);
+    return items;
+  };
+  while (CT > 1 && count_items(CT) < 4 * kNumCU) CT >>= 1;
+  P.CT = CT;
+  P.chunks = static_cast<int>(ceil_div64(C, CT));
+  int64_t items = 0;
+  for (int i = 0; i < L.num; ++i) {
+    P.tiles_x[i] = static_cast<int>(ceil_div64(L.lv[i].W, P.TW));
+    P.tiles_y[i] = static_cast<int>(ceil_div64(L.lv[i].H, P.TH));
+    P.first_item[i] = static_cast<int>(items);
+    items += static_cast<int64_t>(N) * P.tiles_x[i] * P.tiles_y[i] * P.chunks;
+  }
+  for (int i = L.num; i <= DETOPS_MAX_LEVELS; ++i) P.first_item[i] = static_cast<int>(items);
+  if (items > 0x7fffffff) return DETOPS_EUNSUPPORTED;
+  const size_t lds = sizeof(float) * static_cast<size_t>(CT) * P.TH * P.TW;
   dispatch_shape(PH, PW, sr, [&](auto ph, auto pw, auto tab) {
-    hipLaunchKernelGGL((roi_align_bwd_kernel<decltype(ph)::value, decltype(pw)::value, decltype(tab)::value>), grid,
-                       dim3(kBlock), 0, st, L, rois, levels_in, gout, C, K, PH, PW, sr, CT, chunks);
+    hipLaunchKernelGGL((roi_align_bwd_tile_kernel<decltype(ph)::value, decltype(pw)::value, decltype(tab)::value>),
+                       dim3(static_cast<unsigned>(items)), dim3(kBlock), lds, st, L, P, rois, levels_in, gout,
+                       C, K, PH, PW, sr);
   });
   return launch_status();
 }
@@ -412,15 +639,15 @@ DETOPS_API int detops_roi_align_backward_f32(const float* grad_out, const float*
                                              detops_stream_t stream) {
   if (bad_dims(N, C, K, PH, PW) || H < 0 || W < 0) return DETOPS_EINVAL;
   const size_t bytes = sizeof(float) * static_cast<size_t>(N) * C * H * W;
-  if (bytes && !grad_in) return DETOPS_EINVAL;
-  hipStream_t st = as_stream(stream);
-  if (zero_grad_in && bytes) DETOPS_HIP_TRY(hipMemsetAsync(grad_in, 0, bytes, st));
-  if (K == 0 || C == 0 || bytes == 0) return 0;
-  if (!grad_out || !rois) return DETOPS_EINVAL;
+  if (bytes == 0) return 0;
+  if (!grad_in) return DETOPS_EINVAL;
+  if (K > 0 && (!grad_out || !rois)) return DETOPS_EINVAL;
+  if (K == 0 && !zero_grad_in) return 0;
   Levels L{};
   L.num = 1;
   L.lv[0] = Level{nullptr, grad_in, H, W, spatial_scale};
-  return run_backward(L, rois, nullptr, grad_out, C, K, PH, PW, sampling_ratio, st);
+  return run_backward_tiles(L, rois, nullptr, grad_out, N, C, K, PH, PW, sampling_ratio,
+                            zero_grad_in ? 0 : 1, as_stream(stream));
 }
 
 DETOPS_API int detops_roi_align_fpn_forward_f32(
@@ -453,18 +680,15 @@ DETOPS_API int detops_roi_align_fpn_backward_f32(
   if (bad_dims(N, C, K, PH, PW) || num_levels < 1 || num_levels > DETOPS_MAX_LEVELS ||
       !grad_inputs_host || !H_host || !W_host || !scale_host)
     return DETOPS_EINVAL;
-  hipStream_t st = as_stream(stream);
   Levels L{};
   L.num = num_levels;
   for (int i = 0; i < num_levels; ++i) {
     if (!grad_inputs_host[i] || H_host[i] <= 0 || W_host[i] <= 0) return DETOPS_EINVAL;
     L.lv[i] = Level{nullptr, grad_inputs_host[i], H_host[i], W_host[i], scale_host[i]};
-    if (zero_grad_in) {
-      const size_t bytes = sizeof(float) * static_cast<size_t>(N) * C * H_host[i] * W_host[i];
-      if (bytes) DETOPS_HIP_TRY(hipMemsetAsync(grad_inputs_host[i], 0, bytes, st));
-    }
   }
-  if (K == 0 || C == 0 || N == 0) return 0;
-  if (!grad_out || !rois || (num_levels > 1 && !levels)) return DETOPS_EINVAL;
-  return run_backward(L, rois, levels, grad_out, C, K, PH, PW, sampling_ratio, st);
+  if (C == 0 || N == 0) return 0;
+  if (K > 0 && (!grad_out || !rois || (num_levels > 1 && !levels))) return DETOPS_EINVAL;
+  if (K == 0 && !zero_grad_in) return 0;
+  return run_backward_tiles(L, rois, levels, grad_out, N, C, K, PH, PW, sampling_ratio,
+                            zero_grad_in ? 0 : 1, as_stream(stream));
 }

@@ -16,7 +16,6 @@ see exactly the reference's variable-length BoxLists.
 import torch
 
 from maskrcnn_benchmark import _C
-from maskrcnn_benchmark.layers._amp import float_function
 from maskrcnn_benchmark.modeling.box_coder import BoxCoder
 from maskrcnn_benchmark.structures.bounding_box import BoxList
 
@@ -67,9 +66,14 @@ class RPNPostProcessor(torch.nn.Module):
             self._seg_cache[key] = torch.tensor(offs, dtype=torch.int32).to(device)
         return self._seg_cache[key]
 
-    @float_function
     def select(self, anchors_per_level, objectness, box_regression, image_sizes, training):
-        """-> boxes [N,K,4], scores [N,K], valid [N,K] with K = sum_l k_l (level-major per image)."""
+        """-> boxes [N,K,4], scores [N,K], valid [N,K] with K = sum_l k_l (level-major per image).
+        Runs in fp32 with autocast off (the reference marks nms as an fp32 function, layers/nms.py:8)."""
+        with torch.autocast(device_type=objectness[0].device.type, enabled=False):
+            return self._select(anchors_per_level, [o.float() for o in objectness],
+                                [r.float() for r in box_regression], image_sizes, training)
+
+    def _select(self, anchors_per_level, objectness, box_regression, image_sizes, training):
         N = objectness[0].shape[0]
         boxes, scores, oks = [], [], []
         for a, o, r in zip(anchors_per_level, objectness, box_regression):
@@ -79,9 +83,7 @@ class RPNPostProcessor(torch.nn.Module):
             oks.append(ok)
         ks = [b.shape[1] for b in boxes]
         dev = boxes[0].device
-        # one segmented NMS over all (level, image) problems; failed min_size boxes get a score
-        # below every real one and are masked out afterwards (they cannot suppress a real box that
-        # precedes them, and a box they suppress is... they are visited last) — see below.
+        # one segmented NMS over all (level, image) problems
         flat_boxes = torch.cat([b.reshape(-1, 4) for b in boxes], dim=0)
         flat_scores = torch.cat([s.reshape(-1) for s in scores], dim=0)
         flat_ok = torch.cat([k.reshape(-1) for k in oks], dim=0)

@@ -133,6 +133,53 @@ def test_roi_align_backward_fpn_full_size_and_fused():
     torch.testing.assert_close(gins[0], p2, rtol=1e-4, atol=1e-4)
 
 
+def test_roi_align_backward_tile_seams_and_accumulate_flag():
+    """ROIs straddling several 32x64 gradient tiles (odd map size, multi-image) against the oracle,
+    and the C ABI's zero_grad_in = 0 mode (accumulate into the caller's buffer)."""
+    import ctypes
+    from maskrcnn_benchmark import _lib
+    rng = np.random.RandomState(11)
+    N, C, H, W = 2, 6, 75, 150
+    K = 160
+    x1 = rng.uniform(-20, 560, K); y1 = rng.uniform(-20, 280, K)
+    rois = np.stack([rng.randint(0, N, K), x1, y1, x1 + rng.uniform(2, 400, K), y1 + rng.uniform(2, 250, K)], 1).astype(np.float32)
+    for (ph, pw, sr) in ((7, 7, 2), (14, 14, 2), (5, 3, 0)):
+        g = rng.randn(K, C, ph, pw).astype(np.float32)
+        ref = oracle.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, acc64=True)
+        out = _C().roi_align_backward(_t(g), _t(rois), 0.25, ph, pw, N, C, H, W, sr)
+        _close(out, ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()))
+        base = rng.randn(N, C, H, W).astype(np.float32)
+        buf = _t(base)
+        tg, tr = _t(g), _t(rois)
+        rc = _lib.lib.detops_roi_align_backward_f32(tg.data_ptr(), tr.data_ptr(), buf.data_ptr(), N, C, H, W, K, ph, pw,
+                                                    ctypes.c_float(0.25), sr, 0, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        _close(buf, base + ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()))
+    # K = 0 with zero-fill: a pure clear
+    buf = _t(rng.randn(N, C, H, W).astype(np.float32))
+    e = torch.empty((0, 5), device=DEV)
+    rc = _lib.lib.detops_roi_align_backward_f32(None, e.data_ptr(), buf.data_ptr(), N, C, H, W, 0, 7, 7, ctypes.c_float(0.25), 2, 1,
+                                                torch.cuda.current_stream().cuda_stream)
+    assert rc == 0 and float(buf.abs().sum()) == 0.0
+
+
+def test_roi_align_forward_lds_path_large_and_tiny_rois():
+    """fixed-grid fast path: footprints larger than the LDS budget (falls back to gathers inside the
+    kernel), 1-pixel ROIs, ROIs hanging over every border — all bit-equal to the oracle."""
+    rng = np.random.RandomState(12)
+    N, C, H, W = 2, 40, 120, 200
+    inp = rng.randn(N, C, H, W).astype(np.float32)
+    rois = np.array([[0, 0, 0, 799, 479], [1, -50, -50, 900, 600], [0, 10.3, 20.7, 10.9, 21.2], [1, 790, 470, 830, 500],
+                     [0, 400, 0, 420, 479], [1, 0, 200, 799, 210], [0, 795.9, 475.9, 796.0, 476.0]], np.float32)
+    rois = np.concatenate([rois, np.stack([rng.randint(0, N, 60), rng.uniform(0, 700, 60), rng.uniform(0, 400, 60),
+                                           rng.uniform(0, 799, 60), rng.uniform(0, 479, 60)], 1).astype(np.float32)])
+    rois[7:, 3] = np.maximum(rois[7:, 3], rois[7:, 1]); rois[7:, 4] = np.maximum(rois[7:, 4], rois[7:, 2])
+    for (ph, pw, sr) in ((7, 7, 2), (14, 14, 2), (7, 7, 1)):
+        out = _C().roi_align_forward(_t(inp), _t(rois), 0.25, ph, pw, sr).cpu().numpy()
+        ref = oracle.roi_align_forward(inp, rois, 0.25, ph, pw, sr)
+        assert np.array_equal(out, ref), "max diff %g" % np.abs(out - ref).max()
+
+
 def test_roi_align_adjoint_and_linearity_full_size():
     """<fwd(x), g> == <x, bwd(g)> and bwd is linear — size-independent properties at cfg-2 scale."""
     C = _C()
