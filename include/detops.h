@@ -208,6 +208,24 @@ int detops_deformable_col2im_coord(const void* col, const void* im, const void* 
                                    int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
                                    int dil_w, int deformable_group, detops_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused FrozenBatchNorm2d affine (+ residual) (+ ReLU) — the elementwise tail of every backbone
+ * convolution: layers/batch_norm.py:19-31 (`x * scale + bias`), then `F.relu_`, and in the
+ * bottleneck tail `out += identity; relu` (modeling/backbone/resnet.py:343-366).
+ *   x, residual (nullable), y: [N, C, HW] contiguous (NCHW), dtype code as above (fp32 arithmetic)
+ *   scale, bias: fp32 [C]   (scale = weight * rsqrt(running_var), bias = bias - running_mean * scale)
+ *   forward : y = [relu]( x * scale[c] + bias[c] [+ residual] )
+ *   backward: g = relu ? (y > 0 ? grad_y : 0) : grad_y;  grad_x = g * scale[c];
+ *             grad_residual (nullable) = g
+ * ---------------------------------------------------------------------------------------- */
+int detops_frozen_bn_act_forward(const void* x, const float* scale, const float* bias,
+                                 const void* residual, void* y, int dtype, int N, int C, int HW,
+                                 int relu, detops_stream_t stream);
+
+int detops_frozen_bn_act_backward(const void* grad_y, const void* y, const float* scale,
+                                  void* grad_x, void* grad_residual, int dtype, int N, int C,
+                                  int HW, int relu, detops_stream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -21,6 +21,7 @@
 //     keeps its bin's sample offsets + weights in registers across the channel loop (see below).
 //   * backward: tile-centric — a workgroup owns a pixel tile of one gradient map and accumulates
 //     every overlapping ROI in LDS; no global atomics, no separate zero-fill (see below).
+#include <cstdlib>
 #include <type_traits>
 
 #include "detops_common.h"
@@ -309,26 +310,40 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
   }
   const float inv_count = 1.f / static_cast<float>(NS);  // NS in {1,4}: exact reciprocal
 
-  // staging lanes: RS lanes walk one patch row, NT/RS rows in flight
-  const int RS = ps <= 16 ? 16 : (ps <= 32 ? 32 : 64);
-  const int lx = tid & (RS - 1);
-  const int lrow = tid / RS;
-  const int rstep = NT / RS;
+  // staging: element-linear over the patch (lanes run along a patch row, wrap to the next row), four
+  // independent loads in flight per lane before the first LDS store (the loop is latency-bound
+  // otherwise: one L2/MALL round trip per iteration)
+  const float inv_ps = 1.f / static_cast<float>(ps), inv_rows = 1.f / static_cast<float>(rows);
+  constexpr int U = 4;
   const int ctb = min(cend - c0, kLdsPatchFloats / area);
   for (int cs = c0; cs < cend; cs += ctb) {
     const int cn = min(ctb, cend - cs);
     const float* src = base + static_cast<size_t>(cs - c0) * plane;
-    const int total_rows = cn * rows;
-    for (int r = lrow; r < total_rows; r += rstep) {
-      const int c = r / rows;
-      const int y = r - c * rows;
-      const float* srow = src + static_cast<size_t>(c) * plane + static_cast<size_t>(min(ymin + y, H - 1)) * W;
-      float* drow = patch + r * ps;
-      for (int x = lx; x < ps; x += RS) drow[x] = srow[min(xmin + x, W - 1)];
+    const int total = cn * area;
+    for (int e0 = tid; e0 < total; e0 += NT * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * NT;
+        v[u] = 0.f;
+        if (e < total) {
+          const int r = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_ps);   // e / ps  (exact: e < 8192)
+          const int x = e - r * ps;
+          const int c = static_cast<int>((static_cast<float>(r) + 0.5f) * inv_rows);  // r / rows
+          const int y = r - c * rows;
+          v[u] = src[static_cast<size_t>(c) * plane + static_cast<size_t>(min(ymin + y, H - 1)) * W + min(xmin + x, W - 1)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * NT;
+        if (e < total) patch[e] = v[u];
+      }
     }
     __syncthreads();
     if (csub < G) {
       float* o = obase + static_cast<size_t>(cs - c0) * BINS + bin;
+#pragma unroll 2
       for (int c = csub; c < cn; c += G) {
 #pragma clang fp contract(off)
         const float* p = patch + c * area;
@@ -367,7 +382,13 @@ struct BwdPlan {
   int TH, TW, CT, chunks, accumulate;
 };
 
-template <int PH_, int PW_, int kTabCap>
+// Geometry of a ROI that touches the tile, parked in LDS for the unit loop.
+struct HitGeom {
+  float start_w, start_h, bin_w, bin_h;
+  int k, gh, gw;
+};
+
+template <int PH_, int PW_, int SR_>
 __global__ void __launch_bounds__(kBlock)
 roi_align_bwd_tile_kernel(Levels L, BwdPlan P, const float* __restrict__ rois,
                           const int32_t* __restrict__ levels_in, const float* __restrict__ gout, int C,
@@ -376,9 +397,7 @@ roi_align_bwd_tile_kernel(Levels L, BwdPlan P, const float* __restrict__ rois,
   const int PW = PW_ ? PW_ : PWr;
   const int bins = PH * PW;
   extern __shared__ float acc[];
-  __shared__ Tap tabY[kTabCap];
-  __shared__ Tap tabX[kTabCap];
-  __shared__ int s_list[kBwdList];
+  __shared__ HitGeom s_hit[kBwdList];
   __shared__ int s_wcount[kBlock / kWave];
 
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -404,24 +423,26 @@ roi_align_bwd_tile_kernel(Levels L, BwdPlan P, const float* __restrict__ rois,
   const int c0 = chunk * P.CT;
   const int cn = min(P.CT, C - c0);
   const int tarea = TH * TW;
+  const int upr = cn * bins;  // units per ROI: (channel, bin), bin fastest -> coalesced gout reads
 
   for (int e = tid; e < cn * tarea; e += kBlock) acc[e] = 0.f;
   // (the first __syncthreads below orders the clear before any accumulation)
 
   for (int kb = 0; kb < K; kb += kBwdList) {
-    // ---- which of ROIs [kb, kb+256) touch this tile?  ordered compaction
+    // ---- which of ROIs [kb, kb+256) touch this tile?  ordered compaction into s_hit
     const int r = kb + tid;
     bool hit = false;
+    RoiGeom g{};
     if (r < K) {
       const float* roi = rois + static_cast<size_t>(r) * 5;
       const int rl = (L.num > 1) ? levels_in[r] : 0;
       if (rl == lvl && static_cast<int>(roi[0]) == b) {
 #pragma clang fp contract(off)
-        const float sw = roi[1] * scale, sh = roi[2] * scale;
-        const float rw = fmaxf(roi[3] * scale - sw, 1.f), rh = fmaxf(roi[4] * scale - sh, 1.f);
+        g = roi_geometry(roi, scale, PH, PW, SR_ ? SR_ : sr);
+        const float rh = g.bin_h * static_cast<float>(PH), rw = g.bin_w * static_cast<float>(PW);
         // rows/cols any tap of this ROI can touch (conservative): floor(first) .. floor(last)+1
-        const float fy0 = floorf(fmaxf(sh, 0.f)), fy1 = floorf(sh + rh) + 1.f;
-        const float fx0 = floorf(fmaxf(sw, 0.f)), fx1 = floorf(sw + rw) + 1.f;
+        const float fy0 = floorf(fmaxf(g.start_h, 0.f)), fy1 = floorf(g.start_h + rh) + 2.f;
+        const float fx0 = floorf(fmaxf(g.start_w, 0.f)), fx1 = floorf(g.start_w + rw) + 2.f;
         hit = fy0 <= static_cast<float>(y1) && fy1 >= static_cast<float>(y0) &&
               fx0 <= static_cast<float>(x1) && fx1 >= static_cast<float>(x0);
       }
@@ -436,58 +457,54 @@ roi_align_bwd_tile_kernel(Levels L, BwdPlan P, const float* __restrict__ rois,
       if (j < wave) before += v;
       total += v;
     }
-    if (hit) s_list[before + __popcll(m & ((1ull << lane) - 1ull))] = r;
+    if (hit) {
+      HitGeom h;
+      h.start_w = g.start_w; h.start_h = g.start_h; h.bin_w = g.bin_w; h.bin_h = g.bin_h;
+      h.k = r; h.gh = g.gh; h.gw = g.gw;
+      s_hit[before + __popcll(m & ((1ull << lane) - 1ull))] = h;
+    }
     __syncthreads();
 
-    for (int li = 0; li < total; ++li) {
-      const int k = s_list[li];
-      const float* roi = rois + static_cast<size_t>(k) * 5;
-      const RoiGeom g = roi_geometry(roi, scale, PH, PW, sr);
-      const int ny = PH * g.gh, nx = PW * g.gw;
-      const bool use_tab = (ny <= kTabCap) && (nx <= kTabCap);
-      if (use_tab) {
-        for (int t = tid; t < ny + nx; t += kBlock) {
-          if (t < ny) tabY[t] = axis_entry(g.start_h, g.bin_h, t / g.gh, t % g.gh, g.gh, H, 1);
-          else { const int u = t - ny; tabX[u] = axis_entry(g.start_w, g.bin_w, u / g.gw, u % g.gw, g.gw, W, 1); }
-        }
-        __syncthreads();
-      }
-      const int icount = g.gh * g.gw;
-      const bool pow2 = (icount & (icount - 1)) == 0;
-      const float inv_count = 1.f / g.count;
-      const float* go = gout + (static_cast<size_t>(k) * C + c0) * bins;
-      for (int o = tid; o < cn * bins; o += kBlock) {
+    // ---- flat unit loop over (hit ROI, channel, bin): no per-ROI barriers, every lane busy
+    const int units = total * upr;
+    for (int u = tid; u < units; u += kBlock) {
 #pragma clang fp contract(off)
-        const int cl = o / bins;
-        const int bin = o - cl * bins;
-        const int ph = bin / PW;
-        const int pw = bin - ph * PW;
-        const float gval = go[o];
-        float* a = acc + cl * tarea;
-        for (int iy = 0; iy < g.gh; ++iy) {
-          const Tap ty = use_tab ? tabY[ph * g.gh + iy] : axis_entry(g.start_h, g.bin_h, ph, iy, g.gh, H, 1);
-          if ((ty.l == 0.f && ty.h == 0.f) || ty.hi < y0 || ty.lo > y1) continue;
-          const bool in0 = ty.lo >= y0, in1 = ty.hi <= y1;
-          const int r0 = (ty.lo - y0) * TW - x0, r1 = (ty.hi - y0) * TW - x0;
-          for (int ix = 0; ix < g.gw; ++ix) {
-            const Tap tx = use_tab ? tabX[pw * g.gw + ix] : axis_entry(g.start_w, g.bin_w, pw, ix, g.gw, W, 1);
-            if ((tx.l == 0.f && tx.h == 0.f) || tx.hi < x0 || tx.lo > x1) continue;
-            const bool jn0 = tx.lo >= x0, jn1 = tx.hi <= x1;
-            const float w1 = ty.h * tx.h, w2 = ty.h * tx.l, w3 = ty.l * tx.h, w4 = ty.l * tx.l;
-            float g1 = gval * w1, g2 = gval * w2, g3 = gval * w3, g4 = gval * w4;
-            if (pow2) { g1 *= inv_count; g2 *= inv_count; g3 *= inv_count; g4 *= inv_count; }
-            else { g1 /= g.count; g2 /= g.count; g3 /= g.count; g4 /= g.count; }
-            if (in0 && jn0) atomicAdd(a + r0 + tx.lo, g1);
-            if (in0 && jn1) atomicAdd(a + r0 + tx.hi, g2);
-            if (in1 && jn0) atomicAdd(a + r1 + tx.lo, g3);
-            if (in1 && jn1) atomicAdd(a + r1 + tx.hi, g4);
-          }
+      const int li = u / upr;
+      const int o = u - li * upr;
+      const int cl = o / bins;
+      const int bin = o - cl * bins;
+      const int ph = bin / PW;
+      const int pw = bin - ph * PW;
+      const HitGeom h = s_hit[li];
+      const float gval = gout[(static_cast<size_t>(h.k) * C + c0) * bins + o];
+      const int gh = SR_ ? SR_ : h.gh, gw = SR_ ? SR_ : h.gw;
+      const int icount = gh * gw;
+      const float count = static_cast<float>(icount);
+      const bool pow2 = (icount & (icount - 1)) == 0;
+      const float inv_count = 1.f / count;
+      float* a = acc + cl * tarea;
+      for (int iy = 0; iy < gh; ++iy) {
+        const Tap ty = axis_entry(h.start_h, h.bin_h, ph, iy, gh, H, 1);
+        if ((ty.l == 0.f && ty.h == 0.f) || ty.hi < y0 || ty.lo > y1) continue;
+        const bool in0 = ty.lo >= y0, in1 = ty.hi <= y1;
+        const int r0 = (ty.lo - y0) * TW - x0, r1 = (ty.hi - y0) * TW - x0;
+        for (int ix = 0; ix < gw; ++ix) {
+          const Tap tx = axis_entry(h.start_w, h.bin_w, pw, ix, gw, W, 1);
+          if ((tx.l == 0.f && tx.h == 0.f) || tx.hi < x0 || tx.lo > x1) continue;
+          const bool jn0 = tx.lo >= x0, jn1 = tx.hi <= x1;
+          const float w1 = ty.h * tx.h, w2 = ty.h * tx.l, w3 = ty.l * tx.h, w4 = ty.l * tx.l;
+          float g1 = gval * w1, g2 = gval * w2, g3 = gval * w3, g4 = gval * w4;
+          if (pow2) { g1 *= inv_count; g2 *= inv_count; g3 *= inv_count; g4 *= inv_count; }
+          else { g1 /= count; g2 /= count; g3 /= count; g4 /= count; }
+          if (in0 && jn0) atomicAdd(a + r0 + tx.lo, g1);
+          if (in0 && jn1) atomicAdd(a + r0 + tx.hi, g2);
+          if (in1 && jn0) atomicAdd(a + r1 + tx.lo, g3);
+          if (in1 && jn1) atomicAdd(a + r1 + tx.hi, g4);
         }
       }
-      __syncthreads();  // tables are rebuilt for the next ROI
     }
+    __syncthreads();  // s_hit / s_wcount are rewritten by the next round
   }
-  __syncthreads();
 
   // ---- store the tile (row-contiguous); every in-map element of the tile is written exactly once
   const size_t plane = static_cast<size_t>(H) * W;
@@ -545,15 +562,21 @@ void launch_fwd_lds(const Levels& L, const float* rois, const int32_t* levels_in
 int run_forward(const Levels& L, const float* rois, const int32_t* levels_in, int32_t* levels_out,
                 float* out, int C, int K, int PH, int PW, int sr, hipStream_t st) {
   if (K == 0 || C == 0) return 0;
-  if (PH == 7 && PW == 7 && sr == 2) {
+  // DETOPS_ROIALIGN_FWD=generic forces the gather kernel (A/B measurements; default: LDS fast path)
+  static const bool force_generic = [] {
+    const char* e = getenv("DETOPS_ROIALIGN_FWD");
+    return e && e[0] == 'g';
+  }();
+  if (force_generic) {
+  } else if (PH == 7 && PW == 7 && sr == 2) {
     launch_fwd_lds<7, 7, 2, 5>(L, rois, levels_in, levels_out, out, C, K, st);
     return launch_status();
   }
-  if (PH == 14 && PW == 14 && sr == 2) {
+  else if (PH == 14 && PW == 14 && sr == 2) {
     launch_fwd_lds<14, 14, 2, 2>(L, rois, levels_in, levels_out, out, C, K, st);
     return launch_status();
   }
-  if (PH == 7 && PW == 7 && sr == 1) {
+  else if (PH == 7 && PW == 7 && sr == 1) {
     launch_fwd_lds<7, 7, 1, 5>(L, rois, levels_in, levels_out, out, C, K, st);
     return launch_status();
   }
@@ -604,11 +627,16 @@ int run_backward_tiles(const Levels& L, const float* rois, const int32_t* levels
   for (int i = L.num; i <= DETOPS_MAX_LEVELS; ++i) P.first_item[i] = static_cast<int>(items);
   if (items > 0x7fffffff) return DETOPS_EUNSUPPORTED;
   const size_t lds = sizeof(float) * static_cast<size_t>(CT) * P.TH * P.TW;
-  dispatch_shape(PH, PW, sr, [&](auto ph, auto pw, auto tab) {
-    hipLaunchKernelGGL((roi_align_bwd_tile_kernel<decltype(ph)::value, decltype(pw)::value, decltype(tab)::value>),
-                       dim3(static_cast<unsigned>(items)), dim3(kBlock), lds, st, L, P, rois, levels_in, gout,
-                       C, K, PH, PW, sr);
-  });
+  const dim3 grid(static_cast<unsigned>(items));
+#define BWD_LAUNCH(PH_, PW_, SR_)                                                                          \
+  hipLaunchKernelGGL((roi_align_bwd_tile_kernel<PH_, PW_, SR_>), grid, dim3(kBlock), lds, st, L, P, rois, \
+                     levels_in, gout, C, K, PH, PW, sr)
+  if (PH == 7 && PW == 7 && sr == 2) BWD_LAUNCH(7, 7, 2);
+  else if (PH == 14 && PW == 14 && sr == 2) BWD_LAUNCH(14, 14, 2);
+  else if (PH == 7 && PW == 7) BWD_LAUNCH(7, 7, 0);
+  else if (PH == 14 && PW == 14) BWD_LAUNCH(14, 14, 0);
+  else BWD_LAUNCH(0, 0, 0);
+#undef BWD_LAUNCH
   return launch_status();
 }
 

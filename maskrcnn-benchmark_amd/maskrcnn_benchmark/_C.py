@@ -360,6 +360,41 @@ def sigmoid_focalloss_backward_scalar(logits, targets, d_loss, num_classes, gamm
     return d_logits
 
 
+# ------------------------------------------------------------------------------------------ frozen BN
+def frozen_bn_act_forward(x, scale, bias, residual, relu):
+    """Extension: y = [relu](x * scale[c] + bias[c] [+ residual]) in one pass (NCHW contiguous)."""
+    _need_cuda("frozen_bn_act_forward", x, scale, bias, residual)
+    code = _lib.DTYPE_CODE[x.dtype]
+    x = x.contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+        if residual.dtype != x.dtype or residual.shape != x.shape:
+            raise RuntimeError("frozen_bn_act_forward: residual must match x")
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // max(N * C, 1)
+    y = torch.empty_like(x)
+    with _on_device(x):
+        check(lib.detops_frozen_bn_act_forward(ptr(x), ptr(scale), ptr(bias), ptr(residual), ptr(y), code, N, C, HW,
+                                               int(bool(relu)), stream_of(x)), "frozen_bn_act_forward")
+    return y
+
+
+def frozen_bn_act_backward(grad_y, y, scale, relu, need_residual):
+    """Extension: (grad_x, grad_residual or None) of frozen_bn_act_forward."""
+    _need_cuda("frozen_bn_act_backward", grad_y, scale)
+    code = _lib.DTYPE_CODE[grad_y.dtype]
+    grad_y = grad_y.contiguous()
+    N, C = grad_y.shape[0], grad_y.shape[1]
+    HW = grad_y.numel() // max(N * C, 1)
+    gx = torch.empty_like(grad_y)
+    gres = torch.empty_like(grad_y) if need_residual else None
+    with _on_device(grad_y):
+        check(lib.detops_frozen_bn_act_backward(ptr(grad_y), ptr(y) if relu else None, ptr(scale), ptr(gx), ptr(gres),
+                                                code, N, C, HW, int(bool(relu)), stream_of(grad_y)),
+              "frozen_bn_act_backward")
+    return gx, gres
+
+
 # ------------------------------------------------------------------------------------------ deformable conv
 def _dcn_check(name, *tensors):
     _need_cuda(name, *tensors)

@@ -32,16 +32,21 @@ class OverlappedSGD(torch.optim.Optimizer):
         self.deferred = False  # True while a DDP hook applies the updates during backward
 
     @torch.no_grad()
-    def step_params(self, params):
+    def step_params(self, params, grads=None):
+        """Update `params`; `grads` (same order) overrides `p.grad` — the DDP hook passes the
+        bucket's gradient views, which hold the averaged values whatever `p.grad` points at."""
         by_group = {}
-        for p in params:
-            if p.grad is None:
+        for i, p in enumerate(params):
+            gr = p.grad if grads is None else grads[i]
+            if gr is None:
                 continue
-            by_group.setdefault(self._group_of[p], []).append(p)
-        for gi, ps in by_group.items():
+            entry = by_group.setdefault(self._group_of[p], ([], []))
+            entry[0].append(p)
+            entry[1].append(gr)
+        for gi, (ps, grads_g) in by_group.items():
             g = self.param_groups[gi]
             lr, mom, wd = g["lr"], g["momentum"], g["weight_decay"]
-            grads = [p.grad for p in ps]
+            grads = list(grads_g)
             if wd != 0:
                 grads = torch._foreach_add(grads, ps, alpha=wd)
             if mom != 0:
@@ -96,7 +101,7 @@ def _allreduce_then_step(optimizer, process_group):
 
         def apply(f):
             if optimizer.deferred:
-                optimizer.step_params(bucket.parameters())
+                optimizer.step_params(bucket.parameters(), bucket.gradients())
             return bucket.buffer()
 
         return fut.then(apply)

@@ -70,6 +70,15 @@ class Bottleneck(nn.Module):
         _kaiming(self.conv3)
 
     def forward(self, x):
+        if isinstance(self.bn1, FrozenBatchNorm2d) and x.numel() > 0:
+            # fused affine(+residual)+ReLU: one HIP pass per convolution output (csrc/frozen_bn.hip)
+            if self.downsample is None:
+                identity = x
+            else:
+                identity = self.downsample[1].fused(self.downsample[0](x))
+            out = self.bn1.fused(self.conv1(x), relu=True)
+            out = self.bn2.fused(self.conv2(out), relu=True)
+            return self.bn3.fused(self.conv3(out), relu=True, residual=identity)
         identity = x if self.downsample is None else self.downsample(x)
         out = F.relu_(self.bn1(self.conv1(x)))
         out = F.relu_(self.bn2(self.conv2(out)))
@@ -105,7 +114,10 @@ class Stem(nn.Module):
         _kaiming(self.conv1)
 
     def forward(self, x):
-        x = F.relu_(self.bn1(self.conv1(x)))
+        if isinstance(self.bn1, FrozenBatchNorm2d) and x.numel() > 0:
+            x = self.bn1.fused(self.conv1(x), relu=True)
+        else:
+            x = F.relu_(self.bn1(self.conv1(x)))
         return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
 
 

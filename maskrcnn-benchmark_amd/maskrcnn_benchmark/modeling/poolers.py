@@ -14,7 +14,6 @@ from torch.autograd.function import once_differentiable
 
 from maskrcnn_benchmark import _C
 from maskrcnn_benchmark.layers import ROIAlign
-from maskrcnn_benchmark.layers._amp import float_function
 
 from .utils import cat
 
@@ -59,10 +58,11 @@ class _ROIAlignFPN(Function):
         return (None, None, None, None, None, None) + tuple(grads)
 
 
-@float_function
 def roi_align_fpn(features, rois, output_size, scales, sampling_ratio, k_min, k_max):
-    return _ROIAlignFPN.apply(rois, tuple(output_size), tuple(scales), sampling_ratio, k_min, k_max,
-                              *features)
+    """fp32 island (the reference marks ROIAlign.forward `@amp.float_function`, layers/roi_align.py:57)."""
+    with torch.autocast(device_type=rois.device.type, enabled=False):
+        return _ROIAlignFPN.apply(rois.float(), tuple(output_size), tuple(scales), sampling_ratio, k_min, k_max,
+                                  *[f.float() for f in features])
 
 
 class Pooler(nn.Module):

@@ -82,7 +82,21 @@ def _focal_bwd_scalar(logits, targets, d_loss, num_classes, gamma, alpha):
     return torch.from_numpy(oracle.sigmoid_focal_loss_backward(_np(logits.float()), _np(targets), d, gamma, alpha))
 
 
+def _frozen_bn_fwd(x, scale, bias, residual, relu):
+    y = x * scale.reshape(1, -1, 1, 1).to(x.dtype) + bias.reshape(1, -1, 1, 1).to(x.dtype)
+    if residual is not None:
+        y = y + residual
+    return torch.relu(y) if relu else y
+
+
+def _frozen_bn_bwd(grad_y, y, scale, relu, need_residual):
+    g = grad_y * (y > 0).to(grad_y.dtype) if relu else grad_y
+    return g * scale.reshape(1, -1, 1, 1).to(g.dtype), (g.clone() if need_residual else None)
+
+
 _PATCHES = {
+    "frozen_bn_act_forward": _frozen_bn_fwd,
+    "frozen_bn_act_backward": _frozen_bn_bwd,
     "roi_align_forward": _roi_align_forward,
     "roi_align_backward": _roi_align_backward,
     "roi_align_fpn_forward": _fpn_forward,

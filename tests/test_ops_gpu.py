@@ -501,3 +501,52 @@ def test_deform_conv_half_precision(dtype):
     assert out.shape == (2, 16, 20, 24) and torch.isfinite(out).all()
     out.float().sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
+
+
+# ============================================================================ fused FrozenBN
+@pytest.mark.parametrize("shape", [(2, 8, 25, 42), (1, 5, 7, 9), (2, 16, 40, 64), (3, 4, 1, 1)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True), (False, True)])
+def test_frozen_bn_fused_matches_reference_composite(shape, relu, res):
+    """reference layers/batch_norm.py:19-31 (+ relu / residual of resnet.py:343-366) in plain torch
+    fp32 on the CPU vs the fused HIP kernel: forward bit-equal (same mul-then-add roundings),
+    backward bit-equal (mask and one multiply)."""
+    from maskrcnn_benchmark.layers import FrozenBatchNorm2d
+    torch.manual_seed(sum(shape) + relu + 2 * res)
+    bn = FrozenBatchNorm2d(shape[1])
+    bn.weight.copy_(torch.rand(shape[1]) + 0.5); bn.bias.copy_(torch.randn(shape[1]))
+    bn.running_mean.copy_(torch.randn(shape[1])); bn.running_var.copy_(torch.rand(shape[1]) + 0.3)
+    x = torch.randn(shape, requires_grad=True)
+    r = torch.randn(shape, requires_grad=True) if res else None
+    y = bn(x)
+    if res:
+        y = y + r
+    if relu:
+        y = torch.relu(y)
+    gy = torch.randn(shape)
+    y.backward(gy)
+    bn_d = FrozenBatchNorm2d(shape[1]).to(DEV)
+    bn_d.load_state_dict(bn.state_dict())
+    xd = x.detach().to(DEV).requires_grad_(True)
+    rd = r.detach().to(DEV).requires_grad_(True) if res else None
+    yd = bn_d.fused(xd, relu=relu, residual=rd)
+    yd.backward(gy.to(DEV))
+    assert torch.equal(yd.detach().cpu(), y.detach())
+    assert torch.equal(xd.grad.cpu(), x.grad)
+    if res:
+        assert torch.equal(rd.grad.cpu(), r.grad)
+    # buffers changed in place -> the cached folded constants are refreshed
+    bn_d.running_var.mul_(4.0)
+    assert torch.equal(bn_d.fused(xd.detach()), bn_d(xd.detach()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_frozen_bn_fused_half(dtype):
+    from maskrcnn_benchmark.layers import FrozenBatchNorm2d
+    torch.manual_seed(3)
+    bn = FrozenBatchNorm2d(12).to(DEV)
+    bn.weight.copy_(torch.rand(12) + 0.5); bn.running_mean.copy_(torch.randn(12))
+    x = torch.randn(2, 12, 50, 84, device=DEV)
+    r = torch.randn(2, 12, 50, 84, device=DEV)
+    ref = torch.relu(bn(x) + r)
+    out = bn.fused(x.to(dtype), relu=True, residual=r.to(dtype)).float()
+    assert (out - ref).abs().max() <= 2e-2 * ref.abs().max()

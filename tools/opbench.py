@@ -116,6 +116,27 @@ def bench_nms(C, iters):
     return out
 
 
+def bench_frozen_bn(C, iters):
+    """fused FrozenBN+ReLU(+residual) vs the PyTorch elementwise chain, res2-sized activation."""
+    out = []
+    x = torch.randn(2, 256, 200, 336, device="cuda")
+    r = torch.randn_like(x)
+    scale = torch.rand(256, device="cuda") + 0.5
+    bias = torch.randn(256, device="cuda")
+    nb = x.numel() * 4
+    us = dev_time_us(lambda: C.frozen_bn_act_forward(x, scale, bias, None, True), iters)
+    out.append(_entry("frozen_bn_relu fwd fused [2,256,200,336]", us, 2 * nb))
+    us = dev_time_us(lambda: C.frozen_bn_act_forward(x, scale, bias, r, True), iters)
+    out.append(_entry("frozen_bn_add_relu fwd fused", us, 3 * nb))
+    y = C.frozen_bn_act_forward(x, scale, bias, r, True)
+    us = dev_time_us(lambda: C.frozen_bn_act_backward(r, y, scale, True, True), iters)
+    out.append(_entry("frozen_bn_add_relu bwd fused (2 outputs)", us, 4 * nb))
+    s4, b4 = scale.view(1, -1, 1, 1), bias.view(1, -1, 1, 1)
+    us = dev_time_us(lambda: torch.relu_(x * s4 + b4), iters)
+    out.append(_entry("frozen_bn_relu fwd torch chain (3 kernels)", us, 2 * nb))
+    return out
+
+
 def bench_focal(C, iters):
     out = []
     for R in (200000, 403200):
@@ -179,6 +200,8 @@ def main():
         res += bench_roi_align(C, args.iters)
     if not only or "nms" in only:
         res += bench_nms(C, args.iters)
+    if not only or "frozen_bn" in only:
+        res += bench_frozen_bn(C, args.iters)
     if not only or "focal" in only:
         res += bench_focal(C, args.iters)
     if not only or "dcn" in only:
