@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--no-miopen-search", action="store_true",
+                    help="leave torch.backends.cudnn.benchmark off (MIOpen picks from its find-db / heuristics)")
     ap.add_argument("opts", nargs=argparse.REMAINDER, default=[])
     return ap.parse_args()
 
@@ -59,6 +61,28 @@ def algorithmic_bytes(name, feat_bytes):
     if m:
         R, C = int(m.group(2)), int(m.group(3))
         return (4 * R * C + 4 * R) if m.group(1) == "fwd_sum" else (8 * R * C + 4 * R)
+    return None
+
+
+def measured_traffic(kernel_name):
+    """HBM bytes per launch from the committed PMC passes (profiles/*traffic*.json, produced by
+    tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the same
+    launch shape), or None when no measurement matches this kernel."""
+    import glob
+    import re
+    m = re.match(r"roi_align_fpn_(fwd|bwd)\[K=(\d+),C=(\d+),(\d+)x(\d+)\]", kernel_name)
+    if not m:
+        return None
+    want = "roi_align_%s" % m.group(1)
+    ph = m.group(4)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        try:
+            table = json.load(open(path))
+        except Exception:
+            continue
+        for key, v in table.items():
+            if want in key and ("<%s, %s" % (ph, ph)) in key and v.get("tag") == kernel_name:
+                return v["hbm_bytes"]
     return None
 
 
@@ -133,7 +157,14 @@ def main():
         opts += ["DTYPE", args.dtype]
     cfg = load_cfg(args.config, opts)
     torch.manual_seed(1234 + rank)
-    torch.backends.cudnn.benchmark = True  # MIOpen: search the conv algorithm once per (fixed) shape
+    # MIOpen: search the conv algorithm once per (fixed) shape during warm-up
+    torch.backends.cudnn.benchmark = not args.no_miopen_search
+    t_start = time.perf_counter()
+
+    def progress(msg):
+        if rank == 0:
+            print("[bench %6.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
     model, optimizer, scheduler, step = build_training(cfg, device, distributed, local_rank)
     if args.channels_last:
         model.to(memory_format=torch.channels_last)
@@ -149,9 +180,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    progress("model + %d device batches ready" % len(batches))
     losses = None
     for i in range(args.warmup):
         losses = step(*batches[i % len(batches)])
+        torch.cuda.synchronize(device)
+        progress("warm-up step %d done" % (i + 1))
     sync()
     timer = None
     if rank == 0 and not args.no_kernel_timing:
@@ -163,6 +197,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     _C.KERNEL_TIMER = None
+    progress("%d timed steps done" % args.steps)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,7 +242,8 @@ def main():
             if dominant is not None:
                 name, _, e = dominant
                 line["roofline"] = {"kernel": name, "bound": "hbm", "achieved": e["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": round(e["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                                    "unit": "GB/s", "frac": round(e["achieved_GBs"] / HBM_PEAK_GBS, 4),
+                                    "traffic": measured_traffic(name),
                                     "alg_bytes_per_launch": e["alg_bytes"], "mean_us": e["mean_us"]}
         if world == 1 and not args.no_cpu_baseline:
             try:

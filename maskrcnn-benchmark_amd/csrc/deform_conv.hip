@@ -203,6 +203,7 @@ col2im_kernel(const T* __restrict__ col, const T* __restrict__ offset, const T* 
 // instead of 36, and every column element is read exactly once, coalesced along wo.
 constexpr int kColTY = 8, kColTX = 32, kColHalo = 4;
 constexpr int kColLdsFloats = 8192 - 32;
+constexpr int kColCC = 8;  // channels accumulated per LDS pass
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
@@ -253,8 +254,16 @@ col2im_tile_kernel(const T* __restrict__ col, const T* __restrict__ offset, cons
         const bool in_win = ly >= 0 && ly + 1 < RH && lx >= 0 && lx + 1 < RW;
         const int wbase = ly * RW + lx;
         const T* cp = col + (static_cast<size_t>(cs) * K + tap) * ncol + static_cast<size_t>(b) * HWo + pix;
-        for (int c = 0; c < cn; ++c) {
-          const float gv = ld(cp) * m;  // cur_top_grad (:322 / :681)
+        // all channel values of this tap first (kColCC independent loads in flight), then the scatter:
+        // with the load inside the scatter loop every iteration waits one HBM round trip
+        float gvs[kColCC];
+#pragma unroll
+        for (int c = 0; c < kColCC; ++c)
+          gvs[c] = c < cn ? ld(cp + static_cast<size_t>(c) * K * ncol) * m : 0.f;  // cur_top_grad (:322 / :681)
+#pragma unroll
+        for (int c = 0; c < kColCC; ++c) {
+          if (c >= cn) break;
+          const float gv = gvs[c];
           if (in_win) {
             float* w = win + c * rarea + wbase;
             if (s.i1 >= 0) atomicAdd(w, s.w1 * gv);
@@ -268,7 +277,6 @@ col2im_tile_kernel(const T* __restrict__ col, const T* __restrict__ offset, cons
             if (s.i3 >= 0) atomic_add_t(gp + s.i3, s.w3 * gv);
             if (s.i4 >= 0) atomic_add_t(gp + s.i4, s.w4 * gv);
           }
-          cp += static_cast<size_t>(K) * ncol;
         }
       }
     }
@@ -381,8 +389,8 @@ int col2im_t(const void* col, const void* offset, const void* mask, void* grad_i
   const int cpg = g.C / g.dg;
   // tiled path: LDS window = tile footprint + halo
   const int RH = (kColTY - 1) * g.stride_h + (g.kh - 1) * g.dil_h + 2 + 2 * kColHalo;
-  const int RW = (kColTX - 1) * g.stride_w + (g.kw - 1) * g.dil_w + 2 + 2 * kColHalo;
-  const int CC = min(8, kColLdsFloats / (RH * RW));
+  const int RW = ((kColTX - 1) * g.stride_w + (g.kw - 1) * g.dil_w + 2 + 2 * kColHalo) | 1;  // odd: bank spread
+  const int CC = min(kColCC, kColLdsFloats / (RH * RW));
   if (CC >= 1) {
     const int tiles_x = static_cast<int>(ceil_div64(g.Wo, kColTX)), tiles_y = static_cast<int>(ceil_div64(g.Ho, kColTY));
     const int64_t tiles = static_cast<int64_t>(g.B) * tiles_x * tiles_y;

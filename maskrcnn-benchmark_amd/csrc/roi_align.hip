@@ -257,7 +257,7 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
   }
   const int ymin = s_bounds[0], xmin = s_bounds[2];
   const int rows = s_bounds[1] - ymin + 2;   // (lo range) + the lo+1 row
-  const int ps = s_bounds[3] - xmin + 2;     // row stride incl. the lo+1 column
+  const int ps = (s_bounds[3] - xmin + 2) | 1;  // row stride incl. the lo+1 column; odd -> rows spread over LDS banks
   const int area = rows * ps;
   const size_t plane = static_cast<size_t>(H) * W;
   const float* base = in + (static_cast<size_t>(g.b) * C + c0) * plane;
@@ -373,8 +373,9 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
 // that straddle tiles (~2.3x at 32 x 64 tiles for box-head ROIs), paid in LDS/VALU cycles that are
 // not the bottleneck.  ROIs are visited in ascending index order (ballot compaction).
 // ------------------------------------------------------------------------------------------
-constexpr int kAccFloats = 8192;  // 32 KiB LDS accumulator: CT * TH * TW <= kAccFloats
+constexpr int kAccFloats = 8400;  // ~33 KiB LDS accumulator: CT * (TH * (TW + 1) + 3) <= kAccFloats
 constexpr int kBwdList = 256;     // ROIs tested per scan round (one per thread)
+constexpr int kBwdMaxCT = 4;      // channels per workgroup (register-resident gradient values)
 
 struct BwdPlan {
   int first_item[DETOPS_MAX_LEVELS + 1];  // workgroup-id prefix per level
@@ -422,10 +423,13 @@ roi_align_bwd_tile_kernel(Levels L, BwdPlan P, const float* __restrict__ rois,
   const int y1 = min(H, y0 + TH) - 1, x1 = min(W, x0 + TW) - 1;  // inclusive
   const int c0 = chunk * P.CT;
   const int cn = min(P.CT, C - c0);
-  const int tarea = TH * TW;
-  const int upr = cn * bins;  // units per ROI: (channel, bin), bin fastest -> coalesced gout reads
+  // LDS accumulator [cn][TH][TW+1] (+3 per plane): the odd row stride spreads the taps of bins that
+  // share a column (same x, rows a few pixels apart) over different banks — with a 64-dword stride
+  // every such ds_add_f32 of a wavefront would hit ONE bank (7-9-way serialisation, measured 5x)
+  const int TWP = TW + 1;
+  const int pstride = TH * TWP + 3;
 
-  for (int e = tid; e < cn * tarea; e += kBlock) acc[e] = 0.f;
+  for (int e = tid; e < cn * pstride; e += kBlock) acc[e] = 0.f;
   // (the first __syncthreads below orders the clear before any accumulation)
 
   for (int kb = 0; kb < K; kb += kBwdList) {
@@ -465,41 +469,49 @@ roi_align_bwd_tile_kernel(Levels L, BwdPlan P, const float* __restrict__ rois,
     }
     __syncthreads();
 
-    // ---- flat unit loop over (hit ROI, channel, bin): no per-ROI barriers, every lane busy
-    const int units = total * upr;
-    for (int u = tid; u < units; u += kBlock) {
+    // ---- flat loop over (hit ROI, bin) pairs: no per-ROI barriers.  A lane derives its bin's taps
+    //      once and applies them to all (<= kBwdMaxCT) channels of the chunk.
+    const int pairs = total * bins;
+    for (int q = tid; q < pairs; q += kBlock) {
 #pragma clang fp contract(off)
-      const int li = u / upr;
-      const int o = u - li * upr;
-      const int cl = o / bins;
-      const int bin = o - cl * bins;
+      const int li = q / bins;
+      const int bin = q - li * bins;
       const int ph = bin / PW;
       const int pw = bin - ph * PW;
       const HitGeom h = s_hit[li];
-      const float gval = gout[(static_cast<size_t>(h.k) * C + c0) * bins + o];
+      const float* go = gout + (static_cast<size_t>(h.k) * C + c0) * bins + bin;
+      float gv[kBwdMaxCT];
+#pragma unroll
+      for (int cl = 0; cl < kBwdMaxCT; ++cl) gv[cl] = cl < cn ? go[cl * bins] : 0.f;
       const int gh = SR_ ? SR_ : h.gh, gw = SR_ ? SR_ : h.gw;
       const int icount = gh * gw;
       const float count = static_cast<float>(icount);
       const bool pow2 = (icount & (icount - 1)) == 0;
       const float inv_count = 1.f / count;
-      float* a = acc + cl * tarea;
       for (int iy = 0; iy < gh; ++iy) {
         const Tap ty = axis_entry(h.start_h, h.bin_h, ph, iy, gh, H, 1);
         if ((ty.l == 0.f && ty.h == 0.f) || ty.hi < y0 || ty.lo > y1) continue;
         const bool in0 = ty.lo >= y0, in1 = ty.hi <= y1;
-        const int r0 = (ty.lo - y0) * TW - x0, r1 = (ty.hi - y0) * TW - x0;
+        const int r0 = (ty.lo - y0) * TWP - x0, r1 = (ty.hi - y0) * TWP - x0;
         for (int ix = 0; ix < gw; ++ix) {
           const Tap tx = axis_entry(h.start_w, h.bin_w, pw, ix, gw, W, 1);
           if ((tx.l == 0.f && tx.h == 0.f) || tx.hi < x0 || tx.lo > x1) continue;
           const bool jn0 = tx.lo >= x0, jn1 = tx.hi <= x1;
           const float w1 = ty.h * tx.h, w2 = ty.h * tx.l, w3 = ty.l * tx.h, w4 = ty.l * tx.l;
-          float g1 = gval * w1, g2 = gval * w2, g3 = gval * w3, g4 = gval * w4;
-          if (pow2) { g1 *= inv_count; g2 *= inv_count; g3 *= inv_count; g4 *= inv_count; }
-          else { g1 /= count; g2 /= count; g3 /= count; g4 /= count; }
-          if (in0 && jn0) atomicAdd(a + r0 + tx.lo, g1);
-          if (in0 && jn1) atomicAdd(a + r0 + tx.hi, g2);
-          if (in1 && jn0) atomicAdd(a + r1 + tx.lo, g3);
-          if (in1 && jn1) atomicAdd(a + r1 + tx.hi, g4);
+#pragma unroll
+          for (int cl = 0; cl < kBwdMaxCT; ++cl) {
+            if (cl < cn) {
+              const float gval = gv[cl];
+              float g1 = gval * w1, g2 = gval * w2, g3 = gval * w3, g4 = gval * w4;
+              if (pow2) { g1 *= inv_count; g2 *= inv_count; g3 *= inv_count; g4 *= inv_count; }
+              else { g1 /= count; g2 /= count; g3 /= count; g4 /= count; }
+              float* a = acc + cl * pstride;
+              if (in0 && jn0) atomicAdd(a + r0 + tx.lo, g1);
+              if (in0 && jn1) atomicAdd(a + r0 + tx.hi, g2);
+              if (in1 && jn0) atomicAdd(a + r1 + tx.lo, g3);
+              if (in1 && jn1) atomicAdd(a + r1 + tx.hi, g4);
+            }
+          }
         }
       }
     }
@@ -510,6 +522,7 @@ roi_align_bwd_tile_kernel(Levels L, BwdPlan P, const float* __restrict__ rois,
   const size_t plane = static_cast<size_t>(H) * W;
   float* gb = gin + (static_cast<size_t>(b) * C + c0) * plane;
   const int tw_valid = x1 - x0 + 1, th_valid = y1 - y0 + 1;
+  const int tarea = TH * TW;
   for (int e = tid; e < cn * tarea; e += kBlock) {
     const int cl = e / tarea;
     const int rr = e - cl * tarea;
@@ -517,7 +530,7 @@ roi_align_bwd_tile_kernel(Levels L, BwdPlan P, const float* __restrict__ rois,
     const int x = rr - y * TW;
     if (y < th_valid && x < tw_valid) {
       float* dst = gb + static_cast<size_t>(cl) * plane + static_cast<size_t>(y0 + y) * W + (x0 + x);
-      float v = acc[e];
+      float v = acc[cl * pstride + y * TWP + x];
       if (P.accumulate) v += *dst;
       *dst = v;
     }
@@ -606,7 +619,7 @@ int run_backward_tiles(const Levels& L, const float* rois, const int32_t* levels
   P.TW = pow2_at_least(Wmax, 64);
   P.TH = pow2_at_least(Hmax, 32);
   P.accumulate = accumulate;
-  int CT = min(4, max(1, kAccFloats / (P.TH * P.TW)));
+  int CT = min(kBwdMaxCT, max(1, kAccFloats / (P.TH * (P.TW + 1) + 3)));
   CT = min(CT, C);
   auto count_items = [&](int ct) {
     int64_t items = 0;
@@ -626,7 +639,7 @@ int run_backward_tiles(const Levels& L, const float* rois, const int32_t* levels
   }
   for (int i = L.num; i <= DETOPS_MAX_LEVELS; ++i) P.first_item[i] = static_cast<int>(items);
   if (items > 0x7fffffff) return DETOPS_EUNSUPPORTED;
-  const size_t lds = sizeof(float) * static_cast<size_t>(CT) * P.TH * P.TW;
+  const size_t lds = sizeof(float) * static_cast<size_t>(CT) * (P.TH * (P.TW + 1) + 3);
   const dim3 grid(static_cast<unsigned>(items));
 #define BWD_LAUNCH(PH_, PW_, SR_)                                                                          \
   hipLaunchKernelGGL((roi_align_bwd_tile_kernel<PH_, PW_, SR_>), grid, dim3(kBlock), lds, st, L, P, rois, \

@@ -515,22 +515,30 @@ def test_frozen_bn_fused_matches_reference_composite(shape, relu, res):
     bn = FrozenBatchNorm2d(shape[1])
     bn.weight.copy_(torch.rand(shape[1]) + 0.5); bn.bias.copy_(torch.randn(shape[1]))
     bn.running_mean.copy_(torch.randn(shape[1])); bn.running_var.copy_(torch.rand(shape[1]) + 0.3)
-    x = torch.randn(shape, requires_grad=True)
-    r = torch.randn(shape, requires_grad=True) if res else None
-    y = bn(x)
-    if res:
-        y = y + r
-    if relu:
-        y = torch.relu(y)
-    gy = torch.randn(shape)
-    y.backward(gy)
     bn_d = FrozenBatchNorm2d(shape[1]).to(DEV)
     bn_d.load_state_dict(bn.state_dict())
+    # the folded constants (weight * rsqrt(var), ...) are computed on the device; rsqrt differs from the
+    # CPU's in the last bit, so the bit-exact reference uses the SAME constants, and the CPU module
+    # (its own fold) is compared at 1e-6
+    scale, bias = (t.cpu() for t in bn_d.folded())
+    x = torch.randn(shape, requires_grad=True)
+    r = torch.randn(shape, requires_grad=True) if res else None
+    y = x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
+    y_mod = bn(x.detach())
+    if res:
+        y = y + r
+        y_mod = y_mod + r.detach()
+    if relu:
+        y = torch.relu(y)
+        y_mod = torch.relu(y_mod)
+    gy = torch.randn(shape)
+    y.backward(gy)
     xd = x.detach().to(DEV).requires_grad_(True)
     rd = r.detach().to(DEV).requires_grad_(True) if res else None
     yd = bn_d.fused(xd, relu=relu, residual=rd)
     yd.backward(gy.to(DEV))
     assert torch.equal(yd.detach().cpu(), y.detach())
+    torch.testing.assert_close(yd.detach().cpu(), y_mod, rtol=1e-6, atol=1e-6)
     assert torch.equal(xd.grad.cpu(), x.grad)
     if res:
         assert torch.equal(rd.grad.cpu(), r.grad)

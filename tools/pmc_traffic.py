@@ -1,0 +1,53 @@
+"""HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need separate passes:
+TCC has 4 slots, FETCH_SIZE takes 3 and WRITE_SIZE 2 — /opt/skills/guides/MI355X_MICROARCH.md).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out/fetch -o x -- python tools/opbench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out/write -o x -- python tools/opbench.py ...
+    python tools/pmc_traffic.py out/fetch out/write profiles/r01_traffic.json
+
+Corrections applied (guide §HBM): counters are in KiB (x1024); on gfx950 FETCH_SIZE reports HALF the
+bytes of a wide coalesced read (x2) — uncalibrated for narrow gathers, so the read side of a gather
+kernel is an upper bound after the x2.  Output: {kernel substring: {fetch_bytes, write_bytes,
+hbm_bytes, launches}} averaged per launch, for the hand-written kernels only."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+OURS = ("roi_align_fwd", "roi_align_bwd", "nms_", "focal_kernel", "im2col_kernel", "col2im", "frozen_bn", "roi_pool")
+
+
+def load(dirname, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r.get("Counter_Name") != counter:
+                continue
+            name = r["Kernel_Name"]
+            if not any(k in name for k in OURS):
+                continue
+            key = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip()
+            key += "|grid=%s" % r.get("Grid_Size", r.get("Grid_Size_X", ""))
+            acc[key][0] += float(r["Counter_Value"])
+            acc[key][1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items() if v[1]}
+
+
+def main(fetch_dir, write_dir, out):
+    f = load(fetch_dir, "FETCH_SIZE")
+    w = load(write_dir, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(f) | set(w)):
+        fb = f.get(k, (0.0, 0))[0] * 1024 * 2
+        wb = w.get(k, (0.0, 0))[0] * 1024
+        res[k] = {"fetch_bytes": int(fb), "write_bytes": int(wb), "hbm_bytes": int(fb + wb),
+                  "launches": max(f.get(k, (0, 0))[1], w.get(k, (0, 0))[1])}
+        print("%-90s fetch %8.1f MB  write %8.1f MB" % (k[:90], fb / 1e6, wb / 1e6))
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
