@@ -209,6 +209,35 @@ int detops_deformable_col2im_coord(const void* col, const void* im, const void* 
                                    int dil_w, int deformable_group, detops_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Deformable position-sensitive ROI pooling — replaces _C.deform_psroi_pooling_forward /
+ * _C.deform_psroi_pooling_backward
+ *   reference: csrc/deform_pool.h:11-70, csrc/cuda/deform_pool_cuda.cu:38-87,
+ *              csrc/cuda/deform_pool_kernel_cuda.cu:31-364 (CUDA-only there).
+ *   data [N,C,H,W] with C >= output_dim * group_size^2, rois [K,5],
+ *   trans [K, channels_trans, part_size, part_size] (NULL when no_trans; channels_trans = 2 *
+ *   num_classes, output_dim must be a multiple of num_classes),
+ *   out / top_count / out_grad [K, output_dim, pooled_size, pooled_size] (top_count holds the
+ *   number of in-bounds samples of each bin as float, like the reference).
+ *   backward: `zero_grads` != 0 zero-fills data_grad and trans_grad first (the reference's caller
+ *   passes torch.zeros_like buffers, layers/dcn/deform_pool_func.py:72-73); the kernel accumulates.
+ * ---------------------------------------------------------------------------------------- */
+int detops_deform_psroi_pool_forward_f32(const float* data, const float* rois, const float* trans,
+                                         float* out, float* top_count, int N, int C, int H, int W,
+                                         int K, int channels_trans, int no_trans,
+                                         float spatial_scale, int output_dim, int group_size,
+                                         int pooled_size, int part_size, int sample_per_part,
+                                         float trans_std, detops_stream_t stream);
+
+int detops_deform_psroi_pool_backward_f32(const float* out_grad, const float* data,
+                                          const float* rois, const float* trans,
+                                          const float* top_count, float* data_grad,
+                                          float* trans_grad, int N, int C, int H, int W, int K,
+                                          int channels_trans, int no_trans, float spatial_scale,
+                                          int output_dim, int group_size, int pooled_size,
+                                          int part_size, int sample_per_part, float trans_std,
+                                          int zero_grads, detops_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused FrozenBatchNorm2d affine (+ residual) (+ ReLU) — the elementwise tail of every backbone
  * convolution: layers/batch_norm.py:19-31 (`x * scale + bias`), then `F.relu_`, and in the
  * bottleneck tail `out += identity; relu` (modeling/backbone/resnet.py:343-366).

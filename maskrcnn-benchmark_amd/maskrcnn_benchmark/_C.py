@@ -9,8 +9,9 @@ Same names, argument order and ownership rules as the reference's pybind module
     deform_conv_forward, deform_conv_backward_input, deform_conv_backward_parameters,
     modulated_deform_conv_forward, modulated_deform_conv_backward
 
-(the two deform_psroi_pooling_* names are exported and raise NotImplementedError — see
-DESIGN.md "out of scope").  PyTorch is plumbing here: it owns device memory and the current HIP
+    deform_psroi_pooling_forward, deform_psroi_pooling_backward
+
+PyTorch is plumbing here: it owns device memory and the current HIP
 stream; every computation happens in the hand-written gfx950 kernels (GEMMs of the deformable
 convolution go through torch.addmm -> hipBLASLt/rocBLAS, as the reference's go through cuBLAS).
 
@@ -651,11 +652,66 @@ def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, colu
         grad_bias += go.sum(1)
 
 
-def deform_psroi_pooling_forward(*args, **kwargs):
-    """reference csrc/deform_pool.h:11-38.  No model config of the reference uses deformable
-    PS-ROI pooling; it is outside the hot path and not built yet."""
-    raise NotImplementedError("deform_psroi_pooling_forward is not built in this HIP-only library")
+def _psroi_args(name, input, bbox, trans, no_trans, part_size):
+    _need_cuda(name, input, bbox)
+    if not input.is_contiguous():  # deform_pool_cuda.cu:45
+        raise RuntimeError("input tensor has to be contiguous")
+    input = _f32c(name, input)
+    bbox = _f32c(name, bbox)
+    if no_trans:
+        return input, bbox, None, 2  # deform_pool_cuda.cu:51 (`channels_trans = no_trans ? 2 : trans.size(1)`)
+    _need_cuda(name, trans)
+    trans = _f32c(name, trans)
+    if trans.dim() != 4 or trans.size(0) != bbox.size(0) or trans.size(2) != part_size or trans.size(3) != part_size:
+        raise RuntimeError("%s: trans must be [num_bbox, 2*num_classes, part_size, part_size]" % name)
+    return input, bbox, trans, trans.size(1)
 
 
-def deform_psroi_pooling_backward(*args, **kwargs):
-    raise NotImplementedError("deform_psroi_pooling_backward is not built in this HIP-only library")
+def deform_psroi_pooling_forward(input, bbox, trans, out, top_count, no_trans, spatial_scale, output_dim,
+                                 group_size, pooled_size, part_size, sample_per_part, trans_std):
+    """reference csrc/deform_pool.h:11-38 -> deform_pool_cuda.cu:38-62.  Writes into the
+    caller-allocated `out` / `top_count` [num_bbox, output_dim, pooled_size, pooled_size]."""
+    name = "deform_psroi_pooling_forward"
+    input, bbox, trans, ct = _psroi_args(name, input, bbox, trans, no_trans, part_size)
+    N, C, H, W = input.shape
+    K = bbox.size(0)
+    if K != out.size(0):  # deform_pool_cuda.cu:54-56
+        raise RuntimeError("Output shape and bbox number wont match: (%d vs %d)." % (out.size(0), K))
+    _need_cuda(name, out, top_count)
+    if not (out.is_contiguous() and top_count.is_contiguous() and out.dtype == torch.float32
+            and top_count.dtype == torch.float32):
+        raise RuntimeError("%s: out/top_count must be contiguous float32" % name)
+    with _on_device(input), _timed("psroi_fwd[K=%d,D=%d,P=%d]" % (K, output_dim, pooled_size), input):
+        check(lib.detops_deform_psroi_pool_forward_f32(
+            ptr(input), ptr(bbox), ptr(trans), ptr(out), ptr(top_count), N, C, H, W, K, ct,
+            int(bool(no_trans)), float(spatial_scale), output_dim, group_size, pooled_size, part_size,
+            sample_per_part, float(trans_std), stream_of(input)), name)
+
+
+def deform_psroi_pooling_backward(out_grad, input, bbox, trans, top_count, input_grad, trans_grad,
+                                  no_trans, spatial_scale, output_dim, group_size, pooled_size,
+                                  part_size, sample_per_part, trans_std):
+    """reference csrc/deform_pool.h:41-70 -> deform_pool_cuda.cu:64-87.  Accumulates into the
+    caller's (zeroed) `input_grad` / `trans_grad` like the reference's atomicAdd kernel."""
+    name = "deform_psroi_pooling_backward"
+    _need_cuda(name, out_grad, top_count, input_grad)
+    if not out_grad.is_contiguous():  # deform_pool_cuda.cu:71
+        raise RuntimeError("out_grad tensor has to be contiguous")
+    out_grad = _f32c(name, out_grad)
+    input, bbox, trans, ct = _psroi_args(name, input, bbox, trans, no_trans, part_size)
+    top_count = _f32c(name, top_count)
+    N, C, H, W = input.shape
+    K = bbox.size(0)
+    if K != out_grad.size(0):  # deform_pool_cuda.cu:80-82
+        raise RuntimeError("Output shape and bbox number wont match: (%d vs %d)." % (out_grad.size(0), K))
+    if not (input_grad.is_contiguous() and input_grad.dtype == torch.float32):
+        raise RuntimeError("%s: input_grad must be contiguous float32" % name)
+    if not no_trans and not (trans_grad.is_cuda and trans_grad.is_contiguous()
+                             and trans_grad.dtype == torch.float32 and trans_grad.shape == trans.shape):
+        raise RuntimeError("%s: trans_grad must be a contiguous float32 CUDA tensor shaped like trans" % name)
+    with _on_device(input), _timed("psroi_bwd[K=%d,D=%d,P=%d]" % (K, output_dim, pooled_size), input):
+        check(lib.detops_deform_psroi_pool_backward_f32(
+            ptr(out_grad), ptr(input), ptr(bbox), ptr(trans), ptr(top_count), ptr(input_grad),
+            None if no_trans else ptr(trans_grad), N, C, H, W, K, ct, int(bool(no_trans)),
+            float(spatial_scale), output_dim, group_size, pooled_size, part_size, sample_per_part,
+            float(trans_std), 0, stream_of(input)), name)

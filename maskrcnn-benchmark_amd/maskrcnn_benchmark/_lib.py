@@ -43,6 +43,10 @@ SIGNATURES = {
     "detops_deformable_im2col": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),
     "detops_deformable_col2im": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),
     "detops_deformable_col2im_coord": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 14 + [_P]),
+    "detops_deform_psroi_pool_forward_f32": (
+        c_int, [_P] * 5 + [c_int] * 7 + [c_float] + [c_int] * 5 + [c_float, _P]),
+    "detops_deform_psroi_pool_backward_f32": (
+        c_int, [_P] * 7 + [c_int] * 7 + [c_float] + [c_int] * 5 + [c_float, c_int, _P]),
 }
 
 _ERRORS = {-1: "DETOPS_EINVAL (bad shape / null pointer)", -2: "DETOPS_EWORKSPACE (workspace too small)",

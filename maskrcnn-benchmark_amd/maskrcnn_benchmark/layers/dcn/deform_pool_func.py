@@ -1,6 +1,6 @@
-"""Deformable PS-ROI pooling autograd function (reference layers/dcn/deform_pool_func.py:8-95).
-The operator is outside the training hot path (no reference config uses it — SURVEY.md §8f rank 4);
-`_C.deform_psroi_pooling_*` raise NotImplementedError until the kernel is built."""
+"""Deformable PS-ROI pooling autograd function (reference layers/dcn/deform_pool_func.py:8-95)
+over `_C.deform_psroi_pooling_{forward,backward}` (csrc/deform_pool.hip).  HIP-only like the
+reference's (`if not data.is_cuda: raise NotImplementedError`, :29-30)."""
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable

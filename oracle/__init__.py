@@ -217,3 +217,39 @@ def fpn_level(rois, k_min, k_max, canonical_scale=224.0, canonical_level=4.0, ep
     lib().oracle_fpn_level_f32(_p(rois), _i(K), _i(k_min), _i(k_max), _f(canonical_scale),
                                _f(canonical_level), _f(eps), _p(lv))
     return lv
+
+
+def deform_psroi_pool_forward(data, rois, trans, no_trans, spatial_scale, output_dim, group_size,
+                              pooled_size, part_size, sample_per_part, trans_std):
+    """-> (out, top_count), both [K, output_dim, P, P] (deform_pool_kernel_cuda.cu:53-147)."""
+    data, rois = _f32(data), _f32(rois).reshape(-1, 5)
+    trans = None if no_trans else _f32(trans)
+    N, C, H, W = data.shape
+    K = rois.shape[0]
+    ct = 2 if no_trans else trans.shape[1]
+    out = np.empty((K, output_dim, pooled_size, pooled_size), np.float32)
+    cnt = np.empty_like(out)
+    lib().oracle_deform_psroi_pool_forward_f32(
+        _p(data), _p(rois), _p(trans), _p(out), _p(cnt), _i(N), _i(C), _i(H), _i(W), _i(K), _i(ct),
+        _i(int(bool(no_trans))), _f(spatial_scale), _i(output_dim), _i(group_size), _i(pooled_size),
+        _i(part_size), _i(sample_per_part), _f(trans_std))
+    return out, cnt
+
+
+def deform_psroi_pool_backward(grad, data, rois, trans, top_count, no_trans, spatial_scale,
+                               output_dim, group_size, pooled_size, part_size, sample_per_part,
+                               trans_std, acc64=False):
+    """-> (data_grad [N,C,H,W], trans_grad like trans or None) (deform_pool_kernel_cuda.cu:149-264)."""
+    grad, data, rois, top_count = _f32(grad), _f32(data), _f32(rois).reshape(-1, 5), _f32(top_count)
+    trans = None if no_trans else _f32(trans)
+    N, C, H, W = data.shape
+    K = rois.shape[0]
+    ct = 2 if no_trans else trans.shape[1]
+    gin = np.empty_like(data)
+    gtr = None if no_trans else np.empty_like(trans)
+    lib().oracle_deform_psroi_pool_backward_f32(
+        _p(grad), _p(data), _p(rois), _p(trans), _p(top_count), _p(gin), _p(gtr), _i(N), _i(C),
+        _i(H), _i(W), _i(K), _i(ct), _i(int(bool(no_trans))), _f(spatial_scale), _i(output_dim),
+        _i(group_size), _i(pooled_size), _i(part_size), _i(sample_per_part), _f(trans_std),
+        _i(int(acc64)))
+    return gin, gtr

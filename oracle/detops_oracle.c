@@ -845,3 +845,201 @@ ORACLE_API void oracle_fpn_level_f32(const float* rois /* [K,5] */, int K, int k
     levels[i] = (int32_t)t - k_min;
   }
 }
+
+/* ============================================================================================
+ * Deformable PS-ROI pooling — cuda/deform_pool_kernel_cuda.cu:31-52 (bilinear_interp), :53-147
+ * (DeformablePSROIPoolForwardKernel), :149-264 (DeformablePSROIPoolBackwardAccKernel),
+ * scalar_t = float; host shape logic :266-305, :307-364.  CUDA-only in the reference and no
+ * reference test pins its values: PARITY UNPINNED (source-faithful restatement).
+ *
+ * The float/double mixing of the .cu file is kept: literals such as 0.5, 0.1, 0., 1. are double
+ * there, so `x * scale - 0.5`, the `max(.., 0.1)`, the border test and the clamp run in double
+ * and are rounded back to float on assignment.
+ *
+ * data [N,C,H,W], rois [K,5], trans [K, 2*num_classes, part, part] (ignored when no_trans),
+ * out / top_count [K, output_dim, P, P].  Backward accumulates into zeroed data_diff / trans_diff;
+ * acc64 != 0 accumulates in double (bounds the reorder noise of the device's atomics).
+ * ========================================================================================== */
+typedef struct {
+  int roi_batch_ind, part_h, part_w, class_id, gw, gh;
+  float roi_width, roi_height, sub_bin_size_h, sub_bin_size_w, wstart, hstart;
+} psroi_geom_t;
+
+static psroi_geom_t psroi_geometry(const float* bottom_rois, const float* bottom_trans, int n,
+                                   int ctop, int ph, int pw, float spatial_scale,
+                                   int pooled_height, int pooled_width, int no_trans,
+                                   float trans_std, int sample_per_part, int group_size,
+                                   int part_size, int num_classes, int channels_each_class) {
+  psroi_geom_t g;
+  const float* r = bottom_rois + (size_t)n * 5;
+  g.roi_batch_ind = (int)r[0];
+  float roi_start_w = (float)((double)(roundf(r[1]) * spatial_scale) - 0.5); /* :83-86 */
+  float roi_start_h = (float)((double)(roundf(r[2]) * spatial_scale) - 0.5);
+  float roi_end_w = (float)((double)((float)((double)roundf(r[3]) + 1.) * spatial_scale) - 0.5);
+  float roi_end_h = (float)((double)((float)((double)roundf(r[4]) + 1.) * spatial_scale) - 0.5);
+  double rw = (double)(roi_end_w - roi_start_w); /* :89-90 max(float, double 0.1) */
+  double rh = (double)(roi_end_h - roi_start_h);
+  g.roi_width = (float)(rw < 0.1 ? 0.1 : rw);
+  g.roi_height = (float)(rh < 0.1 ? 0.1 : rh);
+  float bin_size_h = g.roi_height / (float)pooled_height; /* :93-94 */
+  float bin_size_w = g.roi_width / (float)pooled_width;
+  g.sub_bin_size_h = bin_size_h / (float)sample_per_part; /* :96-97 */
+  g.sub_bin_size_w = bin_size_w / (float)sample_per_part;
+  g.part_h = (int)floorf((float)ph / pooled_height * part_size); /* :99-100 */
+  g.part_w = (int)floorf((float)pw / pooled_width * part_size);
+  g.class_id = ctop / channels_each_class;
+  float trans_x = 0.f, trans_y = 0.f; /* :102-103 */
+  if (!no_trans) {
+    trans_x = bottom_trans[(((size_t)(n * num_classes + g.class_id) * 2) * part_size + g.part_h) *
+                               part_size + g.part_w] * trans_std;
+    trans_y = bottom_trans[(((size_t)(n * num_classes + g.class_id) * 2 + 1) * part_size + g.part_h) *
+                               part_size + g.part_w] * trans_std;
+  }
+  float wstart = (float)pw * bin_size_w + roi_start_w; /* :105-108 */
+  wstart += trans_x * g.roi_width;
+  float hstart = (float)ph * bin_size_h + roi_start_h;
+  hstart += trans_y * g.roi_height;
+  g.wstart = wstart;
+  g.hstart = hstart;
+  int gw = (int)floorf((float)pw * group_size / pooled_width); /* :112-115 */
+  int gh = (int)floorf((float)ph * group_size / pooled_height);
+  g.gw = gw < 0 ? 0 : (gw > group_size - 1 ? group_size - 1 : gw);
+  g.gh = gh < 0 ? 0 : (gh > group_size - 1 ? group_size - 1 : gh);
+  return g;
+}
+
+/* :126-133: returns 0 if the sample is skipped, else clamps w,h in place */
+static int psroi_sample(float* w, float* h, int width, int height) {
+  if ((double)*w < -0.5 || (double)*w > width - 0.5 || (double)*h < -0.5 || (double)*h > height - 0.5)
+    return 0;
+  double wd = (double)*w < 0. ? 0. : (double)*w;
+  double hd = (double)*h < 0. ? 0. : (double)*h;
+  wd = wd > width - 1. ? width - 1. : wd;
+  hd = hd > height - 1. ? height - 1. : hd;
+  *w = (float)wd;
+  *h = (float)hd;
+  return 1;
+}
+
+ORACLE_API void oracle_deform_psroi_pool_forward_f32(
+    const float* bottom_data, const float* bottom_rois, const float* bottom_trans, float* top_data,
+    float* top_count, int N, int channels, int height, int width, int num_rois, int channels_trans,
+    int no_trans, float spatial_scale, int output_dim, int group_size, int pooled_size,
+    int part_size, int sample_per_part, float trans_std) {
+  (void)N;
+  const int pooled_height = pooled_size, pooled_width = pooled_size;
+  const int num_classes = no_trans ? 1 : channels_trans / 2; /* :289-290 */
+  const int channels_each_class = no_trans ? output_dim : output_dim / num_classes;
+  long count_all = (long)num_rois * output_dim * pooled_height * pooled_width;
+  for (long index = 0; index < count_all; index++) {
+    int pw = index % pooled_width; /* :77-80 */
+    int ph = (index / pooled_width) % pooled_height;
+    int ctop = (index / pooled_width / pooled_height) % output_dim;
+    int n = index / pooled_width / pooled_height / output_dim;
+    psroi_geom_t g = psroi_geometry(bottom_rois, bottom_trans, n, ctop, ph, pw, spatial_scale,
+                                    pooled_height, pooled_width, no_trans, trans_std,
+                                    sample_per_part, group_size, part_size, num_classes,
+                                    channels_each_class);
+    float sum = 0;
+    int count = 0;
+    const float* offset_bottom_data = bottom_data + (size_t)(g.roi_batch_ind * channels) * height * width;
+    for (int ih = 0; ih < sample_per_part; ih++) {
+      for (int iw = 0; iw < sample_per_part; iw++) {
+        float w = g.wstart + iw * g.sub_bin_size_w; /* :123-124 */
+        float h = g.hstart + ih * g.sub_bin_size_h;
+        if (!psroi_sample(&w, &h, width, height)) continue;
+        int c = (ctop * group_size + g.gh) * group_size + g.gw;
+        const float* data = offset_bottom_data + (size_t)c * height * width;
+        /* bilinear_interp :31-52 (value12 is the (y2, x1) tap) */
+        int x1 = (int)floorf(w), x2 = (int)ceilf(w), y1 = (int)floorf(h), y2 = (int)ceilf(h);
+        float dist_x = w - x1, dist_y = h - y1;
+        float value11 = data[y1 * width + x1], value12 = data[y2 * width + x1];
+        float value21 = data[y1 * width + x2], value22 = data[y2 * width + x2];
+        float val = (1 - dist_x) * (1 - dist_y) * value11 + (1 - dist_x) * dist_y * value12 +
+                    dist_x * (1 - dist_y) * value21 + dist_x * dist_y * value22;
+        sum += val;
+        count++;
+      }
+    }
+    top_data[index] = count == 0 ? 0.f : sum / count; /* :142-143 */
+    top_count[index] = (float)count;
+  }
+}
+
+ORACLE_API void oracle_deform_psroi_pool_backward_f32(
+    const float* top_diff, const float* bottom_data, const float* bottom_rois,
+    const float* bottom_trans, const float* top_count, float* bottom_data_diff,
+    float* bottom_trans_diff, int N, int channels, int height, int width, int num_rois,
+    int channels_trans, int no_trans, float spatial_scale, int output_dim, int group_size,
+    int pooled_size, int part_size, int sample_per_part, float trans_std, int acc64) {
+  const int pooled_height = pooled_size, pooled_width = pooled_size;
+  const int num_classes = no_trans ? 1 : channels_trans / 2;
+  const int channels_each_class = no_trans ? output_dim : output_dim / num_classes;
+  const size_t n_data = (size_t)N * channels * height * width;
+  const size_t n_trans = no_trans ? 0 : (size_t)num_rois * channels_trans * part_size * part_size;
+  double* dacc = NULL;
+  double* tacc = NULL;
+  memset(bottom_data_diff, 0, n_data * sizeof(float));
+  if (n_trans) memset(bottom_trans_diff, 0, n_trans * sizeof(float));
+  if (acc64) {
+    dacc = (double*)calloc(n_data ? n_data : 1, sizeof(double));
+    tacc = (double*)calloc(n_trans ? n_trans : 1, sizeof(double));
+  }
+#define PS_ADD_D(i, v) do { if (acc64) dacc[i] += (double)(v); else bottom_data_diff[i] += (v); } while (0)
+#define PS_ADD_T(i, v) do { if (acc64) tacc[i] += (double)(v); else bottom_trans_diff[i] += (v); } while (0)
+  long count_all = (long)num_rois * output_dim * pooled_height * pooled_width;
+  for (long index = 0; index < count_all; index++) {
+    int pw = index % pooled_width;
+    int ph = (index / pooled_width) % pooled_height;
+    int ctop = (index / pooled_width / pooled_height) % output_dim;
+    int n = index / pooled_width / pooled_height / output_dim;
+    psroi_geom_t g = psroi_geometry(bottom_rois, bottom_trans, n, ctop, ph, pw, spatial_scale,
+                                    pooled_height, pooled_width, no_trans, trans_std,
+                                    sample_per_part, group_size, part_size, num_classes,
+                                    channels_each_class);
+    if (top_count[index] <= 0) continue; /* :206-209 */
+    float diff_val = top_diff[index] / top_count[index];
+    size_t img = (size_t)g.roi_batch_ind * channels * height * width;
+    for (int ih = 0; ih < sample_per_part; ih++) {
+      for (int iw = 0; iw < sample_per_part; iw++) {
+        float w = g.wstart + iw * g.sub_bin_size_w;
+        float h = g.hstart + ih * g.sub_bin_size_h;
+        if (!psroi_sample(&w, &h, width, height)) continue;
+        int c = (ctop * group_size + g.gh) * group_size + g.gw;
+        int x0 = (int)floorf(w), x1 = (int)ceilf(w), y0 = (int)floorf(h), y1 = (int)ceilf(h); /* :233-236 */
+        float dist_x = w - x0, dist_y = h - y0;
+        float q00 = (1 - dist_x) * (1 - dist_y);
+        float q01 = (1 - dist_x) * dist_y;
+        float q10 = dist_x * (1 - dist_y);
+        float q11 = dist_x * dist_y;
+        size_t base = img + (size_t)c * height * width;
+        PS_ADD_D(base + y0 * width + x0, q00 * diff_val); /* :243-246 */
+        PS_ADD_D(base + y1 * width + x0, q01 * diff_val);
+        PS_ADD_D(base + y0 * width + x1, q10 * diff_val);
+        PS_ADD_D(base + y1 * width + x1, q11 * diff_val);
+        if (no_trans) continue;
+        float U00 = bottom_data[base + y0 * width + x0]; /* :252-255 */
+        float U01 = bottom_data[base + y1 * width + x0];
+        float U10 = bottom_data[base + y0 * width + x1];
+        float U11 = bottom_data[base + y1 * width + x1];
+        float diff_x = (U11 * dist_y + U10 * (1 - dist_y) - U01 * dist_y - U00 * (1 - dist_y)) *
+                       trans_std * diff_val; /* :256-259 */
+        diff_x *= g.roi_width;
+        float diff_y = (U11 * dist_x + U01 * (1 - dist_x) - U10 * dist_x - U00 * (1 - dist_x)) *
+                       trans_std * diff_val;
+        diff_y *= g.roi_height;
+        size_t tb = (((size_t)(n * num_classes + g.class_id) * 2) * part_size + g.part_h) * part_size + g.part_w;
+        PS_ADD_T(tb, diff_x); /* :261-262 */
+        PS_ADD_T(tb + (size_t)part_size * part_size, diff_y);
+      }
+    }
+  }
+#undef PS_ADD_D
+#undef PS_ADD_T
+  if (acc64) {
+    for (size_t i = 0; i < n_data; i++) bottom_data_diff[i] = (float)dacc[i];
+    for (size_t i = 0; i < n_trans; i++) bottom_trans_diff[i] = (float)tacc[i];
+    free(dacc);
+    free(tacc);
+  }
+}

@@ -90,6 +90,13 @@ def test_no_cpu_fallback_ops_fail_loudly():
         deform_conv(torch.zeros(1, 2, 5, 5), torch.zeros(1, 18, 5, 5), torch.zeros(2, 2, 3, 3), 1, 1)
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         _C.sigmoid_focalloss_forward(torch.zeros(4, 3), torch.zeros(4, dtype=torch.int32), 3, 2.0, 0.25)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        _C.deform_psroi_pooling_forward(torch.zeros(1, 9, 4, 4), torch.zeros(1, 5), torch.zeros(0),
+                                        torch.zeros(1, 1, 3, 3), torch.zeros(1, 1, 3, 3), 1, 1.0, 1, 3, 3, 3, 4, 0.0)
+    from maskrcnn_benchmark.layers import DeformRoIPooling
+
+    with pytest.raises(NotImplementedError):  # reference layers/dcn/deform_pool_func.py:29-30
+        DeformRoIPooling(1.0, 3, 1, True, 3)(torch.zeros(1, 9, 4, 4), torch.zeros(1, 5), torch.zeros(0))
 
 
 def test_argument_validation_without_a_gpu(lib):
@@ -100,6 +107,11 @@ def test_argument_validation_without_a_gpu(lib):
     assert rc == -1  # PH == 0 -> DETOPS_EINVAL
     rc = lib.detops_roi_align_forward_f32(None, None, None, 1, 4, 8, 8, 0, 7, 7, f(1.0), 2, None)
     assert rc == 0  # K == 0 is a no-op
+    ps = lib.detops_deform_psroi_pool_forward_f32
+    ps.restype = ctypes.c_int
+    # C = 8 < output_dim * group_size^2 = 9 -> DETOPS_EINVAL; K == 0 -> no-op
+    assert ps(None, None, None, None, None, 1, 8, 4, 4, 1, 2, 1, f(1.0), 1, 3, 3, 3, 4, f(0.0), None) == -1
+    assert ps(None, None, None, None, None, 1, 9, 4, 4, 0, 2, 1, f(1.0), 1, 3, 3, 3, 4, f(0.0), None) == 0
     lib.detops_nms_workspace_bytes.restype = ctypes.c_size_t
     assert lib.detops_nms_workspace_bytes(2000) >= 2000 * 32 * 8
     assert lib.detops_nms_workspace_bytes(0) > 0

@@ -258,6 +258,75 @@ def test_roi_pool_forward_backward():
     assert repr(ROIPool((7, 7), 0.25)) == "ROIPool(output_size=(7, 7), spatial_scale=0.25)"
 
 
+# ============================================================================ deformable PS-ROI pooling
+def _psroi_inputs(seed, K, output_dim, group_size, H, W, N, ncls, part):
+    rng = np.random.RandomState(seed)
+    data = rng.randn(N, output_dim * group_size * group_size, H, W).astype(np.float32)
+    x1 = rng.uniform(-20, W * 16 - 30, K)
+    y1 = rng.uniform(-20, H * 16 - 30, K)
+    rois = np.stack([rng.randint(0, N, K), x1, y1, x1 + rng.uniform(2, 300, K), y1 + rng.uniform(2, 250, K)],
+                    1).astype(np.float32)
+    rois[0, 1:] = [40.2, 40.7, 40.3, 40.9]
+    trans = (rng.randn(K, 2 * ncls, part, part) * 1.5).astype(np.float32)
+    return data, rois, trans
+
+
+@pytest.mark.parametrize("no_trans,ncls,D,G,P,part,S,std", [
+    (True, 1, 8, 3, 3, 3, 4, 0.0),      # R-FCN style position-sensitive pooling, no offsets
+    (False, 1, 8, 3, 7, 7, 4, 0.1),     # DeformRoIPoolingPack defaults (one offset field)
+    (False, 4, 8, 2, 7, 4, 2, 0.1),     # class-specific offsets, part_size != pooled_size
+    (False, 2, 4, 1, 12, 12, 4, 0.3),   # 12*12*16 samples > LDS table -> direct path
+])
+def test_deform_psroi_pool_vs_oracle(no_trans, ncls, D, G, P, part, S, std):
+    """parity unpinned by the reference (CUDA-only, no test): the oracle restates
+    deform_pool_kernel_cuda.cu and is cross-checked against a torch autograd formulation."""
+    C = _C()
+    data, rois, trans = _psroi_inputs(11 + P, 96, D, G, 50, 84, 2, ncls, part)
+    cfg = (no_trans, 1 / 16, D, G, P, part, S, std)
+    ref, rcnt = oracle.deform_psroi_pool_forward(data, rois, trans, *cfg)
+    d, r = _t(data), _t(rois)
+    t = torch.empty(0, device=DEV) if no_trans else _t(trans)
+    out = torch.empty(ref.shape, device=DEV)
+    cnt = torch.empty(ref.shape, device=DEV)
+    C.deform_psroi_pooling_forward(d, r, t, out, cnt, *cfg)
+    assert np.array_equal(cnt.cpu().numpy(), rcnt) and (rcnt == 0).any()
+    _close(out, ref, rtol=1e-4, atol=1e-5)
+    g = np.random.RandomState(4).randn(*ref.shape).astype(np.float32)
+    gref, tref = oracle.deform_psroi_pool_backward(g, data, rois, trans, rcnt, *cfg, acc64=True)
+    gin = torch.zeros_like(d)
+    gtr = torch.zeros_like(t)
+    C.deform_psroi_pooling_backward(_t(g), d, r, t, cnt, gin, gtr, *cfg)
+    _close(gin, gref, rtol=1e-4, atol=1e-4)
+    if not no_trans:
+        _close(gtr, tref, rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(tref).max())))
+
+
+def test_deform_roi_pooling_modules_autograd():
+    from maskrcnn_benchmark.layers import DeformRoIPooling, DeformRoIPoolingPack, ModulatedDeformRoIPoolingPack
+
+    data, rois, trans = _psroi_inputs(5, 16, 4, 1, 25, 42, 2, 1, 7)
+    d = _t(data).requires_grad_(True)
+    t = _t(trans).requires_grad_(True)
+    pool = DeformRoIPooling(1 / 16, 7, 4, False, 1, None, 4, 0.1)
+    y = pool(d, _t(rois), t)
+    ref, cnt = oracle.deform_psroi_pool_forward(data, rois, trans, False, 1 / 16, 4, 1, 7, 7, 4, 0.1)
+    _close(y, ref, rtol=1e-4, atol=1e-5)
+    y.sum().backward()
+    gref, tref = oracle.deform_psroi_pool_backward(np.ones_like(ref), data, rois, trans, cnt, False, 1 / 16,
+                                                   4, 1, 7, 7, 4, 0.1, acc64=True)
+    _close(d.grad, gref, rtol=1e-4, atol=1e-4)
+    _close(t.grad, tref, rtol=1e-3, atol=1e-3)
+    for cls in (DeformRoIPoolingPack, ModulatedDeformRoIPoolingPack):
+        m = cls(1 / 16, 7, 4, False, 1, None, 4, 0.1, deform_fc_channels=32).to(DEV)
+        out = m(d, _t(rois))
+        assert out.shape == (16, 4, 7, 7) and torch.isfinite(out).all()
+        out.sum().backward()
+    # empty ROI set
+    e = torch.empty((0, 4, 7, 7), device=DEV)
+    _C().deform_psroi_pooling_forward(d.detach(), torch.empty((0, 5), device=DEV), torch.empty(0, device=DEV),
+                                      e, e.clone(), True, 1 / 16, 4, 1, 7, 7, 4, 0.0)
+
+
 # ============================================================================ NMS
 def _nms(b, s, thr):
     return _C().nms(_t(b), _t(s), thr).cpu().numpy()

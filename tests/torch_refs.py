@@ -132,3 +132,65 @@ def deform_conv_torch(x, offset, mask, weight, bias, stride, pad, dil, group, dg
     if bias is not None:
         out = out + bias.view(1, -1, 1, 1)
     return out
+
+
+def deform_psroi_pool_torch(data, rois, trans, no_trans, scale, output_dim, group_size, P, part_size,
+                            S, trans_std):
+    """Deformable PS-ROI pooling from its definition (Deformable ConvNets, eq. 5-6 as the reference
+    discretises it): data [N,C,H,W] double, rois [K,5], trans [K,2*ncls,part,part] or None.
+    Differentiable in `data` and `trans`; the border clamp is straight-through (the operator's
+    offset gradient ignores the clamp).  Returns (out, count) [K,output_dim,P,P]."""
+    N, C, H, W = data.shape
+    dt = data.dtype
+    ncls = 1 if no_trans else trans.shape[1] // 2
+    cec = output_dim if no_trans else output_dim // ncls
+    ar = torch.arange(P, dtype=dt)
+    part = torch.floor(ar / P * part_size).long()
+    grp = torch.floor(ar * group_size / P).long().clamp(0, group_size - 1)
+    sub = torch.arange(S, dtype=dt)
+    cls_of = torch.arange(output_dim) // cec
+    # position-sensitive plane of (ctop, ph, pw)
+    plane = (torch.arange(output_dim)[:, None, None] * group_size + grp[None, :, None]) * group_size + grp[None, None, :]
+    outs, cnts = [], []
+    for k in range(rois.shape[0]):
+        b = int(rois[k, 0])
+        x1, y1, x2, y2 = [float(_c_round(float(v))) for v in rois[k, 1:]]
+        sw, sh = x1 * scale - 0.5, y1 * scale - 0.5
+        ew, eh = (x2 + 1.0) * scale - 0.5, (y2 + 1.0) * scale - 0.5
+        rw, rh = max(ew - sw, 0.1), max(eh - sh, 0.1)
+        bw, bh = rw / P, rh / P
+        if no_trans:
+            tx = torch.zeros(output_dim, P, P, dtype=dt)
+            ty = torch.zeros(output_dim, P, P, dtype=dt)
+        else:
+            t = trans[k].view(ncls, 2, part_size, part_size)[cls_of]          # [D,2,part,part]
+            t = t[:, :, part][:, :, :, part]                                 # [D,2,P,P]
+            tx, ty = t[:, 0] * trans_std, t[:, 1] * trans_std
+        ws = ar[None, None, :] * bw + sw + tx * rw                            # [D,P,P]
+        hs = ar[None, :, None] * bh + sh + ty * rh
+        w = ws[..., None, None] + sub[None, None, None, None, :] * (bw / S)   # [D,P,P,S,S] (ih, iw)
+        h = hs[..., None, None] + sub[None, None, None, :, None] * (bh / S)
+        w, h = torch.broadcast_tensors(w, h)
+        valid = ~((w < -0.5) | (w > W - 0.5) | (h < -0.5) | (h > H - 0.5))
+        wc = w + (w.clamp(0, W - 1) - w).detach()
+        hc = h + (h.clamp(0, H - 1) - h).detach()
+        x0, x1i = wc.detach().floor().long(), wc.detach().ceil().long()
+        y0, y1i = hc.detach().floor().long(), hc.detach().ceil().long()
+        x0, x1i, y0, y1i = [v.clamp(0, m) for v, m in ((x0, W - 1), (x1i, W - 1), (y0, H - 1), (y1i, H - 1))]
+        dx, dy = wc - x0.to(dt), hc - y0.to(dt)
+        img = data[b].reshape(C, H * W)
+        pl = plane[..., None, None].expand_as(x0)
+
+        def tap(yy, xx):
+            return img[pl, yy * W + xx]
+
+        val = ((1 - dx) * (1 - dy) * tap(y0, x0) + (1 - dx) * dy * tap(y1i, x0)
+               + dx * (1 - dy) * tap(y0, x1i) + dx * dy * tap(y1i, x1i))
+        val = torch.where(valid, val, torch.zeros_like(val))
+        cnt = valid.sum((-1, -2)).to(dt)
+        outs.append(torch.where(cnt > 0, val.sum((-1, -2)) / cnt.clamp(min=1), torch.zeros_like(cnt)))
+        cnts.append(cnt)
+    if not outs:
+        z = data.new_zeros((0, output_dim, P, P))
+        return z, z
+    return torch.stack(outs), torch.stack(cnts)
