@@ -43,10 +43,42 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--channels-last", action="store_true")
-    ap.add_argument("--no-miopen-search", action="store_true",
-                    help="leave torch.backends.cudnn.benchmark off (MIOpen picks from its find-db / heuristics)")
+    ap.add_argument("--miopen-search", action="store_true",
+                    help="torch.backends.cudnn.benchmark = True: MIOpen times every applicable conv solver per "
+                         "shape in warm-up (minutes from a cold kernel cache on a fresh box — measured >5 min for "
+                         "this model in fp32; default off = MIOpen immediate mode, or the shipped find-db when "
+                         "maskrcnn-benchmark_amd/miopen_db/ exists)")
+    ap.add_argument("--no-miopen-search", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--export-miopen-db", default=None, metavar="DIR",
+                    help="write MIOpen's find-db + kernel cache of this run to DIR (see setup_miopen_db)")
     ap.add_argument("opts", nargs=argparse.REMAINDER, default=[])
     return ap.parse_args()
+
+
+def setup_miopen_db(export_dir=None):
+    """MIOpen's per-user find-db (measured solver ranking per conv shape) and compiled-kernel cache
+    live under $HOME and start EMPTY on a fresh box (the torch wheel ships no gfx950 find-db), so a
+    cold process either searches for minutes or falls back to heuristics.  A tuning database
+    produced once on an MI355X (`--miopen-search --export-miopen-db DIR`) can be shipped in-tree as
+    maskrcnn-benchmark_amd/miopen_db/{db,cache}; it is copied to a scratch dir (MIOpen writes to it)
+    and selected through MIOpen's own environment variables.  Must run before `import torch`."""
+    import shutil
+    import tempfile
+    if export_dir:
+        os.makedirs(os.path.join(export_dir, "db"), exist_ok=True)
+        os.makedirs(os.path.join(export_dir, "cache"), exist_ok=True)
+        os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(export_dir, "db")
+        os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(export_dir, "cache")
+        return "export:" + export_dir
+    shipped = os.path.join(ROOT, "maskrcnn-benchmark_amd", "miopen_db")
+    if "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(os.path.join(shipped, "db")):
+        return None
+    scratch = tempfile.mkdtemp(prefix="miopen_db_rank%s_" % os.environ.get("RANK", "0"))
+    shutil.copytree(shipped, scratch, dirs_exist_ok=True)
+    os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(scratch, "db")
+    if os.path.isdir(os.path.join(scratch, "cache")):
+        os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(scratch, "cache")
+    return "shipped:" + shipped
 
 
 def algorithmic_bytes(name, feat_bytes):
@@ -131,6 +163,7 @@ def cpu_baseline(sample_rois=1024, min_seconds=8.0):
 
 def main():
     args = parse()
+    miopen_db = setup_miopen_db(args.export_miopen_db)
     import torch
     import torch.distributed as dist
 
@@ -157,8 +190,8 @@ def main():
         opts += ["DTYPE", args.dtype]
     cfg = load_cfg(args.config, opts)
     torch.manual_seed(1234 + rank)
-    # MIOpen: search the conv algorithm once per (fixed) shape during warm-up
-    torch.backends.cudnn.benchmark = not args.no_miopen_search
+    # MIOpen: immediate mode by default (see --miopen-search)
+    torch.backends.cudnn.benchmark = bool(args.miopen_search) and not args.no_miopen_search
     t_start = time.perf_counter()
 
     def progress(msg):
@@ -225,6 +258,7 @@ def main():
             "loss_finite": all(v == v and abs(v) != float("inf") for v in loss_vals.values()),
             "losses": {k: round(v, 4) for k, v in loss_vals.items()},
             "max_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+            "miopen": {"search": bool(torch.backends.cudnn.benchmark), "db": miopen_db},
         }
         if timer is not None:
             kernels, dominant = {}, None

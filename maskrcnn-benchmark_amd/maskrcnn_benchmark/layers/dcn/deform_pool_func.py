@@ -34,6 +34,10 @@ class DeformRoIPoolingFunction(Function):
         data, rois, offset = ctx.saved_tensors
         grad_input = torch.zeros_like(data)
         grad_offset = torch.zeros_like(offset)
+        # `_C` keeps the reference's "out_grad tensor has to be contiguous" check
+        # (deform_pool_cuda.cu:71); an expanded upstream gradient (e.g. from `.sum()`) is
+        # materialised here instead of failing like the reference's Function does.
+        grad_output = grad_output.contiguous()
         _C.deform_psroi_pooling_backward(grad_output, data, rois, offset, ctx.output_count, grad_input,
                                          grad_offset, *ctx.cfg)
         return (grad_input, None, grad_offset, None, None, None, None, None, None, None, None)

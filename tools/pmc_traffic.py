@@ -28,7 +28,7 @@ def load(dirname, counter):
             name = r["Kernel_Name"]
             if not any(k in name for k in OURS):
                 continue
-            key = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip()
+            key = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
             key += "|grid=%s" % r.get("Grid_Size", r.get("Grid_Size_X", ""))
             acc[key][0] += float(r["Counter_Value"])
             acc[key][1] += 1
