@@ -1,6 +1,10 @@
 // detops_common.h — shared host/device helpers for libdetops_gfx950 (gfx950 / CDNA4 only).
 #pragma once
+#ifdef DETOPS_CPU_EMU  // tests/emu: the kernels compiled as host C++ (logic checks without a GPU)
+#include "hip_cpu_emu.h"
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "detops.h"
@@ -19,6 +23,13 @@ static inline int launch_status() { return static_cast<int>(hipGetLastError()); 
     hipError_t _e = (expr);                        \
     if (_e != hipSuccess) return static_cast<int>(_e); \
   } while (0)
+
+// Dynamically sized LDS of a kernel, as `T name[]` (16-byte aligned).
+#ifdef DETOPS_CPU_EMU
+#define DETOPS_DYNAMIC_LDS(T, name) T* name = reinterpret_cast<T*>(emu::dynamic_lds())
+#else
+#define DETOPS_DYNAMIC_LDS(T, name) extern __shared__ __align__(16) T name[]
+#endif
 
 constexpr int kWave = 64;        // CDNA4 wavefront
 constexpr int kNumCU = 256;      // MI355X

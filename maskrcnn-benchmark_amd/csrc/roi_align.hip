@@ -215,7 +215,7 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
   constexpr int BINS = PH * PW;
   constexpr int NS = SR * SR;
   constexpr int NT = ((BINS * G + 63) / 64) * 64;
-  extern __shared__ float patch[];
+  DETOPS_DYNAMIC_LDS(float, patch);
   __shared__ Tap tabY[PH * SR];
   __shared__ Tap tabX[PW * SR];
   __shared__ int s_bounds[4];
@@ -397,7 +397,7 @@ roi_align_bwd_tile_kernel(Levels L, BwdPlan P, const float* __restrict__ rois,
   const int PH = PH_ ? PH_ : PHr;
   const int PW = PW_ ? PW_ : PWr;
   const int bins = PH * PW;
-  extern __shared__ float acc[];
+  DETOPS_DYNAMIC_LDS(float, acc);
   __shared__ HitGeom s_hit[kBwdList];
   __shared__ int s_wcount[kBlock / kWave];
 
@@ -537,6 +537,270 @@ roi_align_bwd_tile_kernel(Levels L, BwdPlan P, const float* __restrict__ rois,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward, pixel-owner ("adjoint gather"): NO atomics of any kind, deterministic.
+//
+// ROIAlign's sampling is separable, so its adjoint factors per ROI r and channel c into two tiny
+// matrices:
+//     grad_in[b_r, c, y, x] += sum_{ph,pw} AY_r[ph, y] * AX_r[pw, x] * grad_out[r, c, ph, pw]
+//     AY_r[ph, y] = (1/gh) * sum_iy ([y == lo(ph,iy)] * hy + [y == hi(ph,iy)] * ly)     (AX alike)
+// with lo/hi/ly/hy exactly the reference's sample taps (ROIAlign_cuda.cu:125-175).  A pixel only
+// receives from bins whose samples lie within one pixel of it, so AY[., y] / AX[., x] have 2-3
+// non-zeros for model-sized ROIs.
+//
+// A workgroup owns an 8 x 32 pixel tile of one gradient map and CT channels; every thread owns ONE
+// pixel and keeps its CT partial sums in registers from the first ROI to the last, so nothing is
+// ever accumulated in memory: no global atomics (205 M per launch in the scatter form; the
+// reference issues 16 per gradient element, ROIAlign_cuda.cu:246-249), no LDS atomics (the
+// tile-scatter kernel above is bound by same-address ds_add_f32 serialisation: 1.46 ms measured),
+// and no zero-fill pass — each gradient-map element is written exactly once, as full 128-byte
+// rows.  ROIs are visited in ascending index order and each pixel's sum is formed sequentially,
+// so the result is bit-reproducible run to run (the reference's atomics are not).
+//
+// Per batch of hit ROIs the workgroup (1) builds the dense per-axis coefficient rows for its tile
+// in LDS (one thread per (ROI, axis, bin), reference tap arithmetic), (2) stages
+// grad_out[r, c0:c0+CT, :, :] transposed to [bin][channel] so that (3) a wave walks the (ph, pw)
+// pairs any of its lanes needs (wave-uniform ballots skip the rest): per pair one broadcast
+// ds_read_b128 per 4 channels + CT FMAs.  Waves are 8 x 8 pixel blocks: a ROI that misses a
+// wave's columns is skipped by that wave.
+// ------------------------------------------------------------------------------------------
+constexpr int kGTH = 8, kGTW = 32;     // tile: 8 rows x 32 columns = 256 threads
+constexpr int kGBins = 256;            // (ROIs per batch) * bins <= kGBins when bins <= kGBins
+constexpr int kGRowPad = kGTW + 1;     // transposition buffer row stride (bank spread)
+
+struct GPlan {
+  int first_item[DETOPS_MAX_LEVELS];   // workgroup-id offset per level (coarsest level first)
+  int n_items[DETOPS_MAX_LEVELS];
+  int tiles_x[DETOPS_MAX_LEVELS], tiles_y[DETOPS_MAX_LEVELS];
+  int chunks, accumulate, batch;       // batch = ROIs staged per round
+};
+
+struct __align__(16) GHit {   // 32 bytes
+  float start_w, start_h, bin_w, bin_h;
+  int k, gh, gw;
+  int xspan;   // (ix0 << 16) | ix1: columns the ROI's taps can reach (conservative), map width < 32768
+};
+
+template <int PH_, int PW_, int CT>
+__global__ void __launch_bounds__(kBlock)
+roi_align_bwd_gather_kernel(Levels L, GPlan P, const float* __restrict__ rois,
+                            const int32_t* __restrict__ levels_in, const float* __restrict__ gout,
+                            int C, int K, int PHr, int PWr, int sr) {
+  static_assert(CT % 4 == 0, "channels are staged as float4 groups");
+  constexpr int CG = CT / 4;
+  const int PH = PH_ ? PH_ : PHr;
+  const int PW = PW_ ? PW_ : PWr;
+  const int bins = PH * PW;
+  const int PPH = (PH + 3) & ~3, PPW = (PW + 3) & ~3;   // coefficient rows padded to float4
+  const int slots = max(bins, kGBins);                   // (ROI, bin) slots per float4 channel group
+
+  DETOPS_DYNAMIC_LDS(float, g_lds);
+  float4* gs4 = reinterpret_cast<float4*>(g_lds);        // [CG][slots] float4   (also the store buffer)
+  const int region = max(slots * CT, CT * kGTH * kGRowPad);
+  float* ayt = g_lds + region;                           // [batch][kGTH][PPH]
+  float* axt = ayt + P.batch * kGTH * PPH;               // [batch][kGTW][PPW]
+  __shared__ GHit s_hit[kBlock];
+  __shared__ int s_wcount[kBlock / kWave];
+
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  // ---- decode the work item (levels are laid out coarsest first: their tiles see the most ROIs)
+  int lvl = 0;
+#pragma unroll
+  for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+    if (i < L.num && static_cast<int>(blockIdx.x) >= P.first_item[i] &&
+        static_cast<int>(blockIdx.x) < P.first_item[i] + P.n_items[i]) lvl = i;
+  float* gin = L.lv[0].gin; int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
+  int ntx = P.tiles_x[0], nty = P.tiles_y[0], first = P.first_item[0];
+#pragma unroll
+  for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+    if (i == lvl) { gin = L.lv[i].gin; H = L.lv[i].H; W = L.lv[i].W; scale = L.lv[i].scale;
+                    ntx = P.tiles_x[i]; nty = P.tiles_y[i]; first = P.first_item[i]; }
+  int rem = static_cast<int>(blockIdx.x) - first;
+  const int chunk = rem % P.chunks; rem /= P.chunks;
+  const int tix = rem % ntx; rem /= ntx;
+  const int tiy = rem % nty;
+  const int b = rem / nty;
+  const int y0 = tiy * kGTH, x0 = tix * kGTW;
+  const int y1 = min(H, y0 + kGTH) - 1, x1 = min(W, x0 + kGTW) - 1;  // inclusive
+  const int c0 = chunk * CT;
+  // this thread's pixel: waves are 8x8 blocks side by side
+  const int yl = lane >> 3, xl = wave * 8 + (lane & 7);
+  const int wx0 = x0 + wave * 8, wx1 = wx0 + 7;
+
+  float acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+
+  for (int kb = 0; kb < K; kb += kBlock) {
+    // ---- which of ROIs [kb, kb+256) touch this tile?  ordered compaction into s_hit
+    const int r = kb + tid;
+    bool hit = false;
+    GHit h{};
+    if (r < K) {
+      const float* roi = rois + static_cast<size_t>(r) * 5;
+      const int rl = (L.num > 1) ? levels_in[r] : 0;
+      if (rl == lvl && static_cast<int>(roi[0]) == b) {
+#pragma clang fp contract(off)
+        const RoiGeom g = roi_geometry(roi, scale, PH, PW, sr);
+        const float rh = g.bin_h * static_cast<float>(PH), rw = g.bin_w * static_cast<float>(PW);
+        // rows/cols any tap of this ROI can touch (conservative): floor(first) .. floor(last)+2
+        const float fy0 = floorf(fmaxf(g.start_h, 0.f)), fy1 = floorf(g.start_h + rh) + 2.f;
+        const float fx0 = floorf(fmaxf(g.start_w, 0.f)), fx1 = floorf(g.start_w + rw) + 2.f;
+        hit = fy0 <= static_cast<float>(y1) && fy1 >= static_cast<float>(y0) &&
+              fx0 <= static_cast<float>(x1) && fx1 >= static_cast<float>(x0);
+        h.start_w = g.start_w; h.start_h = g.start_h; h.bin_w = g.bin_w; h.bin_h = g.bin_h;
+        h.k = r; h.gh = g.gh; h.gw = g.gw;
+        const int ix0 = static_cast<int>(fminf(fx0, static_cast<float>(W)));
+        const int ix1 = static_cast<int>(fminf(fmaxf(fx1, 0.f), static_cast<float>(W)));
+        h.xspan = (ix0 << 16) | ix1;
+      }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_wcount[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < kBlock / kWave; ++j) {
+      const int v = s_wcount[j];
+      if (j < wave) before += v;
+      total += v;
+    }
+    if (hit) s_hit[before + __popcll(m & ((1ull << lane) - 1ull))] = h;
+    __syncthreads();
+
+    for (int h0 = 0; h0 < total; h0 += P.batch) {
+      const int nb = min(P.batch, total - h0);
+      // ---- (1) per-axis coefficient rows of the batch, restricted to this tile
+      for (int t = tid; t < nb * (PH + PW); t += kBlock) {
+        const int j = t / (PH + PW);
+        const int q = t - j * (PH + PW);
+        const GHit hj = s_hit[h0 + j];
+        if (q < PH) {
+          float* row = ayt + j * kGTH * PPH + q;
+          for (int i = 0; i < kGTH; ++i) row[i * PPH] = 0.f;
+          const float inv = 1.f / static_cast<float>(hj.gh);
+          for (int i = 0; i < hj.gh; ++i) {
+            const Tap e = axis_entry(hj.start_h, hj.bin_h, q, i, hj.gh, H, 1);
+            const int a0 = e.lo - y0, a1 = e.hi - y0;
+            if (a0 >= 0 && a0 < kGTH) row[a0 * PPH] += e.h * inv;
+            if (a1 >= 0 && a1 < kGTH) row[a1 * PPH] += e.l * inv;
+          }
+        } else {
+          const int qq = q - PH;
+          float* row = axt + j * kGTW * PPW + qq;
+          for (int i = 0; i < kGTW; ++i) row[i * PPW] = 0.f;
+          const float inv = 1.f / static_cast<float>(hj.gw);
+          for (int i = 0; i < hj.gw; ++i) {
+            const Tap e = axis_entry(hj.start_w, hj.bin_w, qq, i, hj.gw, W, 1);
+            const int a0 = e.lo - x0, a1 = e.hi - x0;
+            if (a0 >= 0 && a0 < kGTW) row[a0 * PPW] += e.h * inv;
+            if (a1 >= 0 && a1 < kGTW) row[a1 * PPW] += e.l * inv;
+          }
+        }
+      }
+      // ---- (2) stage grad_out[r, c0:c0+CT, :, :] as float4 channel groups: [cg][j*bins + bin]
+      //      (global reads run along a channel's contiguous bins; LDS writes are 16-byte, lane-contiguous)
+      for (int u = tid; u < nb * bins * CG; u += kBlock) {
+        const int cg = u / (nb * bins);
+        const int jb = u - cg * (nb * bins);
+        const int j = jb / bins;
+        const int bin = jb - j * bins;
+        const int cbase = c0 + cg * 4;
+        const float* src = gout + (static_cast<size_t>(s_hit[h0 + j].k) * C + cbase) * bins + bin;
+        float4 v;
+        v.x = (cbase + 0 < C) ? src[0] : 0.f;
+        v.y = (cbase + 1 < C) ? src[bins] : 0.f;
+        v.z = (cbase + 2 < C) ? src[2 * bins] : 0.f;
+        v.w = (cbase + 3 < C) ? src[3 * bins] : 0.f;
+        gs4[cg * slots + jb] = v;
+      }
+      __syncthreads();
+      // ---- (3) every pixel gathers from the bins that reach it
+      for (int j = 0; j < nb; ++j) {
+        const int xspan = s_hit[h0 + j].xspan;
+        const int jx0 = xspan >> 16, jx1 = xspan & 0xffff;
+        if (jx1 < wx0 || jx0 > wx1) continue;   // this ROI misses the wave's 8 columns
+        const float* ayr = ayt + (j * kGTH + yl) * PPH;
+        const float* axr = axt + (j * kGTW + xl) * PPW;
+        const float4* gj = gs4 + j * bins;
+        if constexpr (PH_ > 0 && PW_ > 0) {
+          constexpr int QH = (PH_ + 3) / 4, QW = (PW_ + 3) / 4;
+          float ay[QH * 4], ax[QW * 4];
+#pragma unroll
+          for (int q = 0; q < QH; ++q) {
+            const float4 v = reinterpret_cast<const float4*>(ayr)[q];
+            ay[4 * q] = v.x; ay[4 * q + 1] = v.y; ay[4 * q + 2] = v.z; ay[4 * q + 3] = v.w;
+          }
+#pragma unroll
+          for (int q = 0; q < QW; ++q) {
+            const float4 v = reinterpret_cast<const float4*>(axr)[q];
+            ax[4 * q] = v.x; ax[4 * q + 1] = v.y; ax[4 * q + 2] = v.z; ax[4 * q + 3] = v.w;
+          }
+#pragma unroll
+          for (int ph = 0; ph < PH_; ++ph) {
+            if (__ballot(ay[ph] != 0.f) == 0ull) continue;
+#pragma unroll
+            for (int pw = 0; pw < PW_; ++pw) {
+              const float w = ay[ph] * ax[pw];
+              if (__ballot(w != 0.f) == 0ull) continue;
+              if (w != 0.f) {
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) {
+                  const float4 g4 = gj[cg * slots + ph * PW_ + pw];
+                  acc[4 * cg + 0] = fmaf(w, g4.x, acc[4 * cg + 0]);
+                  acc[4 * cg + 1] = fmaf(w, g4.y, acc[4 * cg + 1]);
+                  acc[4 * cg + 2] = fmaf(w, g4.z, acc[4 * cg + 2]);
+                  acc[4 * cg + 3] = fmaf(w, g4.w, acc[4 * cg + 3]);
+                }
+              }
+            }
+          }
+        } else {
+          for (int ph = 0; ph < PH; ++ph) {
+            const float a = ayr[ph];
+            if (__ballot(a != 0.f) == 0ull) continue;
+            for (int pw = 0; pw < PW; ++pw) {
+              const float w = a * axr[pw];
+              if (w != 0.f) {
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) {
+                  const float4 g4 = gj[cg * slots + ph * PW + pw];
+                  acc[4 * cg + 0] = fmaf(w, g4.x, acc[4 * cg + 0]);
+                  acc[4 * cg + 1] = fmaf(w, g4.y, acc[4 * cg + 1]);
+                  acc[4 * cg + 2] = fmaf(w, g4.z, acc[4 * cg + 2]);
+                  acc[4 * cg + 3] = fmaf(w, g4.w, acc[4 * cg + 3]);
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();  // the next batch (or scan round, or the store) rewrites the staging region
+    }
+  }
+
+  // ---- store: registers -> LDS [c][8][33] -> full 128-byte rows; every in-map element of the
+  //      tile is written exactly once (zeros where no ROI reaches)
+  float* tb = g_lds;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) tb[(c * kGTH + yl) * kGRowPad + xl] = acc[c];
+  __syncthreads();
+  const size_t plane = static_cast<size_t>(H) * W;
+  const int cn = min(CT, C - c0);
+  float* gb = gin + (static_cast<size_t>(b) * C + c0) * plane;
+  for (int e = tid; e < cn * kGTH * kGTW; e += kBlock) {
+    const int c = e / (kGTH * kGTW);
+    const int pix = e - c * (kGTH * kGTW);
+    const int yy = pix / kGTW, xx = pix - yy * kGTW;
+    if (y0 + yy <= y1 && x0 + xx <= x1) {
+      float* dst = gb + static_cast<size_t>(c) * plane + static_cast<size_t>(y0 + yy) * W + (x0 + xx);
+      float v = tb[(c * kGTH + yy) * kGRowPad + xx];
+      if (P.accumulate) v += *dst;
+      *dst = v;
+    }
+  }
+}
+
 // Channel chunk per workgroup: enough workgroups to fill 256 CUs several times over while
 // keeping the per-workgroup table build amortised over >= 16 channels.
 inline int pick_chunk(int C, int K) {
@@ -653,6 +917,71 @@ int run_backward_tiles(const Levels& L, const float* rois, const int32_t* levels
   return launch_status();
 }
 
+// Pixel-owner backward launch.  Returns -1 when the shape does not fit its LDS plan (huge bin
+// counts): the caller then uses the tile-scatter kernel.
+int run_backward_gather(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
+                        int N, int C, int K, int PH, int PW, int sr, int accumulate, hipStream_t st) {
+  if (C == 0 || N == 0) return 0;
+  const int bins = PH * PW;
+  const int PPH = (PH + 3) & ~3, PPW = (PW + 3) & ~3;
+  auto count_items = [&](int ct) {
+    int64_t items = 0;
+    for (int i = 0; i < L.num; ++i)
+      items += static_cast<int64_t>(N) * ceil_div64(L.lv[i].H, kGTH) * ceil_div64(L.lv[i].W, kGTW) * ceil_div64(C, ct);
+    return items;
+  };
+  // 16 channels per workgroup unless that leaves the chip underfilled (small maps) or the staged
+  // gradient block would not fit in LDS (bins > 256)
+  int CT = 16;
+  if (count_items(16) < 2 * kNumCU) CT = 4;
+  if (const char* e = getenv("DETOPS_ROIALIGN_BWD_CT")) CT = (atoi(e) == 16) ? 16 : 4;  // tuning / test knob
+  if (bins > kGBins) CT = 4;
+  const int slots = max(bins, kGBins);
+  const int batch = max(1, kGBins / bins);
+  const size_t region = static_cast<size_t>(max(slots * CT, CT * kGTH * kGRowPad));
+  const size_t lds = sizeof(float) * (region + static_cast<size_t>(batch) * (kGTH * PPH + kGTW * PPW));
+  if (lds > 56 * 1024) return -1;
+  for (int i = 0; i < L.num; ++i)
+    if (L.lv[i].W > 32767) return -1;  // GHit::xspan packs two 15-bit column indices
+  GPlan P{};
+  P.chunks = static_cast<int>(ceil_div64(C, CT));
+  P.accumulate = accumulate;
+  P.batch = batch;
+  int64_t items = 0;
+  for (int i = L.num - 1; i >= 0; --i) {  // coarsest level first
+    P.tiles_x[i] = static_cast<int>(ceil_div64(L.lv[i].W, kGTW));
+    P.tiles_y[i] = static_cast<int>(ceil_div64(L.lv[i].H, kGTH));
+    const int64_t n = static_cast<int64_t>(N) * P.tiles_x[i] * P.tiles_y[i] * P.chunks;
+    if (items + n > 0x7fffffff) return DETOPS_EUNSUPPORTED;
+    P.first_item[i] = static_cast<int>(items);
+    P.n_items[i] = static_cast<int>(n);
+    items += n;
+  }
+  if (items == 0) return 0;
+  const dim3 grid(static_cast<unsigned>(items));
+#define GATHER_LAUNCH(PH_, PW_, CT_)                                                                          \
+  hipLaunchKernelGGL((roi_align_bwd_gather_kernel<PH_, PW_, CT_>), grid, dim3(kBlock), lds, st, L, P, rois, \
+                     levels_in, gout, C, K, PH, PW, sr)
+  if (PH == 7 && PW == 7) { if (CT == 16) GATHER_LAUNCH(7, 7, 16); else GATHER_LAUNCH(7, 7, 4); }
+  else if (PH == 14 && PW == 14) { if (CT == 16) GATHER_LAUNCH(14, 14, 16); else GATHER_LAUNCH(14, 14, 4); }
+  else { if (CT == 16) GATHER_LAUNCH(0, 0, 16); else GATHER_LAUNCH(0, 0, 4); }
+#undef GATHER_LAUNCH
+  return launch_status();
+}
+
+// DETOPS_ROIALIGN_BWD=tile forces the LDS-scatter tile kernel (A/B measurements); default: the
+// atomic-free pixel-owner kernel.
+int run_backward(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
+                 int N, int C, int K, int PH, int PW, int sr, int accumulate, hipStream_t st) {
+  const char* e = getenv("DETOPS_ROIALIGN_BWD");  // read per call: tests flip it at run time
+  const bool force_tile = e && e[0] == 't';
+  if (!force_tile) {
+    const int rc = run_backward_gather(L, rois, levels_in, gout, N, C, K, PH, PW, sr, accumulate, st);
+    if (rc != -1) return rc;
+  }
+  return run_backward_tiles(L, rois, levels_in, gout, N, C, K, PH, PW, sr, accumulate, st);
+}
+
 inline bool bad_dims(int N, int C, int K, int PH, int PW) {
   return N < 0 || C < 0 || K < 0 || PH <= 0 || PW <= 0;
 }
@@ -687,8 +1016,8 @@ DETOPS_API int detops_roi_align_backward_f32(const float* grad_out, const float*
   Levels L{};
   L.num = 1;
   L.lv[0] = Level{nullptr, grad_in, H, W, spatial_scale};
-  return run_backward_tiles(L, rois, nullptr, grad_out, N, C, K, PH, PW, sampling_ratio,
-                            zero_grad_in ? 0 : 1, as_stream(stream));
+  return run_backward(L, rois, nullptr, grad_out, N, C, K, PH, PW, sampling_ratio,
+                      zero_grad_in ? 0 : 1, as_stream(stream));
 }
 
 DETOPS_API int detops_roi_align_fpn_forward_f32(
@@ -730,6 +1059,6 @@ DETOPS_API int detops_roi_align_fpn_backward_f32(
   if (C == 0 || N == 0) return 0;
   if (K > 0 && (!grad_out || !rois || (num_levels > 1 && !levels))) return DETOPS_EINVAL;
   if (K == 0 && !zero_grad_in) return 0;
-  return run_backward_tiles(L, rois, levels, grad_out, N, C, K, PH, PW, sampling_ratio,
-                            zero_grad_in ? 0 : 1, as_stream(stream));
+  return run_backward(L, rois, levels, grad_out, N, C, K, PH, PW, sampling_ratio,
+                      zero_grad_in ? 0 : 1, as_stream(stream));
 }

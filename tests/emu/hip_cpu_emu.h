@@ -1,0 +1,209 @@
+// hip_cpu_emu.h — TEST INFRASTRUCTURE ONLY.  A minimal single-process emulation of the HIP
+// execution model, just large enough to compile the kernels of maskrcnn-benchmark_amd/csrc/*.hip
+// as plain C++ and execute them on the host: the container that builds this repo has no GPU, and
+// GPU minutes are scarce, so kernel LOGIC (index arithmetic, barrier placement, LDS layout,
+// ballot compaction) is first checked here against the oracle; parity proper is still the
+// `-m gpu` suite on the real device.  Nothing under maskrcnn-benchmark_amd/ loads this.
+//
+// Model: workgroups run one after another; the threads of a workgroup are ucontext fibers that
+// run round-robin and switch only at __syncthreads() / wave collectives.  Thread 0 therefore
+// races far ahead of the others between barriers — a missing barrier shows up as a wrong result,
+// deterministically.  A wave is 64 consecutive threads; __ballot is a wave-wide rendezvous (every
+// live lane of the wave must reach it — true for the kernels here, whose ballots sit in
+// wave-uniform control flow).  A rendezvous that can never complete aborts with a message.
+#pragma once
+#include <setjmp.h>
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define DETOPS_CPU_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __align__(n) alignas(n)
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+struct alignas(8) int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+
+namespace emu {
+constexpr int kWaveSize = 64;
+constexpr size_t kStackBytes = 256 * 1024;
+constexpr size_t kDynLdsBytes = 160 * 1024;
+
+struct Wave {
+  int alive = 0, arrived = 0;
+  unsigned gen = 0;
+  unsigned long long preds = 0, result[2] = {0, 0};
+};
+
+struct Block {
+  dim3 grid, block, bid;
+  int nthreads = 0, alive = 0, arrived = 0;
+  unsigned gen = 0;
+  std::vector<Wave> waves;
+};
+
+struct Fiber {
+  ucontext_t ctx;   // first entry only; later switches use _setjmp/_longjmp (no sigprocmask syscalls)
+  jmp_buf jb;
+  char* stack = nullptr;
+  bool done = false, started = false;
+  dim3 tid;
+  int linear = 0;
+};
+
+inline Block*& cur_block() { static Block* b = nullptr; return b; }
+inline Fiber*& cur_fiber() { static Fiber* f = nullptr; return f; }
+inline jmp_buf& sched_jb() { static jmp_buf j; return j; }
+inline unsigned long long& progress() { static unsigned long long p = 0; return p; }
+inline void* dynamic_lds() { alignas(64) static unsigned char buf[kDynLdsBytes]; return buf; }
+inline std::function<void()>& body() { static std::function<void()> f; return f; }
+
+inline void yield() {
+  if (!_setjmp(cur_fiber()->jb)) _longjmp(sched_jb(), 1);
+}
+
+inline void trampoline() {
+  body()();
+  Fiber* f = cur_fiber();
+  Block* b = cur_block();
+  f->done = true;
+  --b->alive;
+  --b->waves[f->linear / kWaveSize].alive;
+  ++progress();
+  _longjmp(sched_jb(), 1);
+}
+
+inline void syncthreads() {
+  Block* b = cur_block();
+  const unsigned gen = b->gen;
+  ++b->arrived;
+  ++progress();
+  while (b->gen == gen) {
+    if (b->arrived >= b->alive) { b->arrived = 0; ++b->gen; ++progress(); break; }
+    yield();
+  }
+}
+
+inline unsigned long long ballot(bool pred) {
+  Block* b = cur_block();
+  Fiber* f = cur_fiber();
+  Wave& w = b->waves[f->linear / kWaveSize];
+  const unsigned gen = w.gen;
+  if (pred) w.preds |= 1ull << (f->linear % kWaveSize);
+  ++w.arrived;
+  ++progress();
+  while (w.gen == gen) {
+    if (w.arrived >= w.alive) {
+      w.result[gen & 1] = w.preds;
+      w.preds = 0; w.arrived = 0; ++w.gen; ++progress();
+      break;
+    }
+    yield();
+  }
+  return w.result[gen & 1];
+}
+
+inline void launch(const std::function<void()>& kernel_body, dim3 grid, dim3 block, size_t lds_bytes) {
+  if (lds_bytes > kDynLdsBytes) { fprintf(stderr, "emu: dynamic LDS %zu too large\n", lds_bytes); abort(); }
+  const int nthreads = static_cast<int>(block.x * block.y * block.z);
+  static std::vector<Fiber> fibers;
+  if (static_cast<int>(fibers.size()) < nthreads) {
+    const size_t old = fibers.size();
+    fibers.resize(nthreads);
+    for (size_t i = old; i < fibers.size(); ++i) fibers[i].stack = static_cast<char*>(malloc(kStackBytes));
+  }
+  body() = kernel_body;
+  Block blk;
+  blk.grid = grid; blk.block = block; blk.nthreads = nthreads;
+  cur_block() = &blk;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        blk.bid = dim3(bx, by, bz);
+        blk.alive = nthreads; blk.arrived = 0; blk.gen = 0;
+        blk.waves.assign((nthreads + kWaveSize - 1) / kWaveSize, Wave());
+        for (int t = 0; t < nthreads; ++t) {
+          Fiber& f = fibers[t];
+          f.done = false;
+          f.started = false;
+          f.linear = t;
+          f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+          ++blk.waves[t / kWaveSize].alive;
+          getcontext(&f.ctx);
+          f.ctx.uc_stack.ss_sp = f.stack;
+          f.ctx.uc_stack.ss_size = kStackBytes;
+          f.ctx.uc_link = nullptr;
+          makecontext(&f.ctx, reinterpret_cast<void (*)()>(trampoline), 0);
+        }
+        while (blk.alive > 0) {
+          const unsigned long long before = progress();
+          for (int t = 0; t < nthreads; ++t) {
+            if (fibers[t].done) continue;
+            cur_fiber() = &fibers[t];
+            if (!_setjmp(sched_jb())) {
+              if (!fibers[t].started) { fibers[t].started = true; setcontext(&fibers[t].ctx); }
+              else _longjmp(fibers[t].jb, 1);
+            }
+          }
+          if (progress() == before) {
+            fprintf(stderr, "emu: deadlock in block (%u,%u,%u): a barrier/ballot not reached by all live threads\n", bx, by, bz);
+            abort();
+          }
+        }
+      }
+  cur_block() = nullptr;
+  cur_fiber() = nullptr;
+}
+}  // namespace emu
+
+#define threadIdx (emu::cur_fiber()->tid)
+#define blockIdx (emu::cur_block()->bid)
+#define blockDim (emu::cur_block()->block)
+#define gridDim (emu::cur_block()->grid)
+
+static inline void __syncthreads() { emu::syncthreads(); }
+static inline unsigned long long __ballot(int pred) { return emu::ballot(pred != 0); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+
+// fibers never run concurrently: plain read-modify-write is atomic here
+static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
+static inline int atomicMin(int* p, int v) { const int o = *p; *p = std::min(o, v); return o; }
+static inline int atomicMax(int* p, int v) { const int o = *p; *p = std::max(o, v); return o; }
+
+template <typename T> static inline T min(T a, T b) { return a < b ? a : b; }
+template <typename T> static inline T max(T a, T b) { return a > b ? a : b; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+  emu::launch([&]() { kernel(__VA_ARGS__); }, grid, block, lds)

@@ -1,0 +1,91 @@
+"""Kernel-logic checks WITHOUT a GPU: the HIP sources of the ROIAlign / ROIPool kernels are compiled
+as host C++ and executed by the fiber-based emulation in tests/emu/ (workgroups, barriers, wave
+ballots, LDS), then compared with the oracle.  This is not the parity gate (that is `-m gpu`, on
+the device); it catches indexing / barrier / layout mistakes before GPU minutes are spent.  The
+forward comparisons are bit-exact, which also pins the emulation itself."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+import emu
+
+
+def _edge_rois():
+    return np.array([[0, -50, -50, -20, -20], [0, 300, 300, 400, 400], [0, -10, -10, 500, 500],
+                     [0, 100, 100, 100, 100], [0, 223, 223, 224, 224], [0, -17, 5, 3, 40]], np.float32)
+
+
+@pytest.fixture(params=["gather", "tile"])
+def bwd_impl(request, monkeypatch):
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", request.param)
+    return request.param
+
+
+@pytest.mark.parametrize("ph,pw,sr", [(7, 7, 2), (14, 14, 2), (7, 7, 1), (7, 7, 0), (3, 5, 3), (1, 1, 1)])
+def test_emu_roi_align_forward_bit_exact(ph, pw, sr):
+    inp, rois, scale = synth.cfg1_roi_align(K=48, C=5)
+    rois = np.concatenate([rois, _edge_rois()])
+    out = emu.roi_align_forward(inp, rois, scale, ph, pw, sr)
+    assert np.array_equal(out, oracle.roi_align_forward(inp, rois, scale, ph, pw, sr))
+
+
+@pytest.mark.parametrize("ph,pw,sr", [(7, 7, 2), (14, 14, 2), (7, 7, 0), (3, 5, 3), (20, 20, 2)])
+def test_emu_roi_align_backward_small_map(ph, pw, sr, bwd_impl):
+    inp, rois, scale = synth.cfg1_roi_align(K=40, C=5)
+    rois = np.concatenate([rois, _edge_rois()])
+    g = np.random.RandomState(1).randn(rois.shape[0], 5, ph, pw).astype(np.float32)
+    ref = oracle.roi_align_backward(g, rois, scale, ph, pw, *inp.shape, sr, acc64=True)
+    out = emu.roi_align_backward(g, rois, scale, ph, pw, *inp.shape, sr)  # NaN-prefilled: all written
+    assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("ct", ["4", "16"])
+def test_emu_roi_align_backward_tile_seams_accumulate_and_chunking(ct, monkeypatch):
+    """multi-tile odd-sized maps, 2 images, channel count not a multiple of the chunk, > 256 ROIs
+    (two scan rounds), the accumulate flag, K = 0."""
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "gather")
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_CT", ct)
+    rng = np.random.RandomState(11)
+    N, C, H, W = 2, 6 if ct == "4" else 21, 27, 70
+    K = 300
+    x1 = rng.uniform(-20, 270, K)
+    y1 = rng.uniform(-20, 100, K)
+    rois = np.stack([rng.randint(0, N, K), x1, y1, x1 + rng.uniform(2, 120, K), y1 + rng.uniform(2, 60, K)],
+                    1).astype(np.float32)
+    for (ph, pw, sr) in ((7, 7, 2), (14, 14, 2), (5, 3, 0)):
+        g = rng.randn(K, C, ph, pw).astype(np.float32)
+        ref = oracle.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, acc64=True)
+        out = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr)
+        tol = 1e-5 * max(1.0, np.abs(ref).max())
+        assert np.abs(out - ref).max() <= tol
+        assert np.array_equal(out, emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr))  # deterministic
+        base = rng.randn(N, C, H, W).astype(np.float32)
+        acc = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, into=base)
+        assert np.abs(acc - (base + ref)).max() <= 2 * tol
+    z = emu.roi_align_backward(np.zeros((0, C, 7, 7), np.float32), np.zeros((0, 5), np.float32), 0.25, 7, 7, N, C, H, W, 2)
+    assert not z.any()
+
+
+def test_emu_roi_align_fpn_fused_levels(bwd_impl):
+    """the multi-level entry points: device-side LevelMapper, level-ordered work items."""
+    rng = np.random.RandomState(5)
+    shapes = [(2, 4, 50, 84), (2, 4, 25, 42), (2, 4, 13, 21), (2, 4, 7, 11)]
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    feats = [rng.randn(*s).astype(np.float32) for s in shapes]
+    rois = synth.fpn_rois(seed=4, per_image=40, smin=8, smax=300)
+    rois[:, 1:] *= 0.25  # a 200x336 image
+    lv = synth.level_map(rois)
+    out, levels = emu.roi_align_fpn_forward(feats, rois, scales, 7, 7, 2, 2, 5)
+    assert np.array_equal(levels, lv)
+    for l in range(4):
+        sel = lv == l
+        assert np.array_equal(out[sel], oracle.roi_align_forward(feats[l], rois[sel], scales[l], 7, 7, 2))
+    g = rng.randn(rois.shape[0], 4, 7, 7).astype(np.float32)
+    gins = emu.roi_align_fpn_backward(g, rois, lv, shapes, scales, 7, 7, 2)
+    for l in range(4):
+        sel = lv == l
+        ref = oracle.roi_align_backward(g[sel], rois[sel], scales[l], 7, 7, *shapes[l], 2, acc64=True)
+        assert np.abs(gins[l] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())

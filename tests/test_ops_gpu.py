@@ -101,8 +101,16 @@ def test_roi_align_forward_edge_cases():
 
 
 # ============================================================================ ROIAlign backward
+@pytest.fixture(params=["gather", "tile"])
+def bwd_impl(request, monkeypatch):
+    """Both backward kernels behind the same entry points: the default atomic-free pixel-owner
+    kernel and the LDS-scatter tile kernel (DETOPS_ROIALIGN_BWD is read per call)."""
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("ph,pw,sr", [(7, 7, 2), (14, 14, 2), (7, 7, 0), (3, 5, 3)])
-def test_roi_align_backward_cfg1(ph, pw, sr):
+def test_roi_align_backward_cfg1(ph, pw, sr, bwd_impl):
     inp, rois, scale = synth.cfg1_roi_align()
     g = np.random.RandomState(1).randn(rois.shape[0], 256, ph, pw).astype(np.float32)
     ref = oracle.roi_align_backward(g, rois, scale, ph, pw, *inp.shape, sr, acc64=True)
@@ -112,7 +120,7 @@ def test_roi_align_backward_cfg1(ph, pw, sr):
     np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
 
 
-def test_roi_align_backward_fpn_full_size_and_fused():
+def test_roi_align_backward_fpn_full_size_and_fused(bwd_impl):
     feats_shapes = [(2, 256, h, w) for (h, w) in synth.fpn_shapes()[:4]]
     rois = synth.fpn_rois()
     lv = synth.level_map(rois)
@@ -133,7 +141,7 @@ def test_roi_align_backward_fpn_full_size_and_fused():
     torch.testing.assert_close(gins[0], p2, rtol=1e-4, atol=1e-4)
 
 
-def test_roi_align_backward_tile_seams_and_accumulate_flag():
+def test_roi_align_backward_tile_seams_and_accumulate_flag(bwd_impl):
     """ROIs straddling several 32x64 gradient tiles (odd map size, multi-image) against the oracle,
     and the C ABI's zero_grad_in = 0 mode (accumulate into the caller's buffer)."""
     import ctypes
@@ -180,7 +188,7 @@ def test_roi_align_forward_lds_path_large_and_tiny_rois():
         assert np.array_equal(out, ref), "max diff %g" % np.abs(out - ref).max()
 
 
-def test_roi_align_adjoint_and_linearity_full_size():
+def test_roi_align_adjoint_and_linearity_full_size(bwd_impl):
     """<fwd(x), g> == <x, bwd(g)> and bwd is linear — size-independent properties at cfg-2 scale."""
     C = _C()
     x = torch.randn(2, 256, 100, 168, device=DEV)
@@ -199,7 +207,7 @@ def test_roi_align_adjoint_and_linearity_full_size():
     torch.testing.assert_close(b12, 0.5 * b1 + b2, rtol=1e-4, atol=1e-4)
 
 
-def test_roi_align_backward_edge_cases():
+def test_roi_align_backward_edge_cases(bwd_impl):
     C = _C()
     gin = C.roi_align_backward(torch.zeros(0, 3, 7, 7, device=DEV), torch.zeros(0, 5, device=DEV), 0.5,
                                7, 7, 2, 3, 10, 12, 2)
@@ -217,6 +225,32 @@ def test_roi_align_backward_edge_cases():
     ref = oracle.roi_align_backward(g, rois, 1.0, 7, 7, 1, 2, 128, 128, 0, acc64=True)
     out = C.roi_align_backward(_t(g), _t(rois), 1.0, 7, 7, 1, 2, 128, 128, 0)
     _close(out, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_roi_align_backward_deterministic_and_large_bin_counts():
+    """The pixel-owner kernel has no atomics: two runs are bit-identical (the reference's atomicAdd
+    scatter is not).  Also bin counts beyond the 256-slot staging plan (20x20 -> 4-channel chunks,
+    28x28) and a channel count that is not a multiple of the chunk."""
+    C = _C()
+    rois_np = synth.fpn_rois(seed=5, per_image=128)
+    lv = synth.level_map(rois_np)
+    shapes = [(2, 64, h, w) for (h, w) in synth.fpn_shapes()[:4]]
+    scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
+    g = torch.randn(rois_np.shape[0], 64, 7, 7, device=DEV)
+    a = C.roi_align_fpn_backward(g, _t(rois_np), _t(lv), shapes, scales, 7, 7, 2)
+    b = C.roi_align_fpn_backward(g, _t(rois_np), _t(lv), shapes, scales, 7, 7, 2)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    rng = np.random.RandomState(21)
+    N, Cc, H, W = 2, 5, 37, 70
+    K = 24
+    x1 = rng.uniform(-10, 250, K); y1 = rng.uniform(-10, 130, K)
+    rois = np.stack([rng.randint(0, N, K), x1, y1, x1 + rng.uniform(1, 200, K), y1 + rng.uniform(1, 120, K)], 1).astype(np.float32)
+    for (ph, pw, sr) in ((20, 20, 2), (28, 28, 1), (16, 16, 0), (2, 40, 2)):
+        gg = rng.randn(K, Cc, ph, pw).astype(np.float32)
+        ref = oracle.roi_align_backward(gg, rois, 0.25, ph, pw, N, Cc, H, W, sr, acc64=True)
+        out = C.roi_align_backward(_t(gg), _t(rois), 0.25, ph, pw, N, Cc, H, W, sr)
+        _close(out, ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()))
 
 
 def test_roi_align_layer_autograd_and_amp():
