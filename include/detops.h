@@ -202,6 +202,22 @@ int detops_deformable_col2im(const void* col, const void* offset, const void* ma
                              int dil_h, int dil_w, int deformable_group,
                              detops_stream_t stream);
 
+/* col2im without atomics on the data: the scatter pattern (shared by all channels of a deformable
+ * group) is inverted once per call into per-pixel gather lists held in a caller workspace
+ * (>= detops_deformable_col2im_workspace_bytes(...) bytes, device memory, any contents); each
+ * gradient pixel is then summed in registers in a fixed order (deterministic).  A NULL / too
+ * small workspace, or a shape beyond the 32-bit index plan (workspace_bytes() == 0), runs the
+ * atomic scatter kernels of detops_deformable_col2im instead. */
+size_t detops_deformable_col2im_workspace_bytes(int B, int C, int H, int W, int kh, int kw,
+                                                int pad_h, int pad_w, int stride_h, int stride_w,
+                                                int dil_h, int dil_w, int deformable_group);
+
+int detops_deformable_col2im_ws(const void* col, const void* offset, const void* mask,
+                                void* grad_im, int dtype, int B, int C, int H, int W, int kh,
+                                int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                                int dil_h, int dil_w, int deformable_group, void* workspace,
+                                size_t workspace_bytes, detops_stream_t stream);
+
 int detops_deformable_col2im_coord(const void* col, const void* im, const void* offset,
                                    const void* mask, void* grad_offset, void* grad_mask,
                                    int dtype, int B, int C, int H, int W, int kh, int kw,

@@ -10,8 +10,12 @@
 // mask) once, computes the 4 tap indices + weights once, and then walks a chunk of channels.
 // Lanes run along wo, so offset loads, column stores/loads and gradient stores are coalesced and
 // the 4 gathers of neighbouring lanes fall into neighbouring addresses.
+#ifndef DETOPS_CPU_EMU
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
+#include <hipcub/hipcub.hpp>
+#endif
+#include <cstdlib>
 
 #include "detops_common.h"
 
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__(kBlock)
 col2im_tile_kernel(const T* __restrict__ col, const T* __restrict__ offset, const T* __restrict__ mask,
                    T* __restrict__ grad_im, Geom g, int cchunk, int tiles_x, int tiles_y, int RH, int RW,
                    int CC) {
-  extern __shared__ float win[];  // [CC][RH*RW]
+  DETOPS_DYNAMIC_LDS(float, win);  // [CC][RH*RW]
   const int tid = threadIdx.x;
   int t = blockIdx.x;
   const int tix = t % tiles_x; t /= tiles_x;
@@ -294,6 +298,113 @@ col2im_tile_kernel(const T* __restrict__ col, const T* __restrict__ offset, cons
         atomic_add_t(grad_im + (static_cast<size_t>(b) * g.C + cs + c) * plane + static_cast<size_t>(iy) * g.W + ix, v);
     }
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------ col2im, gather
+// The scatter kernels above are bound by atomic throughput: 4 atomics per (sampling point, channel)
+// — 155 M for one layer2-sized call — and both the global and the LDS (ds_add_f32) form retire
+// roughly one lane every four clocks per CU (measured: 959 us for 155 M LDS atomics).  But the
+// sampling geometry is shared by all channels of a deformable group, so the scatter pattern can be
+// INVERTED once per call and reused by every channel:
+//
+//   1. count   one thread per sampling point (b, dg, tap, ho, wo): +1 (int atomic) on the
+//              (target pixel, tap) counter of each of its <= 4 bilinear targets   [B*dg*H*W*K ints]
+//   2. scan    exclusive prefix sum of the counters (hipCUB) -> sub-list start per (pixel, tap);
+//              a pixel's K sub-lists are adjacent, so its whole list is one contiguous range
+//   3. fill    the same threads again: claim a slot in each target's sub-list and store
+//              (column index of the sampling point, bilinear weight * mask)
+//   4. sort    one thread per (pixel, tap) orders its handful of entries by column index: the
+//              summation order becomes deterministic, and neighbouring pixels walk their lists
+//              tap by tap in step, which makes the gathers below coalesce
+//   5. gather  one thread per (pixel, channel chunk): grad_im[b,c,y,x] += sum_e w_e * col[c, e]
+//              — plain loads, register accumulation, coalesced stores; no atomics on data.
+//
+// Offsets of any magnitude are handled uniformly (no window / halo assumption).  Needs a caller
+// workspace (detops_deformable_col2im_workspace_bytes); without one the scatter path runs.
+struct ColEntry {
+  int32_t colidx;  // tap * ncol + b * Ho*Wo + ho*Wo + wo : offset inside one channel's K rows of `col`
+  float w;
+};
+
+template <typename T, bool FILL>
+__global__ void __launch_bounds__(kBlock)
+col2im_index_kernel(const T* __restrict__ offset, const T* __restrict__ mask, Geom g, int64_t npoints,
+                    int32_t* __restrict__ counter, const int32_t* __restrict__ start,
+                    ColEntry* __restrict__ entries) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= npoints) return;
+  const int dgi = blockIdx.y;
+  const Point q = decode(p, g);
+  const int K = g.kh * g.kw;
+  const Sample s = point_sample(q, g, dgi, offset);
+  if (!s.inside) return;
+  const int HWo = g.Ho * g.Wo;
+  const size_t base = static_cast<size_t>(q.b * g.dg + dgi) * g.H * g.W;
+  const int tgt[4] = {s.i1, s.i2, s.i3, s.i4};
+  const float wgt[4] = {s.w1, s.w2, s.w3, s.w4};
+  float m = 1.f;
+  if (FILL && mask) m = ld(mask + ((static_cast<size_t>(q.b) * g.dg + dgi) * K + q.tap) * HWo + q.pix);
+  const int32_t colidx = q.tap * (g.B * HWo) + q.b * HWo + q.pix;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (tgt[t] < 0) continue;
+    const size_t slot = (base + tgt[t]) * K + q.tap;
+    const int pos = atomicAdd(counter + slot, 1);  // count pass: the tally; fill pass: the claimed slot
+    if (FILL) entries[start[slot] + pos] = ColEntry{colidx, wgt[t] * m};
+  }
+}
+
+// order each (pixel, tap) sub-list by column index (a handful of entries: insertion sort)
+__global__ void __launch_bounds__(kBlock)
+col2im_sort_kernel(const int32_t* __restrict__ start, int64_t nslots, ColEntry* __restrict__ entries) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= nslots) return;
+  const int s0 = start[i], n = start[i + 1] - s0;
+  ColEntry* e = entries + s0;
+  for (int a = 1; a < n; ++a) {
+    const ColEntry x = e[a];
+    int b = a - 1;
+    while (b >= 0 && e[b].colidx > x.colidx) { e[b + 1] = e[b]; --b; }
+    e[b + 1] = x;
+  }
+}
+
+constexpr int kGatherCC = 16;  // channels per thread pass (independent loads in flight)
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+col2im_gather_kernel(const T* __restrict__ col, const int32_t* __restrict__ start,
+                     const ColEntry* __restrict__ entries, T* __restrict__ grad_im, Geom g, int cchunk) {
+  const int HW = g.H * g.W;
+  const int pix = blockIdx.x * kBlock + threadIdx.x;   // pixel within the image plane
+  if (pix >= HW) return;
+  const int b = blockIdx.z;
+  const int cpg = g.C / g.dg;
+  const int chunks_per_g = (cpg + cchunk - 1) / cchunk;
+  const int dgi = blockIdx.y / chunks_per_g;
+  const int c0 = dgi * cpg + (blockIdx.y - dgi * chunks_per_g) * cchunk;
+  const int c1 = min(c0 + cchunk, (dgi + 1) * cpg);
+  const int K = g.kh * g.kw;
+  const size_t chan_stride = static_cast<size_t>(K) * g.B * g.Ho * g.Wo;   // one channel's K rows of col
+  const size_t li = (static_cast<size_t>(b) * g.dg + dgi) * HW + pix;
+  const int s0 = start[li * K], s1 = start[li * K + K];
+  for (int cs = c0; cs < c1; cs += kGatherCC) {
+    float acc[kGatherCC];
+#pragma unroll
+    for (int c = 0; c < kGatherCC; ++c) acc[c] = 0.f;
+    const T* cbase = col + static_cast<size_t>(cs) * chan_stride;
+    for (int j = s0; j < s1; ++j) {
+      const ColEntry en = entries[j];
+      const T* cp = cbase + en.colidx;
+#pragma unroll
+      for (int c = 0; c < kGatherCC; ++c)
+        if (cs + c < c1) acc[c] = fmaf(en.w, ld(cp + static_cast<size_t>(c) * chan_stride), acc[c]);
+    }
+    T* gp = grad_im + (static_cast<size_t>(b) * g.C + cs) * HW + pix;
+#pragma unroll
+    for (int c = 0; c < kGatherCC; ++c)
+      if (cs + c < c1) st(gp + static_cast<size_t>(c) * HW, ld(gp + static_cast<size_t>(c) * HW) + acc[c]);
   }
 }
 
@@ -412,6 +523,81 @@ int col2im_t(const void* col, const void* offset, const void* mask, void* grad_i
   return launch_status();
 }
 
+// Workspace carve of the gather path (all offsets 256-byte aligned).
+struct GatherPlan {
+  int64_t nslots, npoints_per_dg, max_entries;
+  size_t off_count, off_cursor, off_start, off_entries, off_scan, scan_bytes, total;
+};
+
+inline size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+// false: the shape does not fit the 32-bit index plan (the scatter kernels handle it)
+inline bool gather_plan(const Geom& g, GatherPlan& P) {
+  const int64_t K = static_cast<int64_t>(g.kh) * g.kw;
+  const int64_t HWo = static_cast<int64_t>(g.Ho) * g.Wo;
+  P.nslots = static_cast<int64_t>(g.B) * g.dg * g.H * g.W * K;
+  P.npoints_per_dg = static_cast<int64_t>(g.B) * K * HWo;
+  P.max_entries = 4 * P.npoints_per_dg * g.dg;
+  if (P.nslots + 1 > 0x7fffffff || P.max_entries > 0x7fffffff || K * g.B * HWo > 0x7fffffff) return false;
+  P.scan_bytes = 0;
+#ifndef DETOPS_CPU_EMU
+  if (hipcub::DeviceScan::ExclusiveSum(nullptr, P.scan_bytes, static_cast<int32_t*>(nullptr),
+                                       static_cast<int32_t*>(nullptr), static_cast<int>(P.nslots + 1)) != hipSuccess)
+    return false;
+#endif
+  size_t o = 0;
+  P.off_count = o;   o = align256(o + sizeof(int32_t) * (P.nslots + 1));
+  P.off_cursor = o;  o = align256(o + sizeof(int32_t) * P.nslots);
+  P.off_start = o;   o = align256(o + sizeof(int32_t) * (P.nslots + 1));
+  P.off_entries = o; o = align256(o + sizeof(ColEntry) * P.max_entries);
+  P.off_scan = o;    o = align256(o + P.scan_bytes);
+  P.total = o;
+  return true;
+}
+
+template <typename T>
+int col2im_gather_t(const void* col, const void* offset, const void* mask, void* grad_im, const Geom& g,
+                    const GatherPlan& P, void* ws, hipStream_t st_) {
+  if (P.npoints_per_dg == 0) return 0;
+  char* w = static_cast<char*>(ws);
+  int32_t* count = reinterpret_cast<int32_t*>(w + P.off_count);
+  int32_t* cursor = reinterpret_cast<int32_t*>(w + P.off_cursor);
+  int32_t* start = reinterpret_cast<int32_t*>(w + P.off_start);
+  ColEntry* entries = reinterpret_cast<ColEntry*>(w + P.off_entries);
+  // count and cursor are adjacent: one clear
+  DETOPS_HIP_TRY(hipMemsetAsync(count, 0, P.off_start - P.off_count, st_));
+  const dim3 pgrid(static_cast<unsigned>(ceil_div64(P.npoints_per_dg, kBlock)), static_cast<unsigned>(g.dg));
+  hipLaunchKernelGGL((col2im_index_kernel<T, false>), pgrid, dim3(kBlock), 0, st_, static_cast<const T*>(offset),
+                     static_cast<const T*>(mask), g, P.npoints_per_dg, count, static_cast<const int32_t*>(nullptr),
+                     static_cast<ColEntry*>(nullptr));
+#ifdef DETOPS_CPU_EMU
+  {
+    int32_t run = 0;
+    for (int64_t i = 0; i <= P.nslots; ++i) { start[i] = run; run += count[i]; }
+  }
+#else
+  size_t scan_bytes = P.scan_bytes;
+  DETOPS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w + P.off_scan, scan_bytes, count, start,
+                                                  static_cast<int>(P.nslots + 1), st_));
+#endif
+  hipLaunchKernelGGL((col2im_index_kernel<T, true>), pgrid, dim3(kBlock), 0, st_, static_cast<const T*>(offset),
+                     static_cast<const T*>(mask), g, P.npoints_per_dg, cursor, static_cast<const int32_t*>(start),
+                     entries);
+  hipLaunchKernelGGL(col2im_sort_kernel, dim3(static_cast<unsigned>(ceil_div64(P.nslots, kBlock))), dim3(kBlock), 0,
+                     st_, static_cast<const int32_t*>(start), P.nslots, entries);
+  const int cpg = g.C / g.dg;
+  const int64_t pix_blocks = ceil_div64(static_cast<int64_t>(g.H) * g.W, kBlock) * g.B;
+  int cc = cpg;  // channels per workgroup: whole passes of kGatherCC, enough workgroups to fill the chip
+  while (cc > kGatherCC && pix_blocks * g.dg * ceil_div64(cpg, cc) < 4 * kNumCU) cc = max(kGatherCC, cc / 2);
+  cc = static_cast<int>(ceil_div64(cc, kGatherCC)) * kGatherCC;
+  const dim3 ggrid(static_cast<unsigned>(ceil_div64(static_cast<int64_t>(g.H) * g.W, kBlock)),
+                   static_cast<unsigned>(g.dg * ceil_div64(cpg, cc)), static_cast<unsigned>(g.B));
+  hipLaunchKernelGGL(col2im_gather_kernel<T>, ggrid, dim3(kBlock), 0, st_, static_cast<const T*>(col),
+                     static_cast<const int32_t*>(start), static_cast<const ColEntry*>(entries),
+                     static_cast<T*>(grad_im), g, cc);
+  return launch_status();
+}
+
 template <typename T>
 int coord_t(const void* col, const void* im, const void* offset, const void* mask, void* goff,
             void* gmask, const Geom& g, hipStream_t st_) {
@@ -462,6 +648,41 @@ DETOPS_API int detops_deformable_col2im(const void* col, const void* offset, con
   if (B == 0) return 0;
   if (!col || !offset || !grad_im) return DETOPS_EINVAL;
 #define CALL(T) col2im_t<T>(col, offset, mask, grad_im, g, as_stream(stream))
+  DETOPS_DTYPE_SWITCH(dtype, CALL)
+#undef CALL
+}
+
+DETOPS_API size_t detops_deformable_col2im_workspace_bytes(int B, int C, int H, int W, int kh, int kw,
+                                                            int pad_h, int pad_w, int stride_h, int stride_w,
+                                                            int dil_h, int dil_w, int deformable_group) {
+  Geom g;
+  if (make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, deformable_group)) return 0;
+  GatherPlan P;
+  if (B == 0 || !gather_plan(g, P)) return 0;
+  return P.total;
+}
+
+DETOPS_API int detops_deformable_col2im_ws(const void* col, const void* offset, const void* mask,
+                                           void* grad_im, int dtype, int B, int C, int H, int W,
+                                           int kh, int kw, int pad_h, int pad_w, int stride_h,
+                                           int stride_w, int dil_h, int dil_w, int deformable_group,
+                                           void* workspace, size_t workspace_bytes,
+                                           detops_stream_t stream) {
+  Geom g;
+  if (int rc = make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w,
+                         deformable_group))
+    return rc;
+  if (B == 0) return 0;
+  if (!col || !offset || !grad_im) return DETOPS_EINVAL;
+  GatherPlan P;
+  const char* e = getenv("DETOPS_DCN_COL2IM");  // "scatter" forces the atomic kernels (A/B measurements)
+  const bool scatter = (e && e[0] == 's') || !workspace || !gather_plan(g, P) || workspace_bytes < P.total;
+  if (scatter) {
+#define CALL(T) col2im_t<T>(col, offset, mask, grad_im, g, as_stream(stream))
+    DETOPS_DTYPE_SWITCH(dtype, CALL)
+#undef CALL
+  }
+#define CALL(T) col2im_gather_t<T>(col, offset, mask, grad_im, g, P, workspace, as_stream(stream))
   DETOPS_DTYPE_SWITCH(dtype, CALL)
 #undef CALL
 }

@@ -205,13 +205,15 @@ roi_align_fwd_kernel(Levels L, const float* __restrict__ rois, const int32_t* __
 //     reference CPU kernel for finite inputs.
 // Footprints that do not fit the LDS budget fall through to the generic gather loop.
 // ------------------------------------------------------------------------------------------
-constexpr int kLdsPatchFloats = 8192 - 64;  // ~32 KiB dynamic LDS per workgroup -> 4-5 workgroups / CU
+constexpr int kLdsPatchFloats = 8192 - 64;  // default ~32 KiB dynamic LDS per workgroup -> 4-5 workgroups / CU
 
-template <int PH, int PW, int SR, int G>
+// U = staging loads in flight per lane; patch_floats = LDS patch budget (DETOPS_ROIALIGN_FWD_LDS_KB /
+// DETOPS_ROIALIGN_FWD_U select other points of the occupancy / loads-in-flight trade-off at run time)
+template <int PH, int PW, int SR, int G, int U>
 __global__ void __launch_bounds__(((PH * PW * G + 63) / 64) * 64)
 roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
                          int32_t* __restrict__ levels_out, float* __restrict__ out, int C, int K, int CT,
-                         int chunks) {
+                         int chunks, int patch_floats) {
   constexpr int BINS = PH * PW;
   constexpr int NS = SR * SR;
   constexpr int NT = ((BINS * G + 63) / 64) * 64;
@@ -262,7 +264,7 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
   const size_t plane = static_cast<size_t>(H) * W;
   const float* base = in + (static_cast<size_t>(g.b) * C + c0) * plane;
 
-  if (area > kLdsPatchFloats) {  // footprint too large for LDS: gather straight from the map
+  if (area > patch_floats) {  // footprint too large for LDS: gather straight from the map
     for (int o = tid; o < (cend - c0) * BINS; o += NT) {
 #pragma clang fp contract(off)
       const int cl = o / BINS;
@@ -314,8 +316,7 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
   // independent loads in flight per lane before the first LDS store (the loop is latency-bound
   // otherwise: one L2/MALL round trip per iteration)
   const float inv_ps = 1.f / static_cast<float>(ps), inv_rows = 1.f / static_cast<float>(rows);
-  constexpr int U = 4;
-  const int ctb = min(cend - c0, kLdsPatchFloats / area);
+  const int ctb = min(cend - c0, patch_floats / area);
   for (int cs = c0; cs < cend; cs += ctb) {
     const int cn = min(ctb, cend - cs);
     const float* src = base + static_cast<size_t>(cs - c0) * plane;
@@ -327,7 +328,7 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
         const int e = e0 + u * NT;
         v[u] = 0.f;
         if (e < total) {
-          const int r = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_ps);   // e / ps  (exact: e < 8192)
+          const int r = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_ps);   // e / ps  (exact for e < 16384, ps < 2048: brute-forced)
           const int x = e - r * ps;
           const int c = static_cast<int>((static_cast<float>(r) + 0.5f) * inv_rows);  // r / rows
           const int y = r - c * rows;
@@ -831,9 +832,20 @@ void launch_fwd_lds(const Levels& L, const float* rois, const int32_t* levels_in
   while (CT > 16 && static_cast<int64_t>(K) * ceil_div64(C, CT) < 4 * kNumCU) CT >>= 1;
   if (CT > C) CT = C;
   const int chunks = static_cast<int>(ceil_div64(C, CT));
-  hipLaunchKernelGGL((roi_align_fwd_lds_kernel<PH, PW, SR, G>), dim3(static_cast<unsigned>(K) * chunks),
-                     dim3(NT), (kLdsPatchFloats + 64) * sizeof(float), st, L, rois, levels_in, levels_out,
-                     out, C, K, CT, chunks);
+  int patch_floats = kLdsPatchFloats, unroll = 4;
+  if (const char* e = getenv("DETOPS_ROIALIGN_FWD_LDS_KB")) {
+    const int kb = atoi(e);
+    if (kb >= 4 && kb <= 60) patch_floats = kb * 256 - 64;
+  }
+  if (const char* e = getenv("DETOPS_ROIALIGN_FWD_U")) unroll = atoi(e);
+  const dim3 grid(static_cast<unsigned>(K) * chunks);
+  const size_t lds = (patch_floats + 64) * sizeof(float);
+  if (unroll == 8)
+    hipLaunchKernelGGL((roi_align_fwd_lds_kernel<PH, PW, SR, G, 8>), grid, dim3(NT), lds, st, L, rois, levels_in,
+                       levels_out, out, C, K, CT, chunks, patch_floats);
+  else
+    hipLaunchKernelGGL((roi_align_fwd_lds_kernel<PH, PW, SR, G, 4>), grid, dim3(NT), lds, st, L, rois, levels_in,
+                       levels_out, out, C, K, CT, chunks, patch_floats);
 }
 
 int run_forward(const Levels& L, const float* rois, const int32_t* levels_in, int32_t* levels_out,

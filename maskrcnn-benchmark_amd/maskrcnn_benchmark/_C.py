@@ -479,10 +479,14 @@ def deformable_col2im(col, offset, mask, grad_im, kH, kW, padH, padW, dH, dW, di
     """accumulates into grad_im [B,C,H,W] (deform_conv_kernel_cuda.cu:286-342 / :642-700)."""
     code = _dcn_check("deformable_col2im", col, offset, mask, grad_im)
     B, C, H, W = grad_im.shape
+    geom = _geom_args(B, C, H, W, kH, kW, padH, padW, dH, dW, dilH, dilW, dg)
     with _on_device(col):
-        check(lib.detops_deformable_col2im(ptr(col), ptr(offset), ptr(mask), ptr(grad_im), code,
-                                           *_geom_args(B, C, H, W, kH, kW, padH, padW, dH, dW, dilH,
-                                                       dilW, dg), stream_of(col)), "deformable_col2im")
+        # gather lists for the atomic-free path live in a scratch tensor (torch's caching allocator:
+        # stream-ordered reuse, no hipMalloc per call); 0 bytes = shape outside the index plan
+        nbytes = int(lib.detops_deformable_col2im_workspace_bytes(*geom))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=col.device) if nbytes > 0 else None
+        check(lib.detops_deformable_col2im_ws(ptr(col), ptr(offset), ptr(mask), ptr(grad_im), code, *geom,
+                                              ptr(ws), nbytes, stream_of(col)), "deformable_col2im")
 
 
 def deformable_col2im_coord(col, im, offset, mask, grad_offset, grad_mask, kH, kW, padH, padW, dH,

@@ -20,6 +20,11 @@ SIGNATURES = {
     "detops_roi_align_fpn_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),
     "detops_roi_pool_backward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
+    "detops_deformable_im2col": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),
+    "detops_deformable_col2im": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),
+    "detops_deformable_col2im_workspace_bytes": (ctypes.c_size_t, [c_int] * 13),
+    "detops_deformable_col2im_ws": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P, ctypes.c_size_t, _P]),
+    "detops_deformable_col2im_coord": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 14 + [_P]),
 }
 
 
@@ -97,3 +102,64 @@ def roi_align_fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr):
                                                  rois.shape[0], ph, pw, sr, 1, None)
     assert rc == 0, rc
     return gins
+
+
+# ---------------------------------------------------------------------------------- deformable conv
+_DT = {np.dtype(np.float32): 0, np.dtype(np.float16): 1}
+
+
+def _geom(B, C, H, W, kh, kw, pad, stride, dil, dg):
+    return (B, C, H, W, kh, kw, pad[0], pad[1], stride[0], stride[1], dil[0], dil[1], dg)
+
+
+def _out_hw(H, W, kh, kw, pad, stride, dil):
+    return ((H + 2 * pad[0] - (dil[0] * (kh - 1) + 1)) // stride[0] + 1,
+            (W + 2 * pad[1] - (dil[1] * (kw - 1) + 1)) // stride[1] + 1)
+
+
+def deformable_im2col(im, offset, mask, kh, kw, pad, stride, dil, dg):
+    im = np.ascontiguousarray(im)
+    dt = im.dtype
+    offset = np.ascontiguousarray(offset, dtype=dt)
+    mask = None if mask is None else np.ascontiguousarray(mask, dtype=dt)
+    B, C, H, W = im.shape
+    Ho, Wo = _out_hw(H, W, kh, kw, pad, stride, dil)
+    col = np.full((C * kh * kw, B * Ho * Wo), np.nan, dt)
+    rc = lib().detops_deformable_im2col(_p(im), _p(offset), None if mask is None else _p(mask), _p(col), _DT[dt],
+                                        *_geom(B, C, H, W, kh, kw, pad, stride, dil, dg), None)
+    assert rc == 0, rc
+    return col
+
+
+def deformable_col2im(col, offset, mask, B, C, H, W, kh, kw, pad, stride, dil, dg, gather=True, into=None):
+    col = np.ascontiguousarray(col)
+    dt = col.dtype
+    offset = np.ascontiguousarray(offset, dtype=dt)
+    mask = None if mask is None else np.ascontiguousarray(mask, dtype=dt)
+    gim = np.zeros((B, C, H, W), dt) if into is None else np.ascontiguousarray(into, dtype=dt).copy()
+    g = _geom(B, C, H, W, kh, kw, pad, stride, dil, dg)
+    mp = None if mask is None else _p(mask)
+    if gather:
+        nbytes = lib().detops_deformable_col2im_workspace_bytes(*g)
+        assert nbytes > 0
+        ws = np.full((nbytes,), 0xAB, np.uint8)  # arbitrary contents
+        rc = lib().detops_deformable_col2im_ws(_p(col), _p(offset), mp, _p(gim), _DT[dt], *g, _p(ws), nbytes, None)
+    else:
+        rc = lib().detops_deformable_col2im(_p(col), _p(offset), mp, _p(gim), _DT[dt], *g, None)
+    assert rc == 0, rc
+    return gim
+
+
+def deformable_col2im_coord(col, im, offset, mask, kh, kw, pad, stride, dil, dg):
+    col = np.ascontiguousarray(col)
+    dt = col.dtype
+    im, offset = np.ascontiguousarray(im, dtype=dt), np.ascontiguousarray(offset, dtype=dt)
+    mask = None if mask is None else np.ascontiguousarray(mask, dtype=dt)
+    B, C, H, W = im.shape
+    goff = np.full(offset.shape, np.nan, dt)
+    gmask = None if mask is None else np.full(mask.shape, np.nan, dt)
+    rc = lib().detops_deformable_col2im_coord(_p(col), _p(im), _p(offset), None if mask is None else _p(mask), _p(goff),
+                                              None if gmask is None else _p(gmask), _DT[dt],
+                                              *_geom(B, C, H, W, kh, kw, pad, stride, dil, dg), None)
+    assert rc == 0, rc
+    return goff, gmask

@@ -202,6 +202,29 @@ static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; retur
 static inline int atomicMin(int* p, int v) { const int o = *p; *p = std::min(o, v); return o; }
 static inline int atomicMax(int* p, int v) { const int o = *p; *p = std::max(o, v); return o; }
 
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+static inline unsigned atomicCAS(unsigned* p, unsigned cmp, unsigned val) { const unsigned o = *p; if (o == cmp) *p = val; return o; }
+static inline int atomicCAS(int* p, int cmp, int val) { const int o = *p; if (o == cmp) *p = val; return o; }
+static inline int atomicSub(int* p, int v) { const int o = *p; *p = o - v; return o; }
+
+// 16-bit storage types (fp32 arithmetic everywhere in the kernels): IEEE half via _Float16,
+// bfloat16 with round-to-nearest-even like __float2bfloat16
+struct __half { _Float16 v; };
+static inline float __half2float(__half h) { return static_cast<float>(h.v); }
+static inline __half __float2half(float f) { __half h; h.v = static_cast<_Float16>(f); return h; }
+static inline unsigned short __half_as_ushort(__half h) { unsigned short u; memcpy(&u, &h, 2); return u; }
+static inline __half __ushort_as_half(unsigned short u) { __half h; memcpy(&h, &u, 2); return h; }
+struct __hip_bfloat16 { unsigned short bits; };
+static inline float __bfloat162float(__hip_bfloat16 b) { return __uint_as_float(static_cast<unsigned>(b.bits) << 16); }
+static inline __hip_bfloat16 __float2bfloat16(float f) {
+  unsigned u = __float_as_uint(f);
+  __hip_bfloat16 b;
+  if ((u & 0x7fffffffu) > 0x7f800000u) { b.bits = static_cast<unsigned short>((u >> 16) | 0x40); return b; }  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  b.bits = static_cast<unsigned short>(u >> 16);
+  return b;
+}
+
 template <typename T> static inline T min(T a, T b) { return a < b ? a : b; }
 template <typename T> static inline T max(T a, T b) { return a > b ? a : b; }
 

@@ -89,3 +89,47 @@ def test_emu_roi_align_fpn_fused_levels(bwd_impl):
         sel = lv == l
         ref = oracle.roi_align_backward(g[sel], rois[sel], scales[l], 7, 7, *shapes[l], 2, acc64=True)
         assert np.abs(gins[l] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+# ================================================================================ deformable conv
+DCN_GEOMS = [dict(B=2, C=8, H=13, W=17, k=3, stride=1, pad=1, dil=1, dg=1),
+             dict(B=2, C=8, H=14, W=15, k=3, stride=2, pad=2, dil=2, dg=2),
+             dict(B=1, C=20, H=9, W=33, k=3, stride=1, pad=1, dil=1, dg=1)]
+
+
+def _dcn_case(g, modulated, seed=3):
+    x, off, mask, _ = synth.dcn_inputs(g["B"], g["C"], g["H"], g["W"], 4, g["k"], g["dg"], modulated, seed=seed)
+    Ho = (g["H"] + 2 * g["pad"] - (g["dil"] * (g["k"] - 1) + 1)) // g["stride"] + 1
+    Wo = (g["W"] + 2 * g["pad"] - (g["dil"] * (g["k"] - 1) + 1)) // g["stride"] + 1
+    off = np.ascontiguousarray(off[:, :, :Ho, :Wo])
+    mask = None if mask is None else np.ascontiguousarray(mask[:, :, :Ho, :Wo])
+    return x, off, mask
+
+
+@pytest.mark.parametrize("gi", range(len(DCN_GEOMS)))
+@pytest.mark.parametrize("modulated", [False, True])
+def test_emu_deformable_kernels_vs_oracle(gi, modulated):
+    """im2col, col2im (atomic scatter AND the inverted-index gather path) and col2im_coord."""
+    g = DCN_GEOMS[gi]
+    x, off, mask = _dcn_case(g, modulated)
+    k, p, s, d, dg = g["k"], g["pad"], g["stride"], g["dil"], g["dg"]
+    geo = dict(kh=k, kw=k, pad=(p, p), stride=(s, s), dil=(d, d), dg=dg)
+    col = emu.deformable_im2col(x, off, mask, **geo)
+    ref_col = oracle.deformable_im2col(x, off, mask, **geo)
+    np.testing.assert_allclose(col, ref_col, rtol=1e-5, atol=1e-5)
+    gcol = np.random.RandomState(9).randn(*ref_col.shape).astype(np.float32)
+    ref = oracle.deformable_col2im(gcol, off, mask, *x.shape, **geo)
+    tol = dict(rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(emu.deformable_col2im(gcol, off, mask, *x.shape, gather=False, **geo), ref, **tol)
+    out = emu.deformable_col2im(gcol, off, mask, *x.shape, gather=True, **geo)
+    np.testing.assert_allclose(out, ref, **tol)
+    # accumulate semantics (callers hand in a zeroed or partially filled gradient) + determinism
+    base = np.random.RandomState(2).randn(*x.shape).astype(np.float32)
+    np.testing.assert_allclose(emu.deformable_col2im(gcol, off, mask, *x.shape, gather=True, into=base, **geo),
+                               base + ref, rtol=1e-4, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    assert np.array_equal(out, emu.deformable_col2im(gcol, off, mask, *x.shape, gather=True, **geo))
+    goff, gmask = emu.deformable_col2im_coord(gcol, x, off, mask, **geo)
+    roff, rmask = oracle.deformable_col2im_coord(gcol, x, off, mask, **geo)
+    np.testing.assert_allclose(goff, roff, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(roff).max()))
+    if modulated:
+        np.testing.assert_allclose(gmask, rmask, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(rmask).max()))

@@ -528,7 +528,7 @@ def _dcn_case(g, modulated, seed=3):
 
 @pytest.mark.parametrize("gi", range(len(GEOMS)))
 @pytest.mark.parametrize("modulated", [False, True])
-def test_deformable_kernels_vs_oracle_fp32(gi, modulated):
+def test_deformable_kernels_vs_oracle_fp32(gi, modulated, monkeypatch):
     C = _C()
     g = GEOMS[gi]
     x, off, mask, _ = _dcn_case(g, modulated)
@@ -541,8 +541,17 @@ def test_deformable_kernels_vs_oracle_fp32(gi, modulated):
     _close(col, ref_col, rtol=1e-5, atol=1e-5)
     gcol = np.random.RandomState(9).randn(*ref_col.shape).astype(np.float32)
     gim = torch.zeros(*x.shape, device=DEV)
-    C.deformable_col2im(_t(gcol), _t(off), tm, gim, *geo)
-    _close(gim, oracle.deformable_col2im(gcol, off, mask, *x.shape, **ogeo), rtol=1e-4, atol=1e-4)
+    C.deformable_col2im(_t(gcol), _t(off), tm, gim, *geo)   # default: inverted-index gather (no data atomics)
+    ref_gim = oracle.deformable_col2im(gcol, off, mask, *x.shape, **ogeo)
+    _close(gim, ref_gim, rtol=1e-4, atol=1e-4)
+    gim2 = torch.zeros(*x.shape, device=DEV)
+    C.deformable_col2im(_t(gcol), _t(off), tm, gim2, *geo)
+    assert torch.equal(gim, gim2), "gather col2im must be deterministic"
+    monkeypatch.setenv("DETOPS_DCN_COL2IM", "scatter")      # the atomic LDS-window kernel
+    gim3 = torch.zeros(*x.shape, device=DEV)
+    C.deformable_col2im(_t(gcol), _t(off), tm, gim3, *geo)
+    _close(gim3, ref_gim, rtol=1e-4, atol=1e-4)
+    monkeypatch.delenv("DETOPS_DCN_COL2IM")
     goff = torch.empty(*off.shape, device=DEV)
     gmask = None if mask is None else torch.empty(*mask.shape, device=DEV)
     C.deformable_col2im_coord(_t(gcol), _t(x), _t(off), tm, goff, gmask, *geo)

@@ -87,11 +87,27 @@ def bench_roi_align(C, iters, which=("fwd", "bwd")):
             out.append(_entry(f"roi_align_fwd fpn-fused {tag}", us, alg))
             us = dev_time_us(per_level_fwd, iters)
             out.append(_entry(f"roi_align_fwd fpn-per-level(4 launches) {tag}", us, alg))
+        if "fwd" in which:
+            base = C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]
+            for kb, u in (("16", "4"), ("16", "8"), ("32", "8"), ("48", "8"), ("8", "8")):
+                os.environ["DETOPS_ROIALIGN_FWD_LDS_KB"], os.environ["DETOPS_ROIALIGN_FWD_U"] = kb, u
+                us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
+                same = bool(torch.equal(base, C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]))
+                out.append(_entry(f"roi_align_fwd fpn-fused {tag} [LDS {kb} KB, U={u}]", us, alg, {"bit_equal_to_default": same}))
+            del os.environ["DETOPS_ROIALIGN_FWD_LDS_KB"], os.environ["DETOPS_ROIALIGN_FWD_U"]
         if "bwd" in which:
             g = torch.randn(K, 256, ph, ph, device="cuda")
             tl = _t(lv)
             us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
-            out.append(_entry(f"roi_align_bwd fpn-fused (incl. zero-fill) {tag}", us, alg))
+            out.append(_entry(f"roi_align_bwd fpn-fused gather (atomic-free, incl. zero-fill) {tag}", us, alg))
+            os.environ["DETOPS_ROIALIGN_BWD_CT"] = "4"
+            us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
+            out.append(_entry(f"roi_align_bwd fpn-fused gather CT=4 {tag}", us, alg))
+            del os.environ["DETOPS_ROIALIGN_BWD_CT"]
+            os.environ["DETOPS_ROIALIGN_BWD"] = "tile"
+            us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), max(3, iters // 5))
+            del os.environ["DETOPS_ROIALIGN_BWD"]
+            out.append(_entry(f"roi_align_bwd fpn-fused tile (LDS atomics) {tag}", us, alg))
     return out
 
 
@@ -169,7 +185,11 @@ def bench_dcn(C, iters):
             col = torch.randn(Cc * 9, ncol, device="cuda").to(dt)
             gim = torch.zeros_like(x)
             us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), iters)
-            out.append(_entry(f"dcn_col2im C={Cc} {H}x{W} {str(dt)[6:]}", us, alg))
+            out.append(_entry(f"dcn_col2im gather (index+sort+gather, 5 launches) C={Cc} {H}x{W} {str(dt)[6:]}", us, alg))
+            os.environ["DETOPS_DCN_COL2IM"] = "scatter"
+            us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), max(3, iters // 5))
+            del os.environ["DETOPS_DCN_COL2IM"]
+            out.append(_entry(f"dcn_col2im scatter (LDS atomics) C={Cc} {H}x{W} {str(dt)[6:]}", us, alg))
             goff = torch.empty_like(off)
             us = dev_time_us(lambda: C.deformable_col2im_coord(col, x, off, None, goff, None, *geo), iters)
             out.append(_entry(f"dcn_col2im_coord C={Cc} {H}x{W} {str(dt)[6:]}", us, alg))
