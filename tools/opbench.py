@@ -51,12 +51,14 @@ def _entry(name, us, alg_bytes, extra=None):
     return e
 
 
-def bench_roi_align(C, iters, which=("fwd", "bwd")):
+def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False):
+    """fused_only: just the FPN-fused launches with the model's shapes (the PMC traffic passes use this,
+    so every ROIAlign kernel in their trace is the box-head / mask-head launch bench.py times)."""
     out = []
     # cfg-1 (BASELINE configs[0]) ---------------------------------------------------------
     inp, rois, scale = synth.cfg1_roi_align()
     ti, tr = _t(inp), _t(rois)
-    for ph, pw, sr in [(7, 7, 2), (14, 14, 2), (7, 7, 0)]:
+    for ph, pw, sr in ([] if fused_only else [(7, 7, 2), (14, 14, 2), (7, 7, 0)]):
         K, Cc = rois.shape[0], inp.shape[1]
         alg = 4 * K * Cc * ph * pw + 4 * inp.size + 20 * K
         if "fwd" in which:
@@ -85,9 +87,10 @@ def bench_roi_align(C, iters, which=("fwd", "bwd")):
         if "fwd" in which:
             us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
             out.append(_entry(f"roi_align_fwd fpn-fused {tag}", us, alg))
-            us = dev_time_us(per_level_fwd, iters)
-            out.append(_entry(f"roi_align_fwd fpn-per-level(4 launches) {tag}", us, alg))
-        if "fwd" in which:
+            if not fused_only:
+                us = dev_time_us(per_level_fwd, iters)
+                out.append(_entry(f"roi_align_fwd fpn-per-level(4 launches) {tag}", us, alg))
+        if "fwd" in which and not fused_only:
             base = C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]
             for kb, u in (("16", "4"), ("16", "8"), ("32", "8"), ("48", "8"), ("8", "8")):
                 os.environ["DETOPS_ROIALIGN_FWD_LDS_KB"], os.environ["DETOPS_ROIALIGN_FWD_U"] = kb, u
@@ -100,6 +103,8 @@ def bench_roi_align(C, iters, which=("fwd", "bwd")):
             tl = _t(lv)
             us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
             out.append(_entry(f"roi_align_bwd fpn-fused gather (atomic-free, incl. zero-fill) {tag}", us, alg))
+            if fused_only:
+                continue
             os.environ["DETOPS_ROIALIGN_BWD_CT"] = "4"
             us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
             out.append(_entry(f"roi_align_bwd fpn-fused gather CT=4 {tag}", us, alg))
@@ -218,6 +223,8 @@ def main():
         res.append(copy_ceiling(args.iters))
     if not only or "roi_align" in only:
         res += bench_roi_align(C, args.iters)
+    if "roi_align_fpn" in only:
+        res += bench_roi_align(C, args.iters, fused_only=True)
     if not only or "nms" in only:
         res += bench_nms(C, args.iters)
     if not only or "frozen_bn" in only:
