@@ -21,7 +21,11 @@
 //                the later column blocks; finally kept sorted positions are scattered to a bitset
 //                in ORIGINAL index space and compacted with a workgroup prefix sum -> ascending
 //                original indices, exactly at::nonzero(suppressed == 0) (nms_cpu.cpp:64).
+#ifndef DETOPS_CPU_EMU
 #include <hipcub/hipcub.hpp>
+#else
+#include <algorithm>
+#endif
 
 #include "detops_common.h"
 
@@ -65,7 +69,7 @@ struct Work {
 __global__ void __launch_bounds__(1024)
 nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                 const int32_t* __restrict__ seg_offsets, int n_single, int npad, Work w) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
+  DETOPS_DYNAMIC_LDS(unsigned char, smem_raw);
   u64* keys = reinterpret_cast<u64*>(smem_raw);
   const int s = blockIdx.x;
   const SegView sv = seg_view(seg_offsets, n_single, s);
@@ -326,10 +330,14 @@ Layout make_layout(int S, int max_n, bool big) {
     l.off_keys = o;  o = align_up(o + rows * sizeof(u64), 256);
     l.off_keys2 = o; o = align_up(o + rows * sizeof(u64), 256);
     size_t cub = 0;
+#ifndef DETOPS_CPU_EMU
     const hipError_t qe = hipcub::DeviceRadixSort::SortKeys(
         nullptr, cub, static_cast<u64*>(nullptr), static_cast<u64*>(nullptr), max_n);
     // size query failed (e.g. no device visible): use a safe upper bound
     if (qe != hipSuccess || cub == 0) cub = rows * sizeof(u64) * 2 + (1u << 20);
+#else
+    cub = 256;
+#endif
     l.cub_bytes = cub;
     l.off_cub = o; o = align_up(o + cub, 256);
   }
@@ -363,9 +371,14 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
     u64* keys2 = reinterpret_cast<u64*>(base + l.off_keys2);
     hipLaunchKernelGGL(nms_make_keys_kernel, dim3((max_n + 255) / 256), dim3(256), 0, st, scores,
                        max_n, keys);
+#ifndef DETOPS_CPU_EMU
     size_t cub = l.cub_bytes;
     DETOPS_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(base + l.off_cub, cub, keys, keys2, max_n, 0,
                                                      64, st));
+#else
+    std::copy(keys, keys + max_n, keys2);
+    std::sort(keys2, keys2 + max_n);
+#endif
     hipLaunchKernelGGL(nms_gather_kernel, dim3((max_n + 255) / 256), dim3(256), 0, st, boxes, keys2,
                        max_n, w);
   }

@@ -20,6 +20,20 @@ SIGNATURES = {
     "detops_roi_align_fpn_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),
     "detops_roi_pool_backward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
+    "detops_nms_workspace_bytes": (ctypes.c_size_t, [c_int]),
+    "detops_nms_f32": (c_int, [_P, _P, c_int, c_float, _P, _P, _P, ctypes.c_size_t, _P]),
+    "detops_nms_batched_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "detops_nms_batched_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, ctypes.c_size_t, _P]),
+    "detops_nms_batched_mask_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, ctypes.c_size_t, _P]),
+    "detops_sigmoid_focal_loss_forward_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_sigmoid_focal_loss_backward_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_sigmoid_focal_loss_backward_scalar_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_sigmoid_focal_loss_forward_sum_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_frozen_bn_act_forward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    "detops_frozen_bn_act_backward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    "detops_deform_psroi_pool_forward_f32": (c_int, [_P] * 5 + [c_int] * 7 + [c_float] + [c_int] * 5 + [c_float, _P]),
+    "detops_deform_psroi_pool_backward_f32": (
+        c_int, [_P] * 7 + [c_int] * 7 + [c_float] + [c_int] * 5 + [c_float, c_int, _P]),
     "detops_deformable_im2col": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),
     "detops_deformable_col2im": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),
     "detops_deformable_col2im_workspace_bytes": (ctypes.c_size_t, [c_int] * 13),
@@ -163,3 +177,131 @@ def deformable_col2im_coord(col, im, offset, mask, kh, kw, pad, stride, dil, dg)
                                               *_geom(B, C, H, W, kh, kw, pad, stride, dil, dg), None)
     assert rc == 0, rc
     return goff, gmask
+
+
+# ---------------------------------------------------------------------------------- NMS
+def nms(boxes, scores, thr):
+    boxes, scores = _f32(boxes), _f32(scores)
+    n = boxes.shape[0]
+    keep = np.full((max(n, 1),), -1, np.int64)
+    num = np.full((1,), -1, np.int32)
+    nbytes = lib().detops_nms_workspace_bytes(n)
+    ws = np.empty((nbytes,), np.uint8)
+    rc = lib().detops_nms_f32(_p(boxes), _p(scores), n, thr, _p(keep), _p(num), _p(ws), nbytes, None)
+    assert rc == 0, rc
+    return keep[:num[0]].copy()
+
+
+def nms_batched(boxes, scores, offsets, max_n, thr, mask=False):
+    boxes, scores = _f32(boxes), _f32(scores)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    S = offsets.shape[0] - 1
+    num = np.full((S,), -1, np.int32)
+    nbytes = lib().detops_nms_batched_workspace_bytes(S, max_n)
+    ws = np.empty((nbytes,), np.uint8)
+    if mask:
+        km = np.full((boxes.shape[0],), 7, np.uint8)
+        rc = lib().detops_nms_batched_mask_f32(_p(boxes), _p(scores), _p(offsets), S, max_n, thr, _p(km), _p(num),
+                                               _p(ws), nbytes, None)
+        assert rc == 0, rc
+        return km, num
+    keep = np.full((boxes.shape[0],), -1, np.int64)
+    rc = lib().detops_nms_batched_f32(_p(boxes), _p(scores), _p(offsets), S, max_n, thr, _p(keep), _p(num), _p(ws),
+                                      nbytes, None)
+    assert rc == 0, rc
+    return keep, num
+
+
+# ---------------------------------------------------------------------------------- focal loss
+def focal_forward(logits, targets, gamma, alpha, with_sum=False):
+    logits = _f32(logits)
+    targets = np.ascontiguousarray(targets, dtype=np.int32)
+    R, C = logits.shape
+    out = np.full((R, C), np.nan, np.float32)
+    if with_sum:
+        tot = np.zeros((1,), np.float32)
+        rc = lib().detops_sigmoid_focal_loss_forward_sum_f32(_p(logits), _p(targets), _p(out), _p(tot), R, C, gamma,
+                                                             alpha, None)
+        assert rc == 0, rc
+        return out, float(tot[0])
+    rc = lib().detops_sigmoid_focal_loss_forward_f32(_p(logits), _p(targets), _p(out), R, C, gamma, alpha, None)
+    assert rc == 0, rc
+    return out
+
+
+def focal_backward(logits, targets, d, gamma, alpha):
+    logits = _f32(logits)
+    targets = np.ascontiguousarray(targets, dtype=np.int32)
+    R, C = logits.shape
+    out = np.full((R, C), np.nan, np.float32)
+    if np.ndim(d) == 0:
+        ds = np.full((1,), d, np.float32)
+        rc = lib().detops_sigmoid_focal_loss_backward_scalar_f32(_p(logits), _p(targets), _p(ds), _p(out), R, C, gamma,
+                                                                 alpha, None)
+    else:
+        d = _f32(d)
+        rc = lib().detops_sigmoid_focal_loss_backward_f32(_p(logits), _p(targets), _p(d), _p(out), R, C, gamma, alpha,
+                                                          None)
+    assert rc == 0, rc
+    return out
+
+
+# ---------------------------------------------------------------------------------- fused FrozenBN
+def frozen_bn_forward(x, scale, bias, residual, relu):
+    x = np.ascontiguousarray(x)
+    dt = x.dtype
+    N, C = x.shape[:2]
+    HW = int(np.prod(x.shape[2:]))
+    y = np.full(x.shape, np.nan, dt)
+    residual = None if residual is None else np.ascontiguousarray(residual, dtype=dt)
+    rc = lib().detops_frozen_bn_act_forward(_p(x), _p(_f32(scale)), _p(_f32(bias)),
+                                            None if residual is None else _p(residual), _p(y), _DT[dt], N, C, HW,
+                                            int(relu), None)
+    assert rc == 0, rc
+    return y
+
+
+def frozen_bn_backward(gy, y, scale, relu, want_residual):
+    gy = np.ascontiguousarray(gy)
+    dt = gy.dtype
+    y = np.ascontiguousarray(y, dtype=dt)
+    N, C = gy.shape[:2]
+    HW = int(np.prod(gy.shape[2:]))
+    gx = np.full(gy.shape, np.nan, dt)
+    gr = np.full(gy.shape, np.nan, dt) if want_residual else None
+    rc = lib().detops_frozen_bn_act_backward(_p(gy), _p(y), _p(_f32(scale)), _p(gx), None if gr is None else _p(gr),
+                                             _DT[dt], N, C, HW, int(relu), None)
+    assert rc == 0, rc
+    return gx, gr
+
+
+# ---------------------------------------------------------------------------------- deformable PS-ROI pooling
+def psroi_forward(data, rois, trans, no_trans, scale, output_dim, group_size, pooled, part, spp, trans_std):
+    data, rois = _f32(data), _f32(rois)
+    trans = None if trans is None else _f32(trans)
+    N, C, H, W = data.shape
+    K = rois.shape[0]
+    ct = 0 if trans is None else trans.shape[1]
+    out = np.full((K, output_dim, pooled, pooled), np.nan, np.float32)
+    cnt = np.full((K, output_dim, pooled, pooled), np.nan, np.float32)
+    rc = lib().detops_deform_psroi_pool_forward_f32(_p(data), _p(rois), None if trans is None else _p(trans), _p(out),
+                                                    _p(cnt), N, C, H, W, K, ct, int(no_trans), scale, output_dim,
+                                                    group_size, pooled, part, spp, trans_std, None)
+    assert rc == 0, rc
+    return out, cnt
+
+
+def psroi_backward(grad, data, rois, trans, cnt, no_trans, scale, output_dim, group_size, pooled, part, spp, trans_std):
+    grad, data, rois, cnt = _f32(grad), _f32(data), _f32(rois), _f32(cnt)
+    trans = None if trans is None else _f32(trans)
+    N, C, H, W = data.shape
+    K = rois.shape[0]
+    ct = 0 if trans is None else trans.shape[1]
+    dg = np.full(data.shape, np.nan, np.float32)
+    tg = None if trans is None else np.full(trans.shape, np.nan, np.float32)
+    rc = lib().detops_deform_psroi_pool_backward_f32(_p(grad), _p(data), _p(rois), None if trans is None else _p(trans),
+                                                     _p(cnt), _p(dg), None if tg is None else _p(tg), N, C, H, W, K, ct,
+                                                     int(no_trans), scale, output_dim, group_size, pooled, part, spp,
+                                                     trans_std, 1, None)
+    assert rc == 0, rc
+    return dg, tg

@@ -53,13 +53,15 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 
 namespace emu {
 constexpr int kWaveSize = 64;
-constexpr size_t kStackBytes = 256 * 1024;
+constexpr size_t kStackBytes = 128 * 1024;
 constexpr size_t kDynLdsBytes = 160 * 1024;
 
 struct Wave {
   int alive = 0, arrived = 0;
   unsigned gen = 0;
   unsigned long long preds = 0, result[2] = {0, 0};
+  unsigned long long xchg[2][kWaveSize];   // lane values of a wave-wide exchange (shfl / readlane)
+  unsigned long long live[2];              // which lanes deposited
 };
 
 struct Block {
@@ -130,6 +132,28 @@ inline unsigned long long ballot(bool pred) {
   return w.result[gen & 1];
 }
 
+// Wave-wide exchange: every live lane deposits a 64-bit value, then reads any lane's deposit.
+// Returns the generation's value table (valid until two exchanges later) and the deposit mask.
+inline const unsigned long long* exchange(unsigned long long v, unsigned long long* live_mask) {
+  Block* b = cur_block();
+  Fiber* f = cur_fiber();
+  Wave& w = b->waves[f->linear / kWaveSize];
+  const unsigned gen = w.gen;
+  const int lane = f->linear % kWaveSize;
+  if (w.arrived == 0) w.live[gen & 1] = 0;
+  w.xchg[gen & 1][lane] = v;
+  w.live[gen & 1] |= 1ull << lane;
+  ++w.arrived;
+  ++progress();
+  while (w.gen == gen) {
+    if (w.arrived >= w.alive) { w.arrived = 0; w.preds = 0; ++w.gen; ++progress(); break; }
+    yield();
+  }
+  if (live_mask) *live_mask = w.live[gen & 1];
+  return w.xchg[gen & 1];
+}
+inline int lane_id() { return cur_fiber()->linear % kWaveSize; }
+
 inline void launch(const std::function<void()>& kernel_body, dim3 grid, dim3 block, size_t lds_bytes) {
   if (lds_bytes > kDynLdsBytes) { fprintf(stderr, "emu: dynamic LDS %zu too large\n", lds_bytes); abort(); }
   const int nthreads = static_cast<int>(block.x * block.y * block.z);
@@ -195,6 +219,37 @@ static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+
+template <typename T> static inline T __shfl_down(T v, int off) {
+  static_assert(sizeof(T) <= 8, "");
+  unsigned long long raw = 0, live = 0; memcpy(&raw, &v, sizeof(T));
+  const unsigned long long* t = emu::exchange(raw, &live);
+  const int src = emu::lane_id() + off;
+  if (src < emu::kWaveSize && ((live >> src) & 1ull)) { T r; memcpy(&r, &t[src], sizeof(T)); return r; }
+  return v;
+}
+template <typename T> static inline T __shfl_up(T v, int off) {
+  static_assert(sizeof(T) <= 8, "");
+  unsigned long long raw = 0, live = 0; memcpy(&raw, &v, sizeof(T));
+  const unsigned long long* t = emu::exchange(raw, &live);
+  const int src = emu::lane_id() - off;
+  if (src >= 0 && ((live >> src) & 1ull)) { T r; memcpy(&r, &t[src], sizeof(T)); return r; }
+  return v;
+}
+static inline unsigned emu_readlane(unsigned v, int lane) {
+  const unsigned long long* t = emu::exchange(v, nullptr);
+  return static_cast<unsigned>(t[lane]);
+}
+static inline unsigned emu_readfirstlane(unsigned v) {
+  unsigned long long live = 0;
+  const unsigned long long* t = emu::exchange(v, &live);
+  return static_cast<unsigned>(t[__builtin_ctzll(live)]);
+}
+#define __builtin_amdgcn_readlane(v, l) emu_readlane(v, l)
+#define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+
+static inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o | v; return o; }
 
 // fibers never run concurrently: plain read-modify-write is atomic here
 static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }

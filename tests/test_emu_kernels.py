@@ -133,3 +133,99 @@ def test_emu_deformable_kernels_vs_oracle(gi, modulated):
     np.testing.assert_allclose(goff, roff, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(roff).max()))
     if modulated:
         np.testing.assert_allclose(gmask, rmask, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(rmask).max()))
+
+
+# ================================================================================ NMS
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 129, 700])
+def test_emu_nms_bit_exact(n):
+    b, s = synth.nms_boxes(n, seed=n)
+    for thr in (0.3, 0.7):
+        assert np.array_equal(emu.nms(b, s, thr), oracle.nms(b, s, thr))
+
+
+def test_emu_nms_ties_large_n_and_batched():
+    b, s = synth.nms_boxes(300, seed=4)
+    s[::3] = s[0]          # score ties: stable (ascending index) order like the CPU sort
+    b[5] = b[4]            # identical boxes: IoU == 1
+    assert np.array_equal(emu.nms(b, s, 0.5), oracle.nms(b, s, 0.5))
+    b, s = synth.nms_boxes(8300, seed=5)   # > 8192: the radix-sort path (std::sort in emulation)
+    assert np.array_equal(emu.nms(b, s, 0.6), oracle.nms(b, s, 0.6))
+    segs = [synth.nms_boxes(n, seed=10 + i) for i, n in enumerate((130, 1, 64, 257, 40))]
+    boxes = np.concatenate([x for x, _ in segs])
+    scores = np.concatenate([y for _, y in segs])
+    offs = np.cumsum([0] + [len(y) for _, y in segs]).astype(np.int32)
+    keep, num = emu.nms_batched(boxes, scores, offs, 257, 0.7)
+    km, num2 = emu.nms_batched(boxes, scores, offs, 257, 0.7, mask=True)
+    assert np.array_equal(num, num2)
+    for i, (x, y) in enumerate(segs):
+        ref = oracle.nms(x, y, 0.7)
+        assert num[i] == len(ref)
+        assert np.array_equal(keep[offs[i]:offs[i] + num[i]], ref)
+        want = np.zeros(len(y), np.uint8)
+        want[ref] = 1
+        assert np.array_equal(km[offs[i]:offs[i + 1]], want)
+
+
+# ================================================================================ focal loss
+@pytest.mark.parametrize("gamma,alpha,C", [(2.0, 0.25, 80), (1.5, 0.4, 7), (0.0, 0.5, 3)])
+def test_emu_focal_vs_oracle(gamma, alpha, C):
+    logits, targets = synth.focal_inputs(900, C)
+    ref = oracle.sigmoid_focal_loss_forward(logits, targets, gamma, alpha)
+    out = emu.focal_forward(logits, targets, gamma, alpha)
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-6)
+    out2, tot = emu.focal_forward(logits, targets, gamma, alpha, with_sum=True)
+    assert np.array_equal(out, out2)
+    assert abs(tot - float(ref.astype(np.float64).sum())) <= 1e-4 * max(1.0, abs(float(ref.sum())))
+    d = np.random.RandomState(1).rand(*logits.shape).astype(np.float32)
+    np.testing.assert_allclose(emu.focal_backward(logits, targets, d, gamma, alpha),
+                               oracle.sigmoid_focal_loss_backward(logits, targets, d, gamma, alpha), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(emu.focal_backward(logits, targets, np.float32(0.37), gamma, alpha),
+                               oracle.sigmoid_focal_loss_backward(logits, targets, np.full_like(logits, 0.37), gamma, alpha),
+                               rtol=1e-4, atol=1e-6)
+
+
+# ================================================================================ fused FrozenBN
+@pytest.mark.parametrize("shape", [(2, 8, 25, 42), (1, 5, 7, 9), (3, 4, 1, 1)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True), (False, True)])
+def test_emu_frozen_bn(shape, relu, res):
+    rng = np.random.RandomState(3)
+    x = rng.randn(*shape).astype(np.float32)
+    r = rng.randn(*shape).astype(np.float32) if res else None
+    scale = (rng.rand(shape[1]) + 0.5).astype(np.float32)
+    bias = rng.randn(shape[1]).astype(np.float32)
+    y = emu.frozen_bn_forward(x, scale, bias, r, relu)
+    want = x * scale[None, :, None, None] + bias[None, :, None, None]
+    if res:
+        want = want + r
+    if relu:
+        want = np.maximum(want, 0)
+    np.testing.assert_allclose(y, want, rtol=1e-6, atol=1e-6)
+    gy = rng.randn(*shape).astype(np.float32)
+    gx, gr = emu.frozen_bn_backward(gy, y, scale, relu, res)
+    g = np.where(y > 0, gy, 0) if relu else gy
+    np.testing.assert_allclose(gx, g * scale[None, :, None, None], rtol=1e-6, atol=1e-6)
+    if res:
+        np.testing.assert_allclose(gr, g, rtol=0, atol=0)
+
+
+# ================================================================================ deformable PS-ROI pooling
+@pytest.mark.parametrize("no_trans,ncls,D,G,P,part,S,std", [
+    (True, 1, 8, 3, 3, 3, 4, 0.0), (False, 1, 8, 3, 7, 7, 4, 0.1), (False, 4, 8, 2, 7, 4, 2, 0.1)])
+def test_emu_deform_psroi_pool(no_trans, ncls, D, G, P, part, S, std):
+    rng = np.random.RandomState(11 + P)
+    N, H, W, K = 2, 20, 30, 24
+    data = rng.randn(N, D * G * G, H, W).astype(np.float32)
+    x1 = rng.uniform(-20, W * 16 - 30, K)
+    y1 = rng.uniform(-20, H * 16 - 30, K)
+    rois = np.stack([rng.randint(0, N, K), x1, y1, x1 + rng.uniform(2, 300, K), y1 + rng.uniform(2, 250, K)], 1).astype(np.float32)
+    trans = None if no_trans else (rng.randn(K, 2 * ncls, part, part) * 1.5).astype(np.float32)
+    out, cnt = emu.psroi_forward(data, rois, trans, no_trans, 1 / 16, D, G, P, part, S, std)
+    ro, rc = oracle.deform_psroi_pool_forward(data, rois, trans, no_trans, 1 / 16, D, G, P, part, S, std)
+    np.testing.assert_allclose(out, ro, rtol=1e-4, atol=1e-5)
+    assert np.array_equal(cnt, rc)
+    g = rng.randn(*out.shape).astype(np.float32)
+    dg, tg = emu.psroi_backward(g, data, rois, trans, cnt, no_trans, 1 / 16, D, G, P, part, S, std)
+    rdg, rtg = oracle.deform_psroi_pool_backward(g, data, rois, trans, rc, no_trans, 1 / 16, D, G, P, part, S, std, acc64=True)
+    np.testing.assert_allclose(dg, rdg, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(rdg).max()))
+    if not no_trans:
+        np.testing.assert_allclose(tg, rtg, rtol=1e-3, atol=1e-3 * max(1.0, np.abs(rtg).max()))
