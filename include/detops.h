@@ -174,6 +174,15 @@ int detops_sigmoid_focal_loss_forward_sum_f32(const float* logits, const int32_t
                                               int R, int C, float gamma, float alpha,
                                               detops_stream_t stream);
 
+/* As _forward_sum, but workgroup partial sums are spread over `num_slots` words
+ * (partial_sums[num_slots], zeroed by the caller; sum(losses) = sum of the slots): thousands of
+ * workgroups retiring together on one word serialise in L2. */
+int detops_sigmoid_focal_loss_forward_partial_sums_f32(const float* logits, const int32_t* targets,
+                                                       float* losses /* nullable */,
+                                                       float* partial_sums, int num_slots, int R,
+                                                       int C, float gamma, float alpha,
+                                                       detops_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Deformable convolution building blocks — the kernels behind _C.deform_conv_forward,
  * _backward_input, _backward_parameters, _C.modulated_deform_conv_forward/_backward

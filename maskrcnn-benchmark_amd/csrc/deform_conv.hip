@@ -147,18 +147,30 @@ im2col_kernel(const T* __restrict__ im, const T* __restrict__ offset, const T* _
   const size_t ncol = static_cast<size_t>(g.B) * g.Ho * g.Wo;
   const T* ip = im + (static_cast<size_t>(q.b) * g.C + c0) * plane;
   T* cp = col + (static_cast<size_t>(c0) * K + q.tap) * ncol + static_cast<size_t>(q.b) * g.Ho * g.Wo + q.pix;
-  for (int c = c0; c < c1; ++c) {
-    float v = 0.f;
-    if (s.inside) {
-      const float v1 = s.i1 >= 0 ? ld(ip + s.i1) : 0.f;
-      const float v2 = s.i2 >= 0 ? ld(ip + s.i2) : 0.f;
-      const float v3 = s.i3 >= 0 ? ld(ip + s.i3) : 0.f;
-      const float v4 = s.i4 >= 0 ? ld(ip + s.i4) : 0.f;
-      v = (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4);
+  // Taps outside the map read element 0 and are replaced by 0 afterwards: the loads become
+  // unconditional, so 4 channels x 4 taps are in flight before the first use (the loop is
+  // latency-bound otherwise: one L2 round trip per channel).
+  const bool t1 = s.i1 >= 0, t2 = s.i2 >= 0, t3 = s.i3 >= 0, t4 = s.i4 >= 0;
+  const int j1 = t1 ? s.i1 : 0, j2 = t2 ? s.i2 : 0, j3 = t3 ? s.i3 : 0, j4 = t4 ? s.i4 : 0;
+  const size_t cstep = static_cast<size_t>(K) * ncol;
+  constexpr int U = 4;
+  for (int c = c0; c < c1; c += U) {
+    float v1[U], v2[U], v3[U], v4[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const T* pu = ip + static_cast<size_t>(min(u, c1 - 1 - c)) * plane;  // tail: re-read the last channel
+      v1[u] = ld(pu + j1); v2[u] = ld(pu + j2); v3[u] = ld(pu + j3); v4[u] = ld(pu + j4);
     }
-    st(cp, mask ? v * m : v);
-    ip += plane;
-    cp += static_cast<size_t>(K) * ncol;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (c + u < c1) {
+        const float a1 = t1 ? v1[u] : 0.f, a2 = t2 ? v2[u] : 0.f, a3 = t3 ? v3[u] : 0.f, a4 = t4 ? v4[u] : 0.f;
+        const float v = s.inside ? (s.w1 * a1 + s.w2 * a2 + s.w3 * a3 + s.w4 * a4) : 0.f;
+        st(cp + static_cast<size_t>(u) * cstep, mask ? v * m : v);
+      }
+    }
+    ip += static_cast<size_t>(U) * plane;
+    cp += static_cast<size_t>(U) * cstep;
   }
 }
 
@@ -412,45 +424,75 @@ col2im_gather_kernel(const T* __restrict__ col, const int32_t* __restrict__ star
 // One thread per sampling point produces BOTH offset gradients (d/dh, d/dw) and the mask gradient,
 // looping over the channels of its deformable group in ascending order (the reference's
 // accumulation order, :413-439 / :738-766).
-template <typename T>
+template <typename T, int S>
 __global__ void __launch_bounds__(kBlock)
 col2im_coord_kernel(const T* __restrict__ col, const T* __restrict__ im, const T* __restrict__ offset,
                     const T* __restrict__ mask, T* __restrict__ grad_offset, T* __restrict__ grad_mask,
                     Geom g, int64_t npoints_per_dg) {
-  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (p >= npoints_per_dg) return;
+  // S channel slices per sampling point: lanes run along the points (coalesced), the slices of a
+  // point sit in different waves / wave quarters and are combined through LDS in slice order.
+  constexpr int PTS = kBlock / S;
+  __shared__ float s_part[3][kBlock];
+  const int pt = threadIdx.x % PTS, slice = threadIdx.x / PTS;
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * PTS + pt;
+  const bool live = p < npoints_per_dg;
   const int dgi = blockIdx.y;
   const int cpg = g.C / g.dg;
-  const Point q = decode(p, g);
+  const Point q = decode(live ? p : 0, g);
   const int K = g.kh * g.kw;
   const Sample s = point_sample(q, g, dgi, offset);
   const size_t HWo = static_cast<size_t>(g.Ho) * g.Wo;
   float m = 1.f;
   if (mask) m = ld(mask + ((static_cast<size_t>(q.b) * g.dg + dgi) * K + q.tap) * HWo + q.pix);
   float gh = 0.f, gw = 0.f, gm = 0.f;
-  if (s.inside) {
+  if (live && s.inside) {
     const size_t plane = static_cast<size_t>(g.H) * g.W;
-    const size_t ncol = static_cast<size_t>(g.B) * HWo;
-    const int c0 = dgi * cpg;
+    const size_t cstep = static_cast<size_t>(K) * g.B * HWo;
+    const int per = (cpg + S - 1) / S;
+    const int cs = slice * per, ce = min(cpg, cs + per);
+    const int c0 = dgi * cpg + cs;
     const T* ip = im + (static_cast<size_t>(q.b) * g.C + c0) * plane;
-    const T* cp = col + (static_cast<size_t>(c0) * K + q.tap) * ncol + static_cast<size_t>(q.b) * HWo + q.pix;
+    const T* cp = col + (static_cast<size_t>(c0) * K + q.tap) * (static_cast<size_t>(g.B) * HWo) +
+                  static_cast<size_t>(q.b) * HWo + q.pix;
     const float hw = 1.f - s.lw, hh = 1.f - s.lh;
-    for (int c = 0; c < cpg; ++c) {
-      const float gv = ld(cp);
-      const float v1 = s.i1 >= 0 ? ld(ip + s.i1) : 0.f;
-      const float v2 = s.i2 >= 0 ? ld(ip + s.i2) : 0.f;
-      const float v3 = s.i3 >= 0 ? ld(ip + s.i3) : 0.f;
-      const float v4 = s.i4 >= 0 ? ld(ip + s.i4) : 0.f;
-      // get_coordinate_weight, bp_dir 0 (:170-180) and 1 (:181-191)
-      const float wh = -hw * v1 - s.lw * v2 + hw * v3 + s.lw * v4;
-      const float ww = -hh * v1 + hh * v2 - s.lh * v3 + s.lh * v4;
-      gh += wh * gv * m;
-      gw += ww * gv * m;
-      gm += gv * (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4);  // :760
-      ip += plane;
-      cp += static_cast<size_t>(K) * ncol;
+    const bool t1 = s.i1 >= 0, t2 = s.i2 >= 0, t3 = s.i3 >= 0, t4 = s.i4 >= 0;
+    const int j1 = t1 ? s.i1 : 0, j2 = t2 ? s.i2 : 0, j3 = t3 ? s.i3 : 0, j4 = t4 ? s.i4 : 0;
+    constexpr int U = 4;  // channels in flight (5 independent loads each)
+    for (int c = cs; c < ce; c += U) {
+      float gv[U], v1[U], v2[U], v3[U], v4[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int uu = min(u, ce - 1 - c);  // tail: re-read the last channel, discarded below
+        const T* pu = ip + static_cast<size_t>(uu) * plane;
+        gv[u] = ld(cp + static_cast<size_t>(uu) * cstep);
+        v1[u] = ld(pu + j1); v2[u] = ld(pu + j2); v3[u] = ld(pu + j3); v4[u] = ld(pu + j4);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (c + u < ce) {
+          const float a1 = t1 ? v1[u] : 0.f, a2 = t2 ? v2[u] : 0.f, a3 = t3 ? v3[u] : 0.f, a4 = t4 ? v4[u] : 0.f;
+          // get_coordinate_weight, bp_dir 0 (:170-180) and 1 (:181-191)
+          const float wh = -hw * a1 - s.lw * a2 + hw * a3 + s.lw * a4;
+          const float ww = -hh * a1 + hh * a2 - s.lh * a3 + s.lh * a4;
+          gh += wh * gv[u] * m;
+          gw += ww * gv[u] * m;
+          gm += gv[u] * (s.w1 * a1 + s.w2 * a2 + s.w3 * a3 + s.w4 * a4);  // :760
+        }
+      }
+      ip += static_cast<size_t>(U) * plane;
+      cp += static_cast<size_t>(U) * cstep;
     }
   }
+  if (S > 1) {
+    s_part[0][threadIdx.x] = gh; s_part[1][threadIdx.x] = gw; s_part[2][threadIdx.x] = gm;
+    __syncthreads();
+    if (slice == 0) {
+      for (int j = 1; j < S; ++j) {
+        gh += s_part[0][j * PTS + pt]; gw += s_part[1][j * PTS + pt]; gm += s_part[2][j * PTS + pt];
+      }
+    }
+  }
+  if (!live || slice != 0) return;
   T* gop = grad_offset + (static_cast<size_t>(q.b) * g.dg + dgi) * 2 * K * HWo;
   st(gop + (2 * q.tap) * HWo + q.pix, gh);
   st(gop + (2 * q.tap + 1) * HWo + q.pix, gw);
@@ -603,10 +645,20 @@ int coord_t(const void* col, const void* im, const void* offset, const void* mas
             void* gmask, const Geom& g, hipStream_t st_) {
   const int64_t np = static_cast<int64_t>(g.B) * g.kh * g.kw * g.Ho * g.Wo;
   if (np == 0) return 0;
-  const dim3 grid(static_cast<unsigned>(ceil_div64(np, kBlock)), static_cast<unsigned>(g.dg));
-  hipLaunchKernelGGL(col2im_coord_kernel<T>, grid, dim3(kBlock), 0, st_, static_cast<const T*>(col),
-                     static_cast<const T*>(im), static_cast<const T*>(offset),
-                     static_cast<const T*>(mask), static_cast<T*>(goff), static_cast<T*>(gmask), g, np);
+  // channel slices per point: enough workgroups for the chip on small maps (C5: 2 x 9 x 25 x 42 points)
+  const int cpg = g.C / g.dg;
+  int S = 1;
+  while (S < 16 && cpg / (S * 4) >= 8 && ceil_div64(np, kBlock / S) * g.dg < 4 * kNumCU) S *= 4;
+#define COORD_LAUNCH(S_)                                                                                     \
+  hipLaunchKernelGGL((col2im_coord_kernel<T, S_>),                                                           \
+                     dim3(static_cast<unsigned>(ceil_div64(np, kBlock / S_)), static_cast<unsigned>(g.dg)),  \
+                     dim3(kBlock), 0, st_, static_cast<const T*>(col), static_cast<const T*>(im),            \
+                     static_cast<const T*>(offset), static_cast<const T*>(mask), static_cast<T*>(goff),      \
+                     static_cast<T*>(gmask), g, np)
+  if (S == 1) COORD_LAUNCH(1);
+  else if (S == 4) COORD_LAUNCH(4);
+  else COORD_LAUNCH(16);
+#undef COORD_LAUNCH
   return launch_status();
 }
 

@@ -38,6 +38,8 @@ SIGNATURES = {
         c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     "detops_sigmoid_focal_loss_forward_sum_f32": (
         c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_sigmoid_focal_loss_forward_partial_sums_f32": (
+        c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
     "detops_frozen_bn_act_forward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
     "detops_frozen_bn_act_backward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
     "detops_deformable_im2col": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),

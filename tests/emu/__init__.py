@@ -29,6 +29,8 @@ SIGNATURES = {
     "detops_sigmoid_focal_loss_backward_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     "detops_sigmoid_focal_loss_backward_scalar_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     "detops_sigmoid_focal_loss_forward_sum_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_sigmoid_focal_loss_forward_partial_sums_f32": (
+        c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
     "detops_frozen_bn_act_forward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
     "detops_frozen_bn_act_backward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
     "detops_deform_psroi_pool_forward_f32": (c_int, [_P] * 5 + [c_int] * 7 + [c_float] + [c_int] * 5 + [c_float, _P]),
@@ -223,6 +225,11 @@ def focal_forward(logits, targets, gamma, alpha, with_sum=False):
         rc = lib().detops_sigmoid_focal_loss_forward_sum_f32(_p(logits), _p(targets), _p(out), _p(tot), R, C, gamma,
                                                              alpha, None)
         assert rc == 0, rc
+        part = np.zeros((5,), np.float32)
+        rc = lib().detops_sigmoid_focal_loss_forward_partial_sums_f32(_p(logits), _p(targets), None, _p(part), 5, R, C,
+                                                                      gamma, alpha, None)
+        assert rc == 0, rc
+        assert abs(float(part.sum()) - float(tot[0])) <= 1e-5 * max(1.0, abs(float(tot[0])))
         return out, float(tot[0])
     rc = lib().detops_sigmoid_focal_loss_forward_f32(_p(logits), _p(targets), _p(out), R, C, gamma, alpha, None)
     assert rc == 0, rc

@@ -94,7 +94,9 @@ def test_emu_roi_align_fpn_fused_levels(bwd_impl):
 # ================================================================================ deformable conv
 DCN_GEOMS = [dict(B=2, C=8, H=13, W=17, k=3, stride=1, pad=1, dil=1, dg=1),
              dict(B=2, C=8, H=14, W=15, k=3, stride=2, pad=2, dil=2, dg=2),
-             dict(B=1, C=20, H=9, W=33, k=3, stride=1, pad=1, dil=1, dg=1)]
+             dict(B=1, C=20, H=9, W=33, k=3, stride=1, pad=1, dil=1, dg=1),
+             dict(B=1, C=160, H=5, W=7, k=3, stride=1, pad=1, dil=1, dg=1),    # coord kernel: 16 channel slices
+             dict(B=2, C=66, H=6, W=5, k=3, stride=1, pad=1, dil=1, dg=2)]     # 4 slices, ragged channel split
 
 
 def _dcn_case(g, modulated, seed=3):
