@@ -387,15 +387,23 @@ constexpr int kGatherCC = 16;  // channels per thread pass (independent loads in
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 col2im_gather_kernel(const T* __restrict__ col, const int32_t* __restrict__ start,
-                     const ColEntry* __restrict__ entries, T* __restrict__ grad_im, Geom g, int cchunk) {
+                     const ColEntry* __restrict__ entries, T* __restrict__ grad_im, Geom g, int cchunk,
+                     int xcd_remap) {
   const int HW = g.H * g.W;
-  const int pix = blockIdx.x * kBlock + threadIdx.x;   // pixel within the image plane
+  // (pixel block, channel chunk, image) from the linear workgroup id; with xcd_remap every XCD owns
+  // a contiguous run of pixel blocks of one chunk, so the overlapping column windows of
+  // neighbouring pixel blocks are fetched into ONE L2 instead of all eight
+  int64_t lin = (static_cast<int64_t>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  if (xcd_remap) lin = xcd_contiguous(lin, static_cast<int64_t>(gridDim.x) * gridDim.y * gridDim.z);
+  const int bx = static_cast<int>(lin % gridDim.x);
+  const int by = static_cast<int>((lin / gridDim.x) % gridDim.y);
+  const int b = static_cast<int>(lin / (static_cast<int64_t>(gridDim.x) * gridDim.y));
+  const int pix = bx * kBlock + threadIdx.x;   // pixel within the image plane
   if (pix >= HW) return;
-  const int b = blockIdx.z;
   const int cpg = g.C / g.dg;
   const int chunks_per_g = (cpg + cchunk - 1) / cchunk;
-  const int dgi = blockIdx.y / chunks_per_g;
-  const int c0 = dgi * cpg + (blockIdx.y - dgi * chunks_per_g) * cchunk;
+  const int dgi = by / chunks_per_g;
+  const int c0 = dgi * cpg + (by - dgi * chunks_per_g) * cchunk;
   const int c1 = min(c0 + cchunk, (dgi + 1) * cpg);
   const int K = g.kh * g.kw;
   const size_t chan_stride = static_cast<size_t>(K) * g.B * g.Ho * g.Wo;   // one channel's K rows of col
@@ -632,11 +640,13 @@ int col2im_gather_t(const void* col, const void* offset, const void* mask, void*
   int cc = cpg;  // channels per workgroup: whole passes of kGatherCC, enough workgroups to fill the chip
   while (cc > kGatherCC && pix_blocks * g.dg * ceil_div64(cpg, cc) < 4 * kNumCU) cc = max(kGatherCC, cc / 2);
   cc = static_cast<int>(ceil_div64(cc, kGatherCC)) * kGatherCC;
+  const char* sw = getenv("DETOPS_DCN_GATHER_XCD");  // "0": plain block order (A/B measurements)
+  const int xcd_remap = !(sw && sw[0] == '0');
   const dim3 ggrid(static_cast<unsigned>(ceil_div64(static_cast<int64_t>(g.H) * g.W, kBlock)),
                    static_cast<unsigned>(g.dg * ceil_div64(cpg, cc)), static_cast<unsigned>(g.B));
   hipLaunchKernelGGL(col2im_gather_kernel<T>, ggrid, dim3(kBlock), 0, st_, static_cast<const T*>(col),
                      static_cast<const int32_t*>(start), static_cast<const ColEntry*>(entries),
-                     static_cast<T*>(grad_im), g, cc);
+                     static_cast<T*>(grad_im), g, cc, xcd_remap);
   return launch_status();
 }
 
@@ -727,8 +737,13 @@ DETOPS_API int detops_deformable_col2im_ws(const void* col, const void* offset, 
   if (B == 0) return 0;
   if (!col || !offset || !grad_im) return DETOPS_EINVAL;
   GatherPlan P;
-  const char* e = getenv("DETOPS_DCN_COL2IM");  // "scatter" forces the atomic kernels (A/B measurements)
-  const bool scatter = (e && e[0] == 's') || !workspace || !gather_plan(g, P) || workspace_bytes < P.total;
+  // DETOPS_DCN_COL2IM = "scatter" / "gather" forces a path (A/B measurements).  Default: the inverted-
+  // index gather for 16-bit storage and for maps up to 64 x 64; the LDS-window scatter for large fp32
+  // maps — with i.i.d. offsets (the SURVEY.md cfg-5 workload) the gather's column reads lose locality
+  // there (measured, profiles/r01d_opbench.log: 1544 vs 957 us at 100 x 168, 287 vs 378 us at 25 x 42).
+  const char* e = getenv("DETOPS_DCN_COL2IM");
+  const bool want_gather = e ? (e[0] == 'g') : (dtype != DETOPS_F32 || static_cast<int64_t>(H) * W <= 4096);
+  const bool scatter = !want_gather || !workspace || !gather_plan(g, P) || workspace_bytes < P.total;
   if (scatter) {
 #define CALL(T) col2im_t<T>(col, offset, mask, grad_im, g, as_stream(stream))
     DETOPS_DTYPE_SWITCH(dtype, CALL)

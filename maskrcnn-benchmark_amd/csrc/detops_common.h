@@ -35,6 +35,16 @@ constexpr int kWave = 64;        // CDNA4 wavefront
 constexpr int kNumCU = 256;      // MI355X
 constexpr int kNumXCD = 8;
 
+// XCD-contiguous remap of a linear workgroup id (any grid size): the dispatcher deals consecutive
+// workgroups round-robin over the 8 XCDs (observed; speed only, never correctness), so id b runs
+// on XCD b % 8.  The remap gives every XCD one CONTIGUOUS range of logical ids — neighbouring work
+// items then share that XCD's L2.  Bijective on [0, n).
+__device__ __forceinline__ int64_t xcd_contiguous(int64_t bid, int64_t n) {
+  const int64_t q = n / kNumXCD, r = n % kNumXCD;
+  const int64_t x = bid % kNumXCD, i = bid / kNumXCD;
+  return x * q + (x < r ? x : r) + i;
+}
+
 // Workgroup index swizzle: consecutive logical ids land on the same XCD (the dispatcher places
 // block b on XCD b % 8 — observed, used for L2 locality only, never for correctness).
 __device__ __forceinline__ int xcd_swizzle(int bid, int nblocks) {

@@ -21,6 +21,7 @@
 //     keeps its bin's sample offsets + weights in registers across the channel loop (see below).
 //   * backward: tile-centric — a workgroup owns a pixel tile of one gradient map and accumulates
 //     every overlapping ROI in LDS; no global atomics, no separate zero-fill (see below).
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -574,6 +575,7 @@ struct GPlan {
   int n_items[DETOPS_MAX_LEVELS];
   int tiles_x[DETOPS_MAX_LEVELS], tiles_y[DETOPS_MAX_LEVELS];
   int chunks, accumulate, batch;       // batch = ROIs staged per round
+  int groups;                          // > 1: the ROI list is split over blockIdx.y (small maps), see below
 };
 
 struct __align__(16) GHit {   // 32 bytes
@@ -632,12 +634,17 @@ roi_align_bwd_gather_kernel(Levels L, GPlan P, const float* __restrict__ rois,
 #pragma unroll
   for (int c = 0; c < CT; ++c) acc[c] = 0.f;
 
-  for (int kb = 0; kb < K; kb += kBlock) {
+  // Small maps (e.g. the 14 x 14 cfg-1 map: 2 tiles) leave the chip idle and make one workgroup walk
+  // hundreds of ROIs.  There the ROI list is split over blockIdx.y; each group adds its partial
+  // sums with global atomics into the pre-zeroed (tiny) map — the only configuration with atomics.
+  const int r_begin = static_cast<int>(static_cast<int64_t>(K) * blockIdx.y / P.groups);
+  const int r_end = static_cast<int>(static_cast<int64_t>(K) * (blockIdx.y + 1) / P.groups);
+  for (int kb = r_begin; kb < r_end; kb += kBlock) {
     // ---- which of ROIs [kb, kb+256) touch this tile?  ordered compaction into s_hit
     const int r = kb + tid;
     bool hit = false;
     GHit h{};
-    if (r < K) {
+    if (r < r_end) {
       const float* roi = rois + static_cast<size_t>(r) * 5;
       const int rl = (L.num > 1) ? levels_in[r] : 0;
       if (rl == lvl && static_cast<int>(roi[0]) == b) {
@@ -796,8 +803,12 @@ roi_align_bwd_gather_kernel(Levels L, GPlan P, const float* __restrict__ rois,
     if (y0 + yy <= y1 && x0 + xx <= x1) {
       float* dst = gb + static_cast<size_t>(c) * plane + static_cast<size_t>(y0 + yy) * W + (x0 + xx);
       float v = tb[(c * kGTH + yy) * kGRowPad + xx];
-      if (P.accumulate) v += *dst;
-      *dst = v;
+      if (P.groups > 1) {
+        if (v != 0.f) atomicAdd(dst, v);
+      } else {
+        if (P.accumulate) v += *dst;
+        *dst = v;
+      }
     }
   }
 }
@@ -832,7 +843,10 @@ void launch_fwd_lds(const Levels& L, const float* rois, const int32_t* levels_in
   while (CT > 16 && static_cast<int64_t>(K) * ceil_div64(C, CT) < 4 * kNumCU) CT >>= 1;
   if (CT > C) CT = C;
   const int chunks = static_cast<int>(ceil_div64(C, CT));
+  // measured (profiles/r01d_opbench.log): 7x7 bins are fastest at 32 KiB / 4 loads in flight (142 us box
+  // head); the larger 14x14 footprints at 48 KiB / 8 (79 vs 87 us mask head)
   int patch_floats = kLdsPatchFloats, unroll = 4;
+  if (PH * PW >= 196) { patch_floats = 48 * 256 - 64; unroll = 8; }
   if (const char* e = getenv("DETOPS_ROIALIGN_FWD_LDS_KB")) {
     const int kb = atoi(e);
     if (kb >= 4 && kb <= 60) patch_floats = kb * 256 - 64;
@@ -959,6 +973,10 @@ int run_backward_gather(const Levels& L, const float* rois, const int32_t* level
   P.chunks = static_cast<int>(ceil_div64(C, CT));
   P.accumulate = accumulate;
   P.batch = batch;
+  // ROI-list split for underfilled launches: ~32 ROIs per workgroup, at most 32 groups
+  P.groups = 1;
+  if (count_items(CT) < 2 * kNumCU && K > 64) P.groups = static_cast<int>(std::min<int64_t>(32, ceil_div64(K, 32)));
+  if (const char* e = getenv("DETOPS_ROIALIGN_BWD_GROUPS")) P.groups = max(1, min(64, atoi(e)));  // tuning / test knob
   int64_t items = 0;
   for (int i = L.num - 1; i >= 0; --i) {  // coarsest level first
     P.tiles_x[i] = static_cast<int>(ceil_div64(L.lv[i].W, kGTW));
@@ -970,7 +988,10 @@ int run_backward_gather(const Levels& L, const float* rois, const int32_t* level
     items += n;
   }
   if (items == 0) return 0;
-  const dim3 grid(static_cast<unsigned>(items));
+  if (P.groups > 1 && !accumulate)
+    for (int i = 0; i < L.num; ++i)
+      DETOPS_HIP_TRY(hipMemsetAsync(L.lv[i].gin, 0, sizeof(float) * static_cast<size_t>(N) * C * L.lv[i].H * L.lv[i].W, st));
+  const dim3 grid(static_cast<unsigned>(items), static_cast<unsigned>(P.groups));
 #define GATHER_LAUNCH(PH_, PW_, CT_)                                                                          \
   hipLaunchKernelGGL((roi_align_bwd_gather_kernel<PH_, PW_, CT_>), grid, dim3(kBlock), lds, st, L, P, rois, \
                      levels_in, gout, C, K, PH, PW, sr)

@@ -156,10 +156,12 @@ def deformable_col2im(col, offset, mask, B, C, H, W, kh, kw, pad, stride, dil, d
     g = _geom(B, C, H, W, kh, kw, pad, stride, dil, dg)
     mp = None if mask is None else _p(mask)
     if gather:
+        os.environ["DETOPS_DCN_COL2IM"] = "gather"  # the default picks a path by dtype / map size
         nbytes = lib().detops_deformable_col2im_workspace_bytes(*g)
         assert nbytes > 0
         ws = np.full((nbytes,), 0xAB, np.uint8)  # arbitrary contents
         rc = lib().detops_deformable_col2im_ws(_p(col), _p(offset), mp, _p(gim), _DT[dt], *g, _p(ws), nbytes, None)
+        del os.environ["DETOPS_DCN_COL2IM"]
     else:
         rc = lib().detops_deformable_col2im(_p(col), _p(offset), mp, _p(gim), _DT[dt], *g, None)
     assert rc == 0, rc

@@ -231,3 +231,23 @@ def test_emu_deform_psroi_pool(no_trans, ncls, D, G, P, part, S, std):
     np.testing.assert_allclose(dg, rdg, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(rdg).max()))
     if not no_trans:
         np.testing.assert_allclose(tg, rtg, rtol=1e-3, atol=1e-3 * max(1.0, np.abs(rtg).max()))
+
+
+@pytest.mark.parametrize("groups", [None, "3", "7"])
+def test_emu_roi_align_backward_roi_list_split(groups, monkeypatch):
+    """small maps split the ROI list over blockIdx.y (partials combined with atomics on the
+    pre-zeroed map): automatic (K = 100 on a 14x14 map -> 4 groups) and forced group counts,
+    with and without the accumulate flag."""
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "gather")
+    if groups:
+        monkeypatch.setenv("DETOPS_ROIALIGN_BWD_GROUPS", groups)
+    inp, rois, scale = synth.cfg1_roi_align(K=100, C=6)
+    rois = np.concatenate([rois, _edge_rois()])
+    for (ph, pw, sr) in ((7, 7, 2), (14, 14, 2), (3, 5, 0)):
+        g = np.random.RandomState(1).randn(rois.shape[0], 6, ph, pw).astype(np.float32)
+        ref = oracle.roi_align_backward(g, rois, scale, ph, pw, *inp.shape, sr, acc64=True)
+        tol = 1e-5 * max(1.0, np.abs(ref).max())
+        assert np.abs(emu.roi_align_backward(g, rois, scale, ph, pw, *inp.shape, sr) - ref).max() <= tol
+        base = np.random.RandomState(2).randn(*inp.shape).astype(np.float32)
+        acc = emu.roi_align_backward(g, rois, scale, ph, pw, *inp.shape, sr, into=base)
+        assert np.abs(acc - (base + ref)).max() <= 2 * tol

@@ -541,7 +541,8 @@ def test_deformable_kernels_vs_oracle_fp32(gi, modulated, monkeypatch):
     _close(col, ref_col, rtol=1e-5, atol=1e-5)
     gcol = np.random.RandomState(9).randn(*ref_col.shape).astype(np.float32)
     gim = torch.zeros(*x.shape, device=DEV)
-    C.deformable_col2im(_t(gcol), _t(off), tm, gim, *geo)   # default: inverted-index gather (no data atomics)
+    monkeypatch.setenv("DETOPS_DCN_COL2IM", "gather")       # inverted-index gather (no data atomics)
+    C.deformable_col2im(_t(gcol), _t(off), tm, gim, *geo)
     ref_gim = oracle.deformable_col2im(gcol, off, mask, *x.shape, **ogeo)
     _close(gim, ref_gim, rtol=1e-4, atol=1e-4)
     gim2 = torch.zeros(*x.shape, device=DEV)
@@ -551,7 +552,10 @@ def test_deformable_kernels_vs_oracle_fp32(gi, modulated, monkeypatch):
     gim3 = torch.zeros(*x.shape, device=DEV)
     C.deformable_col2im(_t(gcol), _t(off), tm, gim3, *geo)
     _close(gim3, ref_gim, rtol=1e-4, atol=1e-4)
-    monkeypatch.delenv("DETOPS_DCN_COL2IM")
+    monkeypatch.delenv("DETOPS_DCN_COL2IM")                 # default: chosen by dtype / map size
+    gim4 = torch.zeros(*x.shape, device=DEV)
+    C.deformable_col2im(_t(gcol), _t(off), tm, gim4, *geo)
+    _close(gim4, ref_gim, rtol=1e-4, atol=1e-4)
     goff = torch.empty(*off.shape, device=DEV)
     gmask = None if mask is None else torch.empty(*mask.shape, device=DEV)
     C.deformable_col2im_coord(_t(gcol), _t(x), _t(off), tm, goff, gmask, *geo)

@@ -67,7 +67,12 @@ def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False):
         if "bwd" in which:
             g = torch.randn(K, Cc, ph, pw, device="cuda")
             us = dev_time_us(lambda: C.roi_align_backward(g, tr, scale, ph, pw, 1, Cc, 14, 14, sr), iters)
-            out.append(_entry(f"roi_align_bwd cfg1 {ph}x{pw} sr{sr}", us, alg))
+            out.append(_entry(f"roi_align_bwd cfg1 {ph}x{pw} sr{sr} (gather, ROI list split over 16 groups)", us, alg))
+            for grp in ("1", "32"):
+                os.environ["DETOPS_ROIALIGN_BWD_GROUPS"] = grp
+                us = dev_time_us(lambda: C.roi_align_backward(g, tr, scale, ph, pw, 1, Cc, 14, 14, sr), max(3, iters // 5))
+                out.append(_entry(f"roi_align_bwd cfg1 {ph}x{pw} sr{sr} [groups={grp}]", us, alg))
+            del os.environ["DETOPS_ROIALIGN_BWD_GROUPS"]
     # cfg-2 box head: 1024 ROIs over P2..P5, 7x7 sr2; cfg-3 mask head: 256 ROIs, 14x14 sr2 ----
     feats = [torch.randn(2, 256, h, w, device="cuda") for (h, w) in synth.fpn_shapes()[:4]]
     scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
@@ -178,26 +183,38 @@ def bench_focal(C, iters):
 
 def bench_dcn(C, iters):
     out = []
-    for (Cc, H, W) in [(128, 100, 168), (256, 50, 84), (512, 25, 42)]:
+    for (Cc, H, W, smooth) in [(128, 100, 168, False), (256, 50, 84, False), (512, 25, 42, False), (128, 100, 168, True)]:
         for dt, e in ((torch.float32, 4), (torch.float16, 2)):
             x = torch.randn(2, Cc, H, W, device="cuda").to(dt)
-            off = (torch.randn(2, 18, H, W, device="cuda") * 2).to(dt)
+            if smooth:  # spatially smooth offsets (a conv-predicted field): low-resolution noise upsampled, ~2 px
+                lo = torch.randn(2, 18, H // 8 + 2, W // 8 + 2, device="cuda") * 2
+                off = torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False).to(dt)
+            else:       # i.i.d. N(0, 2 px) offsets (worst case for locality)
+                off = (torch.randn(2, 18, H, W, device="cuda") * 2).to(dt)
             geo = (3, 3, 1, 1, 1, 1, 1, 1, 1)
             ncol = 2 * H * W
             alg = e * (x.numel() + off.numel() + Cc * 9 * ncol)
             us = dev_time_us(lambda: C.deformable_im2col(x, off, None, *geo), iters)
-            out.append(_entry(f"dcn_im2col C={Cc} {H}x{W} {str(dt)[6:]}", us, alg))
+            tagx = " smooth-offsets" if smooth else ""
+            out.append(_entry(f"dcn_im2col C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg))
             col = torch.randn(Cc * 9, ncol, device="cuda").to(dt)
             gim = torch.zeros_like(x)
             us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), iters)
-            out.append(_entry(f"dcn_col2im gather (index+sort+gather, 5 launches) C={Cc} {H}x{W} {str(dt)[6:]}", us, alg))
+            out.append(_entry(f"dcn_col2im default C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg))
+            os.environ["DETOPS_DCN_COL2IM"] = "gather"
+            us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), max(3, iters // 5))
+            out.append(_entry(f"dcn_col2im gather (index+sort+gather, XCD-contiguous) C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg))
+            os.environ["DETOPS_DCN_GATHER_XCD"] = "0"
+            us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), max(3, iters // 5))
+            del os.environ["DETOPS_DCN_GATHER_XCD"]
+            out.append(_entry(f"dcn_col2im gather (plain block order) C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg))
             os.environ["DETOPS_DCN_COL2IM"] = "scatter"
             us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), max(3, iters // 5))
             del os.environ["DETOPS_DCN_COL2IM"]
-            out.append(_entry(f"dcn_col2im scatter (LDS atomics) C={Cc} {H}x{W} {str(dt)[6:]}", us, alg))
+            out.append(_entry(f"dcn_col2im scatter (LDS atomics) C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg))
             goff = torch.empty_like(off)
             us = dev_time_us(lambda: C.deformable_col2im_coord(col, x, off, None, goff, None, *geo), iters)
-            out.append(_entry(f"dcn_col2im_coord C={Cc} {H}x{W} {str(dt)[6:]}", us, alg))
+            out.append(_entry(f"dcn_col2im_coord C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg))
     return out
 
 
