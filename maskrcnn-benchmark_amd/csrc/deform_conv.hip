@@ -737,12 +737,12 @@ DETOPS_API int detops_deformable_col2im_ws(const void* col, const void* offset, 
   if (B == 0) return 0;
   if (!col || !offset || !grad_im) return DETOPS_EINVAL;
   GatherPlan P;
-  // DETOPS_DCN_COL2IM = "scatter" / "gather" forces a path (A/B measurements).  Default: the inverted-
-  // index gather for 16-bit storage and for maps up to 64 x 64; the LDS-window scatter for large fp32
-  // maps — with i.i.d. offsets (the SURVEY.md cfg-5 workload) the gather's column reads lose locality
-  // there (measured, profiles/r01d_opbench.log: 1544 vs 957 us at 100 x 168, 287 vs 378 us at 25 x 42).
+  // DETOPS_DCN_COL2IM = "scatter" forces the atomic kernels (A/B measurements).  The gather path is the
+  // default for every dtype / size: with the XCD-contiguous block order it beats the LDS-atomic scatter
+  // on all cfg-5 shapes (profiles/r01e_opbench.log: fp32 814 vs 959 / 349 vs 485 / 235 vs 376 us,
+  // fp16 594 vs 1121 / 266 vs 577 / 157 vs 525 us) and is deterministic.
   const char* e = getenv("DETOPS_DCN_COL2IM");
-  const bool want_gather = e ? (e[0] == 'g') : (dtype != DETOPS_F32 || static_cast<int64_t>(H) * W <= 4096);
+  const bool want_gather = !(e && e[0] == 's');
   const bool scatter = !want_gather || !workspace || !gather_plan(g, P) || workspace_bytes < P.total;
   if (scatter) {
 #define CALL(T) col2im_t<T>(col, offset, mask, grad_im, g, as_stream(stream))

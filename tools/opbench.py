@@ -67,8 +67,8 @@ def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False):
         if "bwd" in which:
             g = torch.randn(K, Cc, ph, pw, device="cuda")
             us = dev_time_us(lambda: C.roi_align_backward(g, tr, scale, ph, pw, 1, Cc, 14, 14, sr), iters)
-            out.append(_entry(f"roi_align_bwd cfg1 {ph}x{pw} sr{sr} (gather, ROI list split over 16 groups)", us, alg))
-            for grp in ("1", "32"):
+            out.append(_entry(f"roi_align_bwd cfg1 {ph}x{pw} sr{sr} (gather, ROI list split over 32 groups)", us, alg))
+            for grp in ("1", "16"):
                 os.environ["DETOPS_ROIALIGN_BWD_GROUPS"] = grp
                 us = dev_time_us(lambda: C.roi_align_backward(g, tr, scale, ph, pw, 1, Cc, 14, 14, sr), max(3, iters // 5))
                 out.append(_entry(f"roi_align_bwd cfg1 {ph}x{pw} sr{sr} [groups={grp}]", us, alg))
