@@ -1,0 +1,99 @@
+"""Randomised small-shape sweeps of the emulated HIP kernels against the oracle (CPU only).  Shapes,
+ROI geometry, bin counts, sampling ratios and channel counts are drawn per case from a seeded
+generator, so every run covers the same 60-odd configurations — odd sizes, ROIs outside the map,
+degenerate ROIs, maps smaller than a tile, channel counts that are not multiples of any chunk."""
+import numpy as np
+import pytest
+
+import emu
+import oracle
+
+
+def _rois(rng, K, N, H, W, scale):
+    img_w, img_h = W / scale, H / scale
+    x1 = rng.uniform(-0.3 * img_w, 1.1 * img_w, K)
+    y1 = rng.uniform(-0.3 * img_h, 1.1 * img_h, K)
+    w = np.exp(rng.uniform(np.log(0.5), np.log(1.5 * img_w), K))
+    h = np.exp(rng.uniform(np.log(0.5), np.log(1.5 * img_h), K))
+    r = np.stack([rng.randint(0, N, K), x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+    if K > 2:
+        r[0, 3:] = r[0, 1:3]           # zero-size ROI
+        r[1, 1:] = [-1e4, -1e4, -9e3, -9e3]  # far outside
+    return r
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_emu_fuzz_roi_align(seed, monkeypatch):
+    rng = np.random.RandomState(1000 + seed)
+    N = int(rng.randint(1, 3))
+    C = int(rng.choice([1, 3, 4, 5, 16, 17, 33]))
+    H, W = int(rng.randint(1, 40)), int(rng.randint(1, 70))
+    K = int(rng.choice([1, 2, 7, 40, 70]))
+    ph, pw = [(7, 7), (14, 14), (1, 1), (2, 5), (5, 2), (7, 7), (3, 3), (9, 4)][seed % 8]
+    sr = int(rng.choice([0, 1, 2, 3]))
+    scale = float(rng.choice([1.0, 0.5, 0.25, 0.0625]))
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    rois = _rois(rng, K, N, H, W, scale)
+    out = emu.roi_align_forward(x, rois, scale, ph, pw, sr)
+    assert np.array_equal(out, oracle.roi_align_forward(x, rois, scale, ph, pw, sr)), "forward must be bit-equal"
+    g = rng.randn(K, C, ph, pw).astype(np.float32)
+    ref = oracle.roi_align_backward(g, rois, scale, ph, pw, N, C, H, W, sr, acc64=True)
+    tol = 2e-5 * max(1.0, np.abs(ref).max())
+    for impl in ("gather", "tile"):
+        monkeypatch.setenv("DETOPS_ROIALIGN_BWD", impl)
+        got = emu.roi_align_backward(g, rois, scale, ph, pw, N, C, H, W, sr)
+        assert np.abs(got - ref).max() <= tol, impl
+    if seed % 3 == 0:
+        monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "gather")
+        monkeypatch.setenv("DETOPS_ROIALIGN_BWD_GROUPS", "5")
+        got = emu.roi_align_backward(g, rois, scale, ph, pw, N, C, H, W, sr)
+        assert np.abs(got - ref).max() <= tol, "ROI-list split"
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_emu_fuzz_nms(seed):
+    rng = np.random.RandomState(2000 + seed)
+    n = int(rng.choice([1, 3, 64, 65, 127, 128, 300, 513]))
+    cx, cy = rng.uniform(0, 200, n), rng.uniform(0, 200, n)
+    w, h = rng.uniform(1, 80, n), rng.uniform(1, 80, n)
+    boxes = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32)
+    if seed % 2:
+        boxes = np.round(boxes)                     # integer boxes: many exact IoU == threshold ties
+    scores = rng.rand(n).astype(np.float32)
+    if seed % 4 == 1:
+        scores = np.round(scores, 1)                # score ties: stable order
+    if seed % 4 == 2 and n > 3:
+        boxes[2] = boxes[1]; scores[2] = scores[1]  # duplicates
+    thr = float(rng.choice([0.0, 0.3, 0.5, 0.7, 1.0]))
+    assert np.array_equal(emu.nms(boxes, scores, thr), oracle.nms(boxes, scores, thr))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_emu_fuzz_deformable(seed):
+    rng = np.random.RandomState(3000 + seed)
+    B = int(rng.randint(1, 3))
+    dg = int(rng.choice([1, 2]))
+    C = dg * int(rng.choice([1, 3, 8, 17]))
+    H, W = int(rng.randint(3, 14)), int(rng.randint(3, 20))
+    k = int(rng.choice([1, 3]))
+    stride, pad, dil = int(rng.choice([1, 2])), int(rng.choice([0, 1, 2])), int(rng.choice([1, 2]))
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    if Ho < 1 or Wo < 1:
+        pytest.skip("empty output")
+    x = rng.randn(B, C, H, W).astype(np.float32)
+    off = (rng.randn(B, dg * 2 * k * k, Ho, Wo) * rng.choice([0.0, 0.7, 3.0])).astype(np.float32)
+    mask = rng.rand(B, dg * k * k, Ho, Wo).astype(np.float32) if seed % 2 else None
+    geo = dict(kh=k, kw=k, pad=(pad, pad), stride=(stride, stride), dil=(dil, dil), dg=dg)
+    ref_col = oracle.deformable_im2col(x, off, mask, **geo)
+    np.testing.assert_allclose(emu.deformable_im2col(x, off, mask, **geo), ref_col, rtol=1e-5, atol=1e-5)
+    gcol = rng.randn(*ref_col.shape).astype(np.float32)
+    ref = oracle.deformable_col2im(gcol, off, mask, B, C, H, W, **geo)
+    tol = dict(rtol=1e-4, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(emu.deformable_col2im(gcol, off, mask, B, C, H, W, gather=True, **geo), ref, **tol)
+    np.testing.assert_allclose(emu.deformable_col2im(gcol, off, mask, B, C, H, W, gather=False, **geo), ref, **tol)
+    goff, gmask = emu.deformable_col2im_coord(gcol, x, off, mask, **geo)
+    roff, rmask = oracle.deformable_col2im_coord(gcol, x, off, mask, **geo)
+    np.testing.assert_allclose(goff, roff, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(roff).max()))
+    if mask is not None:
+        np.testing.assert_allclose(gmask, rmask, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(rmask).max()))
