@@ -584,7 +584,7 @@ struct __align__(16) GHit {   // 32 bytes
   int xspan;   // (ix0 << 16) | ix1: columns the ROI's taps can reach (conservative), map width < 32768
 };
 
-template <int PH_, int PW_, int CT>
+template <int PH_, int PW_, int CT, bool LANE_WALK = false>
 __global__ void __launch_bounds__(kBlock)
 roi_align_bwd_gather_kernel(Levels L, GPlan P, const float* __restrict__ rois,
                             const int32_t* __restrict__ levels_in, const float* __restrict__ gout,
@@ -731,7 +731,39 @@ roi_align_bwd_gather_kernel(Levels L, GPlan P, const float* __restrict__ rois,
         const float* ayr = ayt + (j * kGTH + yl) * PPH;
         const float* axr = axt + (j * kGTW + xl) * PPW;
         const float4* gj = gs4 + j * bins;
-        if constexpr (PH_ > 0 && PW_ > 0) {
+        if constexpr (LANE_WALK) {
+          // EXPERIMENTAL (DETOPS_ROIALIGN_BWD_WALK=lane, off by default, not yet measured on hardware):
+          // every lane walks its OWN contiguous range of contributing bins (the bins with a sample
+          // within one pixel of it: 2-4 per axis for model-sized ROIs) instead of the union over the
+          // wave's 8 x 8 pixels; trip counts are the wave maxima, gradient reads become per-lane
+          // ds_read_b128 instead of broadcasts.
+          int ylo = PH, yhi = -1, xlo = PW, xhi = -1;
+          for (int ph = 0; ph < PH; ++ph) if (ayr[ph] != 0.f) { ylo = min(ylo, ph); yhi = ph; }
+          for (int pw = 0; pw < PW; ++pw) if (axr[pw] != 0.f) { xlo = min(xlo, pw); xhi = pw; }
+          const int ny = yhi - ylo + 1, nx = xhi - xlo + 1;   // <= 0: nothing reaches this pixel
+          int na = 0, nb_ = 0;
+          while (__ballot(na < ny) != 0ull) ++na;
+          while (__ballot(nb_ < nx) != 0ull) ++nb_;
+          for (int a = 0; a < na; ++a) {
+            const int ph = min(ylo + a, PH - 1);
+            const float wy = (a < ny) ? ayr[ph] : 0.f;
+            for (int b2 = 0; b2 < nb_; ++b2) {
+              const int pw = min(xlo + b2, PW - 1);
+              const float w = (b2 < nx) ? wy * axr[pw] : 0.f;
+              if (w != 0.f) {
+                const float4* gp = gj + ph * PW + pw;
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) {
+                  const float4 g4 = gp[cg * slots];
+                  acc[4 * cg + 0] = fmaf(w, g4.x, acc[4 * cg + 0]);
+                  acc[4 * cg + 1] = fmaf(w, g4.y, acc[4 * cg + 1]);
+                  acc[4 * cg + 2] = fmaf(w, g4.z, acc[4 * cg + 2]);
+                  acc[4 * cg + 3] = fmaf(w, g4.w, acc[4 * cg + 3]);
+                }
+              }
+            }
+          }
+        } else if constexpr (PH_ > 0 && PW_ > 0) {
           constexpr int QH = (PH_ + 3) / 4, QW = (PW_ + 3) / 4;
           float ay[QH * 4], ax[QW * 4];
 #pragma unroll
@@ -978,6 +1010,8 @@ int run_backward_gather(const Levels& L, const float* rois, const int32_t* level
   P.groups = 1;
   if (count_items(CT) < 2 * kNumCU && K > 64) P.groups = static_cast<int>(std::min<int64_t>(32, ceil_div64(K, 16)));
   if (const char* e = getenv("DETOPS_ROIALIGN_BWD_GROUPS")) P.groups = max(1, min(64, atoi(e)));  // tuning / test knob
+  const char* we = getenv("DETOPS_ROIALIGN_BWD_WALK");  // "lane": experimental walk, separate instantiation
+  const bool lane_walk = we && we[0] == 'l';
   int64_t items = 0;
   for (int i = L.num - 1; i >= 0; --i) {  // coarsest level first
     P.tiles_x[i] = static_cast<int>(ceil_div64(L.lv[i].W, kGTW));
@@ -993,12 +1027,18 @@ int run_backward_gather(const Levels& L, const float* rois, const int32_t* level
     for (int i = 0; i < L.num; ++i)
       DETOPS_HIP_TRY(hipMemsetAsync(L.lv[i].gin, 0, sizeof(float) * static_cast<size_t>(N) * C * L.lv[i].H * L.lv[i].W, st));
   const dim3 grid(static_cast<unsigned>(items), static_cast<unsigned>(P.groups));
-#define GATHER_LAUNCH(PH_, PW_, CT_)                                                                          \
-  hipLaunchKernelGGL((roi_align_bwd_gather_kernel<PH_, PW_, CT_>), grid, dim3(kBlock), lds, st, L, P, rois, \
+#define GATHER_LAUNCH_W(PH_, PW_, CT_, W_)                                                                          \
+  hipLaunchKernelGGL((roi_align_bwd_gather_kernel<PH_, PW_, CT_, W_>), grid, dim3(kBlock), lds, st, L, P, rois, \
                      levels_in, gout, C, K, PH, PW, sr)
+#define GATHER_LAUNCH(PH_, PW_, CT_)                                  \
+  do {                                                                \
+    if (lane_walk) GATHER_LAUNCH_W(PH_, PW_, CT_, true);              \
+    else GATHER_LAUNCH_W(PH_, PW_, CT_, false);                       \
+  } while (0)
   if (PH == 7 && PW == 7) { if (CT == 16) GATHER_LAUNCH(7, 7, 16); else GATHER_LAUNCH(7, 7, 4); }
   else if (PH == 14 && PW == 14) { if (CT == 16) GATHER_LAUNCH(14, 14, 16); else GATHER_LAUNCH(14, 14, 4); }
   else { if (CT == 16) GATHER_LAUNCH(0, 0, 16); else GATHER_LAUNCH(0, 0, 4); }
+#undef GATHER_LAUNCH_W
 #undef GATHER_LAUNCH
   return launch_status();
 }

@@ -251,3 +251,24 @@ def test_emu_roi_align_backward_roi_list_split(groups, monkeypatch):
         base = np.random.RandomState(2).randn(*inp.shape).astype(np.float32)
         acc = emu.roi_align_backward(g, rois, scale, ph, pw, *inp.shape, sr, into=base)
         assert np.abs(acc - (base + ref)).max() <= 2 * tol
+
+
+@pytest.mark.parametrize("ct", ["4", "16"])
+def test_emu_roi_align_backward_lane_walk_variant(ct, monkeypatch):
+    """experimental per-lane bin-range walk (DETOPS_ROIALIGN_BWD_WALK=lane; opt-in, CPU-checked only)."""
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "gather")
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_WALK", "lane")
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_CT", ct)
+    rng = np.random.RandomState(31)
+    N, C, H, W = 2, 9, 27, 70
+    K = 90
+    x1 = rng.uniform(-20, 270, K)
+    y1 = rng.uniform(-20, 100, K)
+    rois = np.stack([rng.randint(0, N, K), x1, y1, x1 + rng.uniform(0.2, 120, K), y1 + rng.uniform(0.2, 60, K)],
+                    1).astype(np.float32)
+    rois = np.concatenate([rois, _edge_rois()])
+    for (ph, pw, sr) in ((7, 7, 2), (14, 14, 2), (5, 3, 0), (20, 20, 1)):
+        g = rng.randn(rois.shape[0], C, ph, pw).astype(np.float32)
+        ref = oracle.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, acc64=True)
+        out = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr)
+        assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
