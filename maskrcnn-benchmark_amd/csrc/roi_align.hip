@@ -118,19 +118,24 @@ __device__ __forceinline__ int fpn_level(const float* __restrict__ roi, const Le
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int PH_, int PW_, int kTabCap>
+// ORDERED (experimental, opt-in): workgroup ids are remapped XCD-contiguously and ROIs are visited
+// through `order` (a spatial sort, see roi_order_kernel) so overlapping footprints share one L2.
+template <int PH_, int PW_, int kTabCap, bool ORDERED = false>
 __global__ void __launch_bounds__(kBlock)
 roi_align_fwd_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
                      int32_t* __restrict__ levels_out, float* __restrict__ out, int C, int K,
-                     int PHr, int PWr, int sr, int CT, int chunks) {
+                     int PHr, int PWr, int sr, int CT, int chunks, const int32_t* __restrict__ order) {
   const int PH = PH_ ? PH_ : PHr;
   const int PW = PW_ ? PW_ : PWr;
   const int bins = PH * PW;
   __shared__ Tap tabY[kTabCap];
   __shared__ Tap tabX[kTabCap];
 
-  const int k = blockIdx.x / chunks;
-  const int chunk = blockIdx.x - k * chunks;
+  int bid = blockIdx.x;
+  if (ORDERED) bid = static_cast<int>(xcd_contiguous(bid, gridDim.x));
+  int k = bid / chunks;
+  const int chunk = bid - k * chunks;
+  if (ORDERED) k = order[k];
   const float* roi = rois + static_cast<size_t>(k) * 5;
   int lvl = 0;
   if (L.num > 1) lvl = levels_in ? levels_in[k] : fpn_level(roi, L);
@@ -210,11 +215,11 @@ constexpr int kLdsPatchFloats = 8192 - 64;  // default ~32 KiB dynamic LDS per w
 
 // U = staging loads in flight per lane; patch_floats = LDS patch budget (DETOPS_ROIALIGN_FWD_LDS_KB /
 // DETOPS_ROIALIGN_FWD_U select other points of the occupancy / loads-in-flight trade-off at run time)
-template <int PH, int PW, int SR, int G, int U>
+template <int PH, int PW, int SR, int G, int U, bool ORDERED = false>
 __global__ void __launch_bounds__(((PH * PW * G + 63) / 64) * 64)
 roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
                          int32_t* __restrict__ levels_out, float* __restrict__ out, int C, int K, int CT,
-                         int chunks, int patch_floats) {
+                         int chunks, int patch_floats, const int32_t* __restrict__ order) {
   constexpr int BINS = PH * PW;
   constexpr int NS = SR * SR;
   constexpr int NT = ((BINS * G + 63) / 64) * 64;
@@ -224,8 +229,11 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
   __shared__ int s_bounds[4];
 
   const int tid = threadIdx.x;
-  const int k = blockIdx.x / chunks;
-  const int chunk = blockIdx.x - k * chunks;
+  int bid = blockIdx.x;
+  if (ORDERED) bid = static_cast<int>(xcd_contiguous(bid, gridDim.x));
+  int k = bid / chunks;
+  const int chunk = bid - k * chunks;
+  if (ORDERED) k = order[k];
   const float* roi = rois + static_cast<size_t>(k) * 5;
   int lvl = 0;
   if (L.num > 1) lvl = levels_in ? levels_in[k] : fpn_level(roi, L);
@@ -360,6 +368,63 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
     }
     __syncthreads();
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// EXPERIMENTAL (opt-in, DETOPS_ROIALIGN_FWD_ORDER=1; CPU-checked, not yet measured on hardware).
+// Proposals arrive in score order, so two ROIs whose footprints overlap are usually staged by
+// workgroups on different XCDs and the shared feature bytes cross the fabric once per XCD (PMC: FETCH
+// 522 MB vs 183 MB of feature maps for the box-head launch).  This kernel sorts the ROI indices by
+// (level, image, Morton code of the ROI centre in 16-pixel cells of its level); the ORDERED forward
+// instantiations walk that order with XCD-contiguous workgroup ids, so neighbours in space are
+// neighbours in time on ONE L2.  One workgroup, bitonic sort of 64-bit keys in LDS (K <= 8192).
+// ------------------------------------------------------------------------------------------
+constexpr int kOrderMaxK = 8192;
+
+__device__ __forceinline__ unsigned morton8(unsigned x, unsigned y) {  // interleave two 8-bit values
+  unsigned r = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r |= ((x >> i) & 1u) << (2 * i) | ((y >> i) & 1u) << (2 * i + 1);
+  return r;
+}
+
+__global__ void __launch_bounds__(1024)
+roi_order_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in, int K,
+                 int npad, int32_t* __restrict__ order) {
+  DETOPS_DYNAMIC_LDS(unsigned long long, keys);
+  for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+    unsigned long long key = ~0ull;
+    if (i < K) {
+      const float* roi = rois + static_cast<size_t>(i) * 5;
+      int lvl = 0;
+      if (L.num > 1) lvl = levels_in ? levels_in[i] : fpn_level(roi, L);
+      float scale = L.lv[0].scale;
+#pragma unroll
+      for (int j = 1; j < DETOPS_MAX_LEVELS; ++j)
+        if (j == lvl) scale = L.lv[j].scale;
+      const float cx = 0.5f * (roi[1] + roi[3]) * scale, cy = 0.5f * (roi[2] + roi[4]) * scale;
+      const unsigned ux = static_cast<unsigned>(fminf(fmaxf(cx * (1.f / 16.f), 0.f), 255.f));
+      const unsigned uy = static_cast<unsigned>(fminf(fmaxf(cy * (1.f / 16.f), 0.f), 255.f));
+      const unsigned b = static_cast<unsigned>(fminf(fmaxf(roi[0], 0.f), 255.f));
+      key = (static_cast<unsigned long long>(lvl & 7) << 56) | (static_cast<unsigned long long>(b) << 48) |
+            (static_cast<unsigned long long>(morton8(ux, uy)) << 32) | static_cast<unsigned>(i);
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (npad >> 1); t += blockDim.x) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int p = i | j;
+        const unsigned long long a = keys[i], b = keys[p];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < K; i += blockDim.x) order[i] = static_cast<int32_t>(keys[i] & 0xffffffffu);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -869,7 +934,7 @@ inline void dispatch_shape(int PH, int PW, int sr, F&& f) {
 
 template <int PH, int PW, int SR, int G>
 void launch_fwd_lds(const Levels& L, const float* rois, const int32_t* levels_in, int32_t* levels_out,
-                    float* out, int C, int K, hipStream_t st) {
+                    float* out, int C, int K, hipStream_t st, const int32_t* order) {
   constexpr int NT = ((PH * PW * G + 63) / 64) * 64;
   int CT = 64;  // channels per workgroup: >= 4 x 256 workgroups when the problem allows it
   while (CT > 16 && static_cast<int64_t>(K) * ceil_div64(C, CT) < 4 * kNumCU) CT >>= 1;
@@ -886,16 +951,17 @@ void launch_fwd_lds(const Levels& L, const float* rois, const int32_t* levels_in
   if (const char* e = getenv("DETOPS_ROIALIGN_FWD_U")) unroll = atoi(e);
   const dim3 grid(static_cast<unsigned>(K) * chunks);
   const size_t lds = (patch_floats + 64) * sizeof(float);
-  if (unroll == 8)
-    hipLaunchKernelGGL((roi_align_fwd_lds_kernel<PH, PW, SR, G, 8>), grid, dim3(NT), lds, st, L, rois, levels_in,
-                       levels_out, out, C, K, CT, chunks, patch_floats);
-  else
-    hipLaunchKernelGGL((roi_align_fwd_lds_kernel<PH, PW, SR, G, 4>), grid, dim3(NT), lds, st, L, rois, levels_in,
-                       levels_out, out, C, K, CT, chunks, patch_floats);
+#define FWD_LDS_LAUNCH(U_, O_)                                                                                  \
+  hipLaunchKernelGGL((roi_align_fwd_lds_kernel<PH, PW, SR, G, U_, O_>), grid, dim3(NT), lds, st, L, rois,       \
+                     levels_in, levels_out, out, C, K, CT, chunks, patch_floats, order)
+  if (order) { if (unroll == 8) FWD_LDS_LAUNCH(8, true); else FWD_LDS_LAUNCH(4, true); }
+  else { if (unroll == 8) FWD_LDS_LAUNCH(8, false); else FWD_LDS_LAUNCH(4, false); }
+#undef FWD_LDS_LAUNCH
 }
 
 int run_forward(const Levels& L, const float* rois, const int32_t* levels_in, int32_t* levels_out,
-                float* out, int C, int K, int PH, int PW, int sr, hipStream_t st) {
+                float* out, int C, int K, int PH, int PW, int sr, hipStream_t st,
+                const int32_t* order = nullptr) {
   if (K == 0 || C == 0) return 0;
   // DETOPS_ROIALIGN_FWD=generic forces the gather kernel (A/B measurements; default: LDS fast path)
   static const bool force_generic = [] {
@@ -904,24 +970,29 @@ int run_forward(const Levels& L, const float* rois, const int32_t* levels_in, in
   }();
   if (force_generic) {
   } else if (PH == 7 && PW == 7 && sr == 2) {
-    launch_fwd_lds<7, 7, 2, 5>(L, rois, levels_in, levels_out, out, C, K, st);
+    launch_fwd_lds<7, 7, 2, 5>(L, rois, levels_in, levels_out, out, C, K, st, order);
     return launch_status();
   }
   else if (PH == 14 && PW == 14 && sr == 2) {
-    launch_fwd_lds<14, 14, 2, 2>(L, rois, levels_in, levels_out, out, C, K, st);
+    launch_fwd_lds<14, 14, 2, 2>(L, rois, levels_in, levels_out, out, C, K, st, order);
     return launch_status();
   }
   else if (PH == 7 && PW == 7 && sr == 1) {
-    launch_fwd_lds<7, 7, 1, 5>(L, rois, levels_in, levels_out, out, C, K, st);
+    launch_fwd_lds<7, 7, 1, 5>(L, rois, levels_in, levels_out, out, C, K, st, order);
     return launch_status();
   }
   const int CT = pick_chunk(C, K);
   const int chunks = static_cast<int>(ceil_div64(C, CT));
   const dim3 grid(static_cast<unsigned>(K) * chunks);
   dispatch_shape(PH, PW, sr, [&](auto ph, auto pw, auto tab) {
-    hipLaunchKernelGGL((roi_align_fwd_kernel<decltype(ph)::value, decltype(pw)::value, decltype(tab)::value>), grid,
-                       dim3(kBlock), 0, st, L, rois, levels_in, levels_out, out, C, K, PH, PW, sr,
-                       CT, chunks);
+    if (order)
+      hipLaunchKernelGGL((roi_align_fwd_kernel<decltype(ph)::value, decltype(pw)::value, decltype(tab)::value, true>),
+                         grid, dim3(kBlock), 0, st, L, rois, levels_in, levels_out, out, C, K, PH, PW, sr, CT, chunks,
+                         order);
+    else
+      hipLaunchKernelGGL((roi_align_fwd_kernel<decltype(ph)::value, decltype(pw)::value, decltype(tab)::value, false>),
+                         grid, dim3(kBlock), 0, st, L, rois, levels_in, levels_out, out, C, K, PH, PW, sr, CT, chunks,
+                         order);
   });
   return launch_status();
 }
@@ -1115,6 +1186,37 @@ DETOPS_API int detops_roi_align_fpn_forward_f32(
   hipStream_t st = as_stream(stream);
   if (num_levels == 1 && levels_out) DETOPS_HIP_TRY(hipMemsetAsync(levels_out, 0, sizeof(int32_t) * K, st));
   return run_forward(L, rois, nullptr, levels_out, output, C, K, PH, PW, sampling_ratio, st);
+}
+
+DETOPS_API int detops_roi_align_fpn_forward_ordered_f32(
+    const float* const* inputs_host, const int* H_host, const int* W_host, const float* scale_host,
+    int num_levels, const float* rois, float* output, int32_t* levels_out, int N, int C, int K,
+    int PH, int PW, int sampling_ratio, int k_min, int k_max, float canonical_scale,
+    float canonical_level, float eps, int32_t* order_ws, detops_stream_t stream) {
+  if (!order_ws || K > kOrderMaxK || K < 2)
+    return detops_roi_align_fpn_forward_f32(inputs_host, H_host, W_host, scale_host, num_levels, rois, output,
+                                            levels_out, N, C, K, PH, PW, sampling_ratio, k_min, k_max,
+                                            canonical_scale, canonical_level, eps, stream);
+  if (bad_dims(N, C, K, PH, PW) || num_levels < 1 || num_levels > DETOPS_MAX_LEVELS ||
+      !inputs_host || !H_host || !W_host || !scale_host)
+    return DETOPS_EINVAL;
+  if (k_max - k_min + 1 != num_levels) return DETOPS_EINVAL;
+  if (C == 0) return 0;
+  if (!rois || !output) return DETOPS_EINVAL;
+  Levels L{};
+  L.num = num_levels;
+  L.k_min = k_min; L.k_max = k_max; L.s0 = canonical_scale; L.lvl0 = canonical_level; L.eps = eps;
+  for (int i = 0; i < num_levels; ++i) {
+    if (!inputs_host[i] || H_host[i] <= 0 || W_host[i] <= 0) return DETOPS_EINVAL;
+    L.lv[i] = Level{inputs_host[i], nullptr, H_host[i], W_host[i], scale_host[i]};
+  }
+  hipStream_t st = as_stream(stream);
+  if (num_levels == 1 && levels_out) DETOPS_HIP_TRY(hipMemsetAsync(levels_out, 0, sizeof(int32_t) * K, st));
+  int npad = 2;
+  while (npad < K) npad <<= 1;
+  hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(min(1024, max(64, npad / 2))), npad * sizeof(unsigned long long),
+                     st, L, rois, static_cast<const int32_t*>(nullptr), K, npad, order_ws);
+  return run_forward(L, rois, nullptr, levels_out, output, C, K, PH, PW, sampling_ratio, st, order_ws);
 }
 
 DETOPS_API int detops_roi_align_fpn_backward_f32(

@@ -272,3 +272,20 @@ def test_emu_roi_align_backward_lane_walk_variant(ct, monkeypatch):
         ref = oracle.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, acc64=True)
         out = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr)
         assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_emu_roi_align_fpn_forward_ordered_variant():
+    """experimental spatially ordered forward (opt-in): bit-identical output, the order is a
+    permutation grouped by level."""
+    rng = np.random.RandomState(5)
+    shapes = [(2, 4, 50, 84), (2, 4, 25, 42), (2, 4, 13, 21), (2, 4, 7, 11)]
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    feats = [rng.randn(*s).astype(np.float32) for s in shapes]
+    rois = synth.fpn_rois(seed=4, per_image=45, smin=8, smax=300)
+    rois[:, 1:] *= 0.25
+    for (ph, sr) in ((7, 2), (14, 2), (7, 0)):
+        base, lv = emu.roi_align_fpn_forward(feats, rois, scales, ph, ph, sr, 2, 5)
+        out, lv2, order = emu.roi_align_fpn_forward(feats, rois, scales, ph, ph, sr, 2, 5, ordered=True)
+        assert np.array_equal(out, base) and np.array_equal(lv, lv2)
+        assert np.array_equal(np.sort(order), np.arange(rois.shape[0]))
+        assert np.all(np.diff(lv[order]) >= 0), "sorted by level first"
