@@ -51,7 +51,7 @@ def _entry(name, us, alg_bytes, extra=None):
     return e
 
 
-def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False):
+def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False, experimental=False):
     """fused_only: just the FPN-fused launches with the model's shapes (the PMC traffic passes use this,
     so every ROIAlign kernel in their trace is the box-head / mask-head launch bench.py times)."""
     out = []
@@ -103,6 +103,13 @@ def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False):
                 same = bool(torch.equal(base, C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]))
                 out.append(_entry(f"roi_align_fwd fpn-fused {tag} [LDS {kb} KB, U={u}]", us, alg, {"bit_equal_to_default": same}))
             del os.environ["DETOPS_ROIALIGN_FWD_LDS_KB"], os.environ["DETOPS_ROIALIGN_FWD_U"]
+            if experimental:
+                os.environ["DETOPS_ROIALIGN_FWD_ORDER"] = "1"
+                us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
+                same = bool(torch.equal(base, C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]))
+                del os.environ["DETOPS_ROIALIGN_FWD_ORDER"]
+                out.append(_entry(f"roi_align_fwd fpn-fused {tag} [EXPERIMENTAL spatial order + XCD-contiguous]", us, alg,
+                                  {"bit_equal_to_default": same}))
         if "bwd" in which:
             g = torch.randn(K, 256, ph, ph, device="cuda")
             tl = _t(lv)
@@ -110,6 +117,15 @@ def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False):
             out.append(_entry(f"roi_align_bwd fpn-fused gather (atomic-free, incl. zero-fill) {tag}", us, alg))
             if fused_only:
                 continue
+            if experimental:
+                ref_g = C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2)
+                os.environ["DETOPS_ROIALIGN_BWD_WALK"] = "lane"
+                us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
+                got = C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2)
+                del os.environ["DETOPS_ROIALIGN_BWD_WALK"]
+                err = max(float((a - b).abs().max()) for a, b in zip(ref_g, got))
+                out.append(_entry(f"roi_align_bwd fpn-fused gather {tag} [EXPERIMENTAL per-lane bin walk]", us, alg,
+                                  {"max_abs_diff_vs_default": err}))
             os.environ["DETOPS_ROIALIGN_BWD_CT"] = "4"
             us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
             out.append(_entry(f"roi_align_bwd fpn-fused gather CT=4 {tag}", us, alg))
@@ -230,6 +246,8 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--json", default=None)
     ap.add_argument("--only", default="")
+    ap.add_argument("--experimental", action="store_true",
+                    help="also time the opt-in, not-yet-measured kernel variants (DESIGN.md section 7)")
     args = ap.parse_args()
     from maskrcnn_benchmark import _C as C
 
@@ -239,7 +257,7 @@ def main():
     if not only or "copy" in only:
         res.append(copy_ceiling(args.iters))
     if not only or "roi_align" in only:
-        res += bench_roi_align(C, args.iters)
+        res += bench_roi_align(C, args.iters, experimental=args.experimental)
     if "roi_align_fpn" in only:
         res += bench_roi_align(C, args.iters, fused_only=True)
     if not only or "nms" in only:
