@@ -144,6 +144,7 @@ def cpu_baseline(sample_rois=1024, min_seconds=8.0):
         if time.perf_counter() - t0 >= min_seconds or reps >= 50:
             break
     dt = (time.perf_counter() - t0) / reps
+    extra = cpu_baseline_extras(ref)
     # scale the sample to the full launch: per-ROI cost dominates; bytes per §8d for the full launch
     full_bytes = 4 * 1024 * 256 * 49 + sum(f.nbytes for f in rng_feats) + 20 * 1024
     est_full_s = dt * 1024.0 / sample_rois
@@ -154,7 +155,49 @@ def cpu_baseline(sample_rois=1024, min_seconds=8.0):
                           sample_rois, reps, dt, 1024.0 / sample_rois,
                           "reference csrc/cpu/ROIAlign_cpu.cpp compiled in oracle/_ref" if ref is not None
                           else "C restatement oracle/detops_oracle.c"),
-            "roi_align_fwd_ms_est": round(est_full_s * 1e3, 2)}
+            "roi_align_fwd_ms_est": round(est_full_s * 1e3, 2), **extra}
+
+
+def cpu_baseline_extras(ref, budget_s=6.0):
+    """The other CPU paths of SURVEY.md §8(d), timed beside the ROIAlign figure on the same host
+    (1 thread, bounded): the reference's own `nms` CPU kernel on the step's 10 RPN segments, the C
+    restatements of the CUDA-only ROIAlign backward and SigmoidFocalLoss (sampled, scaled)."""
+    import numpy as np
+    import torch
+
+    import oracle
+    import synth
+
+    out = {}
+    try:
+        segs = synth.rpn_nms_segments()
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 3 and time.perf_counter() - t0 < budget_s / 3:
+            for b, sc in segs:
+                if ref is not None:
+                    ref.nms(torch.from_numpy(b), torch.from_numpy(sc), 0.7)
+                else:
+                    oracle.nms(b, sc, 0.7)
+            reps += 1
+        out["nms_10_rpn_segments_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 2)
+        out["nms_kind"] = "reference" if ref is not None else "port"
+        # ROIAlign backward (CUDA-only in the reference: C restatement), 64 of the 1024 box-head ROIs on P4
+        rois = synth.fpn_rois(seed=3, per_image=512, n_images=2)
+        lv = synth.level_map(rois)
+        sel = np.nonzero(lv == 2)[0][:64]
+        g = np.random.RandomState(1).randn(len(sel), 256, 7, 7).astype(np.float32)
+        t0 = time.perf_counter()
+        oracle.roi_align_backward(g, rois[sel], 1.0 / 16, 7, 7, 2, 256, 50, 84, 2)
+        out["roi_align_bwd_ms_est_port"] = round((time.perf_counter() - t0) * 1024.0 / max(len(sel), 1) * 1e3, 1)
+        # SigmoidFocalLoss forward (C restatement of the .cu formula), 20,000 of the 403,200 rows
+        logits, targets = synth.focal_inputs(20000, 80)
+        t0 = time.perf_counter()
+        oracle.sigmoid_focal_loss_forward(logits, targets, 2.0, 0.25)
+        out["focal_fwd_ms_est_port"] = round((time.perf_counter() - t0) * 403200.0 / 20000.0 * 1e3, 1)
+    except Exception as e:  # extras never cost the main figure
+        out["extras_error"] = repr(e)
+    return out
 
 
 def main():
