@@ -112,3 +112,52 @@ def test_overlapped_sgd_single_process_equals_torch_sgd():
             o.step()
     for a, c in zip(m1.parameters(), m2.parameters()):
         torch.testing.assert_close(a, c, rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------ the detector itself under the DDP hook
+def _detector_worker(rank, world, port, config, out_dir):
+    """What bench.py / train_net.py do at N > 1, on the CPU shim: build_training(distributed=True) wraps
+    the detector in DDP with the overlapped-SGD hook; three iterations must run (a parameter that gets
+    no gradient would make DDP raise on the second one) and leave both ranks with identical weights."""
+    sys.path.insert(0, PKG)
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_shim
+    import maskrcnn_benchmark.layers.sigmoid_focal_loss as sfl
+    from maskrcnn_benchmark.data.synthetic import BatchCollator, SyntheticCOCODataset
+    from maskrcnn_benchmark.engine.bench_step import build_training, load_cfg
+    cfg = load_cfg(config, ["MODEL.DEVICE", "cpu", "MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 100, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 150,
+                            "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 32, "MODEL.RESNETS.RES2_OUT_CHANNELS", 16,
+                            "MODEL.RESNETS.WIDTH_PER_GROUP", 4, "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 16,
+                            "MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM", 32, "MODEL.ROI_MASK_HEAD.CONV_LAYERS", (16, 16),
+                            "SOLVER.BASE_LR", 0.002])
+    torch.manual_seed(7 + rank)  # different initial weights per rank: DDP must broadcast rank 0's
+    model, opt, sched, step = build_training(cfg, torch.device("cpu"), distributed=True, local_rank=rank)
+    assert isinstance(model, torch.nn.parallel.DistributedDataParallel) and opt.deferred
+    ds = SyntheticCOCODataset(length=2, height=96, width=128, with_masks=cfg.MODEL.MASK_ON, min_objects=2,
+                              max_objects=4, seed=rank)
+    images, targets, _ = BatchCollator(32)([ds[0], ds[1]])
+    sfl.SigmoidFocalLoss.forward = lambda self, l, t: sfl.sigmoid_focal_loss_sum(l.float(), t, self.gamma, self.alpha)
+    with cpu_shim.install():
+        for _ in range(3):
+            losses = step(images, list(targets))
+    vals = {k: float(v.detach()) for k, v in losses.items()}
+    torch.save({"params": [p.detach().clone() for p in model.module.parameters()], "losses": vals},
+               os.path.join(out_dir, "det_rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("config", ["e2e_mask_rcnn_R_50_FPN_1x.yaml", "retinanet/retinanet_R-50-FPN_1x.yaml"])
+def test_detector_trains_under_ddp_hook_world2(tmp_path, config):
+    port = _free_port()
+    mp.spawn(_detector_worker, args=(2, port, config, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "det_rank0.pt"))
+    r1 = torch.load(os.path.join(str(tmp_path), "det_rank1.pt"))
+    assert all(v == v and abs(v) != float("inf") for v in r0["losses"].values())
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b), "ranks diverged: the averaged update must be identical on both"
