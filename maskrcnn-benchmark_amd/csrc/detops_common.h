@@ -31,6 +31,13 @@ static inline int launch_status() { return static_cast<int>(hipGetLastError()); 
 #define DETOPS_DYNAMIC_LDS(T, name) extern __shared__ __align__(16) T name[]
 #endif
 
+// Work counters of the host emulation (tests/emu): compiled out of the device build.
+#ifdef DETOPS_CPU_EMU
+#define DETOPS_STAT(name, n) emu::stat(name, n)
+#else
+#define DETOPS_STAT(name, n) ((void)0)
+#endif
+
 constexpr int kWave = 64;        // CDNA4 wavefront
 constexpr int kNumCU = 256;      // MI355X
 constexpr int kNumXCD = 8;

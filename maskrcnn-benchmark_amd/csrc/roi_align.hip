@@ -744,9 +744,11 @@ roi_align_bwd_gather_kernel(Levels L, GPlan P, const float* __restrict__ rois,
     }
     if (hit) s_hit[before + __popcll(m & ((1ull << lane) - 1ull))] = h;
     __syncthreads();
+    if (tid == 0) { DETOPS_STAT("bwd.scan_rounds", 1); DETOPS_STAT("bwd.hits", total); }
 
     for (int h0 = 0; h0 < total; h0 += P.batch) {
       const int nb = min(P.batch, total - h0);
+      if (tid == 0) DETOPS_STAT("bwd.batches", 1);
       // ---- (1) per-axis coefficient rows of the batch, restricted to this tile
       for (int t = tid; t < nb * (PH + PW); t += kBlock) {
         const int j = t / (PH + PW);
@@ -797,6 +799,7 @@ roi_align_bwd_gather_kernel(Levels L, GPlan P, const float* __restrict__ rois,
         const int xspan = s_hit[h0 + j].xspan;
         const int jx0 = xspan >> 16, jx1 = xspan & 0xffff;
         if (jx1 < wx0 || jx0 > wx1) continue;   // this ROI misses the wave's 8 columns
+        if (lane == 0) DETOPS_STAT("bwd.wave_roi_tasks", 1);
         const float* ayr = ayt + (j * kGTH + yl) * PPH;
         const float* axr = axt + (j * kGTW + xl) * PPW;
         const float4* gj = gs4 + j * bins;
@@ -817,9 +820,11 @@ roi_align_bwd_gather_kernel(Levels L, GPlan P, const float* __restrict__ rois,
             const int ph = min(ylo + a, PH - 1);
             const float wy = (a < ny) ? ayr[ph] : 0.f;
             for (int b2 = 0; b2 < nb_; ++b2) {
+              if (lane == 0) DETOPS_STAT("bwd.bodies_lane_walk", 1);
               const int pw = min(xlo + b2, PW - 1);
               const float w = (b2 < nx) ? wy * axr[pw] : 0.f;
               if (w != 0.f) {
+                DETOPS_STAT("bwd.active_lane_bodies", 1);
                 const float4* gp = gj + ph * PW + pw;
 #pragma unroll
                 for (int cg = 0; cg < CG; ++cg) {
@@ -852,7 +857,9 @@ roi_align_bwd_gather_kernel(Levels L, GPlan P, const float* __restrict__ rois,
             for (int pw = 0; pw < PW_; ++pw) {
               const float w = ay[ph] * ax[pw];
               if (__ballot(w != 0.f) == 0ull) continue;
+              if (lane == 0) DETOPS_STAT("bwd.bodies_union_walk", 1);
               if (w != 0.f) {
+                DETOPS_STAT("bwd.active_lane_bodies", 1);
 #pragma unroll
                 for (int cg = 0; cg < CG; ++cg) {
                   const float4 g4 = gj[cg * slots + ph * PW_ + pw];
@@ -888,6 +895,7 @@ roi_align_bwd_gather_kernel(Levels L, GPlan P, const float* __restrict__ rois,
     }
   }
 
+  if (tid == 0) DETOPS_STAT("bwd.workgroups", 1);
   // ---- store: registers -> LDS [c][8][33] -> full 128-byte rows; every in-map element of the
   //      tile is written exactly once (zeros where no ROI reaches)
   float* tb = g_lds;

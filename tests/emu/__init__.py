@@ -323,3 +323,16 @@ def psroi_backward(grad, data, rois, trans, cnt, no_trans, scale, output_dim, gr
                                                      trans_std, 1, None)
     assert rc == 0, rc
     return dg, tg
+
+
+def stats(reset=True):
+    """work counters accumulated by DETOPS_STAT in the emulated kernels -> {name: value}"""
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib().detops_emu_stats.restype = c_int
+    lib().detops_emu_stats.argtypes = [ctypes.c_char_p, c_int, c_int]
+    lib().detops_emu_stats(buf, len(buf), int(reset))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        k, v = line.split("=")
+        out[k] = float(v)
+    return out

@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <string>
 #include <vector>
 
 #define DETOPS_CPU_EMU 1
@@ -86,6 +88,10 @@ inline jmp_buf& sched_jb() { static jmp_buf j; return j; }
 inline unsigned long long& progress() { static unsigned long long p = 0; return p; }
 inline void* dynamic_lds() { alignas(64) static unsigned char buf[kDynLdsBytes]; return buf; }
 inline std::function<void()>& body() { static std::function<void()> f; return f; }
+
+// named work counters (DETOPS_STAT in the kernels): e.g. FMA bodies executed per wave, batches, scans
+inline std::map<std::string, double>& stats() { static std::map<std::string, double> m; return m; }
+inline void stat(const char* name, double n) { stats()[name] += n; }
 
 inline void yield() {
   if (!_setjmp(cur_fiber()->jb)) _longjmp(sched_jb(), 1);
@@ -285,3 +291,11 @@ template <typename T> static inline T max(T a, T b) { return a > b ? a : b; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
   emu::launch([&]() { kernel(__VA_ARGS__); }, grid, block, lds)
+
+extern "C" __attribute__((visibility("default"), used, weak)) int detops_emu_stats(char* buf, int cap, int reset) {
+  std::string out;
+  for (auto& kv : emu::stats()) out += kv.first + "=" + std::to_string(kv.second) + "\n";
+  if (reset) emu::stats().clear();
+  if (buf && cap > 0) { strncpy(buf, out.c_str(), cap - 1); buf[cap - 1] = 0; }
+  return static_cast<int>(out.size());
+}
