@@ -1058,6 +1058,255 @@ int run_backward_tiles(const Levels& L, const float* rois, const int32_t* levels
   return launch_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// EXPERIMENTAL backward "gather3" (DETOPS_ROIALIGN_BWD=gather3; CPU-checked in the host emulation,
+// NOT yet measured on hardware — prepared from the work statistics of tools/emu_workstats.py).
+// Same pixel-owner formulation as roi_align_bwd_gather_kernel, restructured around what those
+// statistics say costs the time: ~27 K (batch, channel-chunk) stage -> barrier -> walk -> barrier
+// round trips and ~49 K ROI-scan rounds per launch, each latency-bound, against a small FMA walk at
+// 10 % lane utilisation.  Here a workgroup owns a tile and G channel chunks (G x 16 channels,
+// G x 16 accumulators per thread): the ROI scan and the per-axis coefficient rows are built once
+// per G chunks, the gradients of all G chunks of a batch are staged in ONE phase, and the walk is
+// the per-lane bin-range walk (each lane visits only its own 2-4 x 2-4 contributing bins; one
+// weight product feeds G x 16 FMAs).  Round trips and scans drop G-fold.
+// ------------------------------------------------------------------------------------------
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+roi_align_bwd_gather3_kernel(Levels L, GPlan P, const float* __restrict__ rois,
+                             const int32_t* __restrict__ levels_in, const float* __restrict__ gout,
+                             int C, int K, int PH, int PW, int sr) {
+  constexpr int CT = 16, CG = 4, GC = G * CG;            // float4 channel groups per workgroup
+  const int bins = PH * PW;
+  const int PPH = (PH + 3) & ~3, PPW = (PW + 3) & ~3;
+  const int slots = P.batch * bins;                        // (ROI, bin) slots per float4 channel group
+
+  DETOPS_DYNAMIC_LDS(float, g_lds);
+  float4* gs4 = reinterpret_cast<float4*>(g_lds);          // [GC][slots] float4 (also the store buffer)
+  const int region = max(slots * GC * 4, CT * kGTH * kGRowPad);
+  float* ayt = g_lds + region;                             // [batch][kGTH][PPH]
+  float* axt = ayt + P.batch * kGTH * PPH;                 // [batch][kGTW][PPW]
+  __shared__ GHit s_hit[kBlock];
+  __shared__ int s_wcount[kBlock / kWave];
+
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  int lvl = 0;
+#pragma unroll
+  for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+    if (i < L.num && static_cast<int>(blockIdx.x) >= P.first_item[i] &&
+        static_cast<int>(blockIdx.x) < P.first_item[i] + P.n_items[i]) lvl = i;
+  float* gin = L.lv[0].gin; int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
+  int ntx = P.tiles_x[0], nty = P.tiles_y[0], first = P.first_item[0];
+#pragma unroll
+  for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+    if (i == lvl) { gin = L.lv[i].gin; H = L.lv[i].H; W = L.lv[i].W; scale = L.lv[i].scale;
+                    ntx = P.tiles_x[i]; nty = P.tiles_y[i]; first = P.first_item[i]; }
+  int rem = static_cast<int>(blockIdx.x) - first;
+  const int cgrp = rem % P.chunks; rem /= P.chunks;        // P.chunks = channel-chunk GROUPS here
+  const int tix = rem % ntx; rem /= ntx;
+  const int tiy = rem % nty;
+  const int b = rem / nty;
+  const int y0 = tiy * kGTH, x0 = tix * kGTW;
+  const int y1 = min(H, y0 + kGTH) - 1, x1 = min(W, x0 + kGTW) - 1;
+  const int c0 = cgrp * G * CT;
+  const int yl = lane >> 3, xl = wave * 8 + (lane & 7);
+  const int wx0 = x0 + wave * 8, wx1 = wx0 + 7;
+
+  float acc[G * CT];
+#pragma unroll
+  for (int c = 0; c < G * CT; ++c) acc[c] = 0.f;
+
+  for (int kb = 0; kb < K; kb += kBlock) {
+    const int r = kb + tid;
+    bool hit = false;
+    GHit h{};
+    if (r < K) {
+      const float* roi = rois + static_cast<size_t>(r) * 5;
+      const int rl = (L.num > 1) ? levels_in[r] : 0;
+      if (rl == lvl && static_cast<int>(roi[0]) == b) {
+#pragma clang fp contract(off)
+        const RoiGeom g = roi_geometry(roi, scale, PH, PW, sr);
+        const float rh = g.bin_h * static_cast<float>(PH), rw = g.bin_w * static_cast<float>(PW);
+        const float fy0 = floorf(fmaxf(g.start_h, 0.f)), fy1 = floorf(g.start_h + rh) + 2.f;
+        const float fx0 = floorf(fmaxf(g.start_w, 0.f)), fx1 = floorf(g.start_w + rw) + 2.f;
+        hit = fy0 <= static_cast<float>(y1) && fy1 >= static_cast<float>(y0) &&
+              fx0 <= static_cast<float>(x1) && fx1 >= static_cast<float>(x0);
+        h.start_w = g.start_w; h.start_h = g.start_h; h.bin_w = g.bin_w; h.bin_h = g.bin_h;
+        h.k = r; h.gh = g.gh; h.gw = g.gw;
+        const int ix0 = static_cast<int>(fminf(fx0, static_cast<float>(W)));
+        const int ix1 = static_cast<int>(fminf(fmaxf(fx1, 0.f), static_cast<float>(W)));
+        h.xspan = (ix0 << 16) | ix1;
+      }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_wcount[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < kBlock / kWave; ++j) {
+      const int v = s_wcount[j];
+      if (j < wave) before += v;
+      total += v;
+    }
+    if (hit) s_hit[before + __popcll(m & ((1ull << lane) - 1ull))] = h;
+    __syncthreads();
+    if (tid == 0) { DETOPS_STAT("bwd3.scan_rounds", 1); DETOPS_STAT("bwd3.hits", total); }
+
+    for (int h0 = 0; h0 < total; h0 += P.batch) {
+      const int nb = min(P.batch, total - h0);
+      if (tid == 0) DETOPS_STAT("bwd3.batches", 1);
+      // (1) coefficient rows: once for all G chunks
+      for (int t = tid; t < nb * (PH + PW); t += kBlock) {
+        const int j = t / (PH + PW);
+        const int q = t - j * (PH + PW);
+        const GHit hj = s_hit[h0 + j];
+        if (q < PH) {
+          float* row = ayt + j * kGTH * PPH + q;
+          for (int i = 0; i < kGTH; ++i) row[i * PPH] = 0.f;
+          const float inv = 1.f / static_cast<float>(hj.gh);
+          for (int i = 0; i < hj.gh; ++i) {
+            const Tap e = axis_entry(hj.start_h, hj.bin_h, q, i, hj.gh, H, 1);
+            const int a0 = e.lo - y0, a1 = e.hi - y0;
+            if (a0 >= 0 && a0 < kGTH) row[a0 * PPH] += e.h * inv;
+            if (a1 >= 0 && a1 < kGTH) row[a1 * PPH] += e.l * inv;
+          }
+        } else {
+          const int qq = q - PH;
+          float* row = axt + j * kGTW * PPW + qq;
+          for (int i = 0; i < kGTW; ++i) row[i * PPW] = 0.f;
+          const float inv = 1.f / static_cast<float>(hj.gw);
+          for (int i = 0; i < hj.gw; ++i) {
+            const Tap e = axis_entry(hj.start_w, hj.bin_w, qq, i, hj.gw, W, 1);
+            const int a0 = e.lo - x0, a1 = e.hi - x0;
+            if (a0 >= 0 && a0 < kGTW) row[a0 * PPW] += e.h * inv;
+            if (a1 >= 0 && a1 < kGTW) row[a1 * PPW] += e.l * inv;
+          }
+        }
+      }
+      // (2) ONE staging phase for the G x 16 channels of the batch: [gc][j*bins + bin] float4
+      for (int u = tid; u < nb * bins * GC; u += kBlock) {
+        const int gc = u / (nb * bins);
+        const int jb = u - gc * (nb * bins);
+        const int j = jb / bins;
+        const int bin = jb - j * bins;
+        const int cbase = c0 + gc * 4;
+        const float* src = gout + (static_cast<size_t>(s_hit[h0 + j].k) * C + cbase) * bins + bin;
+        float4 v;
+        v.x = (cbase + 0 < C) ? src[0] : 0.f;
+        v.y = (cbase + 1 < C) ? src[bins] : 0.f;
+        v.z = (cbase + 2 < C) ? src[2 * bins] : 0.f;
+        v.w = (cbase + 3 < C) ? src[3 * bins] : 0.f;
+        gs4[gc * slots + jb] = v;
+      }
+      __syncthreads();
+      // (3) per-lane bin-range walk; one weight product feeds all G x 16 channels
+      for (int j = 0; j < nb; ++j) {
+        const int xspan = s_hit[h0 + j].xspan;
+        const int jx0 = xspan >> 16, jx1 = xspan & 0xffff;
+        if (jx1 < wx0 || jx0 > wx1) continue;
+        const float* ayr = ayt + (j * kGTH + yl) * PPH;
+        const float* axr = axt + (j * kGTW + xl) * PPW;
+        const float4* gj = gs4 + j * bins;
+        int ylo = PH, yhi = -1, xlo = PW, xhi = -1;
+        for (int ph = 0; ph < PH; ++ph) if (ayr[ph] != 0.f) { ylo = min(ylo, ph); yhi = ph; }
+        for (int pw = 0; pw < PW; ++pw) if (axr[pw] != 0.f) { xlo = min(xlo, pw); xhi = pw; }
+        const int ny = yhi - ylo + 1, nx = xhi - xlo + 1;
+        int na = 0, nb_ = 0;
+        while (__ballot(na < ny) != 0ull) ++na;
+        while (__ballot(nb_ < nx) != 0ull) ++nb_;
+        if (lane == 0) DETOPS_STAT("bwd3.wave_roi_tasks", 1);
+        for (int a = 0; a < na; ++a) {
+          const int ph = min(ylo + a, PH - 1);
+          const float wy = (a < ny) ? ayr[ph] : 0.f;
+          for (int b2 = 0; b2 < nb_; ++b2) {
+            const int pw = min(xlo + b2, PW - 1);
+            const float w = (b2 < nx) ? wy * axr[pw] : 0.f;
+            if (lane == 0) DETOPS_STAT("bwd3.bodies", 1);
+            if (w != 0.f) {
+              const float4* gp = gj + ph * PW + pw;
+#pragma unroll
+              for (int gc = 0; gc < GC; ++gc) {
+                const float4 g4 = gp[gc * slots];
+                acc[4 * gc + 0] = fmaf(w, g4.x, acc[4 * gc + 0]);
+                acc[4 * gc + 1] = fmaf(w, g4.y, acc[4 * gc + 1]);
+                acc[4 * gc + 2] = fmaf(w, g4.z, acc[4 * gc + 2]);
+                acc[4 * gc + 3] = fmaf(w, g4.w, acc[4 * gc + 3]);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- store, one 16-channel chunk at a time through the [16][8][33] transposition buffer
+  float* tb = g_lds;
+  const size_t plane = static_cast<size_t>(H) * W;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int cc0 = c0 + g * CT;
+    if (cc0 >= C) break;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) tb[(c * kGTH + yl) * kGRowPad + xl] = acc[g * CT + c];
+    __syncthreads();
+    const int cn = min(CT, C - cc0);
+    float* gb = gin + (static_cast<size_t>(b) * C + cc0) * plane;
+    for (int e = tid; e < cn * kGTH * kGTW; e += kBlock) {
+      const int c = e / (kGTH * kGTW);
+      const int pix = e - c * (kGTH * kGTW);
+      const int yy = pix / kGTW, xx = pix - yy * kGTW;
+      if (y0 + yy <= y1 && x0 + xx <= x1) {
+        float* dst = gb + static_cast<size_t>(c) * plane + static_cast<size_t>(y0 + yy) * W + (x0 + xx);
+        float v = tb[(c * kGTH + yy) * kGRowPad + xx];
+        if (P.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// gather3 launch: -1 = not applicable (generic shapes, underfilled launches, LDS plan) -> gather
+int run_backward_gather3(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
+                         int N, int C, int K, int PH, int PW, int sr, int accumulate, hipStream_t st) {
+  if (C == 0 || N == 0) return 0;
+  const int bins = PH * PW;
+  if (bins > kGBins) return -1;
+  const int PPH = (PH + 3) & ~3, PPW = (PW + 3) & ~3;
+  int G = (bins <= 64) ? 4 : 2;
+  if (const char* e = getenv("DETOPS_ROIALIGN_BWD_G")) G = (atoi(e) == 4) ? 4 : (atoi(e) == 2 ? 2 : 1);
+  int batch = max(1, 128 / bins);                      // 7x7: 2 ROIs per batch, 14x14: 1
+  if (const char* e = getenv("DETOPS_ROIALIGN_BWD_BATCH")) batch = max(1, min(8, atoi(e)));
+  const int cgroups = static_cast<int>(ceil_div64(C, 16 * G));
+  GPlan P{};
+  P.chunks = cgroups;
+  P.accumulate = accumulate;
+  P.batch = batch;
+  P.groups = 1;
+  int64_t items = 0;
+  for (int i = L.num - 1; i >= 0; --i) {
+    if (L.lv[i].W > 32767) return -1;
+    P.tiles_x[i] = static_cast<int>(ceil_div64(L.lv[i].W, kGTW));
+    P.tiles_y[i] = static_cast<int>(ceil_div64(L.lv[i].H, kGTH));
+    const int64_t n = static_cast<int64_t>(N) * P.tiles_x[i] * P.tiles_y[i] * cgroups;
+    if (items + n > 0x7fffffff) return DETOPS_EUNSUPPORTED;
+    P.first_item[i] = static_cast<int>(items);
+    P.n_items[i] = static_cast<int>(n);
+    items += n;
+  }
+  if (items < 2 * kNumCU && !getenv("DETOPS_ROIALIGN_BWD_G")) return -1;   // underfilled: the ROI-split kernel
+  const size_t region = static_cast<size_t>(max(batch * bins * G * 16, 16 * kGTH * kGRowPad));
+  const size_t lds = sizeof(float) * (region + static_cast<size_t>(batch) * (kGTH * PPH + kGTW * PPW));
+  if (lds > 56 * 1024) return -1;
+  const dim3 grid(static_cast<unsigned>(items));
+#define G3_LAUNCH(G_)                                                                                          \
+  hipLaunchKernelGGL((roi_align_bwd_gather3_kernel<G_>), grid, dim3(kBlock), lds, st, L, P, rois, levels_in, \
+                     gout, C, K, PH, PW, sr)
+  if (G == 4) G3_LAUNCH(4); else if (G == 2) G3_LAUNCH(2); else G3_LAUNCH(1);
+#undef G3_LAUNCH
+  return launch_status();
+}
+
 // Pixel-owner backward launch.  Returns -1 when the shape does not fit its LDS plan (huge bin
 // counts): the caller then uses the tile-scatter kernel.
 int run_backward_gather(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
@@ -1132,6 +1381,10 @@ int run_backward(const Levels& L, const float* rois, const int32_t* levels_in, c
                  int N, int C, int K, int PH, int PW, int sr, int accumulate, hipStream_t st) {
   const char* e = getenv("DETOPS_ROIALIGN_BWD");  // read per call: tests flip it at run time
   const bool force_tile = e && e[0] == 't';
+  if (e && e[0] == 'g' && e[1] == 'a' && e[6] == '3') {   // "gather3": experimental, opt-in
+    const int rc = run_backward_gather3(L, rois, levels_in, gout, N, C, K, PH, PW, sr, accumulate, st);
+    if (rc != -1) return rc;
+  }
   if (!force_tile) {
     const int rc = run_backward_gather(L, rois, levels_in, gout, N, C, K, PH, PW, sr, accumulate, st);
     if (rc != -1) return rc;

@@ -19,14 +19,19 @@ import synth  # noqa: E402
 
 
 def run(tag, K, ph, walk):
-    C = 16  # one 16-channel chunk: every chunk of the 256 repeats this work
+    # one 16-channel chunk (every chunk of the 256 repeats this work); gather3 owns G chunks per workgroup
+    C = 64 if walk == "gather3" else 16
     shapes = [(2, C, h, w) for (h, w) in synth.fpn_shapes()[:4]]
     scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
     rois = synth.fpn_rois(per_image=K // 2)
     lv = synth.level_map(rois)
     g = np.random.RandomState(0).randn(K, C, ph, ph).astype(np.float32)
-    os.environ["DETOPS_ROIALIGN_BWD"] = "gather"
+    os.environ["DETOPS_ROIALIGN_BWD"] = "gather3" if walk == "gather3" else "gather"
     os.environ["DETOPS_ROIALIGN_BWD_CT"] = "16"
+    if walk == "gather3":
+        os.environ["DETOPS_ROIALIGN_BWD_G"] = "4" if ph == 7 else "2"
+    else:
+        os.environ.pop("DETOPS_ROIALIGN_BWD_G", None)
     if walk == "lane":
         os.environ["DETOPS_ROIALIGN_BWD_WALK"] = "lane"
     else:
@@ -38,6 +43,9 @@ def run(tag, K, ph, walk):
     print("%s  walk=%s  (%.0f s)" % (tag, walk, time.time() - t))
     for k in sorted(st):
         print("    %-28s %12.0f" % (k, st[k]))
+    if walk == "gather3":
+        print("    (64 channels = 4 chunks of the default kernel at 7x7, 2 x 2 chunks at 14x14)")
+        return
     wg, tasks = st.get("bwd.workgroups", 1), max(st.get("bwd.wave_roi_tasks", 1), 1)
     bodies = st.get("bwd.bodies_lane_walk", 0) + st.get("bwd.bodies_union_walk", 0)
     print("    per chunk: %.0f workgroups, %.2f hits / workgroup, %.1f bodies / wave-ROI task, lane utilisation %.0f %%" % (
@@ -46,5 +54,5 @@ def run(tag, K, ph, walk):
 
 if __name__ == "__main__":
     for tag, K, ph in (("box head 1024 x 7x7", 1024, 7), ("mask head 256 x 14x14", 256, 14)):
-        for walk in ("union", "lane"):
+        for walk in ("union", "lane", "gather3"):
             run(tag, K, ph, walk)

@@ -126,6 +126,17 @@ def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False, experiment
                 err = max(float((a - b).abs().max()) for a, b in zip(ref_g, got))
                 out.append(_entry(f"roi_align_bwd fpn-fused gather {tag} [EXPERIMENTAL per-lane bin walk]", us, alg,
                                   {"max_abs_diff_vs_default": err}))
+                for gsz, bsz in (("4", None), ("2", None), ("4", "1"), ("4", "3")) if ph == 7 else (("2", None), ("1", None)):
+                    os.environ["DETOPS_ROIALIGN_BWD"], os.environ["DETOPS_ROIALIGN_BWD_G"] = "gather3", gsz
+                    if bsz:
+                        os.environ["DETOPS_ROIALIGN_BWD_BATCH"] = bsz
+                    us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
+                    got = C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2)
+                    del os.environ["DETOPS_ROIALIGN_BWD"], os.environ["DETOPS_ROIALIGN_BWD_G"]
+                    os.environ.pop("DETOPS_ROIALIGN_BWD_BATCH", None)
+                    err = max(float((a - b).abs().max()) for a, b in zip(ref_g, got))
+                    out.append(_entry(f"roi_align_bwd fpn-fused gather3 {tag} [EXPERIMENTAL G={gsz} batch={bsz or 'auto'}]",
+                                      us, alg, {"max_abs_diff_vs_default": err}))
             os.environ["DETOPS_ROIALIGN_BWD_CT"] = "4"
             us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
             out.append(_entry(f"roi_align_bwd fpn-fused gather CT=4 {tag}", us, alg))
