@@ -333,6 +333,7 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
     const int cn = min(ctb, cend - cs);
     const float* src = base + static_cast<size_t>(cs - c0) * plane;
     const int total = cn * area;
+    if (tid == 0) { DETOPS_STAT("fwd.stage_batches", 1); DETOPS_STAT("fwd.staged_floats", total); }
     for (int e0 = tid; e0 < total; e0 += NT * U) {
       float v[U];
 #pragma unroll
