@@ -254,9 +254,25 @@ def main():
 
     progress("model + %d device batches ready" % len(batches))
     losses = None
+    ddp_mode = "overlapped-sgd-hook" if distributed else "single"
     for i in range(args.warmup):
-        losses = step(*batches[i % len(batches)])
-        torch.cuda.synchronize(device)
+        try:
+            losses = step(*batches[i % len(batches)])
+            torch.cuda.synchronize(device)
+        except Exception as e:  # noqa: BLE001
+            # Safety net for the N > 1 path (only gloo world-2 runs exist of the overlapped hook): a
+            # Python-level failure in the first step falls back to stock DDP (all-reduce, then the
+            # optimizer after backward) instead of losing the scaling measurement.  Reported below.
+            if not distributed or i > 0 or ddp_mode != "overlapped-sgd-hook":
+                raise
+            progress("overlapped DDP hook failed (%r): falling back to plain DDP" % (e,))
+            ddp_mode = "plain-ddp (fallback: %s)" % type(e).__name__
+            del model, optimizer, scheduler, step
+            torch.manual_seed(1234 + rank)
+            model, optimizer, scheduler, step = build_training(cfg, device, distributed, local_rank,
+                                                               overlap_optimizer=False)
+            losses = step(*batches[i % len(batches)])
+            torch.cuda.synchronize(device)
         progress("warm-up step %d done" % (i + 1))
     sync()
     timer = None
@@ -300,6 +316,7 @@ def main():
             "losses": {k: round(v, 4) for k, v in loss_vals.items()},
             "max_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
             "miopen": {"search": bool(torch.backends.cudnn.benchmark), "db": miopen_db},
+            "ddp": ddp_mode,
         }
         if timer is not None:
             kernels, dominant = {}, None
