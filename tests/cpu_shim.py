@@ -108,11 +108,64 @@ _PATCHES = {
 }
 
 
+# ---------------------------------------------------------------------------------------------
+# Second backend: the HIP kernel SOURCES executed by the host emulation (tests/emu) instead of the
+# oracle — the same entry points the GPU build exports, called with the model's real argument
+# patterns (proposal distributions, padded ROI sets, multi-level launches).
+# ---------------------------------------------------------------------------------------------
+def _emu_patches():
+    import emu
+
+    def fpn_forward(inputs, rois, scales, ph, pw, sr, k_min, k_max, canonical_scale=224.0, canonical_level=4.0, eps=1e-6):
+        out, lv = emu.roi_align_fpn_forward([_np(f.float()) for f in inputs], _np(rois.float()),
+                                            [float(s) for s in scales], ph, pw, sr, k_min, k_max)
+        return torch.from_numpy(out), torch.from_numpy(lv)
+
+    def fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr):
+        outs = emu.roi_align_fpn_backward(_np(grad.float()), _np(rois.float()), _np(levels), [tuple(s) for s in shapes],
+                                          [float(s) for s in scales], ph, pw, sr)
+        return [torch.from_numpy(o) for o in outs]
+
+    def nms_batched_mask(boxes, scores, seg_offsets, max_n, thr):
+        km, num = emu.nms_batched(_np(boxes.float()), _np(scores.float()), _np(seg_offsets), int(max_n), float(thr), mask=True)
+        return torch.from_numpy(km.astype(bool)), torch.from_numpy(num)
+
+    def nms(dets, scores, thr):
+        if dets.numel() == 0:
+            return torch.empty((0,), dtype=torch.long)
+        return torch.from_numpy(emu.nms(_np(dets.float()), _np(scores.float()), float(thr)))
+
+    def focal_sum(logits, targets, num_classes, gamma, alpha):
+        return torch.tensor(emu.focal_forward(_np(logits.float()), _np(targets), float(gamma), float(alpha), with_sum=True)[1])
+
+    def focal_bwd_scalar(logits, targets, d_loss, num_classes, gamma, alpha):
+        return torch.from_numpy(emu.focal_backward(_np(logits.float()), _np(targets), np.float32(float(d_loss)),
+                                                   float(gamma), float(alpha)))
+
+    def bn_fwd(x, scale, bias, residual, relu):
+        return torch.from_numpy(emu.frozen_bn_forward(_np(x.float()), _np(scale), _np(bias),
+                                                      None if residual is None else _np(residual.float()), bool(relu)))
+
+    def bn_bwd(grad_y, y, scale, relu, need_residual):
+        yy = grad_y if y is None else y   # y is only read for the ReLU mask
+        gx, gr = emu.frozen_bn_backward(_np(grad_y.float()), _np(yy.float()), _np(scale), bool(relu), bool(need_residual))
+        return torch.from_numpy(gx), (None if gr is None else torch.from_numpy(gr))
+
+    return {"roi_align_fpn_forward": fpn_forward, "roi_align_fpn_backward": fpn_backward, "nms": nms,
+            "nms_batched_mask": nms_batched_mask, "sigmoid_focalloss_forward_sum": focal_sum,
+            "sigmoid_focalloss_backward_scalar": focal_bwd_scalar, "frozen_bn_act_forward": bn_fwd,
+            "frozen_bn_act_backward": bn_bwd}
+
+
 @contextlib.contextmanager
-def install():
-    saved = {k: getattr(_C, k) for k in _PATCHES}
+def install(backend="oracle"):
+    """backend = "oracle" (C restatement) or "emu" (the HIP sources under the host emulation)."""
+    patches = dict(_PATCHES)
+    if backend == "emu":
+        patches.update(_emu_patches())
+    saved = {k: getattr(_C, k) for k in patches}
     try:
-        for k, v in _PATCHES.items():
+        for k, v in patches.items():
             setattr(_C, k, v)
         yield
     finally:
