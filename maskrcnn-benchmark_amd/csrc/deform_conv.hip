@@ -573,13 +573,236 @@ int col2im_t(const void* col, const void* offset, const void* mask, void* grad_i
   return launch_status();
 }
 
+inline size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+// ------------------------------------------------------------------------------------ col2im, ELL gather
+// EXPERIMENTAL (DETOPS_DCN_COL2IM=ell; CPU-checked in the host emulation, NOT yet measured on hardware).
+// rocprofv3 of the CSR pipeline above (profiles/r01e_opbench_kernel_stats.csv) shows that at layer2 size
+// the index build is a third of the time (count 47 + fill 90 + sort 150 us of 817) and that the gather
+// reads its per-pixel entry lists with one cache line per lane.  Here the inverted index is a fixed-width
+// table instead: every (pixel, tap) owns kEllCap slots stored pixel-fastest ([b*dg][tap][slot][pixel]),
+// so ONE pass fills it (slot = atomicAdd on the (pixel, tap) counter), a coalesced pass sorts each
+// slot column by column index (deterministic summation order), and the gather reads counters and
+// entries coalesced across the wave.  The rare (pixel, tap) with more than kEllCap contributions
+// spills to an overflow list that a small atomic kernel adds afterwards.
+constexpr int kEllCap = 8;
+
+struct EllOverflow {
+  int32_t li;       // (b*dg + dgi) * H*W + pixel
+  int32_t colidx;
+  float w;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+col2im_ell_fill_kernel(const T* __restrict__ offset, const T* __restrict__ mask, Geom g, int64_t npoints,
+                       int32_t* __restrict__ counter, int32_t* __restrict__ ent_idx, float* __restrict__ ent_w,
+                       int32_t* __restrict__ ovf_count, EllOverflow* __restrict__ ovf, int ovf_cap) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= npoints) return;
+  const int dgi = blockIdx.y;
+  const Point q = decode(p, g);
+  const int K = g.kh * g.kw;
+  const Sample s = point_sample(q, g, dgi, offset);
+  if (!s.inside) return;
+  const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
+  const int tgt[4] = {s.i1, s.i2, s.i3, s.i4};
+  const float wgt[4] = {s.w1, s.w2, s.w3, s.w4};
+  float m = 1.f;
+  if (mask) m = ld(mask + ((static_cast<size_t>(q.b) * g.dg + dgi) * K + q.tap) * HWo + q.pix);
+  const int32_t colidx = q.tap * (g.B * HWo) + q.b * HWo + q.pix;
+  const size_t img = static_cast<size_t>(q.b) * g.dg + dgi;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (tgt[t] < 0) continue;
+    const size_t cslot = (img * K + q.tap) * HW + tgt[t];          // counter: [img][tap][pixel]
+    const int pos = atomicAdd(counter + cslot, 1);
+    if (pos < kEllCap) {
+      const size_t e = ((img * K + q.tap) * kEllCap + pos) * HW + tgt[t];   // [img][tap][slot][pixel]
+      ent_idx[e] = colidx;
+      ent_w[e] = wgt[t] * m;
+    } else {
+      const int o = atomicAdd(ovf_count, 1);
+      if (o < ovf_cap) ovf[o] = EllOverflow{static_cast<int32_t>(img * HW + tgt[t]), colidx, wgt[t] * m};
+    }
+  }
+}
+
+// sort the (<= kEllCap) entries of each (pixel, tap) by column index: coalesced loads / stores, in registers
+__global__ void __launch_bounds__(kBlock)
+col2im_ell_sort_kernel(const int32_t* __restrict__ counter, int64_t ncols, int HW, int32_t* __restrict__ ent_idx,
+                       float* __restrict__ ent_w) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;   // (img, tap, pixel) linear
+  if (i >= ncols) return;
+  const int n = min(counter[i], kEllCap);
+  if (n < 2) return;
+  const int64_t it = i / HW;             // img * K + tap
+  const int pix = static_cast<int>(i - it * HW);
+  int32_t* ei = ent_idx + static_cast<size_t>(it) * kEllCap * HW + pix;
+  float* ew = ent_w + static_cast<size_t>(it) * kEllCap * HW + pix;
+  int32_t k[kEllCap];
+  float w[kEllCap];
+#pragma unroll
+  for (int j = 0; j < kEllCap; ++j) {
+    k[j] = j < n ? ei[static_cast<size_t>(j) * HW] : 0x7fffffff;
+    w[j] = j < n ? ew[static_cast<size_t>(j) * HW] : 0.f;
+  }
+  // odd-even transposition sort on 8 registers (static indices)
+#pragma unroll
+  for (int r = 0; r < kEllCap; ++r) {
+#pragma unroll
+    for (int j = (r & 1); j + 1 < kEllCap; j += 2) {
+      const bool sw = k[j] > k[j + 1];
+      const int32_t ka = sw ? k[j + 1] : k[j], kb = sw ? k[j] : k[j + 1];
+      const float wa = sw ? w[j + 1] : w[j], wb = sw ? w[j] : w[j + 1];
+      k[j] = ka; k[j + 1] = kb; w[j] = wa; w[j + 1] = wb;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kEllCap; ++j)
+    if (j < n) { ei[static_cast<size_t>(j) * HW] = k[j]; ew[static_cast<size_t>(j) * HW] = w[j]; }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+col2im_ell_gather_kernel(const T* __restrict__ col, const int32_t* __restrict__ counter,
+                         const int32_t* __restrict__ ent_idx, const float* __restrict__ ent_w,
+                         T* __restrict__ grad_im, Geom g, int cchunk, int xcd_remap) {
+  const int HW = g.H * g.W;
+  int64_t lin = (static_cast<int64_t>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  if (xcd_remap) lin = xcd_contiguous(lin, static_cast<int64_t>(gridDim.x) * gridDim.y * gridDim.z);
+  const int bx = static_cast<int>(lin % gridDim.x);
+  const int by = static_cast<int>((lin / gridDim.x) % gridDim.y);
+  const int b = static_cast<int>(lin / (static_cast<int64_t>(gridDim.x) * gridDim.y));
+  const int pix = bx * kBlock + threadIdx.x;
+  const bool live = pix < HW;            // dead lanes stay for the wave-wide ballots
+  const int cpg = g.C / g.dg;
+  const int chunks_per_g = (cpg + cchunk - 1) / cchunk;
+  const int dgi = by / chunks_per_g;
+  const int c0 = dgi * cpg + (by - dgi * chunks_per_g) * cchunk;
+  const int c1 = min(c0 + cchunk, (dgi + 1) * cpg);
+  const int K = g.kh * g.kw;
+  const size_t chan_stride = static_cast<size_t>(K) * g.B * g.Ho * g.Wo;
+  const size_t img = static_cast<size_t>(b) * g.dg + dgi;
+  const int p = live ? pix : 0;
+  for (int cs = c0; cs < c1; cs += kGatherCC) {
+    float acc[kGatherCC];
+#pragma unroll
+    for (int c = 0; c < kGatherCC; ++c) acc[c] = 0.f;
+    const T* cbase = col + static_cast<size_t>(cs) * chan_stride;
+    for (int tap = 0; tap < K; ++tap) {
+      const int n = live ? min(counter[(img * K + tap) * HW + p], kEllCap) : 0;
+      const int32_t* ei = ent_idx + (img * K + tap) * kEllCap * HW + p;
+      const float* ew = ent_w + (img * K + tap) * kEllCap * HW + p;
+      for (int j = 0; j < kEllCap; ++j) {
+        if (__ballot(j < n) == 0ull) break;        // wave-uniform trip count
+        if (j < n) {
+          const int32_t ci = ei[static_cast<size_t>(j) * HW];
+          const float w = ew[static_cast<size_t>(j) * HW];
+          const T* cp = cbase + ci;
+#pragma unroll
+          for (int c = 0; c < kGatherCC; ++c)
+            if (cs + c < c1) acc[c] = fmaf(w, ld(cp + static_cast<size_t>(c) * chan_stride), acc[c]);
+        }
+      }
+    }
+    if (live) {
+      T* gp = grad_im + (static_cast<size_t>(b) * g.C + cs) * HW + pix;
+#pragma unroll
+      for (int c = 0; c < kGatherCC; ++c)
+        if (cs + c < c1) st(gp + static_cast<size_t>(c) * HW, ld(gp + static_cast<size_t>(c) * HW) + acc[c]);
+    }
+  }
+}
+
+// contributions beyond kEllCap per (pixel, tap): added with atomics after the gather (rare)
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+col2im_ell_overflow_kernel(const T* __restrict__ col, const int32_t* __restrict__ ovf_count,
+                           const EllOverflow* __restrict__ ovf, int ovf_cap, T* __restrict__ grad_im, Geom g) {
+  const int n = min(*ovf_count, ovf_cap);
+  const int HW = g.H * g.W;
+  const int cpg = g.C / g.dg;
+  const size_t chan_stride = static_cast<size_t>(g.kh) * g.kw * g.B * g.Ho * g.Wo;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < static_cast<int64_t>(n) * cpg;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int e = static_cast<int>(i / cpg);
+    const int cl = static_cast<int>(i - static_cast<int64_t>(e) * cpg);
+    const EllOverflow o = ovf[e];
+    const int imgi = o.li / HW, pix = o.li - imgi * HW;
+    const int b = imgi / g.dg, dgi = imgi - b * g.dg;
+    const int c = dgi * cpg + cl;
+    const float v = o.w * ld(col + static_cast<size_t>(c) * chan_stride + o.colidx);
+    atomic_add_t(grad_im + (static_cast<size_t>(b) * g.C + c) * HW + pix, v);
+  }
+}
+
+struct EllPlan {
+  int64_t ncols, npoints_per_dg;     // ncols = B*dg*K*H*W  (pixel, tap) columns
+  int ovf_cap;
+  size_t off_count, off_ovf_count, off_idx, off_w, off_ovf, total;
+};
+
+inline bool ell_plan(const Geom& g, EllPlan& P) {
+  const int64_t K = static_cast<int64_t>(g.kh) * g.kw;
+  const int64_t HWo = static_cast<int64_t>(g.Ho) * g.Wo;
+  P.ncols = static_cast<int64_t>(g.B) * g.dg * K * g.H * g.W;
+  P.npoints_per_dg = static_cast<int64_t>(g.B) * K * HWo;
+  const int64_t max_entries = 4 * P.npoints_per_dg * g.dg;
+  if (P.ncols * kEllCap > 0x7fffffff || max_entries > 0x7fffffff || K * g.B * HWo > 0x7fffffff ||
+      static_cast<int64_t>(g.B) * g.dg * g.H * g.W > 0x7fffffff)
+    return false;
+  P.ovf_cap = static_cast<int>(max_entries);
+  size_t o = 0;
+  P.off_count = o;     o = align256(o + sizeof(int32_t) * P.ncols);
+  P.off_ovf_count = o; o = align256(o + sizeof(int32_t));
+  P.off_idx = o;       o = align256(o + sizeof(int32_t) * P.ncols * kEllCap);
+  P.off_w = o;         o = align256(o + sizeof(float) * P.ncols * kEllCap);
+  P.off_ovf = o;       o = align256(o + sizeof(EllOverflow) * static_cast<size_t>(P.ovf_cap));
+  P.total = o;
+  return true;
+}
+
+template <typename T>
+int col2im_ell_t(const void* col, const void* offset, const void* mask, void* grad_im, const Geom& g,
+                 const EllPlan& P, void* ws, hipStream_t st_) {
+  if (P.npoints_per_dg == 0) return 0;
+  char* w = static_cast<char*>(ws);
+  int32_t* count = reinterpret_cast<int32_t*>(w + P.off_count);
+  int32_t* ovf_count = reinterpret_cast<int32_t*>(w + P.off_ovf_count);
+  int32_t* ent_idx = reinterpret_cast<int32_t*>(w + P.off_idx);
+  float* ent_w = reinterpret_cast<float*>(w + P.off_w);
+  EllOverflow* ovf = reinterpret_cast<EllOverflow*>(w + P.off_ovf);
+  DETOPS_HIP_TRY(hipMemsetAsync(count, 0, P.off_idx - P.off_count, st_));   // counters + overflow counter
+  const dim3 pgrid(static_cast<unsigned>(ceil_div64(P.npoints_per_dg, kBlock)), static_cast<unsigned>(g.dg));
+  hipLaunchKernelGGL(col2im_ell_fill_kernel<T>, pgrid, dim3(kBlock), 0, st_, static_cast<const T*>(offset),
+                     static_cast<const T*>(mask), g, P.npoints_per_dg, count, ent_idx, ent_w, ovf_count, ovf,
+                     P.ovf_cap);
+  hipLaunchKernelGGL(col2im_ell_sort_kernel, dim3(static_cast<unsigned>(ceil_div64(P.ncols, kBlock))), dim3(kBlock),
+                     0, st_, static_cast<const int32_t*>(count), P.ncols, g.H * g.W, ent_idx, ent_w);
+  const int cpg = g.C / g.dg;
+  const int64_t pix_blocks = ceil_div64(static_cast<int64_t>(g.H) * g.W, kBlock) * g.B;
+  int cc = cpg;
+  while (cc > kGatherCC && pix_blocks * g.dg * ceil_div64(cpg, cc) < 4 * kNumCU) cc = max(kGatherCC, cc / 2);
+  cc = static_cast<int>(ceil_div64(cc, kGatherCC)) * kGatherCC;
+  const char* sw = getenv("DETOPS_DCN_GATHER_XCD");
+  const int xcd_remap = !(sw && sw[0] == '0');
+  const dim3 ggrid(static_cast<unsigned>(ceil_div64(static_cast<int64_t>(g.H) * g.W, kBlock)),
+                   static_cast<unsigned>(g.dg * ceil_div64(cpg, cc)), static_cast<unsigned>(g.B));
+  hipLaunchKernelGGL(col2im_ell_gather_kernel<T>, ggrid, dim3(kBlock), 0, st_, static_cast<const T*>(col),
+                     static_cast<const int32_t*>(count), static_cast<const int32_t*>(ent_idx),
+                     static_cast<const float*>(ent_w), static_cast<T*>(grad_im), g, cc, xcd_remap);
+  hipLaunchKernelGGL(col2im_ell_overflow_kernel<T>, dim3(kNumCU), dim3(kBlock), 0, st_, static_cast<const T*>(col),
+                     static_cast<const int32_t*>(ovf_count), static_cast<const EllOverflow*>(ovf), P.ovf_cap,
+                     static_cast<T*>(grad_im), g);
+  return launch_status();
+}
+
 // Workspace carve of the gather path (all offsets 256-byte aligned).
 struct GatherPlan {
   int64_t nslots, npoints_per_dg, max_entries;
   size_t off_count, off_cursor, off_start, off_entries, off_scan, scan_bytes, total;
 };
-
-inline size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 
 // false: the shape does not fit the 32-bit index plan (the scatter kernels handle it)
 inline bool gather_plan(const Geom& g, GatherPlan& P) {
@@ -721,7 +944,9 @@ DETOPS_API size_t detops_deformable_col2im_workspace_bytes(int B, int C, int H, 
   if (make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, deformable_group)) return 0;
   GatherPlan P;
   if (B == 0 || !gather_plan(g, P)) return 0;
-  return P.total;
+  EllPlan E;   // the experimental ELL path shares the workspace: size for the larger plan
+  const size_t ell = ell_plan(g, E) ? E.total : 0;
+  return P.total > ell ? P.total : ell;
 }
 
 DETOPS_API int detops_deformable_col2im_ws(const void* col, const void* offset, const void* mask,
@@ -743,6 +968,14 @@ DETOPS_API int detops_deformable_col2im_ws(const void* col, const void* offset, 
   // fp16 594 vs 1121 / 266 vs 577 / 157 vs 525 us) and is deterministic.
   const char* e = getenv("DETOPS_DCN_COL2IM");
   const bool want_gather = !(e && e[0] == 's');
+  if (e && e[0] == 'e' && workspace) {   // "ell": experimental fixed-width index, opt-in
+    EllPlan E;
+    if (ell_plan(g, E) && workspace_bytes >= E.total) {
+#define CALL(T) col2im_ell_t<T>(col, offset, mask, grad_im, g, E, workspace, as_stream(stream))
+      DETOPS_DTYPE_SWITCH(dtype, CALL)
+#undef CALL
+    }
+  }
   const bool scatter = !want_gather || !workspace || !gather_plan(g, P) || workspace_bytes < P.total;
   if (scatter) {
 #define CALL(T) col2im_t<T>(col, offset, mask, grad_im, g, as_stream(stream))

@@ -156,7 +156,11 @@ def deformable_im2col(im, offset, mask, kh, kw, pad, stride, dil, dg):
     return col
 
 
-def deformable_col2im(col, offset, mask, B, C, H, W, kh, kw, pad, stride, dil, dg, gather=True, into=None):
+def deformable_col2im(col, offset, mask, B, C, H, W, kh, kw, pad, stride, dil, dg, gather=True, into=None, mode=None):
+    """mode: "gather" (CSR inverted index), "ell" (experimental fixed-width index) or "scatter"; the
+    legacy `gather` flag maps to "gather" / "scatter"."""
+    mode = mode or ("gather" if gather else "scatter")
+    gather = mode != "scatter"
     col = np.ascontiguousarray(col)
     dt = col.dtype
     offset = np.ascontiguousarray(offset, dtype=dt)
@@ -165,7 +169,7 @@ def deformable_col2im(col, offset, mask, B, C, H, W, kh, kw, pad, stride, dil, d
     g = _geom(B, C, H, W, kh, kw, pad, stride, dil, dg)
     mp = None if mask is None else _p(mask)
     if gather:
-        os.environ["DETOPS_DCN_COL2IM"] = "gather"  # the default picks a path by dtype / map size
+        os.environ["DETOPS_DCN_COL2IM"] = mode
         nbytes = lib().detops_deformable_col2im_workspace_bytes(*g)
         assert nbytes > 0
         ws = np.full((nbytes,), 0xAB, np.uint8)  # arbitrary contents

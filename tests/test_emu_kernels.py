@@ -320,3 +320,41 @@ def test_emu_roi_align_backward_gather3_variant(G, monkeypatch):
         base = rng.randn(N, C, H, W).astype(np.float32)
         acc = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, into=base)
         assert np.abs(acc - (base + ref)).max() <= 2 * tol
+
+
+@pytest.mark.parametrize("gi", range(len(DCN_GEOMS)))
+@pytest.mark.parametrize("modulated", [False, True])
+def test_emu_deformable_col2im_ell_variant(gi, modulated):
+    """experimental fixed-width (ELL) inverted index (DETOPS_DCN_COL2IM=ell; opt-in, CPU-checked only)."""
+    g = DCN_GEOMS[gi]
+    x, off, mask = _dcn_case(g, modulated)
+    k, p, s, d, dg = g["k"], g["pad"], g["stride"], g["dil"], g["dg"]
+    geo = dict(kh=k, kw=k, pad=(p, p), stride=(s, s), dil=(d, d), dg=dg)
+    ncol = oracle.deformable_im2col(x, off, mask, **geo).shape
+    gcol = np.random.RandomState(9).randn(*ncol).astype(np.float32)
+    ref = oracle.deformable_col2im(gcol, off, mask, *x.shape, **geo)
+    out = emu.deformable_col2im(gcol, off, mask, *x.shape, mode="ell", **geo)
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ref).max()))
+    base = np.random.RandomState(2).randn(*x.shape).astype(np.float32)
+    np.testing.assert_allclose(emu.deformable_col2im(gcol, off, mask, *x.shape, mode="ell", into=base, **geo),
+                               base + ref, rtol=1e-4, atol=2e-5 * max(1.0, np.abs(ref).max()))
+
+
+def test_emu_deformable_col2im_ell_overflow():
+    """offsets that pile every sampling point of a tap onto the same pixel: far more than 8 entries per
+    (pixel, tap) -> the overflow list + atomic kernel carry the rest."""
+    B, C, H, W, k = 1, 5, 9, 11, 3
+    geo = dict(kh=k, kw=k, pad=(1, 1), stride=(1, 1), dil=(1, 1), dg=1)
+    rng = np.random.RandomState(3)
+    off = np.zeros((B, 2 * k * k, H, W), np.float32)
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    for t in range(k * k):
+        i, j = t // k, t % k
+        off[0, 2 * t] = 4.3 - (ys - 1 + i)      # every sample of tap t lands at (4.3, 5.6)
+        off[0, 2 * t + 1] = 5.6 - (xs - 1 + j)
+    off += rng.randn(*off.shape).astype(np.float32) * 0.05
+    gcol = rng.randn(C * k * k, B * H * W).astype(np.float32)
+    ref = oracle.deformable_col2im(gcol, off, None, B, C, H, W, **geo)
+    for mode in ("ell", "gather", "scatter"):
+        out = emu.deformable_col2im(gcol, off, None, B, C, H, W, mode=mode, **geo)
+        np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()), err_msg=mode)

@@ -208,7 +208,7 @@ def bench_focal(C, iters):
     return out
 
 
-def bench_dcn(C, iters):
+def bench_dcn(C, iters, experimental=False):
     out = []
     for (Cc, H, W, smooth) in [(128, 100, 168, False), (256, 50, 84, False), (512, 25, 42, False), (128, 100, 168, True)]:
         for dt, e in ((torch.float32, 4), (torch.float16, 2)):
@@ -239,6 +239,17 @@ def bench_dcn(C, iters):
             us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), max(3, iters // 5))
             del os.environ["DETOPS_DCN_COL2IM"]
             out.append(_entry(f"dcn_col2im scatter (LDS atomics) C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg))
+            if experimental:
+                ref_g = torch.zeros_like(x)
+                C.deformable_col2im(col, off, None, ref_g, *geo)
+                os.environ["DETOPS_DCN_COL2IM"] = "ell"
+                us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), max(3, iters // 5))
+                got = torch.zeros_like(x)
+                C.deformable_col2im(col, off, None, got, *geo)
+                del os.environ["DETOPS_DCN_COL2IM"]
+                err = float((got.float() - ref_g.float()).abs().max())
+                out.append(_entry(f"dcn_col2im ELL index [EXPERIMENTAL] C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg,
+                                  {"max_abs_diff_vs_default": err}))
             goff = torch.empty_like(off)
             us = dev_time_us(lambda: C.deformable_col2im_coord(col, x, off, None, goff, None, *geo), iters)
             out.append(_entry(f"dcn_col2im_coord C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg))
@@ -278,7 +289,7 @@ def main():
     if not only or "focal" in only:
         res += bench_focal(C, args.iters)
     if not only or "dcn" in only:
-        res += bench_dcn(C, args.iters)
+        res += bench_dcn(C, args.iters, experimental=args.experimental)
     for r in res:
         print("%-70s %10.2f us  %9.1f GB/s  (%.1f%% of 8 TB/s) %s" % (
             r["op"], r["us"], r["gbs"], 100 * r["frac_of_8TBs"],
