@@ -7,6 +7,7 @@
 set -x
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+DETOPS_TEST_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_experimental_gpu.py -m gpu -q -p no:cacheprovider > gpurun_out/pytest_experimental.log 2>&1; tail -3 gpurun_out/pytest_experimental.log
 timeout 180 python tools/opbench.py --iters 30 --only roi_align,dcn --experimental --json gpurun_out/opbench_experimental.json > gpurun_out/opbench_experimental.log 2>&1
 grep -v "^/opt" gpurun_out/opbench_experimental.log | grep "fpn-fused\|dcn_col2im" | cut -c1-220
 timeout 90 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch_x -o x -- env DETOPS_ROIALIGN_FWD_ORDER=1 python tools/opbench.py --iters 3 --only roi_align_fpn > gpurun_out/pmc_fetch_x.log 2>&1
