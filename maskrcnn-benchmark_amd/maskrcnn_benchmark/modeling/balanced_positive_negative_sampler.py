@@ -9,7 +9,11 @@ among the candidates are a uniformly random `k`-subset, which is the same distri
 `__call__` returns the reference's two lists of boolean masks; `sample_fixed` returns a
 fixed-length index set (positives first) for the padded training path.
 """
+import os
+
 import torch
+
+_THRESHOLD_SELECT = os.environ.get("DETOPS_SAMPLER", "") == "topk"
 
 
 class BalancedPositiveNegativeSampler(object):
@@ -24,13 +28,26 @@ class BalancedPositiveNegativeSampler(object):
         n = labels.shape[-1]
         pos = labels >= 1
         neg = labels == 0
+        n_pos = pos.sum(dim=-1, keepdim=True).clamp(max=max_pos)
+        n_neg = neg.sum(dim=-1, keepdim=True).clamp(max=B).minimum(B - n_pos)
+        if _THRESHOLD_SELECT and n >= B:
+            # EXPERIMENTAL (DETOPS_SAMPLER=topk, off by default, not yet measured): the k smallest keys
+            # are found with one top-k per class and a threshold compare instead of two full argsorts
+            # per class (4 sorts of [N, 268,569] for the RPN = 1.6 ms/step of merge-sort launches).
+            # float64 keys: a tie AT the threshold has probability ~1e-10 instead of ~1e-2.
+            u = torch.rand(labels.shape, device=labels.device, dtype=torch.float64)
+
+            def pick(cand, k_dev, k_max):
+                keys = torch.where(cand, u, u + 2)
+                small = keys.topk(k_max, dim=-1, largest=False, sorted=True).values     # ascending
+                thr = small.gather(-1, (k_dev - 1).clamp(min=0))
+                return cand & (keys <= thr) & (k_dev > 0)
+
+            return pick(pos, n_pos, max_pos), pick(neg, n_neg, B)
         u = torch.rand(labels.shape, device=labels.device)
         # rank of each candidate's key inside its class (0 = smallest); non-candidates pushed last
         rank_pos = torch.where(pos, u, u + 2).argsort(dim=-1).argsort(dim=-1)
         rank_neg = torch.where(neg, u, u + 2).argsort(dim=-1).argsort(dim=-1)
-        n_pos = pos.sum(dim=-1, keepdim=True).clamp(max=max_pos)
-        n_neg = neg.sum(dim=-1, keepdim=True).clamp(max=B).minimum(B - n_pos)
-        del n
         return pos & (rank_pos < n_pos), neg & (rank_neg < n_neg)
 
     def __call__(self, matched_idxs):

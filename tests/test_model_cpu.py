@@ -226,6 +226,33 @@ def test_balanced_sampler_counts_and_uniformity():
     assert int(valid.sum()) == 10 and (few[0][idx[0][valid[0]]] == 0).all()
 
 
+def test_balanced_sampler_topk_threshold_variant(monkeypatch):
+    """experimental DETOPS_SAMPLER=topk selection: same counts, candidates only, uniform."""
+    import maskrcnn_benchmark.modeling.balanced_positive_negative_sampler as bs
+    monkeypatch.setattr(bs, "_THRESHOLD_SELECT", True)
+    torch.manual_seed(0)
+    s = bs.BalancedPositiveNegativeSampler(64, 0.25)
+    labels = torch.zeros(2, 500, dtype=torch.int64)
+    labels[0, :40] = 3
+    labels[0, 400:] = -1
+    labels[1, :5] = 1
+    pos, neg = s._masks(labels)
+    assert int(pos[0].sum()) == 16 and int(neg[0].sum()) == 48
+    assert int(pos[1].sum()) == 5 and int(neg[1].sum()) == 59
+    assert not (pos & (labels < 1)).any() and not (neg & (labels != 0)).any()
+    none = torch.full((1, 200), -1, dtype=torch.int64)
+    none[0, :100] = 0                     # no positives at all
+    p, q = s._masks(none)
+    assert int(p.sum()) == 0 and int(q.sum()) == 64
+    hits = torch.zeros(40)
+    for _ in range(300):
+        p, _ = s._masks(labels[:1])
+        hits += p[0][:40].float()
+    assert hits.min() > 60 and hits.max() < 180
+    idx, valid = s.sample_fixed(labels)
+    assert idx.shape == (2, 64) and valid.all()
+
+
 # ------------------------------------------------------------------ mask targets
 def test_mask_targets_match_reference_binary_mask_path():
     from maskrcnn_benchmark.modeling.roi_heads.mask_head.loss import project_masks_on_boxes
