@@ -82,18 +82,6 @@ int detops_roi_align_fpn_forward_f32(const float* const* inputs_host, const int*
                                      float canonical_scale, float canonical_level, float eps,
                                      detops_stream_t stream);
 
-/* EXPERIMENTAL: same result as detops_roi_align_fpn_forward_f32 (bit-identical), but the ROIs are
- * visited in a spatial order (sorted on device into order_ws[K], int32 scratch) with XCD-contiguous
- * workgroup ids, so overlapping footprints share one L2.  order_ws == NULL, K < 2 or K > 8192 fall
- * back to the plain entry point. */
-int detops_roi_align_fpn_forward_ordered_f32(const float* const* inputs_host, const int* H_host,
-                                             const int* W_host, const float* scale_host,
-                                             int num_levels, const float* rois, float* output,
-                                             int32_t* levels_out, int N, int C, int K, int PH,
-                                             int PW, int sampling_ratio, int k_min, int k_max,
-                                             float canonical_scale, float canonical_level,
-                                             float eps, int32_t* order_ws, detops_stream_t stream);
-
 int detops_roi_align_fpn_backward_f32(const float* grad_out, const float* rois,
                                       const int32_t* levels, float* const* grad_inputs_host,
                                       const int* H_host, const int* W_host,

@@ -576,7 +576,7 @@ int col2im_t(const void* col, const void* offset, const void* mask, void* grad_i
 inline size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 
 // ------------------------------------------------------------------------------------ col2im, ELL gather
-// EXPERIMENTAL (DETOPS_DCN_COL2IM=ell; CPU-checked in the host emulation, NOT yet measured on hardware).
+// Default for fp32 and for large maps (measured r02a: 1.3-1.75x over the CSR pipeline at layer2/3).
 // rocprofv3 of the CSR pipeline above (profiles/r01e_opbench_kernel_stats.csv) shows that at layer2 size
 // the index build is a third of the time (count 47 + fill 90 + sort 150 us of 817) and that the gather
 // reads its per-pixel entry lists with one cache line per lane.  Here the inverted index is a fixed-width
@@ -944,7 +944,7 @@ DETOPS_API size_t detops_deformable_col2im_workspace_bytes(int B, int C, int H, 
   if (make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, deformable_group)) return 0;
   GatherPlan P;
   if (B == 0 || !gather_plan(g, P)) return 0;
-  EllPlan E;   // the experimental ELL path shares the workspace: size for the larger plan
+  EllPlan E;   // the ELL and CSR paths share the workspace: size for the larger plan
   const size_t ell = ell_plan(g, E) ? E.total : 0;
   return P.total > ell ? P.total : ell;
 }
@@ -962,13 +962,16 @@ DETOPS_API int detops_deformable_col2im_ws(const void* col, const void* offset, 
   if (B == 0) return 0;
   if (!col || !offset || !grad_im) return DETOPS_EINVAL;
   GatherPlan P;
-  // DETOPS_DCN_COL2IM = "scatter" forces the atomic kernels (A/B measurements).  The gather path is the
-  // default for every dtype / size: with the XCD-contiguous block order it beats the LDS-atomic scatter
-  // on all cfg-5 shapes (profiles/r01e_opbench.log: fp32 814 vs 959 / 349 vs 485 / 235 vs 376 us,
-  // fp16 594 vs 1121 / 266 vs 577 / 157 vs 525 us) and is deterministic.
+  // Default: the fixed-width (ELL) inverted index for fp32 and for large maps, the CSR index + gather
+  // otherwise (profiles/r02a_opbench_experimental_ab.log, ELL vs CSR: fp32 448 vs 785 / 281 vs 355 /
+  // 231 vs 235 us at layer2/3/4; fp16 401 vs 592 / 264 vs 264 / 212 vs 152 us).  Both are free of data
+  // atomics except ELL's overflow list.  DETOPS_DCN_COL2IM = "scatter" | "gather" | "ell" forces one
+  // (A/B measurements, tests).
   const char* e = getenv("DETOPS_DCN_COL2IM");
   const bool want_gather = !(e && e[0] == 's');
-  if (e && e[0] == 'e' && workspace) {   // "ell": experimental fixed-width index, opt-in
+  const bool big = static_cast<int64_t>(g.B) * g.H * g.W >= 16384;
+  const bool want_ell = e ? e[0] == 'e' : (dtype == DETOPS_F32 || big);
+  if (want_ell && workspace) {
     EllPlan E;
     if (ell_plan(g, E) && workspace_bytes >= E.total) {
 #define CALL(T) col2im_ell_t<T>(col, offset, mask, grad_im, g, E, workspace, as_stream(stream))

@@ -121,24 +121,20 @@ __device__ __forceinline__ int fpn_level(const float* __restrict__ roi, const Le
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-// ORDERED (experimental, opt-in): workgroup ids are remapped XCD-contiguously and ROIs are visited
-// through `order` (a spatial sort, see roi_order_kernel) so overlapping footprints share one L2.
-template <int PH_, int PW_, int kTabCap, bool ORDERED = false>
+template <int PH_, int PW_, int kTabCap>
 __global__ void __launch_bounds__(kBlock)
 roi_align_fwd_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
                      int32_t* __restrict__ levels_out, float* __restrict__ out, int C, int K,
-                     int PHr, int PWr, int sr, int CT, int chunks, const int32_t* __restrict__ order) {
+                     int PHr, int PWr, int sr, int CT, int chunks) {
   const int PH = PH_ ? PH_ : PHr;
   const int PW = PW_ ? PW_ : PWr;
   const int bins = PH * PW;
   __shared__ Tap tabY[kTabCap];
   __shared__ Tap tabX[kTabCap];
 
-  int bid = blockIdx.x;
-  if (ORDERED) bid = static_cast<int>(xcd_contiguous(bid, gridDim.x));
-  int k = bid / chunks;
+  const int bid = blockIdx.x;
+  const int k = bid / chunks;
   const int chunk = bid - k * chunks;
-  if (ORDERED) k = order[k];
   const float* roi = rois + static_cast<size_t>(k) * 5;
   int lvl = 0;
   if (L.num > 1) lvl = levels_in ? levels_in[k] : fpn_level(roi, L);
@@ -218,11 +214,11 @@ constexpr int kLdsPatchFloats = 8192 - 64;  // default ~32 KiB dynamic LDS per w
 
 // U = staging loads in flight per lane; patch_floats = LDS patch budget (DETOPS_ROIALIGN_FWD_LDS_KB /
 // DETOPS_ROIALIGN_FWD_U select other points of the occupancy / loads-in-flight trade-off at run time)
-template <int PH, int PW, int SR, int G, int U, bool ORDERED = false>
+template <int PH, int PW, int SR, int G, int U>
 __global__ void __launch_bounds__(((PH * PW * G + 63) / 64) * 64)
 roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
                          int32_t* __restrict__ levels_out, float* __restrict__ out, int C, int K, int CT,
-                         int chunks, int patch_floats, const int32_t* __restrict__ order) {
+                         int chunks, int patch_floats) {
   constexpr int BINS = PH * PW;
   constexpr int NS = SR * SR;
   constexpr int NT = ((BINS * G + 63) / 64) * 64;
@@ -232,11 +228,9 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
   __shared__ int s_bounds[4];
 
   const int tid = threadIdx.x;
-  int bid = blockIdx.x;
-  if (ORDERED) bid = static_cast<int>(xcd_contiguous(bid, gridDim.x));
-  int k = bid / chunks;
+  const int bid = blockIdx.x;
+  const int k = bid / chunks;
   const int chunk = bid - k * chunks;
-  if (ORDERED) k = order[k];
   const float* roi = rois + static_cast<size_t>(k) * 5;
   int lvl = 0;
   if (L.num > 1) lvl = levels_in ? levels_in[k] : fpn_level(roi, L);
@@ -372,63 +366,6 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
     }
     __syncthreads();
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// EXPERIMENTAL (opt-in, DETOPS_ROIALIGN_FWD_ORDER=1; CPU-checked, not yet measured on hardware).
-// Proposals arrive in score order, so two ROIs whose footprints overlap are usually staged by
-// workgroups on different XCDs and the shared feature bytes cross the fabric once per XCD (PMC: FETCH
-// 522 MB vs 183 MB of feature maps for the box-head launch).  This kernel sorts the ROI indices by
-// (level, image, Morton code of the ROI centre in 16-pixel cells of its level); the ORDERED forward
-// instantiations walk that order with XCD-contiguous workgroup ids, so neighbours in space are
-// neighbours in time on ONE L2.  One workgroup, bitonic sort of 64-bit keys in LDS (K <= 8192).
-// ------------------------------------------------------------------------------------------
-constexpr int kOrderMaxK = 8192;
-
-__device__ __forceinline__ unsigned morton8(unsigned x, unsigned y) {  // interleave two 8-bit values
-  unsigned r = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) r |= ((x >> i) & 1u) << (2 * i) | ((y >> i) & 1u) << (2 * i + 1);
-  return r;
-}
-
-__global__ void __launch_bounds__(1024)
-roi_order_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in, int K,
-                 int npad, int32_t* __restrict__ order) {
-  DETOPS_DYNAMIC_LDS(unsigned long long, keys);
-  for (int i = threadIdx.x; i < npad; i += blockDim.x) {
-    unsigned long long key = ~0ull;
-    if (i < K) {
-      const float* roi = rois + static_cast<size_t>(i) * 5;
-      int lvl = 0;
-      if (L.num > 1) lvl = levels_in ? levels_in[i] : fpn_level(roi, L);
-      float scale = L.lv[0].scale;
-#pragma unroll
-      for (int j = 1; j < DETOPS_MAX_LEVELS; ++j)
-        if (j == lvl) scale = L.lv[j].scale;
-      const float cx = 0.5f * (roi[1] + roi[3]) * scale, cy = 0.5f * (roi[2] + roi[4]) * scale;
-      const unsigned ux = static_cast<unsigned>(fminf(fmaxf(cx * (1.f / 16.f), 0.f), 255.f));
-      const unsigned uy = static_cast<unsigned>(fminf(fmaxf(cy * (1.f / 16.f), 0.f), 255.f));
-      const unsigned b = static_cast<unsigned>(fminf(fmaxf(roi[0], 0.f), 255.f));
-      key = (static_cast<unsigned long long>(lvl & 7) << 56) | (static_cast<unsigned long long>(b) << 48) |
-            (static_cast<unsigned long long>(morton8(ux, uy)) << 32) | static_cast<unsigned>(i);
-    }
-    keys[i] = key;
-  }
-  __syncthreads();
-  for (int k = 2; k <= npad; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < (npad >> 1); t += blockDim.x) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int p = i | j;
-        const unsigned long long a = keys[i], b = keys[p];
-        const bool up = (i & k) == 0;
-        if ((a > b) == up) { keys[i] = b; keys[p] = a; }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = threadIdx.x; i < K; i += blockDim.x) order[i] = static_cast<int32_t>(keys[i] & 0xffffffffu);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -654,7 +591,7 @@ struct __align__(16) GHit {   // 32 bytes
   int xspan;   // (ix0 << 16) | ix1: columns the ROI's taps can reach (conservative), map width < 32768
 };
 
-template <int PH_, int PW_, int CT, bool LANE_WALK = false>
+template <int PH_, int PW_, int CT>
 __global__ void __launch_bounds__(kBlock)
 roi_align_bwd_gather_kernel(Levels L, GPlan P, const float* __restrict__ rois,
                             const int32_t* __restrict__ levels_in, const float* __restrict__ gout,
@@ -804,89 +741,35 @@ roi_align_bwd_gather_kernel(Levels L, GPlan P, const float* __restrict__ rois,
         const float* ayr = ayt + (j * kGTH + yl) * PPH;
         const float* axr = axt + (j * kGTW + xl) * PPW;
         const float4* gj = gs4 + j * bins;
-        if constexpr (LANE_WALK) {
-          // EXPERIMENTAL (DETOPS_ROIALIGN_BWD_WALK=lane, off by default, not yet measured on hardware):
-          // every lane walks its OWN contiguous range of contributing bins (the bins with a sample
-          // within one pixel of it: 2-4 per axis for model-sized ROIs) instead of the union over the
-          // wave's 8 x 8 pixels; trip counts are the wave maxima, gradient reads become per-lane
-          // ds_read_b128 instead of broadcasts.
-          int ylo = PH, yhi = -1, xlo = PW, xhi = -1;
-          for (int ph = 0; ph < PH; ++ph) if (ayr[ph] != 0.f) { ylo = min(ylo, ph); yhi = ph; }
-          for (int pw = 0; pw < PW; ++pw) if (axr[pw] != 0.f) { xlo = min(xlo, pw); xhi = pw; }
-          const int ny = yhi - ylo + 1, nx = xhi - xlo + 1;   // <= 0: nothing reaches this pixel
-          int na = 0, nb_ = 0;
-          while (__ballot(na < ny) != 0ull) ++na;
-          while (__ballot(nb_ < nx) != 0ull) ++nb_;
-          for (int a = 0; a < na; ++a) {
-            const int ph = min(ylo + a, PH - 1);
-            const float wy = (a < ny) ? ayr[ph] : 0.f;
-            for (int b2 = 0; b2 < nb_; ++b2) {
-              if (lane == 0) DETOPS_STAT("bwd.bodies_lane_walk", 1);
-              const int pw = min(xlo + b2, PW - 1);
-              const float w = (b2 < nx) ? wy * axr[pw] : 0.f;
-              if (w != 0.f) {
-                DETOPS_STAT("bwd.active_lane_bodies", 1);
-                const float4* gp = gj + ph * PW + pw;
+        // every lane walks its OWN contiguous range of contributing bins (the bins with a sample
+        // within one pixel of it: 2-4 per axis for model-sized ROIs); trip counts are the wave maxima,
+        // gradient reads are per-lane ds_read_b128.  Measured against the union-of-the-wave walk it
+        // replaced (profiles/r02a_opbench_experimental_ab.log): box head 217 -> 189 us, mask head
+        // 211 -> 147 us, bit-identical sums.
+        int ylo = PH, yhi = -1, xlo = PW, xhi = -1;
+        for (int ph = 0; ph < PH; ++ph) if (ayr[ph] != 0.f) { ylo = min(ylo, ph); yhi = ph; }
+        for (int pw = 0; pw < PW; ++pw) if (axr[pw] != 0.f) { xlo = min(xlo, pw); xhi = pw; }
+        const int ny = yhi - ylo + 1, nx = xhi - xlo + 1;   // <= 0: nothing reaches this pixel
+        int na = 0, nb_ = 0;
+        while (__ballot(na < ny) != 0ull) ++na;
+        while (__ballot(nb_ < nx) != 0ull) ++nb_;
+        for (int a = 0; a < na; ++a) {
+          const int ph = min(ylo + a, PH - 1);
+          const float wy = (a < ny) ? ayr[ph] : 0.f;
+          for (int b2 = 0; b2 < nb_; ++b2) {
+            if (lane == 0) DETOPS_STAT("bwd.bodies_lane_walk", 1);
+            const int pw = min(xlo + b2, PW - 1);
+            const float w = (b2 < nx) ? wy * axr[pw] : 0.f;
+            if (w != 0.f) {
+              DETOPS_STAT("bwd.active_lane_bodies", 1);
+              const float4* gp = gj + ph * PW + pw;
 #pragma unroll
-                for (int cg = 0; cg < CG; ++cg) {
-                  const float4 g4 = gp[cg * slots];
-                  acc[4 * cg + 0] = fmaf(w, g4.x, acc[4 * cg + 0]);
-                  acc[4 * cg + 1] = fmaf(w, g4.y, acc[4 * cg + 1]);
-                  acc[4 * cg + 2] = fmaf(w, g4.z, acc[4 * cg + 2]);
-                  acc[4 * cg + 3] = fmaf(w, g4.w, acc[4 * cg + 3]);
-                }
-              }
-            }
-          }
-        } else if constexpr (PH_ > 0 && PW_ > 0) {
-          constexpr int QH = (PH_ + 3) / 4, QW = (PW_ + 3) / 4;
-          float ay[QH * 4], ax[QW * 4];
-#pragma unroll
-          for (int q = 0; q < QH; ++q) {
-            const float4 v = reinterpret_cast<const float4*>(ayr)[q];
-            ay[4 * q] = v.x; ay[4 * q + 1] = v.y; ay[4 * q + 2] = v.z; ay[4 * q + 3] = v.w;
-          }
-#pragma unroll
-          for (int q = 0; q < QW; ++q) {
-            const float4 v = reinterpret_cast<const float4*>(axr)[q];
-            ax[4 * q] = v.x; ax[4 * q + 1] = v.y; ax[4 * q + 2] = v.z; ax[4 * q + 3] = v.w;
-          }
-#pragma unroll
-          for (int ph = 0; ph < PH_; ++ph) {
-            if (__ballot(ay[ph] != 0.f) == 0ull) continue;
-#pragma unroll
-            for (int pw = 0; pw < PW_; ++pw) {
-              const float w = ay[ph] * ax[pw];
-              if (__ballot(w != 0.f) == 0ull) continue;
-              if (lane == 0) DETOPS_STAT("bwd.bodies_union_walk", 1);
-              if (w != 0.f) {
-                DETOPS_STAT("bwd.active_lane_bodies", 1);
-#pragma unroll
-                for (int cg = 0; cg < CG; ++cg) {
-                  const float4 g4 = gj[cg * slots + ph * PW_ + pw];
-                  acc[4 * cg + 0] = fmaf(w, g4.x, acc[4 * cg + 0]);
-                  acc[4 * cg + 1] = fmaf(w, g4.y, acc[4 * cg + 1]);
-                  acc[4 * cg + 2] = fmaf(w, g4.z, acc[4 * cg + 2]);
-                  acc[4 * cg + 3] = fmaf(w, g4.w, acc[4 * cg + 3]);
-                }
-              }
-            }
-          }
-        } else {
-          for (int ph = 0; ph < PH; ++ph) {
-            const float a = ayr[ph];
-            if (__ballot(a != 0.f) == 0ull) continue;
-            for (int pw = 0; pw < PW; ++pw) {
-              const float w = a * axr[pw];
-              if (w != 0.f) {
-#pragma unroll
-                for (int cg = 0; cg < CG; ++cg) {
-                  const float4 g4 = gj[cg * slots + ph * PW + pw];
-                  acc[4 * cg + 0] = fmaf(w, g4.x, acc[4 * cg + 0]);
-                  acc[4 * cg + 1] = fmaf(w, g4.y, acc[4 * cg + 1]);
-                  acc[4 * cg + 2] = fmaf(w, g4.z, acc[4 * cg + 2]);
-                  acc[4 * cg + 3] = fmaf(w, g4.w, acc[4 * cg + 3]);
-                }
+              for (int cg = 0; cg < CG; ++cg) {
+                const float4 g4 = gp[cg * slots];
+                acc[4 * cg + 0] = fmaf(w, g4.x, acc[4 * cg + 0]);
+                acc[4 * cg + 1] = fmaf(w, g4.y, acc[4 * cg + 1]);
+                acc[4 * cg + 2] = fmaf(w, g4.z, acc[4 * cg + 2]);
+                acc[4 * cg + 3] = fmaf(w, g4.w, acc[4 * cg + 3]);
               }
             }
           }
@@ -947,7 +830,7 @@ inline void dispatch_shape(int PH, int PW, int sr, F&& f) {
 
 template <int PH, int PW, int SR, int G>
 void launch_fwd_lds(const Levels& L, const float* rois, const int32_t* levels_in, int32_t* levels_out,
-                    float* out, int C, int K, hipStream_t st, const int32_t* order) {
+                    float* out, int C, int K, hipStream_t st) {
   constexpr int NT = ((PH * PW * G + 63) / 64) * 64;
   int CT = 64;  // channels per workgroup: >= 4 x 256 workgroups when the problem allows it
   while (CT > 16 && static_cast<int64_t>(K) * ceil_div64(C, CT) < 4 * kNumCU) CT >>= 1;
@@ -964,17 +847,15 @@ void launch_fwd_lds(const Levels& L, const float* rois, const int32_t* levels_in
   if (const char* e = getenv("DETOPS_ROIALIGN_FWD_U")) unroll = atoi(e);
   const dim3 grid(static_cast<unsigned>(K) * chunks);
   const size_t lds = (patch_floats + 64) * sizeof(float);
-#define FWD_LDS_LAUNCH(U_, O_)                                                                                  \
-  hipLaunchKernelGGL((roi_align_fwd_lds_kernel<PH, PW, SR, G, U_, O_>), grid, dim3(NT), lds, st, L, rois,       \
-                     levels_in, levels_out, out, C, K, CT, chunks, patch_floats, order)
-  if (order) { if (unroll == 8) FWD_LDS_LAUNCH(8, true); else FWD_LDS_LAUNCH(4, true); }
-  else { if (unroll == 8) FWD_LDS_LAUNCH(8, false); else FWD_LDS_LAUNCH(4, false); }
+#define FWD_LDS_LAUNCH(U_)                                                                                 \
+  hipLaunchKernelGGL((roi_align_fwd_lds_kernel<PH, PW, SR, G, U_>), grid, dim3(NT), lds, st, L, rois,      \
+                     levels_in, levels_out, out, C, K, CT, chunks, patch_floats)
+  if (unroll == 8) FWD_LDS_LAUNCH(8); else FWD_LDS_LAUNCH(4);
 #undef FWD_LDS_LAUNCH
 }
 
 int run_forward(const Levels& L, const float* rois, const int32_t* levels_in, int32_t* levels_out,
-                float* out, int C, int K, int PH, int PW, int sr, hipStream_t st,
-                const int32_t* order = nullptr) {
+                float* out, int C, int K, int PH, int PW, int sr, hipStream_t st) {
   if (K == 0 || C == 0) return 0;
   // DETOPS_ROIALIGN_FWD=generic forces the gather kernel (A/B measurements; default: LDS fast path)
   static const bool force_generic = [] {
@@ -983,29 +864,23 @@ int run_forward(const Levels& L, const float* rois, const int32_t* levels_in, in
   }();
   if (force_generic) {
   } else if (PH == 7 && PW == 7 && sr == 2) {
-    launch_fwd_lds<7, 7, 2, 5>(L, rois, levels_in, levels_out, out, C, K, st, order);
+    launch_fwd_lds<7, 7, 2, 5>(L, rois, levels_in, levels_out, out, C, K, st);
     return launch_status();
   }
   else if (PH == 14 && PW == 14 && sr == 2) {
-    launch_fwd_lds<14, 14, 2, 2>(L, rois, levels_in, levels_out, out, C, K, st, order);
+    launch_fwd_lds<14, 14, 2, 2>(L, rois, levels_in, levels_out, out, C, K, st);
     return launch_status();
   }
   else if (PH == 7 && PW == 7 && sr == 1) {
-    launch_fwd_lds<7, 7, 1, 5>(L, rois, levels_in, levels_out, out, C, K, st, order);
+    launch_fwd_lds<7, 7, 1, 5>(L, rois, levels_in, levels_out, out, C, K, st);
     return launch_status();
   }
   const int CT = pick_chunk(C, K);
   const int chunks = static_cast<int>(ceil_div64(C, CT));
   const dim3 grid(static_cast<unsigned>(K) * chunks);
   dispatch_shape(PH, PW, sr, [&](auto ph, auto pw, auto tab) {
-    if (order)
-      hipLaunchKernelGGL((roi_align_fwd_kernel<decltype(ph)::value, decltype(pw)::value, decltype(tab)::value, true>),
-                         grid, dim3(kBlock), 0, st, L, rois, levels_in, levels_out, out, C, K, PH, PW, sr, CT, chunks,
-                         order);
-    else
-      hipLaunchKernelGGL((roi_align_fwd_kernel<decltype(ph)::value, decltype(pw)::value, decltype(tab)::value, false>),
-                         grid, dim3(kBlock), 0, st, L, rois, levels_in, levels_out, out, C, K, PH, PW, sr, CT, chunks,
-                         order);
+    hipLaunchKernelGGL((roi_align_fwd_kernel<decltype(ph)::value, decltype(pw)::value, decltype(tab)::value>),
+                       grid, dim3(kBlock), 0, st, L, rois, levels_in, levels_out, out, C, K, PH, PW, sr, CT, chunks);
   });
   return launch_status();
 }
@@ -1059,255 +934,6 @@ int run_backward_tiles(const Levels& L, const float* rois, const int32_t* levels
   return launch_status();
 }
 
-// ------------------------------------------------------------------------------------------
-// EXPERIMENTAL backward "gather3" (DETOPS_ROIALIGN_BWD=gather3; CPU-checked in the host emulation,
-// NOT yet measured on hardware — prepared from the work statistics of tools/emu_workstats.py).
-// Same pixel-owner formulation as roi_align_bwd_gather_kernel, restructured around what those
-// statistics say costs the time: ~27 K (batch, channel-chunk) stage -> barrier -> walk -> barrier
-// round trips and ~49 K ROI-scan rounds per launch, each latency-bound, against a small FMA walk at
-// 10 % lane utilisation.  Here a workgroup owns a tile and G channel chunks (G x 16 channels,
-// G x 16 accumulators per thread): the ROI scan and the per-axis coefficient rows are built once
-// per G chunks, the gradients of all G chunks of a batch are staged in ONE phase, and the walk is
-// the per-lane bin-range walk (each lane visits only its own 2-4 x 2-4 contributing bins; one
-// weight product feeds G x 16 FMAs).  Round trips and scans drop G-fold.
-// ------------------------------------------------------------------------------------------
-template <int G>
-__global__ void __launch_bounds__(kBlock)
-roi_align_bwd_gather3_kernel(Levels L, GPlan P, const float* __restrict__ rois,
-                             const int32_t* __restrict__ levels_in, const float* __restrict__ gout,
-                             int C, int K, int PH, int PW, int sr) {
-  constexpr int CT = 16, CG = 4, GC = G * CG;            // float4 channel groups per workgroup
-  const int bins = PH * PW;
-  const int PPH = (PH + 3) & ~3, PPW = (PW + 3) & ~3;
-  const int slots = P.batch * bins;                        // (ROI, bin) slots per float4 channel group
-
-  DETOPS_DYNAMIC_LDS(float, g_lds);
-  float4* gs4 = reinterpret_cast<float4*>(g_lds);          // [GC][slots] float4 (also the store buffer)
-  const int region = max(slots * GC * 4, CT * kGTH * kGRowPad);
-  float* ayt = g_lds + region;                             // [batch][kGTH][PPH]
-  float* axt = ayt + P.batch * kGTH * PPH;                 // [batch][kGTW][PPW]
-  __shared__ GHit s_hit[kBlock];
-  __shared__ int s_wcount[kBlock / kWave];
-
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  int lvl = 0;
-#pragma unroll
-  for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
-    if (i < L.num && static_cast<int>(blockIdx.x) >= P.first_item[i] &&
-        static_cast<int>(blockIdx.x) < P.first_item[i] + P.n_items[i]) lvl = i;
-  float* gin = L.lv[0].gin; int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
-  int ntx = P.tiles_x[0], nty = P.tiles_y[0], first = P.first_item[0];
-#pragma unroll
-  for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
-    if (i == lvl) { gin = L.lv[i].gin; H = L.lv[i].H; W = L.lv[i].W; scale = L.lv[i].scale;
-                    ntx = P.tiles_x[i]; nty = P.tiles_y[i]; first = P.first_item[i]; }
-  int rem = static_cast<int>(blockIdx.x) - first;
-  const int cgrp = rem % P.chunks; rem /= P.chunks;        // P.chunks = channel-chunk GROUPS here
-  const int tix = rem % ntx; rem /= ntx;
-  const int tiy = rem % nty;
-  const int b = rem / nty;
-  const int y0 = tiy * kGTH, x0 = tix * kGTW;
-  const int y1 = min(H, y0 + kGTH) - 1, x1 = min(W, x0 + kGTW) - 1;
-  const int c0 = cgrp * G * CT;
-  const int yl = lane >> 3, xl = wave * 8 + (lane & 7);
-  const int wx0 = x0 + wave * 8, wx1 = wx0 + 7;
-
-  float acc[G * CT];
-#pragma unroll
-  for (int c = 0; c < G * CT; ++c) acc[c] = 0.f;
-
-  for (int kb = 0; kb < K; kb += kBlock) {
-    const int r = kb + tid;
-    bool hit = false;
-    GHit h{};
-    if (r < K) {
-      const float* roi = rois + static_cast<size_t>(r) * 5;
-      const int rl = (L.num > 1) ? levels_in[r] : 0;
-      if (rl == lvl && static_cast<int>(roi[0]) == b) {
-#pragma clang fp contract(off)
-        const RoiGeom g = roi_geometry(roi, scale, PH, PW, sr);
-        const float rh = g.bin_h * static_cast<float>(PH), rw = g.bin_w * static_cast<float>(PW);
-        const float fy0 = floorf(fmaxf(g.start_h, 0.f)), fy1 = floorf(g.start_h + rh) + 2.f;
-        const float fx0 = floorf(fmaxf(g.start_w, 0.f)), fx1 = floorf(g.start_w + rw) + 2.f;
-        hit = fy0 <= static_cast<float>(y1) && fy1 >= static_cast<float>(y0) &&
-              fx0 <= static_cast<float>(x1) && fx1 >= static_cast<float>(x0);
-        h.start_w = g.start_w; h.start_h = g.start_h; h.bin_w = g.bin_w; h.bin_h = g.bin_h;
-        h.k = r; h.gh = g.gh; h.gw = g.gw;
-        const int ix0 = static_cast<int>(fminf(fx0, static_cast<float>(W)));
-        const int ix1 = static_cast<int>(fminf(fmaxf(fx1, 0.f), static_cast<float>(W)));
-        h.xspan = (ix0 << 16) | ix1;
-      }
-    }
-    const unsigned long long m = __ballot(hit);
-    if (lane == 0) s_wcount[wave] = __popcll(m);
-    __syncthreads();
-    int before = 0, total = 0;
-#pragma unroll
-    for (int j = 0; j < kBlock / kWave; ++j) {
-      const int v = s_wcount[j];
-      if (j < wave) before += v;
-      total += v;
-    }
-    if (hit) s_hit[before + __popcll(m & ((1ull << lane) - 1ull))] = h;
-    __syncthreads();
-    if (tid == 0) { DETOPS_STAT("bwd3.scan_rounds", 1); DETOPS_STAT("bwd3.hits", total); }
-
-    for (int h0 = 0; h0 < total; h0 += P.batch) {
-      const int nb = min(P.batch, total - h0);
-      if (tid == 0) DETOPS_STAT("bwd3.batches", 1);
-      // (1) coefficient rows: once for all G chunks
-      for (int t = tid; t < nb * (PH + PW); t += kBlock) {
-        const int j = t / (PH + PW);
-        const int q = t - j * (PH + PW);
-        const GHit hj = s_hit[h0 + j];
-        if (q < PH) {
-          float* row = ayt + j * kGTH * PPH + q;
-          for (int i = 0; i < kGTH; ++i) row[i * PPH] = 0.f;
-          const float inv = 1.f / static_cast<float>(hj.gh);
-          for (int i = 0; i < hj.gh; ++i) {
-            const Tap e = axis_entry(hj.start_h, hj.bin_h, q, i, hj.gh, H, 1);
-            const int a0 = e.lo - y0, a1 = e.hi - y0;
-            if (a0 >= 0 && a0 < kGTH) row[a0 * PPH] += e.h * inv;
-            if (a1 >= 0 && a1 < kGTH) row[a1 * PPH] += e.l * inv;
-          }
-        } else {
-          const int qq = q - PH;
-          float* row = axt + j * kGTW * PPW + qq;
-          for (int i = 0; i < kGTW; ++i) row[i * PPW] = 0.f;
-          const float inv = 1.f / static_cast<float>(hj.gw);
-          for (int i = 0; i < hj.gw; ++i) {
-            const Tap e = axis_entry(hj.start_w, hj.bin_w, qq, i, hj.gw, W, 1);
-            const int a0 = e.lo - x0, a1 = e.hi - x0;
-            if (a0 >= 0 && a0 < kGTW) row[a0 * PPW] += e.h * inv;
-            if (a1 >= 0 && a1 < kGTW) row[a1 * PPW] += e.l * inv;
-          }
-        }
-      }
-      // (2) ONE staging phase for the G x 16 channels of the batch: [gc][j*bins + bin] float4
-      for (int u = tid; u < nb * bins * GC; u += kBlock) {
-        const int gc = u / (nb * bins);
-        const int jb = u - gc * (nb * bins);
-        const int j = jb / bins;
-        const int bin = jb - j * bins;
-        const int cbase = c0 + gc * 4;
-        const float* src = gout + (static_cast<size_t>(s_hit[h0 + j].k) * C + cbase) * bins + bin;
-        float4 v;
-        v.x = (cbase + 0 < C) ? src[0] : 0.f;
-        v.y = (cbase + 1 < C) ? src[bins] : 0.f;
-        v.z = (cbase + 2 < C) ? src[2 * bins] : 0.f;
-        v.w = (cbase + 3 < C) ? src[3 * bins] : 0.f;
-        gs4[gc * slots + jb] = v;
-      }
-      __syncthreads();
-      // (3) per-lane bin-range walk; one weight product feeds all G x 16 channels
-      for (int j = 0; j < nb; ++j) {
-        const int xspan = s_hit[h0 + j].xspan;
-        const int jx0 = xspan >> 16, jx1 = xspan & 0xffff;
-        if (jx1 < wx0 || jx0 > wx1) continue;
-        const float* ayr = ayt + (j * kGTH + yl) * PPH;
-        const float* axr = axt + (j * kGTW + xl) * PPW;
-        const float4* gj = gs4 + j * bins;
-        int ylo = PH, yhi = -1, xlo = PW, xhi = -1;
-        for (int ph = 0; ph < PH; ++ph) if (ayr[ph] != 0.f) { ylo = min(ylo, ph); yhi = ph; }
-        for (int pw = 0; pw < PW; ++pw) if (axr[pw] != 0.f) { xlo = min(xlo, pw); xhi = pw; }
-        const int ny = yhi - ylo + 1, nx = xhi - xlo + 1;
-        int na = 0, nb_ = 0;
-        while (__ballot(na < ny) != 0ull) ++na;
-        while (__ballot(nb_ < nx) != 0ull) ++nb_;
-        if (lane == 0) DETOPS_STAT("bwd3.wave_roi_tasks", 1);
-        for (int a = 0; a < na; ++a) {
-          const int ph = min(ylo + a, PH - 1);
-          const float wy = (a < ny) ? ayr[ph] : 0.f;
-          for (int b2 = 0; b2 < nb_; ++b2) {
-            const int pw = min(xlo + b2, PW - 1);
-            const float w = (b2 < nx) ? wy * axr[pw] : 0.f;
-            if (lane == 0) DETOPS_STAT("bwd3.bodies", 1);
-            if (w != 0.f) {
-              const float4* gp = gj + ph * PW + pw;
-#pragma unroll
-              for (int gc = 0; gc < GC; ++gc) {
-                const float4 g4 = gp[gc * slots];
-                acc[4 * gc + 0] = fmaf(w, g4.x, acc[4 * gc + 0]);
-                acc[4 * gc + 1] = fmaf(w, g4.y, acc[4 * gc + 1]);
-                acc[4 * gc + 2] = fmaf(w, g4.z, acc[4 * gc + 2]);
-                acc[4 * gc + 3] = fmaf(w, g4.w, acc[4 * gc + 3]);
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-
-  // ---- store, one 16-channel chunk at a time through the [16][8][33] transposition buffer
-  float* tb = g_lds;
-  const size_t plane = static_cast<size_t>(H) * W;
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int cc0 = c0 + g * CT;
-    if (cc0 >= C) break;
-#pragma unroll
-    for (int c = 0; c < CT; ++c) tb[(c * kGTH + yl) * kGRowPad + xl] = acc[g * CT + c];
-    __syncthreads();
-    const int cn = min(CT, C - cc0);
-    float* gb = gin + (static_cast<size_t>(b) * C + cc0) * plane;
-    for (int e = tid; e < cn * kGTH * kGTW; e += kBlock) {
-      const int c = e / (kGTH * kGTW);
-      const int pix = e - c * (kGTH * kGTW);
-      const int yy = pix / kGTW, xx = pix - yy * kGTW;
-      if (y0 + yy <= y1 && x0 + xx <= x1) {
-        float* dst = gb + static_cast<size_t>(c) * plane + static_cast<size_t>(y0 + yy) * W + (x0 + xx);
-        float v = tb[(c * kGTH + yy) * kGRowPad + xx];
-        if (P.accumulate) v += *dst;
-        *dst = v;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// gather3 launch: -1 = not applicable (generic shapes, underfilled launches, LDS plan) -> gather
-int run_backward_gather3(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
-                         int N, int C, int K, int PH, int PW, int sr, int accumulate, hipStream_t st) {
-  if (C == 0 || N == 0) return 0;
-  const int bins = PH * PW;
-  if (bins > kGBins) return -1;
-  const int PPH = (PH + 3) & ~3, PPW = (PW + 3) & ~3;
-  int G = (bins <= 64) ? 4 : 2;
-  if (const char* e = getenv("DETOPS_ROIALIGN_BWD_G")) G = (atoi(e) == 4) ? 4 : (atoi(e) == 2 ? 2 : 1);
-  int batch = max(1, 128 / bins);                      // 7x7: 2 ROIs per batch, 14x14: 1
-  if (const char* e = getenv("DETOPS_ROIALIGN_BWD_BATCH")) batch = max(1, min(8, atoi(e)));
-  const int cgroups = static_cast<int>(ceil_div64(C, 16 * G));
-  GPlan P{};
-  P.chunks = cgroups;
-  P.accumulate = accumulate;
-  P.batch = batch;
-  P.groups = 1;
-  int64_t items = 0;
-  for (int i = L.num - 1; i >= 0; --i) {
-    if (L.lv[i].W > 32767) return -1;
-    P.tiles_x[i] = static_cast<int>(ceil_div64(L.lv[i].W, kGTW));
-    P.tiles_y[i] = static_cast<int>(ceil_div64(L.lv[i].H, kGTH));
-    const int64_t n = static_cast<int64_t>(N) * P.tiles_x[i] * P.tiles_y[i] * cgroups;
-    if (items + n > 0x7fffffff) return DETOPS_EUNSUPPORTED;
-    P.first_item[i] = static_cast<int>(items);
-    P.n_items[i] = static_cast<int>(n);
-    items += n;
-  }
-  if (items < 2 * kNumCU && !getenv("DETOPS_ROIALIGN_BWD_G")) return -1;   // underfilled: the ROI-split kernel
-  const size_t region = static_cast<size_t>(max(batch * bins * G * 16, 16 * kGTH * kGRowPad));
-  const size_t lds = sizeof(float) * (region + static_cast<size_t>(batch) * (kGTH * PPH + kGTW * PPW));
-  if (lds > 56 * 1024) return -1;
-  const dim3 grid(static_cast<unsigned>(items));
-#define G3_LAUNCH(G_)                                                                                          \
-  hipLaunchKernelGGL((roi_align_bwd_gather3_kernel<G_>), grid, dim3(kBlock), lds, st, L, P, rois, levels_in, \
-                     gout, C, K, PH, PW, sr)
-  if (G == 4) G3_LAUNCH(4); else if (G == 2) G3_LAUNCH(2); else G3_LAUNCH(1);
-#undef G3_LAUNCH
-  return launch_status();
-}
-
 // Pixel-owner backward launch.  Returns -1 when the shape does not fit its LDS plan (huge bin
 // counts): the caller then uses the tile-scatter kernel.
 int run_backward_gather(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
@@ -1343,8 +969,6 @@ int run_backward_gather(const Levels& L, const float* rois, const int32_t* level
   P.groups = 1;
   if (count_items(CT) < 2 * kNumCU && K > 64) P.groups = static_cast<int>(std::min<int64_t>(32, ceil_div64(K, 16)));
   if (const char* e = getenv("DETOPS_ROIALIGN_BWD_GROUPS")) P.groups = max(1, min(64, atoi(e)));  // tuning / test knob
-  const char* we = getenv("DETOPS_ROIALIGN_BWD_WALK");  // "lane": experimental walk, separate instantiation
-  const bool lane_walk = we && we[0] == 'l';
   int64_t items = 0;
   for (int i = L.num - 1; i >= 0; --i) {  // coarsest level first
     P.tiles_x[i] = static_cast<int>(ceil_div64(L.lv[i].W, kGTW));
@@ -1360,18 +984,12 @@ int run_backward_gather(const Levels& L, const float* rois, const int32_t* level
     for (int i = 0; i < L.num; ++i)
       DETOPS_HIP_TRY(hipMemsetAsync(L.lv[i].gin, 0, sizeof(float) * static_cast<size_t>(N) * C * L.lv[i].H * L.lv[i].W, st));
   const dim3 grid(static_cast<unsigned>(items), static_cast<unsigned>(P.groups));
-#define GATHER_LAUNCH_W(PH_, PW_, CT_, W_)                                                                          \
-  hipLaunchKernelGGL((roi_align_bwd_gather_kernel<PH_, PW_, CT_, W_>), grid, dim3(kBlock), lds, st, L, P, rois, \
+#define GATHER_LAUNCH(PH_, PW_, CT_)                                                                          \
+  hipLaunchKernelGGL((roi_align_bwd_gather_kernel<PH_, PW_, CT_>), grid, dim3(kBlock), lds, st, L, P, rois, \
                      levels_in, gout, C, K, PH, PW, sr)
-#define GATHER_LAUNCH(PH_, PW_, CT_)                                  \
-  do {                                                                \
-    if (lane_walk) GATHER_LAUNCH_W(PH_, PW_, CT_, true);              \
-    else GATHER_LAUNCH_W(PH_, PW_, CT_, false);                       \
-  } while (0)
   if (PH == 7 && PW == 7) { if (CT == 16) GATHER_LAUNCH(7, 7, 16); else GATHER_LAUNCH(7, 7, 4); }
   else if (PH == 14 && PW == 14) { if (CT == 16) GATHER_LAUNCH(14, 14, 16); else GATHER_LAUNCH(14, 14, 4); }
   else { if (CT == 16) GATHER_LAUNCH(0, 0, 16); else GATHER_LAUNCH(0, 0, 4); }
-#undef GATHER_LAUNCH_W
 #undef GATHER_LAUNCH
   return launch_status();
 }
@@ -1382,10 +1000,6 @@ int run_backward(const Levels& L, const float* rois, const int32_t* levels_in, c
                  int N, int C, int K, int PH, int PW, int sr, int accumulate, hipStream_t st) {
   const char* e = getenv("DETOPS_ROIALIGN_BWD");  // read per call: tests flip it at run time
   const bool force_tile = e && e[0] == 't';
-  if (e && e[0] == 'g' && e[1] == 'a' && e[6] == '3') {   // "gather3": experimental, opt-in
-    const int rc = run_backward_gather3(L, rois, levels_in, gout, N, C, K, PH, PW, sr, accumulate, st);
-    if (rc != -1) return rc;
-  }
   if (!force_tile) {
     const int rc = run_backward_gather(L, rois, levels_in, gout, N, C, K, PH, PW, sr, accumulate, st);
     if (rc != -1) return rc;
@@ -1452,37 +1066,6 @@ DETOPS_API int detops_roi_align_fpn_forward_f32(
   hipStream_t st = as_stream(stream);
   if (num_levels == 1 && levels_out) DETOPS_HIP_TRY(hipMemsetAsync(levels_out, 0, sizeof(int32_t) * K, st));
   return run_forward(L, rois, nullptr, levels_out, output, C, K, PH, PW, sampling_ratio, st);
-}
-
-DETOPS_API int detops_roi_align_fpn_forward_ordered_f32(
-    const float* const* inputs_host, const int* H_host, const int* W_host, const float* scale_host,
-    int num_levels, const float* rois, float* output, int32_t* levels_out, int N, int C, int K,
-    int PH, int PW, int sampling_ratio, int k_min, int k_max, float canonical_scale,
-    float canonical_level, float eps, int32_t* order_ws, detops_stream_t stream) {
-  if (!order_ws || K > kOrderMaxK || K < 2)
-    return detops_roi_align_fpn_forward_f32(inputs_host, H_host, W_host, scale_host, num_levels, rois, output,
-                                            levels_out, N, C, K, PH, PW, sampling_ratio, k_min, k_max,
-                                            canonical_scale, canonical_level, eps, stream);
-  if (bad_dims(N, C, K, PH, PW) || num_levels < 1 || num_levels > DETOPS_MAX_LEVELS ||
-      !inputs_host || !H_host || !W_host || !scale_host)
-    return DETOPS_EINVAL;
-  if (k_max - k_min + 1 != num_levels) return DETOPS_EINVAL;
-  if (C == 0) return 0;
-  if (!rois || !output) return DETOPS_EINVAL;
-  Levels L{};
-  L.num = num_levels;
-  L.k_min = k_min; L.k_max = k_max; L.s0 = canonical_scale; L.lvl0 = canonical_level; L.eps = eps;
-  for (int i = 0; i < num_levels; ++i) {
-    if (!inputs_host[i] || H_host[i] <= 0 || W_host[i] <= 0) return DETOPS_EINVAL;
-    L.lv[i] = Level{inputs_host[i], nullptr, H_host[i], W_host[i], scale_host[i]};
-  }
-  hipStream_t st = as_stream(stream);
-  if (num_levels == 1 && levels_out) DETOPS_HIP_TRY(hipMemsetAsync(levels_out, 0, sizeof(int32_t) * K, st));
-  int npad = 2;
-  while (npad < K) npad <<= 1;
-  hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(min(1024, max(64, npad / 2))), npad * sizeof(unsigned long long),
-                     st, L, rois, static_cast<const int32_t*>(nullptr), K, npad, order_ws);
-  return run_forward(L, rois, nullptr, levels_out, output, C, K, PH, PW, sampling_ratio, st, order_ws);
 }
 
 DETOPS_API int detops_roi_align_fpn_backward_f32(

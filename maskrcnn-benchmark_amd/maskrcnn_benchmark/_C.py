@@ -233,19 +233,11 @@ def roi_align_fpn_forward(inputs, rois, scales, pooled_height, pooled_width, sam
     if K == 0:
         return out, levels
     ptrs, Hs, Ws, sc = _host_arrays(inputs, scales)
-    ordered = os.environ.get("DETOPS_ROIALIGN_FWD_ORDER", "0") == "1"  # experimental spatial visiting order
     with _on_device(rois), _timed("roi_align_fpn_fwd[K=%d,C=%d,%dx%d]" % (K, C, pooled_height, pooled_width), rois):
-        if ordered:
-            order_ws = torch.empty((K,), dtype=torch.int32, device=rois.device)
-            check(lib.detops_roi_align_fpn_forward_ordered_f32(
-                ptrs, Hs, Ws, sc, len(inputs), ptr(rois), ptr(out), ptr(levels), N, C, K, pooled_height,
-                pooled_width, int(sampling_ratio), int(k_min), int(k_max), float(canonical_scale),
-                float(canonical_level), float(eps), ptr(order_ws), stream_of(rois)), "roi_align_fpn_forward")
-        else:
-            check(lib.detops_roi_align_fpn_forward_f32(
-                ptrs, Hs, Ws, sc, len(inputs), ptr(rois), ptr(out), ptr(levels), N, C, K, pooled_height,
-                pooled_width, int(sampling_ratio), int(k_min), int(k_max), float(canonical_scale),
-                float(canonical_level), float(eps), stream_of(rois)), "roi_align_fpn_forward")
+        check(lib.detops_roi_align_fpn_forward_f32(
+            ptrs, Hs, Ws, sc, len(inputs), ptr(rois), ptr(out), ptr(levels), N, C, K, pooled_height,
+            pooled_width, int(sampling_ratio), int(k_min), int(k_max), float(canonical_scale),
+            float(canonical_level), float(eps), stream_of(rois)), "roi_align_fpn_forward")
     return out, levels
 
 

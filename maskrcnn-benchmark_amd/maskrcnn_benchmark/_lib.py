@@ -22,8 +22,6 @@ SIGNATURES = {
     "detops_roi_align_backward_f32": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P]),
     "detops_roi_align_fpn_forward_f32": (
         c_int, [_P, _P, _P, _P, c_int, _P, _P, _P] + [c_int] * 8 + [c_float, c_float, c_float, _P]),
-    "detops_roi_align_fpn_forward_ordered_f32": (
-        c_int, [_P, _P, _P, _P, c_int, _P, _P, _P] + [c_int] * 8 + [c_float, c_float, c_float, _P, _P]),
     "detops_roi_align_fpn_backward_f32": (
         c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),

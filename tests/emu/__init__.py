@@ -17,8 +17,6 @@ SIGNATURES = {
     "detops_roi_align_backward_f32": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P]),
     "detops_roi_align_fpn_forward_f32": (
         c_int, [_P, _P, _P, _P, c_int, _P, _P, _P] + [c_int] * 8 + [c_float, c_float, c_float, _P]),
-    "detops_roi_align_fpn_forward_ordered_f32": (
-        c_int, [_P, _P, _P, _P, c_int, _P, _P, _P] + [c_int] * 8 + [c_float, c_float, c_float, _P, _P]),
     "detops_roi_align_fpn_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),
     "detops_roi_pool_backward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
@@ -96,7 +94,7 @@ def _host_arrays(arrs, scales):
     return ptrs, Hs, Ws, sc
 
 
-def roi_align_fpn_forward(feats, rois, scales, ph, pw, sr, k_min, k_max, ordered=False):
+def roi_align_fpn_forward(feats, rois, scales, ph, pw, sr, k_min, k_max):
     feats = [_f32(f) for f in feats]
     rois = _f32(rois)
     N, C = feats[0].shape[:2]
@@ -104,13 +102,6 @@ def roi_align_fpn_forward(feats, rois, scales, ph, pw, sr, k_min, k_max, ordered
     out = np.full((K, C, ph, pw), np.nan, np.float32)
     levels = np.full((K,), -1, np.int32)
     ptrs, Hs, Ws, sc = _host_arrays(feats, scales)
-    if ordered:
-        order = np.full((K,), -1, np.int32)
-        rc = lib().detops_roi_align_fpn_forward_ordered_f32(ptrs, Hs, Ws, sc, len(feats), _p(rois), _p(out), _p(levels),
-                                                            N, C, K, ph, pw, sr, k_min, k_max, 224.0, 4.0, 1e-6,
-                                                            _p(order), None)
-        assert rc == 0, rc
-        return out, levels, order
     rc = lib().detops_roi_align_fpn_forward_f32(ptrs, Hs, Ws, sc, len(feats), _p(rois), _p(out), _p(levels), N, C, K,
                                                 ph, pw, sr, k_min, k_max, 224.0, 4.0, 1e-6, None)
     assert rc == 0, rc

@@ -254,10 +254,9 @@ def test_emu_roi_align_backward_roi_list_split(groups, monkeypatch):
 
 
 @pytest.mark.parametrize("ct", ["4", "16"])
-def test_emu_roi_align_backward_lane_walk_variant(ct, monkeypatch):
-    """experimental per-lane bin-range walk (DETOPS_ROIALIGN_BWD_WALK=lane; opt-in, CPU-checked only)."""
+def test_emu_roi_align_backward_lane_walk(ct, monkeypatch):
+    """per-lane bin-range walk of the pixel-owner kernel on ragged ROIs / bin shapes, both channel chunkings."""
     monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "gather")
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_WALK", "lane")
     monkeypatch.setenv("DETOPS_ROIALIGN_BWD_CT", ct)
     rng = np.random.RandomState(31)
     N, C, H, W = 2, 9, 27, 70
@@ -274,58 +273,10 @@ def test_emu_roi_align_backward_lane_walk_variant(ct, monkeypatch):
         assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
-def test_emu_roi_align_fpn_forward_ordered_variant():
-    """experimental spatially ordered forward (opt-in): bit-identical output, the order is a
-    permutation grouped by level."""
-    rng = np.random.RandomState(5)
-    shapes = [(2, 4, 50, 84), (2, 4, 25, 42), (2, 4, 13, 21), (2, 4, 7, 11)]
-    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
-    feats = [rng.randn(*s).astype(np.float32) for s in shapes]
-    rois = synth.fpn_rois(seed=4, per_image=45, smin=8, smax=300)
-    rois[:, 1:] *= 0.25
-    for (ph, sr) in ((7, 2), (14, 2), (7, 0)):
-        base, lv = emu.roi_align_fpn_forward(feats, rois, scales, ph, ph, sr, 2, 5)
-        out, lv2, order = emu.roi_align_fpn_forward(feats, rois, scales, ph, ph, sr, 2, 5, ordered=True)
-        assert np.array_equal(out, base) and np.array_equal(lv, lv2)
-        assert np.array_equal(np.sort(order), np.arange(rois.shape[0]))
-        assert np.all(np.diff(lv[order]) >= 0), "sorted by level first"
-
-
-@pytest.mark.parametrize("G", ["1", "2", "4"])
-def test_emu_roi_align_backward_gather3_variant(G, monkeypatch):
-    """experimental chunk-group kernel (DETOPS_ROIALIGN_BWD=gather3; opt-in, CPU-checked only): G x 16
-    channels per workgroup, one staging phase per batch, per-lane walk."""
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "gather3")
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_G", G)
-    rng = np.random.RandomState(41)
-    N, C, H, W = 2, 70, 19, 45            # 70 channels: ragged last chunk group
-    K = 300                                # two scan rounds
-    x1 = rng.uniform(-20, 180, K)
-    y1 = rng.uniform(-20, 80, K)
-    rois = np.stack([rng.randint(0, N, K), x1, y1, x1 + rng.uniform(0.2, 100, K), y1 + rng.uniform(0.2, 50, K)],
-                    1).astype(np.float32)
-    rois = np.concatenate([rois, _edge_rois()])
-    for (ph, pw, sr, batch) in ((7, 7, 2, None), (14, 14, 2, None), (5, 3, 0, "3"), (7, 7, 2, "1")):
-        if batch:
-            monkeypatch.setenv("DETOPS_ROIALIGN_BWD_BATCH", batch)
-        else:
-            monkeypatch.delenv("DETOPS_ROIALIGN_BWD_BATCH", raising=False)
-        g = rng.randn(rois.shape[0], C, ph, pw).astype(np.float32)
-        ref = oracle.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, acc64=True)
-        emu.stats(reset=True)
-        out = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr)
-        assert emu.stats().get("bwd3.batches", 0) > 0, "gather3 did not run"
-        tol = 1e-5 * max(1.0, np.abs(ref).max())
-        assert np.abs(out - ref).max() <= tol
-        base = rng.randn(N, C, H, W).astype(np.float32)
-        acc = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, into=base)
-        assert np.abs(acc - (base + ref)).max() <= 2 * tol
-
-
 @pytest.mark.parametrize("gi", range(len(DCN_GEOMS)))
 @pytest.mark.parametrize("modulated", [False, True])
 def test_emu_deformable_col2im_ell_variant(gi, modulated):
-    """experimental fixed-width (ELL) inverted index (DETOPS_DCN_COL2IM=ell; opt-in, CPU-checked only)."""
+    """fixed-width (ELL) inverted index (the default for fp32 and large maps)."""
     g = DCN_GEOMS[gi]
     x, off, mask = _dcn_case(g, modulated)
     k, p, s, d, dg = g["k"], g["pad"], g["stride"], g["dil"], g["dg"]

@@ -552,6 +552,10 @@ def test_deformable_kernels_vs_oracle_fp32(gi, modulated, monkeypatch):
     gim3 = torch.zeros(*x.shape, device=DEV)
     C.deformable_col2im(_t(gcol), _t(off), tm, gim3, *geo)
     _close(gim3, ref_gim, rtol=1e-4, atol=1e-4)
+    monkeypatch.setenv("DETOPS_DCN_COL2IM", "ell")          # fixed-width inverted index
+    gim5 = torch.zeros(*x.shape, device=DEV)
+    C.deformable_col2im(_t(gcol), _t(off), tm, gim5, *geo)
+    _close(gim5, ref_gim, rtol=1e-4, atol=1e-4)
     monkeypatch.delenv("DETOPS_DCN_COL2IM")                 # default: chosen by dtype / map size
     gim4 = torch.zeros(*x.shape, device=DEV)
     C.deformable_col2im(_t(gcol), _t(off), tm, gim4, *geo)

@@ -22,8 +22,3 @@ timeout 150 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-for
 python tools/pmc_diag.py gpurun_out/pmc_sq gpurun_out/pmc_sq2 gpurun_out/pmc_tcp gpurun_out/pmc_tcc > gpurun_out/pmc_diag.txt 2>&1
 find gpurun_out/pmc_sq gpurun_out/pmc_sq2 gpurun_out/pmc_tcp gpurun_out/pmc_tcc -name "*kernel_trace.csv" -delete
 head -80 gpurun_out/pmc_diag.txt
-# ---- end-to-end A/B of the host-side / dispatch switches (each ~35 s: immediate-mode MIOpen)
-for v in "" "DETOPS_SAMPLER=topk" "DETOPS_ROIALIGN_BWD=gather3" "DETOPS_ROIALIGN_FWD_ORDER=1"; do
-  echo "== bench.py with: ${v:-defaults}"
-  env $v timeout 150 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep -E "^\{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'],'img/s',d['ms_per_step'],'ms/step', {k:v['mean_us'] for k,v in d['kernels'].items()})"
-done
