@@ -35,14 +35,20 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="e2e_mask_rcnn_R_50_FPN_1x.yaml")
     ap.add_argument("--dtype", default=None, help="override cfg.DTYPE (float32 | bfloat16 | float16)")
     ap.add_argument("--images-per-gpu", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="N = 1 only: wrap the model in DDP over a 1-rank RCCL group so the overlapped-SGD hook "
+                         "(bucket all-reduce -> update in the completion callback on a side stream) is what runs")
+    ap.add_argument("--allow-ddp-fallback", action="store_true",
+                    help="if the overlapped hook raises in the first distributed step, retry with stock DDP "
+                         "(reported in \"ddp\"); default: fail loudly")
     ap.add_argument("--miopen-search", action="store_true",
                     help="torch.backends.cudnn.benchmark = True: MIOpen times every applicable conv solver per "
                          "shape in warm-up (minutes from a cold kernel cache on a fresh box — measured >5 min for "
@@ -218,6 +224,9 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", init_method="env://")
+    elif args.force_ddp:
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % (29500 + os.getpid() % 400),
+                                rank=0, world_size=1)
 
     from maskrcnn_benchmark import _C
     from maskrcnn_benchmark.engine.bench_step import build_training, load_cfg, make_device_batches
@@ -237,7 +246,8 @@ def main():
         if rank == 0:
             print("[bench %6.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
-    model, optimizer, scheduler, step = build_training(cfg, device, distributed, local_rank)
+    model, optimizer, scheduler, step = build_training(cfg, device, distributed, local_rank,
+                                                       force_ddp=args.force_ddp and not distributed)
     if args.channels_last:
         model.to(memory_format=torch.channels_last)
     batches = make_device_batches(cfg, device, images_per_gpu=args.images_per_gpu, num_batches=2, seed=rank)
@@ -254,16 +264,16 @@ def main():
 
     progress("model + %d device batches ready" % len(batches))
     losses = None
-    ddp_mode = "overlapped-sgd-hook" if distributed else "single"
+    ddp_mode = "overlapped-sgd-hook" if (distributed or args.force_ddp) else "single"
     for i in range(args.warmup):
         try:
             losses = step(*batches[i % len(batches)])
             torch.cuda.synchronize(device)
         except Exception as e:  # noqa: BLE001
-            # Safety net for the N > 1 path (only gloo world-2 runs exist of the overlapped hook): a
-            # Python-level failure in the first step falls back to stock DDP (all-reduce, then the
-            # optimizer after backward) instead of losing the scaling measurement.  Reported below.
-            if not distributed or i > 0 or ddp_mode != "overlapped-sgd-hook":
+            # Opt-in (--allow-ddp-fallback) safety net for the N > 1 path: a Python-level failure of the
+            # overlapped hook in the first step falls back to stock DDP (all-reduce, then the optimizer
+            # after backward).  Off by default: a scaling run must measure the design DESIGN.md describes.
+            if not args.allow_ddp_fallback or not distributed or i > 0 or ddp_mode != "overlapped-sgd-hook":
                 raise
             progress("overlapped DDP hook failed (%r): falling back to plain DDP" % (e,))
             ddp_mode = "plain-ddp (fallback: %s)" % type(e).__name__
@@ -343,7 +353,7 @@ def main():
             except Exception as e:  # the baseline is a reported extra; never lose the bench line
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
-    if distributed:
+    if distributed or args.force_ddp:
         dist.destroy_process_group()
 
 

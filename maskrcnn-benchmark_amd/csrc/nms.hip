@@ -10,7 +10,7 @@
 //   1. sort      one workgroup per segment: 64-bit keys (~orderable(score) << 32 | index) sorted
 //                ascending by an LDS bitonic network (n <= 8192) — score descending, ties by
 //                ascending index (stable, like the CPU sort); gathers boxes + areas in order.
-//                (n > 8192, single-segment only: hipCUB radix sort of the same keys.)
+//                (n > 8192: one hipCUB radix sort of the same keys per segment.)
 //   2. mask      64x64 tiles, one wavefront per tile, upper triangle only: lane r holds row box r,
 //                the 64 column boxes sit in LDS; bit c of word (row, colblock) = IoU >= thr.
 //                IoU arithmetic follows nms_cpu.cpp:49-60 operation by operation with FP
@@ -108,22 +108,32 @@ nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ score
   }
 }
 
-// large-n path (single segment): keys -> hipcub sort -> gather
-__global__ void nms_make_keys_kernel(const float* __restrict__ scores, int n, u64* __restrict__ keys) {
+// large-n path (n > 8192, any number of segments): per-segment key rows padded to `stride` with
+// ~0 keys -> one hipcub radix sort per segment (host loop; the reference's non-FPN configs have one
+// 12000-candidate problem per image) -> gather.  blockIdx.y = segment.
+__global__ void nms_make_keys_kernel(const float* __restrict__ scores, const int32_t* __restrict__ seg_offsets,
+                                     int n_single, int stride, u64* __restrict__ keys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) keys[i] = make_key(scores[i], static_cast<unsigned>(i));
+  const int s = blockIdx.y;
+  if (i >= stride) return;
+  const SegView sv = seg_view(seg_offsets, n_single, s);
+  keys[static_cast<size_t>(s) * stride + i] =
+      (i < sv.n) ? make_key(scores[sv.begin + i], static_cast<unsigned>(i)) : ~0ull;
 }
 
-__global__ void nms_gather_kernel(const float* __restrict__ boxes, const u64* __restrict__ keys, int n,
-                                  Work w) {
+__global__ void nms_gather_kernel(const float* __restrict__ boxes, const u64* __restrict__ keys,
+                                  const int32_t* __restrict__ seg_offsets, int n_single, Work w) {
 #pragma clang fp contract(off)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int src = static_cast<int>(keys[i] & 0xffffffffu);
-  const float4 b = reinterpret_cast<const float4*>(boxes)[src];
-  w.boxes[i] = b;
-  w.areas[i] = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
-  w.order[i] = src;
+  const int s = blockIdx.y;
+  const SegView sv = seg_view(seg_offsets, n_single, s);
+  if (i >= sv.n) return;
+  const size_t o = static_cast<size_t>(s) * w.stride + i;
+  const int src = static_cast<int>(keys[o] & 0xffffffffu);
+  const float4 b = (reinterpret_cast<const float4*>(boxes) + sv.begin)[src];
+  w.boxes[o] = b;
+  w.areas[o] = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+  w.order[o] = src;
 }
 
 // ---------------------------------------------------------------------------- 2. IoU bitmask
@@ -369,18 +379,21 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
   } else {
     u64* keys = reinterpret_cast<u64*>(base + l.off_keys);
     u64* keys2 = reinterpret_cast<u64*>(base + l.off_keys2);
-    hipLaunchKernelGGL(nms_make_keys_kernel, dim3((max_n + 255) / 256), dim3(256), 0, st, scores,
-                       max_n, keys);
+    hipLaunchKernelGGL(nms_make_keys_kernel, dim3((max_n + 255) / 256, S), dim3(256), 0, st, scores,
+                       seg_offsets, max_n, max_n, keys);
+    for (int sg = 0; sg < S; ++sg) {
+      u64* k1 = keys + static_cast<size_t>(sg) * max_n;
+      u64* k2 = keys2 + static_cast<size_t>(sg) * max_n;
 #ifndef DETOPS_CPU_EMU
-    size_t cub = l.cub_bytes;
-    DETOPS_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(base + l.off_cub, cub, keys, keys2, max_n, 0,
-                                                     64, st));
+      size_t cub = l.cub_bytes;
+      DETOPS_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(base + l.off_cub, cub, k1, k2, max_n, 0, 64, st));
 #else
-    std::copy(keys, keys + max_n, keys2);
-    std::sort(keys2, keys2 + max_n);
+      std::copy(k1, k1 + max_n, k2);
+      std::sort(k2, k2 + max_n);
 #endif
-    hipLaunchKernelGGL(nms_gather_kernel, dim3((max_n + 255) / 256), dim3(256), 0, st, boxes, keys2,
-                       max_n, w);
+    }
+    hipLaunchKernelGGL(nms_gather_kernel, dim3((max_n + 255) / 256, S), dim3(256), 0, st, boxes, keys2,
+                       seg_offsets, max_n, w);
   }
   int rc = launch_status();
   if (rc) return rc;
@@ -413,7 +426,7 @@ DETOPS_API int detops_nms_f32(const float* boxes, const float* scores, int n, fl
 
 DETOPS_API size_t detops_nms_batched_workspace_bytes(int num_segments, int max_n) {
   if (num_segments <= 0 || max_n <= 0) return 256;
-  return make_layout(num_segments, max_n, false).total;
+  return make_layout(num_segments, max_n, max_n > kSortLdsMax).total;
 }
 
 DETOPS_API int detops_nms_batched_f32(const float* boxes, const float* scores,
@@ -428,7 +441,7 @@ DETOPS_API int detops_nms_batched_f32(const float* boxes, const float* scores,
   if (max_n == 0)
     return static_cast<int>(hipMemsetAsync(num_keep, 0, sizeof(int32_t) * num_segments, st));
   if (!boxes || !scores || !keep) return DETOPS_EINVAL;
-  if (max_n > kSortLdsMax) return DETOPS_EUNSUPPORTED;
+  if (max_n > kScanMaxN) return DETOPS_EUNSUPPORTED;
   return run_nms(boxes, scores, seg_offsets, num_segments, max_n, threshold, keep, num_keep,
                  nullptr, workspace, workspace_bytes, st);
 }
@@ -445,7 +458,7 @@ DETOPS_API int detops_nms_batched_mask_f32(const float* boxes, const float* scor
   if (max_n == 0)
     return static_cast<int>(hipMemsetAsync(num_keep, 0, sizeof(int32_t) * num_segments, st));
   if (!boxes || !scores || !keep_mask) return DETOPS_EINVAL;
-  if (max_n > kSortLdsMax) return DETOPS_EUNSUPPORTED;
+  if (max_n > kScanMaxN) return DETOPS_EUNSUPPORTED;
   return run_nms(boxes, scores, seg_offsets, num_segments, max_n, threshold, nullptr, num_keep,
                  keep_mask, workspace, workspace_bytes, st);
 }

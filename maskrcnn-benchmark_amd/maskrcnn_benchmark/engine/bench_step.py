@@ -25,16 +25,18 @@ def load_cfg(config_file, opts=()):
     return cfg
 
 
-def build_training(cfg, device, distributed=False, local_rank=0, overlap_optimizer=True):
-    """-> (model (DDP-wrapped when distributed), optimizer, scheduler, TrainStep)."""
+def build_training(cfg, device, distributed=False, local_rank=0, overlap_optimizer=True, force_ddp=False):
+    """-> (model (DDP-wrapped when distributed), optimizer, scheduler, TrainStep).  `force_ddp` wraps
+    even at world size 1 (the process group must exist)."""
     model = build_detection_model(cfg).to(device)
     model.train()
     optimizer = make_overlapped_sgd(cfg, model)
     scheduler = make_lr_scheduler(cfg, optimizer)
     fp16 = cfg.DTYPE == "float16"
-    if distributed:
+    if distributed or force_ddp:
         ids = [local_rank] if torch.device(device).type == "cuda" else None
-        model = wrap_data_parallel(model, optimizer, device_ids=ids, overlap_optimizer=overlap_optimizer and not fp16)
+        model = wrap_data_parallel(model, optimizer, device_ids=ids, overlap_optimizer=overlap_optimizer and not fp16,
+                                   force=force_ddp)
     step = TrainStep(model, optimizer, scheduler, dtype=cfg.DTYPE, device_type=torch.device(device).type)
     return model, optimizer, scheduler, step
 

@@ -101,6 +101,8 @@ def _allreduce_then_step(optimizer, process_group):
 
         def apply(f):
             if optimizer.deferred:
+                if buf.is_cuda:  # which stream the update kernels are enqueued on (read by the tests)
+                    optimizer.last_update_stream = torch.cuda.current_stream(buf.device).cuda_stream
                 optimizer.step_params(bucket.parameters(), bucket.gradients())
             return bucket.buffer()
 
@@ -110,10 +112,16 @@ def _allreduce_then_step(optimizer, process_group):
 
 
 def wrap_data_parallel(model, optimizer=None, device_ids=None, bucket_cap_mb=25, process_group=None,
-                       overlap_optimizer=True):
+                       overlap_optimizer=True, force=False):
     """DistributedDataParallel over RCCL (or gloo in tests) with the optimizer overlapped into the
-    gradient all-reduce.  Returns the wrapped model (the bare model for a single process)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    gradient all-reduce.  Returns the wrapped model (the bare model for a single process, unless
+    `force`: then a 1-rank process group runs the very same bucket -> all-reduce -> update-in-the-
+    callback path, which is how the hook is exercised on a single MI355X)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if force:
+            raise RuntimeError("force=True needs an initialised process group (world size 1 is fine)")
+        return model
+    if dist.get_world_size() == 1 and not force:
         return model
     ddp = torch.nn.parallel.DistributedDataParallel(
         model, device_ids=device_ids, output_device=None if device_ids is None else device_ids[0],

@@ -86,8 +86,10 @@ class ModulatedDeformConvFunction(Function):
             bias = input.new_empty(1)  # fake tensor
         if not input.is_cuda:
             raise NotImplementedError
+        # decided on the ORIGINAL arguments: a .to(dtype) copy made under no-grad reports requires_grad=False
+        needs_grad = weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad
         offset, mask, weight, bias = _same_dtype(input, offset, mask, weight, bias)
-        if weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad:
+        if needs_grad:
             ctx.save_for_backward(input, offset, mask, weight, bias)
         output = input.new_empty(ModulatedDeformConvFunction._infer_shape(ctx, input, weight))
         ctx._bufs = [input.new_empty(0), input.new_empty(0)]

@@ -41,6 +41,11 @@ class PostProcessor(nn.Module):
         NMS problems (classes 1..C-1) run as ONE segmented launch."""
         n, C = scores.shape
         W, H = image_shape
+        if n == 0:  # no proposals: an empty result like the reference's (inference.py:108-149 on empty input)
+            out = BoxList(boxes.new_zeros((0, 4)), image_shape, mode="xyxy")
+            out.add_field("scores", scores.new_zeros((0,)))
+            out.add_field("labels", torch.zeros((0,), dtype=torch.int64, device=scores.device))
+            return out
         boxes = boxes.view(n, C, 4)
         hi = boxes.new_tensor([W - 1, H - 1, W - 1, H - 1])
         boxes = torch.minimum(boxes.clamp(min=0), hi)

@@ -48,7 +48,14 @@ class ROIMaskHead(torch.nn.Module):
             proposals, positive_inds = keep_only_positive_boxes(
                 proposals, self.max_positives if fixed else None)
         if self.training and self.cfg.MODEL.ROI_MASK_HEAD.SHARE_BOX_FEATURE_EXTRACTOR:
-            x = features[torch.cat(positive_inds, dim=0)]
+            # `features` are the box head's pooled features of ALL sampled proposals, image after image:
+            # per-image slot indices become rows of that tensor by adding each image's offset (the
+            # reference concatenates per-image boolean masks, mask_head.py:60-63)
+            rows, base = [], 0
+            for sel, b in zip(positive_inds, all_proposals):
+                rows.append(sel + base)
+                base += len(b)
+            x = features[torch.cat(rows, dim=0)]
         else:
             x = self.feature_extractor(features, proposals)
         mask_logits = self.predictor(x)

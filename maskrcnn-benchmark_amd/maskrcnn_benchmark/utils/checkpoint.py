@@ -40,8 +40,12 @@ class DetectronCheckpointer(object):
     def has_checkpoint(self):
         return bool(self.save_dir) and os.path.exists(os.path.join(self.save_dir, "last_checkpoint"))
 
-    def load(self, f=None):
-        if self.has_checkpoint():
+    def load(self, f=None, use_latest=True):
+        """reference utils/checkpoint.py:52-73: `last_checkpoint` overrides `f` unless use_latest=False.
+        Keys saved from a DDP-wrapped model (leading "module.", which is what the reference writes) are
+        accepted: the prefix is stripped like the reference's strip_prefix_if_present.  The file format is
+        otherwise this package's own ({"model": unwrapped state_dict, ...})."""
+        if self.has_checkpoint() and use_latest:
             with open(os.path.join(self.save_dir, "last_checkpoint")) as fh:
                 f = fh.read().strip()
         if not f:
@@ -49,7 +53,10 @@ class DetectronCheckpointer(object):
             return {}
         self.logger.info("Loading checkpoint from {}".format(f))
         data = torch.load(f, map_location="cpu")
-        self._module().load_state_dict(data.pop("model"))
+        state = data.pop("model")
+        if state and all(k.startswith("module.") for k in state):
+            state = {k[len("module."):]: v for k, v in state.items()}
+        self._module().load_state_dict(state)
         if "optimizer" in data and self.optimizer is not None:
             self.optimizer.load_state_dict(data.pop("optimizer"))
         if "scheduler" in data and self.scheduler is not None:

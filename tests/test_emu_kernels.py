@@ -168,6 +168,21 @@ def test_emu_nms_ties_large_n_and_batched():
         assert np.array_equal(km[offs[i]:offs[i + 1]], want)
 
 
+def test_emu_nms_batched_segments_beyond_the_lds_sort():
+    """segments with more than 8192 candidates (the reference's non-FPN PRE_NMS_TOP_N_TRAIN = 12000): per-
+    segment radix sort instead of the in-LDS bitonic network; ragged segment lengths."""
+    segs = [synth.nms_boxes(n, seed=20 + i) for i, n in enumerate((8300, 700, 9000))]
+    boxes = np.concatenate([x for x, _ in segs])
+    scores = np.concatenate([y for _, y in segs])
+    offs = np.cumsum([0] + [len(y) for _, y in segs]).astype(np.int32)
+    km, num = emu.nms_batched(boxes, scores, offs, 9000, 0.7, mask=True)
+    for i, (x, y) in enumerate(segs):
+        ref = oracle.nms(x, y, 0.7)
+        want = np.zeros(len(y), np.uint8)
+        want[ref] = 1
+        assert num[i] == len(ref) and np.array_equal(km[offs[i]:offs[i + 1]], want)
+
+
 # ================================================================================ focal loss
 @pytest.mark.parametrize("gamma,alpha,C", [(2.0, 0.25, 80), (1.5, 0.4, 7), (0.0, 0.5, 3)])
 def test_emu_focal_vs_oracle(gamma, alpha, C):

@@ -25,8 +25,25 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
-def T(a):
-    return torch.from_numpy(np.ascontiguousarray(a))
+def T(a, dev="cpu"):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.fixture(params=["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def dev(request):
+    """The reference-generated fixtures are checked twice: on the CPU (host logic; HIP-only operators
+    replaced by the oracle through cpu_shim) and, in the `-m gpu` suite, on the device through the real
+    HIP kernels (no shim)."""
+    return request.param
+
+
+def _shim(dev):
+    import contextlib
+    return cpu_shim.install() if dev == "cpu" else contextlib.nullcontext()
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
 
 
 # ------------------------------------------------------------------ config
@@ -71,21 +88,21 @@ def test_anchors_match_reference():
 
 
 # ------------------------------------------------------------------ matcher
-def test_matcher_matches_reference_including_ties_and_batched():
+def test_matcher_matches_reference_including_ties_and_batched(dev):
     g = load("model_matcher.npz")
     for c, (hi, lo, lq) in enumerate(g["cfgs"]):
         m = Matcher(float(hi), float(lo), allow_low_quality_matches=bool(lq))
         for k in range(4):
-            q = T(g["q_%d_%d" % (c, k)])
-            np.testing.assert_array_equal(m(q).numpy(), g["m_%d_%d" % (c, k)])
+            q = T(g["q_%d_%d" % (c, k)], dev)
+            np.testing.assert_array_equal(N_(m(q)), g["m_%d_%d" % (c, k)])
             # batched + padded rows give the same answer
-            pad = torch.full((3, q.shape[1]), -1.0)
+            pad = torch.full((3, q.shape[1]), -1.0, device=dev)
             qb = torch.stack([torch.cat([q, pad]), torch.cat([q, pad])])
-            rv = torch.zeros(2, q.shape[0] + 3, dtype=torch.bool)
+            rv = torch.zeros(2, q.shape[0] + 3, dtype=torch.bool, device=dev)
             rv[:, :q.shape[0]] = True
             out = m(qb, rv)
-            np.testing.assert_array_equal(out[0].numpy(), g["m_%d_%d" % (c, k)])
-            np.testing.assert_array_equal(out[1].numpy(), g["m_%d_%d" % (c, k)])
+            np.testing.assert_array_equal(N_(out[0]), g["m_%d_%d" % (c, k)])
+            np.testing.assert_array_equal(N_(out[1]), g["m_%d_%d" % (c, k)])
     with pytest.raises(ValueError):
         Matcher(0.5, 0.5)(torch.zeros(0, 4))
 
@@ -125,16 +142,16 @@ def test_to_image_list_pads_to_divisor():
 
 
 # ------------------------------------------------------------------ target assignment + RPN loss
-def _targets_setup(g):
+def _targets_setup(g, dev="cpu"):
     H, W = (int(v) for v in g["canvas"])
-    ag = AnchorGenerator(sizes=((32,), (64,), (128,)), anchor_strides=(8, 16, 32), straddle_thresh=0)
-    feats = [torch.zeros(2, 1, H // s, W // s) for s in (8, 16, 32)]
-    il = ImageList(torch.zeros(2, 3, H, W), [tuple(int(v) for v in s) for s in g["image_sizes"]])
+    ag = AnchorGenerator(sizes=((32,), (64,), (128,)), anchor_strides=(8, 16, 32), straddle_thresh=0).to(dev)
+    feats = [torch.zeros(2, 1, H // s, W // s, device=dev) for s in (8, 16, 32)]
+    il = ImageList(torch.zeros(2, 3, H, W, device=dev), [tuple(int(v) for v in s) for s in g["image_sizes"]])
     anchors = ag(il, feats)
     targets = []
     for i, (h, w) in enumerate(il.image_sizes):
-        t = BoxList(T(g["gt_%d" % i]), (w, h))
-        t.add_field("labels", T(g["gt_labels_%d" % i]))
+        t = BoxList(T(g["gt_%d" % i], dev), (w, h))
+        t.add_field("labels", T(g["gt_labels_%d" % i], dev))
         targets.append(t)
     return anchors, targets
 
@@ -148,43 +165,43 @@ class _FixedSampler(object):
         return pos & (pos.cumsum(-1) <= self.n_pos), neg & (neg.cumsum(-1) <= self.n_neg)
 
 
-def test_rpn_and_retinanet_target_assignment_and_rpn_loss_match_reference():
+def test_rpn_and_retinanet_target_assignment_and_rpn_loss_match_reference(dev):
     from maskrcnn_benchmark.modeling.rpn.loss import RPNLossComputation, generate_rpn_labels
     from maskrcnn_benchmark.modeling.rpn.retinanet.loss import generate_retinanet_labels
     g = load("model_targets.npz")
-    anchors, targets = _targets_setup(g)
+    anchors, targets = _targets_setup(g, dev)
     rpn = RPNLossComputation(Matcher(0.7, 0.3, True), _FixedSampler(16, 48), BoxCoder((1., 1., 1., 1.)), generate_rpn_labels)
     lab, reg = rpn.prepare_targets(anchors, targets)
     for i in range(2):
-        np.testing.assert_array_equal(lab[i].numpy(), g["rpn_labels_%d" % i])
+        np.testing.assert_array_equal(N_(lab[i]), g["rpn_labels_%d" % i])
         sel = g["rpn_labels_%d" % i] > 0  # regression targets only matter on positives; all are compared anyway
-        np.testing.assert_allclose(reg[i].numpy(), g["rpn_reg_%d" % i], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(N_(reg[i]), g["rpn_reg_%d" % i], rtol=1e-4, atol=1e-5)
         assert sel.sum() > 0
-    obj = [T(g["objectness_%d" % l]) for l in range(3)]
-    breg = [T(g["box_reg_%d" % l]) for l in range(3)]
+    obj = [T(g["objectness_%d" % l], dev) for l in range(3)]
+    breg = [T(g["box_reg_%d" % l], dev) for l in range(3)]
     lo, lb = rpn(anchors, obj, breg, targets)
     np.testing.assert_allclose([float(lo), float(lb)], g["rpn_loss"], rtol=1e-5)
     ret = RPNLossComputation(Matcher(0.5, 0.4, True), None, BoxCoder((10., 10., 5., 5.)), generate_retinanet_labels)
     ret.copied_fields, ret.discard_cases = ["labels"], ["between_thresholds"]
     lab, reg = ret.prepare_targets(anchors, targets)
     for i in range(2):
-        np.testing.assert_array_equal(lab[i].numpy(), g["ret_labels_%d" % i])
-        np.testing.assert_allclose(reg[i].numpy(), g["ret_reg_%d" % i], rtol=1e-4, atol=1e-5)
+        np.testing.assert_array_equal(N_(lab[i]), g["ret_labels_%d" % i])
+        np.testing.assert_allclose(N_(reg[i]), g["ret_reg_%d" % i], rtol=1e-4, atol=1e-5)
 
 
-def test_fast_rcnn_target_assignment_matches_reference():
+def test_fast_rcnn_target_assignment_matches_reference(dev):
     from maskrcnn_benchmark.modeling.roi_heads.box_head.loss import FastRCNNLossComputation, stack_proposals
     g = load("model_targets.npz")
-    _, targets = _targets_setup(g)
+    _, targets = _targets_setup(g, dev)
     sizes = [(int(w), int(h)) for h, w in g["image_sizes"]]
-    props = [BoxList(T(g["props_%d" % i]), sizes[i]) for i in range(2)]
+    props = [BoxList(T(g["props_%d" % i], dev), sizes[i]) for i in range(2)]
     frc = FastRCNNLossComputation(Matcher(0.5, 0.5, False), BalancedPositiveNegativeSampler(32, 0.25), BoxCoder((10., 10., 5., 5.)))
     boxes, valid = stack_proposals(props)
     lab, reg, _ = frc.prepare_targets(boxes, valid, targets)
     for i in range(2):
         n = len(props[i])
-        np.testing.assert_array_equal(lab[i, :n].numpy(), g["frc_labels_%d" % i])
-        np.testing.assert_allclose(reg[i, :n].numpy(), g["frc_reg_%d" % i], rtol=1e-4, atol=1e-5)
+        np.testing.assert_array_equal(N_(lab[i, :n]), g["frc_labels_%d" % i])
+        np.testing.assert_allclose(N_(reg[i, :n]), g["frc_reg_%d" % i], rtol=1e-4, atol=1e-5)
         assert (lab[i, n:] == -1).all()
     # fixed-length sampling: positives first, <= 25 % positives, invalid slots flagged
     out = frc.subsample(props, targets)
@@ -254,13 +271,13 @@ def test_balanced_sampler_topk_threshold_variant(monkeypatch):
 
 
 # ------------------------------------------------------------------ mask targets
-def test_mask_targets_match_reference_binary_mask_path():
+def test_mask_targets_match_reference_binary_mask_path(dev):
     from maskrcnn_benchmark.modeling.roi_heads.mask_head.loss import project_masks_on_boxes
     from maskrcnn_benchmark.structures.segmentation_mask import SegmentationMask
     g = load("model_masks.npz")
-    masks, props, which = T(g["masks"]), T(g["props"]), T(g["which"])
-    out_u8 = project_masks_on_boxes(masks, which, props, 28).numpy()
-    out_f32 = project_masks_on_boxes(masks.float(), which, props, 28).numpy()
+    masks, props, which = T(g["masks"], dev), T(g["props"], dev), T(g["which"], dev)
+    out_u8 = N_(project_masks_on_boxes(masks, which, props, 28))
+    out_f32 = N_(project_masks_on_boxes(masks.float(), which, props, 28))
     np.testing.assert_allclose(out_f32, g["targets_f32"], atol=2e-6)
     # integer masks truncate the interpolated value (a sum one ulp below 1.0 becomes 0): the
     # projection follows the CPU kernel operation by operation, so this is exact
@@ -269,26 +286,26 @@ def test_mask_targets_match_reference_binary_mask_path():
     W, H = (int(v) for v in g["size"])
     seg = SegmentationMask(masks.float(), (W, H))
     for j in (0, 7, 39):
-        r = seg[int(which[j])].crop(props[j]).resize((28, 28)).get_mask_tensor().numpy()
+        r = N_(seg[int(which[j])].crop(props[j]).resize((28, 28)).get_mask_tensor())
         np.testing.assert_allclose(r, g["targets_f32"][j], atol=2e-6)
 
 
 # ------------------------------------------------------------------ proposal selection
 @pytest.mark.parametrize("tag", ["train", "train_perimg", "test"])
-def test_rpn_proposal_selection_matches_reference(tag):
+def test_rpn_proposal_selection_matches_reference(tag, dev):
     from maskrcnn_benchmark.modeling.rpn.inference import RPNPostProcessor
     g = load("model_proposals.npz")
     H, W = (int(v) for v in g["canvas"])
-    ag = AnchorGenerator(sizes=((32,), (64,), (128,)), anchor_strides=(8, 16, 32), straddle_thresh=0)
-    feats = [torch.zeros(2, 1, H // s, W // s) for s in (8, 16, 32)]
-    il = ImageList(torch.zeros(2, 3, H, W), [tuple(int(v) for v in s) for s in g["image_sizes"]])
+    ag = AnchorGenerator(sizes=((32,), (64,), (128,)), anchor_strides=(8, 16, 32), straddle_thresh=0).to(dev)
+    feats = [torch.zeros(2, 1, H // s, W // s, device=dev) for s in (8, 16, 32)]
+    il = ImageList(torch.zeros(2, 3, H, W, device=dev), [tuple(int(v) for v in s) for s in g["image_sizes"]])
     anchors = ag(il, feats)
-    obj = [T(g["objectness_%d" % l]) for l in range(3)]
-    breg = [T(g["box_reg_%d" % l]) for l in range(3)]
+    obj = [T(g["objectness_%d" % l], dev) for l in range(3)]
+    breg = [T(g["box_reg_%d" % l], dev) for l in range(3)]
     pre, post, min_size, fpn_post, per_batch = (int(v) for v in g["%s_cfg" % tag])
     pp = RPNPostProcessor(pre, post, 0.7, min_size, BoxCoder((1., 1., 1., 1.)), fpn_post, bool(per_batch))
     pp.train(tag.startswith("train"))
-    with cpu_shim.install():
+    with _shim(dev):
         res = pp(anchors, obj, breg, None)
     for i, r in enumerate(res):
         s = r.get_field("objectness")
@@ -297,8 +314,8 @@ def test_rpn_proposal_selection_matches_reference(tag):
             v = r.get_field("valid")
             s, b = s[v], b[v]
         order = torch.argsort(s, descending=True, stable=True)
-        np.testing.assert_allclose(s[order].numpy(), g["%s_scores_%d" % (tag, i)], rtol=1e-6)
-        np.testing.assert_allclose(b[order].numpy(), g["%s_boxes_%d" % (tag, i)], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(N_(s[order]), g["%s_scores_%d" % (tag, i)], rtol=1e-6)
+        np.testing.assert_allclose(N_(b[order]), g["%s_boxes_%d" % (tag, i)], rtol=1e-5, atol=1e-4)
 
 
 # ------------------------------------------------------------------ solver
@@ -424,3 +441,36 @@ def test_tiny_model_through_emulated_hip_kernels_matches_oracle_backend(config, 
     assert len(results["oracle"][1]) == len(results["emu"][1]) > 10
     for a, b in zip(results["oracle"][1], results["emu"][1]):
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-4 * max(1.0, float(a.abs().max())))
+
+
+# ------------------------------------------------------------------ mask head on shared box features
+def test_mask_head_shared_box_features_uses_global_rows_for_every_image():
+    """SHARE_BOX_FEATURE_EXTRACTOR (the C4 configs): the mask head indexes the box head's pooled features of
+    ALL images; image i's slots must be offset by the proposals of images < i (reference mask_head.py:60-63)."""
+    from types import SimpleNamespace
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head.mask_head import ROIMaskHead
+    head = ROIMaskHead.__new__(ROIMaskHead)
+    torch.nn.Module.__init__(head)
+    head.cfg = SimpleNamespace(MODEL=SimpleNamespace(ROI_MASK_HEAD=SimpleNamespace(SHARE_BOX_FEATURE_EXTRACTOR=True)))
+    head.max_positives = 3
+    head.predictor = lambda x: x
+    seen = {}
+    head.loss_evaluator = lambda props, logits, targets: seen.setdefault("x", logits).sum() * 0
+    head.train()
+    props = []
+    for n in (5, 4):
+        b = BoxList(torch.zeros(n, 4), (10, 10))
+        lab = torch.zeros(n, dtype=torch.int64)
+        lab[:2] = 1
+        b.add_field("labels", lab)
+        b.add_field("valid", torch.ones(n, dtype=torch.bool))
+        props.append(b)
+    feats = torch.arange(9, dtype=torch.float32).view(9, 1)   # row id of the box head's feature tensor
+    head(feats, props, None)
+    assert seen["x"].flatten().tolist() == [0, 1, 2, 5, 6, 7]
+    # variable-length path (no "valid" field): nonzero() indices per image
+    for b in props:
+        b.extra_fields.pop("valid")
+    seen.clear()
+    head(feats, props, None)
+    assert seen["x"].flatten().tolist() == [0, 1, 5, 6]

@@ -32,6 +32,23 @@ def test_nms_batched_mask_matches_oracle():
         assert num[i] == len(keep)
 
 
+def test_nms_batched_mask_12000_candidates_per_segment():
+    """PRE_NMS_TOP_N_TRAIN = 12000 (the reference's non-FPN default): segments beyond the in-LDS sort."""
+    from maskrcnn_benchmark import _C
+    segs = [synth.nms_boxes(n, seed=31 + i) for i, n in enumerate((12000, 9500))]
+    boxes = np.concatenate([b for b, _ in segs]).astype(np.float32)
+    scores = np.concatenate([s for _, s in segs]).astype(np.float32)
+    offs = np.cumsum([0] + [len(b) for b, _ in segs]).astype(np.int32)
+    mask, num = _C.nms_batched_mask(torch.from_numpy(boxes).to(_dev()), torch.from_numpy(scores).to(_dev()),
+                                    torch.from_numpy(offs).to(_dev()), 12000, 0.7)
+    mask, num = mask.cpu().numpy(), num.cpu().numpy()
+    for i, (b, s) in enumerate(segs):
+        keep = oracle.nms(b, s, 0.7)
+        want = np.zeros(len(b), bool)
+        want[keep] = True
+        assert np.array_equal(mask[offs[i]:offs[i + 1]], want) and num[i] == len(keep)
+
+
 def test_pooler_matches_per_level_oracle():
     from maskrcnn_benchmark.modeling.poolers import Pooler
     from maskrcnn_benchmark.structures.bounding_box import BoxList
@@ -80,3 +97,63 @@ def test_train_step_dcn_bf16():
     for _ in range(2):
         losses = step(images, targets)
     assert all(torch.isfinite(v) for v in losses.values())
+
+
+def test_train_step_r101_dcn_fp16_cfg5():
+    """BASELINE configs[4]: e2e_mask_rcnn_R_101_FPN_1x + deformable conv in C3-C5 + fp16 mixed precision
+    (GradScaler path): training steps are finite and the scaler did not have to skip them all."""
+    from maskrcnn_benchmark.engine.bench_step import build_training, load_cfg, make_device_batches
+    cfg = load_cfg("e2e_mask_rcnn_R_101_FPN_1x.yaml",
+                   ["MODEL.RESNETS.STAGE_WITH_DCN", "(False, True, True, True)", "DTYPE", "float16",
+                    "MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 300, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 64])
+    torch.manual_seed(0)
+    model, opt, sched, step = build_training(cfg, _dev())
+    assert step.scaler is not None
+    n_dcn = sum(1 for m in model.modules() if type(m).__name__ in ("DFConv2d", "DeformConv", "ModulatedDeformConv"))
+    assert n_dcn >= 30, "R-101 with DCN in C3-C5 has 4 + 23 + 3 deformable 3x3 convs (got %d modules)" % n_dcn
+    (images, targets), = make_device_batches(cfg, _dev(), images_per_gpu=1, num_batches=1, height=192, width=256)
+    before = [p.detach().clone() for p in list(model.parameters())[:8] if p.requires_grad]
+    for _ in range(3):
+        losses = step(images, targets)
+    assert all(torch.isfinite(v) for v in losses.values())
+    assert step.scaler.get_scale() > 0
+
+
+def test_forced_ddp_hook_world1_nccl_matches_plain_step():
+    """The overlapped-SGD DDP hook on the one MI355X we have: a 1-rank NCCL (= RCCL) process group wraps the
+    detector, the bucket update runs in the all-reduce's completion callback on a side stream, and the
+    parameters after 3 steps equal the non-DDP run (bit-for-bit when the backward itself is deterministic)."""
+    import torch.distributed as dist
+    from maskrcnn_benchmark.engine.bench_step import build_training, load_cfg, make_device_batches
+    cfg = load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml",
+                   ["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 300, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 300,
+                    "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 64])
+    (images, targets), = make_device_batches(cfg, _dev(), images_per_gpu=1, num_batches=1, height=192, width=256)
+
+    def run(force):
+        torch.manual_seed(0)
+        model, opt, sched, step = build_training(cfg, _dev(), force_ddp=force)
+        torch.manual_seed(1)
+        for _ in range(3):
+            step(images, targets)
+        torch.cuda.synchronize()
+        m = model.module if force else model
+        return [p.detach().clone() for p in m.parameters() if p.requires_grad], opt, model
+
+    plain_a, _, _ = run(False)
+    plain_b, _, _ = run(False)
+    deterministic = all(torch.equal(a, b) for a, b in zip(plain_a, plain_b))
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1)
+    try:
+        ddp_p, opt, model = run(True)
+        assert isinstance(model, torch.nn.parallel.DistributedDataParallel) and opt.deferred
+        side = getattr(opt, "last_update_stream", None)
+        assert side is not None, "the hook's update callback never ran"
+        assert side != torch.cuda.default_stream(_dev()).cuda_stream, "update kernels must run on a side stream"
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(plain_a, ddp_p):
+        if deterministic:
+            assert torch.equal(a, b)
+        else:
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)

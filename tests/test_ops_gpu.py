@@ -127,18 +127,15 @@ def test_roi_align_backward_fpn_full_size_and_fused(bwd_impl):
     scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
     g = np.random.RandomState(2).randn(rois.shape[0], 256, 7, 7).astype(np.float32)
     refs = []
-    for l in (1, 2, 3):  # P3..P5 against the oracle (P2 is 138 MB; covered by the fused run below)
+    for l in (0, 1, 2, 3):  # every level against the fp64-accumulated oracle (P2 = 75 % of the gradient bytes)
         idx = np.nonzero(lv == l)[0]
         ref = oracle.roi_align_backward(g[idx], rois[idx], scales[l], 7, 7, *feats_shapes[l], 2, acc64=True)
         out = _C().roi_align_backward(_t(g[idx]), _t(rois[idx]), scales[l], 7, 7, *feats_shapes[l], 2)
         _close(out, ref, rtol=1e-4, atol=1e-4)
         refs.append(ref)
     gins = _C().roi_align_fpn_backward(_t(g), _t(rois), _t(lv), feats_shapes, scales, 7, 7, 2)
-    for l in (1, 2, 3):
-        _close(gins[l], refs[l - 1], rtol=1e-4, atol=1e-4)
-    idx = np.nonzero(lv == 0)[0]
-    p2 = _C().roi_align_backward(_t(g[idx]), _t(rois[idx]), scales[0], 7, 7, *feats_shapes[0], 2)
-    torch.testing.assert_close(gins[0], p2, rtol=1e-4, atol=1e-4)
+    for l in (0, 1, 2, 3):
+        _close(gins[l], refs[l], rtol=1e-4, atol=1e-4)
 
 
 def test_roi_align_backward_tile_seams_and_accumulate_flag(bwd_impl):
@@ -621,6 +618,86 @@ def test_deform_conv_half_precision(dtype):
     assert out.shape == (2, 16, 20, 24) and torch.isfinite(out).all()
     out.float().sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
+
+
+# cfg-5: the three DCN layer shapes of R-101-FPN + DCN at 800x1344, B = 2
+CFG5_SHAPES = [(128, 100, 168), (256, 50, 84), (512, 25, 42)]
+_OG = dict(pad=(1, 1), stride=(1, 1), dil=(1, 1), group=1, dg=1)
+_KG = dict(kh=3, kw=3, pad=(1, 1), stride=(1, 1), dil=(1, 1), dg=1)
+_GEO = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+
+
+@pytest.mark.parametrize("shape", CFG5_SHAPES)
+@pytest.mark.parametrize("modulated", [False, True])
+def test_deform_conv_cfg5_shapes_fp32(shape, modulated):
+    """deform_conv / modulated_deform_conv forward + every gradient at the cfg-5 layer shapes, fp32 <= 1e-4
+    (relative to each tensor's scale) against the oracle (reference deform_conv_kernel_cuda.cu:197-472)."""
+    from maskrcnn_benchmark.layers import deform_conv, modulated_deform_conv
+    Cc, H, W = shape
+    x, off, mask, wgt = synth.dcn_inputs(2, Cc, H, W, Cc, 3, 1, modulated, seed=13)
+    tx, toff, tw = (_t(a).requires_grad_(True) for a in (x, off, wgt))
+    if modulated:
+        tmask = _t(mask).requires_grad_(True)
+        y = modulated_deform_conv(tx, toff, tmask, tw, None, 1, 1, 1, 1, 1)
+    else:
+        y = deform_conv(tx, toff, tw, 1, 1, 1, 1, 1)
+    ref = oracle.deform_conv_forward(x, off, mask, wgt, None, **_OG)
+    _close(y, ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()))
+    go = np.random.RandomState(7).randn(*ref.shape).astype(np.float32)
+    y.backward(_t(go))
+    gin, goff, gmask, gw, _ = oracle.deform_conv_backward(x, off, mask, wgt, go, False, **_OG)
+    _close(tx.grad, gin, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(gin).max()))
+    _close(toff.grad, goff, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(goff).max()))
+    _close(tw.grad, gw, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(gw).max()))
+    if modulated:
+        _close(tmask.grad, gmask, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(gmask).max()))
+
+
+@pytest.mark.parametrize("shape", CFG5_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_deformable_kernels_cfg5_shapes_half(shape, dtype):
+    """im2col / col2im / col2im_coord with fp16 / bf16 storage at the cfg-5 layer shapes: <= 2e-2 of the
+    result's scale against the fp32 oracle evaluated on the same rounded inputs (modulated form)."""
+    C = _C()
+    Cc, H, W = shape
+    x, off, mask, _ = synth.dcn_inputs(2, Cc, H, W, Cc, 3, 1, True, seed=14)
+    hx, hoff, hmask = (_t(a).to(dtype) for a in (x, off, mask))
+    rx, roff, rmask = (t.float().cpu().numpy() for t in (hx, hoff, hmask))
+    col = C.deformable_im2col(hx, hoff, hmask, *_GEO)
+    ref_col = oracle.deformable_im2col(rx, roff, rmask, **_KG)
+    assert col.dtype == dtype
+    assert np.abs(col.float().cpu().numpy() - ref_col).max() <= 2e-2 * np.abs(ref_col).max()
+    gcol = _t(np.random.RandomState(9).randn(*ref_col.shape).astype(np.float32)).to(dtype)
+    rgcol = gcol.float().cpu().numpy()
+    gim = torch.zeros_like(hx)
+    C.deformable_col2im(gcol, hoff, hmask, gim, *_GEO)
+    ref_gim = oracle.deformable_col2im(rgcol, roff, rmask, *x.shape, **_KG)
+    assert np.abs(gim.float().cpu().numpy() - ref_gim).max() <= 2e-2 * np.abs(ref_gim).max()
+    goff, gmask = torch.empty_like(hoff), torch.empty_like(hmask)
+    C.deformable_col2im_coord(gcol, hx, hoff, hmask, goff, gmask, *_GEO)
+    rgoff, rgmask = oracle.deformable_col2im_coord(rgcol, rx, roff, rmask, **_KG)
+    assert np.abs(goff.float().cpu().numpy() - rgoff).max() <= 2e-2 * np.abs(rgoff).max()
+    assert np.abs(gmask.float().cpu().numpy() - rgmask).max() <= 2e-2 * np.abs(rgmask).max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_deform_conv_cfg5_layer4_half_fwd_bwd(dtype):
+    """the whole layer (im2col + GEMM, and the three backward paths) in half precision at the layer4 shape."""
+    from maskrcnn_benchmark.layers import modulated_deform_conv
+    Cc, H, W = CFG5_SHAPES[2]
+    x, off, mask, wgt = synth.dcn_inputs(2, Cc, H, W, Cc, 3, 1, True, seed=15)
+    wgt = wgt * 0.25   # keeps |y| ~ 1 in fp16
+    hx, hoff, hmask, hw = (_t(a).to(dtype).requires_grad_(True) for a in (x, off, mask, wgt))
+    rx, roff, rmask, rw = (t.detach().float().cpu().numpy() for t in (hx, hoff, hmask, hw))
+    y = modulated_deform_conv(hx, hoff, hmask, hw, None, 1, 1, 1, 1, 1)
+    ref = oracle.deform_conv_forward(rx, roff, rmask, rw, None, **_OG)
+    assert y.dtype == dtype
+    assert np.abs(y.float().detach().cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max()
+    go = _t(np.random.RandomState(7).randn(*ref.shape).astype(np.float32)).to(dtype)
+    y.backward(go)
+    gin, goff, gmask, gw, _ = oracle.deform_conv_backward(rx, roff, rmask, rw, go.float().cpu().numpy(), False, **_OG)
+    for got, want in ((hx.grad, gin), (hoff.grad, goff), (hmask.grad, gmask), (hw.grad, gw)):
+        assert np.abs(got.float().cpu().numpy() - want).max() <= 2e-2 * np.abs(want).max()
 
 
 # ============================================================================ fused FrozenBN
