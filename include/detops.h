@@ -63,6 +63,21 @@ int detops_roi_align_backward_f32(const float* grad_out, const float* rois, floa
                                   float spatial_scale, int sampling_ratio, int zero_grad_in,
                                   detops_stream_t stream);
 
+/* Backward with a caller-provided workspace: selects the binned pixel-owner kernel (a pre-pass launch
+ * builds per-ROI adjoint rows and per-tile hit lists in the workspace, the main launch only gathers).
+ * `detops_roi_align_backward_workspace_bytes` returns the size for a set of maps (H_host/W_host:
+ * num_levels entries; 1 for the single-map call), or 0 when the shape is served by the
+ * workspace-free kernels.  workspace == NULL or too small: same result through the workspace-free
+ * path (what detops_roi_align_backward_f32 / detops_roi_align_fpn_backward_f32 do). */
+size_t detops_roi_align_backward_workspace_bytes(const int* H_host, const int* W_host,
+                                                 int num_levels, int N, int C, int K, int PH, int PW);
+
+int detops_roi_align_backward_ws_f32(const float* grad_out, const float* rois, float* grad_in,
+                                     int N, int C, int H, int W, int K, int PH, int PW,
+                                     float spatial_scale, int sampling_ratio, int zero_grad_in,
+                                     void* workspace, size_t workspace_bytes,
+                                     detops_stream_t stream);
+
 /* Multi-level (FPN) ROIAlign in ONE launch — the sync-free form of
  * modeling/poolers.py:91-121 (LevelMapper :11-42 + per-level ROIAlign :116-119).
  *   inputs[l] : device pointer to level l's feature map [N,C,H[l],W[l]], scale[l] its stride^-1
@@ -81,6 +96,14 @@ int detops_roi_align_fpn_forward_f32(const float* const* inputs_host, const int*
                                      int sampling_ratio, int k_min, int k_max,
                                      float canonical_scale, float canonical_level, float eps,
                                      detops_stream_t stream);
+
+int detops_roi_align_fpn_backward_ws_f32(const float* grad_out, const float* rois,
+                                         const int32_t* levels, float* const* grad_inputs_host,
+                                         const int* H_host, const int* W_host,
+                                         const float* scale_host, int num_levels, int N, int C,
+                                         int K, int PH, int PW, int sampling_ratio,
+                                         int zero_grad_in, void* workspace, size_t workspace_bytes,
+                                         detops_stream_t stream);
 
 int detops_roi_align_fpn_backward_f32(const float* grad_out, const float* rois,
                                       const int32_t* levels, float* const* grad_inputs_host,

@@ -38,6 +38,29 @@ static inline int launch_status() { return static_cast<int>(hipGetLastError()); 
 #define DETOPS_STAT(name, n) ((void)0)
 #endif
 
+// Resident workgroups per CU of a kernel at a block size / dynamic LDS size (sizes persistent grids; the
+// value is advisory and only affects speed).  Host emulation: a fixed 4.
+#ifdef DETOPS_CPU_EMU
+#define DETOPS_OCCUPANCY(out, kernel, block, lds) ((out) = 4)
+#else
+#define DETOPS_OCCUPANCY(out, kernel, block, lds)                                                         \
+  do {                                                                                                    \
+    int _n = 0;                                                                                           \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&_n, reinterpret_cast<const void*>(kernel), (block), (lds)) == hipSuccess && _n > 0) \
+      (out) = _n;                                                                                         \
+  } while (0)
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() lowers to `s_waitcnt vmcnt(0) lgkmcnt(0);
+// s_barrier`: it drains every outstanding GLOBAL load and store of the wave first, which serialises a
+// software pipeline (prefetch loads in flight across the barrier, fire-and-forget result stores).  Use only
+// where no thread reads global memory another thread of the workgroup wrote before the barrier.
+#ifdef DETOPS_CPU_EMU
+#define DETOPS_LDS_BARRIER() __syncthreads()
+#else
+#define DETOPS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 constexpr int kWave = 64;        // CDNA4 wavefront
 constexpr int kNumCU = 256;      // MI355X
 constexpr int kNumXCD = 8;

@@ -934,6 +934,526 @@ int run_backward_tiles(const Levels& L, const float* rois, const int32_t* levels
   return launch_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// backward, BINNED pixel-owner (the default for filled launches; needs a caller workspace).
+//
+// Same adjoint-gather formulation and the same per-lane walk as roi_align_bwd_gather_kernel, with
+// everything that kernel re-derived per (tile, channel chunk) workgroup hoisted into one small
+// pre-pass launch (rocprofv3 PMC of the scan kernel, profiles/r02a_pmc_diag.txt: 63 % of the wave
+// cycles parked at barriers / memory waits, 68 M VALU wave-instructions of which ~40 M were the
+// 4 ROI-scan rounds of every workgroup and the per-batch coefficient-row builds, replicated over
+// the 16 channel chunks):
+//   roi_bwd_prep_kernel, role A — one wave per ROI, a lane per (axis, footprint pixel): the pixel's row of
+//       the adjoint matrix AY_r[y, 0:PH] (or AX_r[x, 0:PW]) from the reference's sample taps, plus
+//       the pixel's contiguous range of contributing bins packed into the row's spare column.
+//       Rows are stored footprint-relative (row 0 = the ROI's first reachable pixel) in a per-ROI
+//       slot of the workspace.
+//   roi_bwd_prep_kernel, role B — a wave per gradient-map tile (8 tiles per workgroup sharing one LDS copy
+//       of the ROI footprints): ordered (ascending ROI index) ballot compaction of the ROIs that reach the tile -> hit list [tile][cap] of
+//       {roi, fy0, fx0, ny|nx} + count.  Tiles nothing reaches get count 0.
+// The main kernel then only (1) reads its tile's list, (2) per batch of hits copies the 8 + 32
+// coefficient rows and the pooled gradients of its channel chunk into LDS — the NEXT batch's
+// global loads are issued before the walk of the current one —, (3) walks.  Empty tiles are pure
+// zero-stores.  Determinism and the one-store-per-element property are unchanged.
+// ------------------------------------------------------------------------------------------
+struct BinPlan {
+  int first_tile[DETOPS_MAX_LEVELS];   // tile-id offset per level (coarsest level first)
+  int n_tiles[DETOPS_MAX_LEVELS];
+  int tiles_x[DETOPS_MAX_LEVELS], tiles_y[DETOPS_MAX_LEVELS];
+  int num_tiles, cap;                  // cap = hit-list capacity per tile (= K)
+  int chunks, accumulate, batch;
+  int PPH, PPW;                        // coefficient-row strides: bins + >= 1 spare column, multiple of 4
+  int Hmax, Wmax;                      // per-ROI table slot = Hmax * PPH + Wmax * PPW floats
+  int tab_blocks;                      // prep launch: blocks [0, tab_blocks) = role A, the rest role B
+  int debug;                           // ablation knob (DETOPS_ROIALIGN_BWD_DEBUG): 1 = skip the walk
+};
+
+struct BinWs {
+  float* tabs;       // [K][Hmax * PPH + Wmax * PPW]
+  int4* heads;       // [num_tiles] {hit count, level | image << 8, y0, x0}
+  int4* lists;       // [num_tiles][cap]
+};
+
+struct RoiExtent {
+  int b;
+  int fy0, ny, fx0, nx;   // rows / columns any tap of the ROI can reach, clipped to the map (n <= 0: none)
+};
+
+// Conservative footprint from the scaled ROI rectangle alone (cheap: evaluated per (tile, ROI) pair by
+// the binning role): taps lie in floor(first sample) .. floor(last sample) + 1, samples in
+// [start, start + extent * (1 + a few ulp)); "+ 2" covers the rounding of the sample coordinate.
+__device__ __forceinline__ RoiExtent roi_extent(const float* __restrict__ roi, float scale, int H, int W) {
+#pragma clang fp contract(off)
+  RoiExtent e;
+  e.b = static_cast<int>(roi[0]);
+  const float start_w = roi[1] * scale, start_h = roi[2] * scale;
+  const float rw = fmaxf(roi[3] * scale - start_w, 1.f), rh = fmaxf(roi[4] * scale - start_h, 1.f);
+  const float fy0 = fminf(floorf(fmaxf(start_h, 0.f)), static_cast<float>(H));
+  const float fy1 = fminf(fmaxf(floorf(start_h + rh) + 2.f, -1.f), static_cast<float>(H - 1));
+  const float fx0 = fminf(floorf(fmaxf(start_w, 0.f)), static_cast<float>(W));
+  const float fx1 = fminf(fmaxf(floorf(start_w + rw) + 2.f, -1.f), static_cast<float>(W - 1));
+  e.fy0 = static_cast<int>(fy0); e.ny = static_cast<int>(fy1) - e.fy0 + 1;
+  e.fx0 = static_cast<int>(fx0); e.nx = static_cast<int>(fx1) - e.fx0 + 1;
+  if (!(fy1 >= fy0)) e.ny = 0;   // also catches NaN coordinates
+  if (!(fx1 >= fx0)) e.nx = 0;
+  return e;
+}
+
+constexpr int kPrepTiles = 4;      // tiles per role-B workgroup (1 per wave)
+constexpr int kPrepRois = 1024;    // ROI footprints parked in LDS per pass
+
+__global__ void __launch_bounds__(kBlock)
+roi_bwd_prep_kernel(Levels L, BinPlan P, BinWs ws, const float* __restrict__ rois,
+                    const int32_t* __restrict__ levels_in, int K, int PH, int PW, int sr) {
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  if (static_cast<int>(blockIdx.x) < P.tab_blocks) {
+    // ---- role A: adjoint rows.  One wave per ROI; lanes stride over its ny + nx footprint pixels
+    const int r = static_cast<int>(blockIdx.x) * (kBlock / kWave) + wave;
+    if (r >= K || (P.debug & 2)) return;
+    const float* roi = rois + static_cast<size_t>(r) * 5;
+    const int lvl = (L.num > 1) ? levels_in[r] : 0;
+    int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
+#pragma unroll
+    for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+      if (i == lvl) { H = L.lv[i].H; W = L.lv[i].W; scale = L.lv[i].scale; }
+    if (lvl < 0 || lvl >= L.num) return;
+    const RoiGeom g = roi_geometry(roi, scale, PH, PW, sr);
+    const RoiExtent e = roi_extent(roi, scale, H, W);
+    float* slot = ws.tabs + static_cast<size_t>(r) * (static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(P.Wmax) * P.PPW);
+    const int ny = max(e.ny, 0), nx = max(e.nx, 0);
+    for (int p = lane; p < ny + nx; p += kWave) {
+      const bool isy = p < ny;
+      const int pi = isy ? p : p - ny;
+      const int pix = (isy ? e.fy0 : e.fx0) + pi;
+      const int PB = isy ? PH : PW, PP = isy ? P.PPH : P.PPW;
+      const int grid = isy ? g.gh : g.gw, size = isy ? H : W;
+      const float start = isy ? g.start_h : g.start_w, bin = isy ? g.bin_h : g.bin_w;
+      float* row = slot + (isy ? 0 : static_cast<size_t>(P.Hmax) * P.PPH) + static_cast<size_t>(pi) * PP;
+      const float inv = 1.f / static_cast<float>(grid);
+      for (int q = 0; q < PP; ++q) row[q] = 0.f;
+      // only samples whose coordinate lies within one pixel of `pix` can have a tap on it (border pixels
+      // also collect the clamped samples: c in [-1, 0] -> pixel 0, c in [size-1, size] -> pixel size-1).
+      // Candidate sample range from the inverse of c(s) = start + (s + .5) * bin / grid, widened by one
+      // sample on each side; the exact reference arithmetic then decides.
+      const float step = bin * inv;
+      const float clo = (pix == 0) ? -1.f : static_cast<float>(pix - 1);
+      const float chi = (pix == size - 1) ? static_cast<float>(size) : static_cast<float>(pix + 1);
+      const int ns = PB * grid;
+      int s0 = static_cast<int>(fminf(fmaxf(floorf((clo - start) / step - 0.5f) - 1.f, 0.f), static_cast<float>(ns)));
+      int s1 = static_cast<int>(fminf(fmaxf(ceilf((chi - start) / step - 0.5f) + 1.f, -1.f), static_cast<float>(ns - 1)));
+      if (!(step > 0.f)) { s0 = 0; s1 = ns - 1; }   // degenerate geometry (NaN / inf): look at everything
+      // compact row: [0] = first contributing bin | count << 16, [1 ...] = the weights of bins lo, lo + 1, ...
+      // (zero-filled beyond), so the walk gets range + the first three weights with ONE 16-byte LDS read
+      int lo = -1, hi = -1;
+      int q = s0 / grid, i = s0 - q * grid;
+      float w = 0.f;
+      for (int sidx = s0; sidx <= s1; ++sidx) {   // per bin: samples in ascending order, like the scan kernel
+        const Tap tp = axis_entry(start, bin, q, i, grid, size, 1);
+        if (tp.lo == pix) w += tp.h * inv;
+        if (tp.hi == pix) w += tp.l * inv;
+        if (++i == grid || sidx == s1) {
+          if (w != 0.f) {
+            if (lo < 0) lo = q;
+            hi = q;
+            row[1 + q - lo] = w;
+          }
+          w = 0.f; i = 0; ++q;
+        }
+      }
+      row[0] = __int_as_float((lo >= 0) ? (lo | ((hi - lo + 1) << 16)) : 0);
+    }
+    return;
+  }
+  // ---- role B: hit lists.  A workgroup owns kPrepTiles tiles.  Per pass of <= 1024 ROIs: (1) all threads
+  //      park the ROIs' footprints {roi | level | image, fy0, fx0, ny | nx} in LDS — every ROI is read from
+  //      memory once per WORKGROUP, not once per tile: with a block per tile the ~3000 waves of the launch
+  //      queued on the same few cache lines of `rois` (5.5 us floor measured at K = 2) —, (2) each wave
+  //      takes tiles of the set and compacts the ROIs reaching it in ascending index (ballot + popcount).
+  __shared__ int4 s_ext[kPrepRois];
+  const int tile0 = (static_cast<int>(blockIdx.x) - P.tab_blocks) * kPrepTiles;
+  if (P.debug & 4) return;
+  int cnt[kPrepTiles / (kBlock / kWave)];
+#pragma unroll
+  for (int t = 0; t < kPrepTiles / (kBlock / kWave); ++t) cnt[t] = 0;
+  for (int r0 = 0; r0 < K; r0 += kPrepRois) {
+    const int nr = min(kPrepRois, K - r0);
+    // all four ROIs of a thread are fetched before any is used (one memory round trip per pass, not four)
+    constexpr int kPer = kPrepRois / kBlock;
+    float rv[kPer][5];
+    int rlv[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int i = tid + k * kBlock;
+      const int r = r0 + min(i, nr - 1);
+      const float* roi = rois + static_cast<size_t>(r) * 5;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) rv[k][c] = roi[c];
+      rlv[k] = (L.num > 1) ? levels_in[r] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int i = tid + k * kBlock;
+      if (i >= nr) continue;
+      const int r = r0 + i;
+      const int rl = rlv[k];
+      int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
+#pragma unroll
+      for (int q = 1; q < DETOPS_MAX_LEVELS; ++q)
+        if (q == rl) { H = L.lv[q].H; W = L.lv[q].W; scale = L.lv[q].scale; }
+      int4 ent = make_int4(-1, 0, 0, 0);   // never matches a tile
+      if (rl >= 0 && rl < L.num) {
+        const RoiExtent e = roi_extent(rv[k], scale, H, W);
+        if (e.ny > 0 && e.nx > 0 && e.b >= 0 && e.b < 4096)
+          ent = make_int4(r | (rl << 16) | (e.b << 19), e.fy0, e.fx0, (e.ny << 16) | e.nx);
+      }
+      s_ext[i] = ent;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kPrepTiles / (kBlock / kWave); ++t) {
+      const int tile = tile0 + t * (kBlock / kWave) + wave;
+      if (tile >= P.num_tiles || (P.debug & 8)) continue;
+      int lvl = 0;
+#pragma unroll
+      for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+        if (i < L.num && tile >= P.first_tile[i] && tile < P.first_tile[i] + P.n_tiles[i]) lvl = i;
+      int H = L.lv[0].H, W = L.lv[0].W;
+      int ntx = P.tiles_x[0], nty = P.tiles_y[0], first = P.first_tile[0];
+#pragma unroll
+      for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+        if (i == lvl) { H = L.lv[i].H; W = L.lv[i].W; ntx = P.tiles_x[i]; nty = P.tiles_y[i]; first = P.first_tile[i]; }
+      int rem = tile - first;
+      const int tix = rem % ntx; rem /= ntx;
+      const int tiy = rem % nty;
+      const int b = rem / nty;
+      const int y0 = tiy * kGTH, x0 = tix * kGTW;
+      const int y1 = min(H, y0 + kGTH) - 1, x1 = min(W, x0 + kGTW) - 1;
+      const int key = (lvl << 16) | (b << 19);
+      int4* list = ws.lists + static_cast<size_t>(tile) * P.cap;
+      int c = cnt[t];
+      for (int i0 = 0; i0 < nr; i0 += 4 * kWave) {   // four footprints per lane in flight per trip
+        int4 en[4];
+        bool hit[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) en[u] = s_ext[min(i0 + u * kWave + lane, nr - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          hit[u] = i0 + u * kWave + lane < nr && (en[u].x & ~0xffff) == key && en[u].x >= 0 && en[u].y <= y1 &&
+                   en[u].y + (en[u].w >> 16) - 1 >= y0 && en[u].z <= x1 && en[u].z + (en[u].w & 0xffff) - 1 >= x0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned long long m = __ballot(hit[u]);
+          if (hit[u] && !(P.debug & 16)) { en[u].x &= 0xffff; list[c + __popcll(m & ((1ull << lane) - 1ull))] = en[u]; }
+          c += __popcll(m);
+        }
+      }
+      cnt[t] = c;
+    }
+    __syncthreads();   // s_ext is rewritten by the next pass
+  }
+#pragma unroll
+  for (int t = 0; t < kPrepTiles / (kBlock / kWave); ++t) {
+    const int tile = tile0 + t * (kBlock / kWave) + wave;
+    if (tile >= P.num_tiles || lane != 0) continue;
+    int lvl = 0;
+#pragma unroll
+    for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+      if (i < L.num && tile >= P.first_tile[i] && tile < P.first_tile[i] + P.n_tiles[i]) lvl = i;
+    int ntx = P.tiles_x[0], nty = P.tiles_y[0], first = P.first_tile[0];
+#pragma unroll
+    for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+      if (i == lvl) { ntx = P.tiles_x[i]; nty = P.tiles_y[i]; first = P.first_tile[i]; }
+    int rem = tile - first;
+    const int tix = rem % ntx; rem /= ntx;
+    ws.heads[tile] = make_int4(cnt[t], lvl | ((rem / nty) << 8), (rem % nty) * kGTH, tix * kGTW);
+  }
+}
+
+// One bin row of a (wave, hit) task of the binned walk with a compile-time column count: NB bodies,
+// straight-line, so the 4 * NB gradient reads are in flight together (the generic loop is a chain of
+// dependent LDS round trips per body).  wx is zero beyond a lane's own range, bin indices are clamped into
+// the hit's staged block (a zero weight times a staged value: exact for finite gradients).
+template <int NB, int CG>
+__device__ __forceinline__ void binned_walk_row(float* __restrict__ acc, const float4* __restrict__ grow, int slots,
+                                                int PW, int xlo, float wya, const float* wx) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float w = wya * wx[b];
+    const float4* gp = grow + min(xlo + b, PW - 1);
+#pragma unroll
+    for (int cg = 0; cg < CG; ++cg) {
+      const float4 g4 = gp[cg * slots];
+      acc[4 * cg + 0] = fmaf(w, g4.x, acc[4 * cg + 0]);
+      acc[4 * cg + 1] = fmaf(w, g4.y, acc[4 * cg + 1]);
+      acc[4 * cg + 2] = fmaf(w, g4.z, acc[4 * cg + 2]);
+      acc[4 * cg + 3] = fmaf(w, g4.w, acc[4 * cg + 3]);
+    }
+  }
+}
+
+constexpr int kBinMaxBatch = 8;      // hits staged per batch (<= 256 bins of gradients per float4 channel group)
+constexpr int kBinRound = 64;        // hit-list entries parked in LDS per round
+
+// Main kernel.  One workgroup per work item (tile, CT-channel chunk); the design goal is RESIDENCY: the
+// kernel is a chain of short dependent phases (hit list -> staged gradients / adjoint rows -> walk -> store),
+// so it is the number of workgroups a CU can interleave that hides their latencies (measured on the way here:
+// 4 -> 5 waves per SIMD = 140 -> 118 us; a persistent, register-prefetching variant at 4 waves per SIMD was
+// slower than either).  Hence: <= 64 VGPRs (no data held in registers across a barrier except the CT
+// accumulators), ~19 KiB of LDS -> 8 workgroups per CU.
+//   lanes       = pixels: wave w owns rows 2w, 2w+1 of the 8 x 32 tile, lane = (row & 1) * 32 + column.  A
+//                 wave's store of one channel is two full 128-byte rows straight from the accumulator
+//                 registers — no LDS transposition, no barrier on the store path.
+//   batch       = <= P.batch hits: global -> LDS staging of their pooled gradients (float4 channel groups,
+//                 slot = hit * bins + bin) and of the 8 + 32 compact adjoint rows of the tile | barrier | walk
+//                 | barrier.  The walk reads {first bin | count, 3 weights} of a pixel with one 16-byte LDS
+//                 read per axis and runs bin rows with the column count as a compile-time constant.
+template <int PH_, int PW_, int CT>
+__global__ void __launch_bounds__(kBlock, (CT <= 16 ? 6 : 3))   // 2nd argument: waves per SIMD the register budget must allow
+roi_align_bwd_binned_kernel(Levels L, BinPlan P, BinWs ws, const float* __restrict__ gout, int C, int PHr, int PWr) {
+  static_assert(CT % 4 == 0, "channels are staged as float4 groups");
+  constexpr int CG = CT / 4;
+  const int PH = PH_ ? PH_ : PHr;
+  const int PW = PW_ ? PW_ : PWr;
+  const int bins = PH * PW;
+  const int PPH = PH_ ? ((PH_ + 4) & ~3) : P.PPH;          // compile-time strides for the model's shapes
+  const int PPW = PW_ ? ((PW_ + 4) & ~3) : P.PPW;
+  const int PXS = PPW + 1;                                 // AX rows in LDS: odd stride, 32 columns -> 32 banks
+  const int slots = P.batch * bins;                        // (hit, bin) slots per float4 channel group
+
+  DETOPS_DYNAMIC_LDS(float, g_lds);
+  float4* gs4 = reinterpret_cast<float4*>(g_lds);          // [CG][slots] float4
+  float* ayt = g_lds + slots * CT;                         // [batch][kGTH][PPH]
+  float* axt = ayt + P.batch * kGTH * PPH;                 // [batch][kGTW][PXS]
+  __shared__ int4 s_ent[kBinRound];
+
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int yl = 2 * wave + (lane >> 5), xl = lane & 31;   // this thread's pixel within the tile
+  const int tile = static_cast<int>(blockIdx.x) / P.chunks;
+  const int c0 = (static_cast<int>(blockIdx.x) - tile * P.chunks) * CT;
+  const int4 hd = ws.heads[tile];                          // {hit count, level | image << 8, y0, x0}, wave-uniform
+  const int total = __builtin_amdgcn_readfirstlane(hd.x);
+  const int lvl = __builtin_amdgcn_readfirstlane(hd.y) & 0xff, b = __builtin_amdgcn_readfirstlane(hd.y) >> 8;
+  const int y0 = __builtin_amdgcn_readfirstlane(hd.z), x0 = __builtin_amdgcn_readfirstlane(hd.w);
+  const size_t tab_stride = static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(P.Wmax) * P.PPW;
+  const size_t ax_off = static_cast<size_t>(P.Hmax) * P.PPH;
+  const int4* list = ws.lists + static_cast<size_t>(tile) * P.cap;
+  const bool full = c0 + CT <= C;                          // no channel tail in this chunk
+  const int wy0 = y0 + 2 * wave;                           // the wave's two rows: wy0, wy0 + 1
+
+  float acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+
+  // staging roles (no divisions inside the loops): gradients — thread t owns slot t = (hit, bin) of every
+  // channel group (t < batch * bins <= 256); adjoint rows — float4 unit u = tid + i * 256 of the batch
+  const int g_j = tid / bins, g_bin = tid - g_j * bins;
+  const int tabq = (kGTH * PPH + kGTW * PPW) / 4;          // float4 units per hit
+  const int qy = kGTH * PPH / 4, rqy = PPH / 4, rqx = PPW / 4;
+
+  for (int r0 = 0; r0 < total; r0 += kBinRound) {
+    const int nr = min(kBinRound, total - r0);
+    if (tid < nr) s_ent[tid] = list[r0 + tid];
+    __syncthreads();
+    if (tid == 0) { DETOPS_STAT("bwdb.rounds", r0 > 0); if (r0 == 0) DETOPS_STAT("bwdb.hits", total); }
+    for (int h0 = 0; h0 < nr; h0 += P.batch) {
+      const int nb = min(P.batch, nr - h0);
+      if (tid == 0) DETOPS_STAT("bwdb.batches", 1);
+      // ---- stage the batch: global -> (registers) -> LDS
+      if (g_j < nb) {
+        const float* src = gout + (static_cast<size_t>(s_ent[h0 + g_j].x) * C + c0) * bins + g_bin;
+        if (full) {
+#pragma unroll
+          for (int cg = 0; cg < CG; ++cg)
+            gs4[cg * slots + tid] = make_float4(src[(cg * 4 + 0) * bins], src[(cg * 4 + 1) * bins],
+                                                src[(cg * 4 + 2) * bins], src[(cg * 4 + 3) * bins]);
+        } else {
+#pragma unroll
+          for (int cg = 0; cg < CG; ++cg) {
+            const int cb = c0 + cg * 4;
+            gs4[cg * slots + tid] = make_float4((cb + 0 < C) ? src[(cg * 4 + 0) * bins] : 0.f,
+                                                (cb + 1 < C) ? src[(cg * 4 + 1) * bins] : 0.f,
+                                                (cb + 2 < C) ? src[(cg * 4 + 2) * bins] : 0.f,
+                                                (cb + 3 < C) ? src[(cg * 4 + 3) * bins] : 0.f);
+          }
+        }
+      }
+      for (int u = tid; u < nb * tabq; u += kBlock) {
+        const int j = u / tabq, q = u - j * tabq;
+        const int4 en = s_ent[h0 + j];
+        const float* slot = ws.tabs + static_cast<size_t>(en.x) * tab_stride;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < qy) {            // AY row of tile row yy
+          const int yy = q / rqy, k4 = q - yy * rqy;
+          const int ri = y0 + yy - en.y;
+          if (ri >= 0 && ri < (en.w >> 16)) v = reinterpret_cast<const float4*>(slot + static_cast<size_t>(ri) * P.PPH)[k4];
+          reinterpret_cast<float4*>(ayt + j * kGTH * PPH)[q] = v;
+        } else {                 // AX row of tile column xx (odd LDS stride: scalar writes)
+          const int qq = q - qy;
+          const int xx = qq / rqx, k4 = qq - xx * rqx;
+          const int ri = x0 + xx - en.z;
+          if (ri >= 0 && ri < (en.w & 0xffff)) v = reinterpret_cast<const float4*>(slot + ax_off + static_cast<size_t>(ri) * P.PPW)[k4];
+          float* d = axt + (j * kGTW + xx) * PXS + k4 * 4;
+          d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+      }
+      __syncthreads();
+      // ---- walk: every pixel gathers from the bins of this batch's hits that reach it
+      for (int j = 0; j < ((P.debug & 1) ? 0 : nb); ++j) {
+        const int4 en = s_ent[h0 + j];
+        if (en.y + (en.w >> 16) - 1 < wy0 || en.y > wy0 + 1) continue;   // this ROI misses the wave's two rows
+        if (lane == 0) DETOPS_STAT("bwdb.wave_roi_tasks", 1);
+        const float* ayr = ayt + (j * kGTH + yl) * PPH;
+        const float* axr = axt + (j * kGTW + xl) * PXS;
+        const float4* gj = gs4 + j * bins;
+        // head of the pixel's compact rows: {first bin | count, w[0], w[1], w[2]}
+        const float4 hy = *reinterpret_cast<const float4*>(ayr);
+        const float hx0 = axr[0], hx1 = axr[1], hx2 = axr[2], hx3 = axr[3];   // AX rows have an odd LDS stride
+        const int ry = __float_as_int(hy.x), rx = __float_as_int(hx0);
+        const int ylo = ry & 0xffff, ny = ry >> 16, xlo = rx & 0xffff, nx = rx >> 16;
+        int na = 0, nb_ = 0;
+        while (__ballot(na < ny) != 0ull) ++na;
+        while (__ballot(nb_ < nx) != 0ull) ++nb_;
+        if (lane == 0) DETOPS_STAT("bwdb.bodies", na * nb_);
+        if (na <= 3 && nb_ <= 3) {
+          const float wx[3] = {hx1, hx2, hx3};
+          for (int a = 0; a < na; ++a) {   // wave-uniform trip count; one LDS round trip per bin row
+            const float wya = (a == 0) ? hy.y : (a == 1) ? hy.z : hy.w;   // zero beyond the lane's own range
+            const float4* grow = gj + min(ylo + a, PH - 1) * PW;
+            if (nb_ >= 2) binned_walk_row<2, CG>(acc, grow, slots, PW, xlo, wya, wx);            // 8 reads in flight
+            if (nb_ & 1) binned_walk_row<1, CG>(acc, grow, slots, PW, xlo + nb_ - 1, wya, wx + nb_ - 1);
+          }
+        } else {
+          // long ranges (ROIs smaller than their bin grid): generic loop over the compact rows
+          for (int a = 0; a < na; ++a) {
+            const int ph = min(ylo + a, PH - 1);
+            const float wya = (a < ny) ? ayr[1 + a] : 0.f;
+            for (int b2 = 0; b2 < nb_; ++b2) {
+              const int pw = min(xlo + b2, PW - 1);
+              const float w = (b2 < nx) ? wya * axr[1 + b2] : 0.f;
+              if (w != 0.f) {
+                const float4* gp = gj + ph * PW + pw;
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) {
+                  const float4 g4 = gp[cg * slots];
+                  acc[4 * cg + 0] = fmaf(w, g4.x, acc[4 * cg + 0]);
+                  acc[4 * cg + 1] = fmaf(w, g4.y, acc[4 * cg + 1]);
+                  acc[4 * cg + 2] = fmaf(w, g4.z, acc[4 * cg + 2]);
+                  acc[4 * cg + 3] = fmaf(w, g4.w, acc[4 * cg + 3]);
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();  // the next batch / round rewrites the staging region
+    }
+  }
+
+  if (tid == 0) DETOPS_STAT("bwdb.workgroups", 1);
+  if (total == 0 && P.accumulate) return;   // nothing to add
+  // ---- store: two full 128-byte rows per wave and channel, straight from the accumulators; every in-map
+  //      element of the tile is written exactly once (zeros where no ROI reaches)
+  float* gin = L.lv[0].gin; int H = L.lv[0].H, W = L.lv[0].W;
+#pragma unroll
+  for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+    if (i == lvl) { gin = L.lv[i].gin; H = L.lv[i].H; W = L.lv[i].W; }
+  if (y0 + yl < H && x0 + xl < W) {
+    const size_t plane = static_cast<size_t>(H) * W;
+    float* dst = gin + (static_cast<size_t>(b) * C + c0) * plane + static_cast<size_t>(y0 + yl) * W + (x0 + xl);
+    if (full && !P.accumulate) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) dst[c * plane] = acc[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if (c0 + c < C) {
+          float v = acc[c];
+          if (P.accumulate) v += dst[c * plane];
+          dst[c * plane] = v;
+        }
+      }
+    }
+  }
+}
+
+// Plan + workspace carve of the binned backward.  Returns false when the shape is outside its plan
+// (bins > 256, coefficient rows beyond the prefetch registers, maps wider than the packed fields).
+struct BinLayout { size_t off_counts, off_lists, off_tabs, total; };
+
+bool bin_plan(const Levels& L, int N, int C, int K, int PH, int PW, int CT, BinPlan& P, BinLayout& lay) {
+  const int bins = PH * PW;
+  if (bins > kGBins || K <= 0 || K > 65535 || N > 4096) return false;
+  P = BinPlan{};
+  P.PPH = (PH + 4) & ~3;
+  P.PPW = (PW + 4) & ~3;
+  P.batch = max(1, min(kBinMaxBatch, kGBins / bins));
+  if (const char* e = getenv("DETOPS_ROIALIGN_BWD_BATCH")) P.batch = max(1, min(P.batch, atoi(e)));   // tuning knob
+  // LDS plan: gradients of a batch (16 x bins floats per hit at CT = 16) + its adjoint rows, <= 48 KiB
+  while (P.batch > 1 && static_cast<int64_t>(P.batch) * (bins * 32 + kGTH * P.PPH + kGTW * (P.PPW + 1)) * 4 > 48 * 1024) --P.batch;
+  if (static_cast<int64_t>(bins * 32 + kGTH * P.PPH + kGTW * (P.PPW + 1)) * 4 > 60 * 1024) return false;
+  P.cap = K;
+  P.chunks = static_cast<int>(ceil_div64(C, CT));
+  int64_t tiles = 0;
+  for (int i = L.num - 1; i >= 0; --i) {  // coarsest level first (its tiles see the most ROIs)
+    if (L.lv[i].W > 32767 || L.lv[i].H > 32767) return false;
+    P.Hmax = max(P.Hmax, L.lv[i].H);
+    P.Wmax = max(P.Wmax, L.lv[i].W);
+    P.tiles_x[i] = static_cast<int>(ceil_div64(L.lv[i].W, kGTW));
+    P.tiles_y[i] = static_cast<int>(ceil_div64(L.lv[i].H, kGTH));
+    const int64_t n = static_cast<int64_t>(N) * P.tiles_x[i] * P.tiles_y[i];
+    P.first_tile[i] = static_cast<int>(tiles);
+    P.n_tiles[i] = static_cast<int>(n);
+    tiles += n;
+  }
+  if (tiles <= 0 || tiles * P.chunks > 0x7fffffff) return false;
+  P.num_tiles = static_cast<int>(tiles);
+  P.tab_blocks = static_cast<int>(ceil_div64(K, kBlock / kWave));   // role A: one wave per ROI
+  auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  size_t o = 0;
+  lay.off_counts = o; o = up(o + sizeof(int4) * P.num_tiles);
+  lay.off_lists = o;  o = up(o + sizeof(int4) * static_cast<size_t>(P.num_tiles) * P.cap);
+  lay.off_tabs = o;   o = up(o + sizeof(float) * static_cast<size_t>(K) *
+                                 (static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(P.Wmax) * P.PPW));
+  lay.total = o;
+  return true;
+}
+
+inline int bin_default_ct() {
+  if (const char* e = getenv("DETOPS_ROIALIGN_BWD_CT")) return atoi(e) == 32 ? 32 : 16;   // tuning / test knob
+  return 16;
+}
+
+// -1: not applicable (no / too small workspace, shape outside the plan, underfilled launch) -> scan kernel
+int run_backward_binned(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
+                        int N, int C, int K, int PH, int PW, int sr, int accumulate, void* workspace,
+                        size_t workspace_bytes, bool forced, hipStream_t st) {
+  if (C == 0 || N == 0) return 0;
+  if (!workspace || K == 0) return -1;
+  const int CT = bin_default_ct();
+  BinPlan P; BinLayout lay;
+  if (!bin_plan(L, N, C, K, PH, PW, CT, P, lay) || workspace_bytes < lay.total) return -1;
+  // underfilled launches (a handful of tiles): the scan kernel's ROI-list split serves them better
+  if (!forced && static_cast<int64_t>(P.num_tiles) * ceil_div64(C, 16) < 2 * kNumCU) return -1;
+  P.accumulate = accumulate;
+  if (const char* e = getenv("DETOPS_ROIALIGN_BWD_DEBUG")) P.debug = atoi(e);
+  unsigned char* base = static_cast<unsigned char*>(workspace);
+  BinWs ws{reinterpret_cast<float*>(base + lay.off_tabs), reinterpret_cast<int4*>(base + lay.off_counts),
+           reinterpret_cast<int4*>(base + lay.off_lists)};
+  hipLaunchKernelGGL(roi_bwd_prep_kernel, dim3(static_cast<unsigned>(P.tab_blocks + ceil_div64(P.num_tiles, kPrepTiles))), dim3(kBlock), 0, st,
+                     L, P, ws, rois, levels_in, K, PH, PW, sr);
+  const size_t lds = sizeof(float) * (static_cast<size_t>(P.batch) * PH * PW * CT +
+                                      static_cast<size_t>(P.batch) * (kGTH * P.PPH + kGTW * (P.PPW + 1)));
+  const dim3 grid(static_cast<unsigned>(static_cast<int64_t>(P.num_tiles) * P.chunks));
+#define BINNED_LAUNCH(PH_, PW_, CT_)                                                                              \
+  hipLaunchKernelGGL((roi_align_bwd_binned_kernel<PH_, PW_, CT_>), grid, dim3(kBlock), lds, st, L, P, ws, gout, \
+                     C, PH, PW)
+  if (PH == 7 && PW == 7) { if (CT == 32) BINNED_LAUNCH(7, 7, 32); else BINNED_LAUNCH(7, 7, 16); }
+  else if (PH == 14 && PW == 14) { if (CT == 32) BINNED_LAUNCH(14, 14, 32); else BINNED_LAUNCH(14, 14, 16); }
+  else { if (CT == 32) BINNED_LAUNCH(0, 0, 32); else BINNED_LAUNCH(0, 0, 16); }
+#undef BINNED_LAUNCH
+  return launch_status();
+}
+
 // Pixel-owner backward launch.  Returns -1 when the shape does not fit its LDS plan (huge bin
 // counts): the caller then uses the tile-scatter kernel.
 int run_backward_gather(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
@@ -994,12 +1514,23 @@ int run_backward_gather(const Levels& L, const float* rois, const int32_t* level
   return launch_status();
 }
 
-// DETOPS_ROIALIGN_BWD=tile forces the LDS-scatter tile kernel (A/B measurements); default: the
-// atomic-free pixel-owner kernel.
+// Dispatch: the binned pixel-owner kernel when the caller supplies a workspace and the launch fills the
+// chip; otherwise the scan pixel-owner kernel (small maps: ROI-list split); the LDS-scatter tile kernel for
+// bin counts beyond both plans.  DETOPS_ROIALIGN_BWD = "tile" | "gather" (= scan) | "binned" forces one
+// (A/B measurements, tests); read per call.
 int run_backward(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
-                 int N, int C, int K, int PH, int PW, int sr, int accumulate, hipStream_t st) {
-  const char* e = getenv("DETOPS_ROIALIGN_BWD");  // read per call: tests flip it at run time
+                 int N, int C, int K, int PH, int PW, int sr, int accumulate, hipStream_t st,
+                 void* workspace = nullptr, size_t workspace_bytes = 0) {
+  const char* e = getenv("DETOPS_ROIALIGN_BWD");
   const bool force_tile = e && e[0] == 't';
+  const bool force_scan = e && e[0] == 'g';
+  if (!force_tile && !force_scan) {
+    const bool forced = e && e[0] == 'b' && K > 0;
+    const int rc = run_backward_binned(L, rois, levels_in, gout, N, C, K, PH, PW, sr, accumulate, workspace,
+                                       workspace_bytes, forced, st);
+    if (rc != -1) return rc;
+    if (forced) return DETOPS_EWORKSPACE;   // "binned" was demanded but is not applicable
+  }
   if (!force_tile) {
     const int rc = run_backward_gather(L, rois, levels_in, gout, N, C, K, PH, PW, sr, accumulate, st);
     if (rc != -1) return rc;
@@ -1027,11 +1558,11 @@ DETOPS_API int detops_roi_align_forward_f32(const float* input, const float* roi
                      as_stream(stream));
 }
 
-DETOPS_API int detops_roi_align_backward_f32(const float* grad_out, const float* rois,
-                                             float* grad_in, int N, int C, int H, int W, int K,
-                                             int PH, int PW, float spatial_scale,
-                                             int sampling_ratio, int zero_grad_in,
-                                             detops_stream_t stream) {
+DETOPS_API int detops_roi_align_backward_ws_f32(const float* grad_out, const float* rois,
+                                                float* grad_in, int N, int C, int H, int W, int K,
+                                                int PH, int PW, float spatial_scale,
+                                                int sampling_ratio, int zero_grad_in, void* workspace,
+                                                size_t workspace_bytes, detops_stream_t stream) {
   if (bad_dims(N, C, K, PH, PW) || H < 0 || W < 0) return DETOPS_EINVAL;
   const size_t bytes = sizeof(float) * static_cast<size_t>(N) * C * H * W;
   if (bytes == 0) return 0;
@@ -1042,7 +1573,33 @@ DETOPS_API int detops_roi_align_backward_f32(const float* grad_out, const float*
   L.num = 1;
   L.lv[0] = Level{nullptr, grad_in, H, W, spatial_scale};
   return run_backward(L, rois, nullptr, grad_out, N, C, K, PH, PW, sampling_ratio,
-                      zero_grad_in ? 0 : 1, as_stream(stream));
+                      zero_grad_in ? 0 : 1, as_stream(stream), workspace, workspace_bytes);
+}
+
+DETOPS_API int detops_roi_align_backward_f32(const float* grad_out, const float* rois,
+                                             float* grad_in, int N, int C, int H, int W, int K,
+                                             int PH, int PW, float spatial_scale,
+                                             int sampling_ratio, int zero_grad_in,
+                                             detops_stream_t stream) {
+  return detops_roi_align_backward_ws_f32(grad_out, rois, grad_in, N, C, H, W, K, PH, PW, spatial_scale,
+                                          sampling_ratio, zero_grad_in, nullptr, 0, stream);
+}
+
+DETOPS_API size_t detops_roi_align_backward_workspace_bytes(const int* H_host, const int* W_host,
+                                                            int num_levels, int N, int C, int K, int PH,
+                                                            int PW) {
+  if (!H_host || !W_host || num_levels < 1 || num_levels > DETOPS_MAX_LEVELS || bad_dims(N, C, K, PH, PW) ||
+      K == 0 || C == 0 || N == 0)
+    return 0;
+  Levels L{};
+  L.num = num_levels;
+  for (int i = 0; i < num_levels; ++i) {
+    if (H_host[i] <= 0 || W_host[i] <= 0) return 0;
+    L.lv[i] = Level{nullptr, nullptr, H_host[i], W_host[i], 1.f};
+  }
+  BinPlan P; BinLayout lay;
+  if (!bin_plan(L, N, C, K, PH, PW, 16, P, lay)) return 0;
+  return lay.total;
 }
 
 DETOPS_API int detops_roi_align_fpn_forward_f32(
@@ -1068,10 +1625,11 @@ DETOPS_API int detops_roi_align_fpn_forward_f32(
   return run_forward(L, rois, nullptr, levels_out, output, C, K, PH, PW, sampling_ratio, st);
 }
 
-DETOPS_API int detops_roi_align_fpn_backward_f32(
+DETOPS_API int detops_roi_align_fpn_backward_ws_f32(
     const float* grad_out, const float* rois, const int32_t* levels, float* const* grad_inputs_host,
     const int* H_host, const int* W_host, const float* scale_host, int num_levels, int N, int C,
-    int K, int PH, int PW, int sampling_ratio, int zero_grad_in, detops_stream_t stream) {
+    int K, int PH, int PW, int sampling_ratio, int zero_grad_in, void* workspace, size_t workspace_bytes,
+    detops_stream_t stream) {
   if (bad_dims(N, C, K, PH, PW) || num_levels < 1 || num_levels > DETOPS_MAX_LEVELS ||
       !grad_inputs_host || !H_host || !W_host || !scale_host)
     return DETOPS_EINVAL;
@@ -1085,5 +1643,14 @@ DETOPS_API int detops_roi_align_fpn_backward_f32(
   if (K > 0 && (!grad_out || !rois || (num_levels > 1 && !levels))) return DETOPS_EINVAL;
   if (K == 0 && !zero_grad_in) return 0;
   return run_backward(L, rois, levels, grad_out, N, C, K, PH, PW, sampling_ratio,
-                      zero_grad_in ? 0 : 1, as_stream(stream));
+                      zero_grad_in ? 0 : 1, as_stream(stream), workspace, workspace_bytes);
+}
+
+DETOPS_API int detops_roi_align_fpn_backward_f32(
+    const float* grad_out, const float* rois, const int32_t* levels, float* const* grad_inputs_host,
+    const int* H_host, const int* W_host, const float* scale_host, int num_levels, int N, int C,
+    int K, int PH, int PW, int sampling_ratio, int zero_grad_in, detops_stream_t stream) {
+  return detops_roi_align_fpn_backward_ws_f32(grad_out, rois, levels, grad_inputs_host, H_host, W_host,
+                                              scale_host, num_levels, N, C, K, PH, PW, sampling_ratio,
+                                              zero_grad_in, nullptr, 0, stream);
 }

@@ -203,11 +203,22 @@ def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, b
     K = rois.size(0)
     gin = torch.empty((batch_size, channels, height, width), dtype=grad.dtype, device=grad.device)
     with _on_device(grad):
-        check(lib.detops_roi_align_backward_f32(ptr(grad), ptr(rois), ptr(gin), batch_size, channels,
-                                                height, width, K, pooled_height, pooled_width,
-                                                float(spatial_scale), int(sampling_ratio), 1,
-                                                stream_of(grad)), "roi_align_backward")
+        Hs, Ws = (ctypes.c_int * 1)(height), (ctypes.c_int * 1)(width)
+        ws, nbytes = _bwd_workspace(grad.device, Hs, Ws, 1, batch_size, channels, K, pooled_height, pooled_width)
+        check(lib.detops_roi_align_backward_ws_f32(ptr(grad), ptr(rois), ptr(gin), batch_size, channels,
+                                                   height, width, K, pooled_height, pooled_width,
+                                                   float(spatial_scale), int(sampling_ratio), 1, ptr(ws), nbytes,
+                                                   stream_of(grad)), "roi_align_backward")
     return gin
+
+
+def _bwd_workspace(device, Hs, Ws, L, N, C, K, ph, pw):
+    """Scratch for the binned ROIAlign backward (per-ROI adjoint rows + per-tile hit lists), from
+    torch's stream-ordered caching allocator; (None, 0) when the shape uses the workspace-free kernels."""
+    nbytes = int(lib.detops_roi_align_backward_workspace_bytes(Hs, Ws, L, int(N), int(C), int(K), int(ph), int(pw)))
+    if nbytes <= 0:
+        return None, 0
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device), nbytes
 
 
 def _host_arrays(tensors, scales):
@@ -250,10 +261,12 @@ def roi_align_fpn_backward(grad, rois, levels, shapes, scales, pooled_height, po
     gins = [torch.empty(tuple(s), dtype=torch.float32, device=grad.device) for s in shapes]
     N, C = shapes[0][:2]
     ptrs, Hs, Ws, sc = _host_arrays(gins, scales)
-    with _on_device(grad), _timed("roi_align_fpn_bwd[K=%d,C=%d,%dx%d]" % (K, C, pooled_height, pooled_width), grad):
-        check(lib.detops_roi_align_fpn_backward_f32(
-            ptr(grad), ptr(rois), ptr(levels), ptrs, Hs, Ws, sc, len(gins), N, C, K, pooled_height,
-            pooled_width, int(sampling_ratio), 1, stream_of(grad)), "roi_align_fpn_backward")
+    with _on_device(grad):
+        ws, nbytes = _bwd_workspace(grad.device, Hs, Ws, len(gins), N, C, K, pooled_height, pooled_width)
+        with _timed("roi_align_fpn_bwd[K=%d,C=%d,%dx%d]" % (K, C, pooled_height, pooled_width), grad):
+            check(lib.detops_roi_align_fpn_backward_ws_f32(
+                ptr(grad), ptr(rois), ptr(levels), ptrs, Hs, Ws, sc, len(gins), N, C, K, pooled_height,
+                pooled_width, int(sampling_ratio), 1, ptr(ws), nbytes, stream_of(grad)), "roi_align_fpn_backward")
     return gins
 
 

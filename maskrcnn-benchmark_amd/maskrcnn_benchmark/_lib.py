@@ -24,6 +24,11 @@ SIGNATURES = {
         c_int, [_P, _P, _P, _P, c_int, _P, _P, _P] + [c_int] * 8 + [c_float, c_float, c_float, _P]),
     "detops_roi_align_fpn_backward_f32": (
         c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P]),
+    "detops_roi_align_fpn_backward_ws_f32": (
+        c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P, c_size_t, _P]),
+    "detops_roi_align_backward_ws_f32": (
+        c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P, c_size_t, _P]),
+    "detops_roi_align_backward_workspace_bytes": (c_size_t, [_P, _P] + [c_int] * 6),
     "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),
     "detops_roi_pool_backward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "detops_nms_workspace_bytes": (c_size_t, [c_int]),

@@ -18,6 +18,11 @@ SIGNATURES = {
     "detops_roi_align_fpn_forward_f32": (
         c_int, [_P, _P, _P, _P, c_int, _P, _P, _P] + [c_int] * 8 + [c_float, c_float, c_float, _P]),
     "detops_roi_align_fpn_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P]),
+    "detops_roi_align_fpn_backward_ws_f32": (
+        c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P, ctypes.c_size_t, _P]),
+    "detops_roi_align_backward_ws_f32": (
+        c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P, ctypes.c_size_t, _P]),
+    "detops_roi_align_backward_workspace_bytes": (ctypes.c_size_t, [_P, _P] + [c_int] * 6),
     "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),
     "detops_roi_pool_backward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "detops_nms_workspace_bytes": (ctypes.c_size_t, [c_int]),
@@ -79,8 +84,11 @@ def roi_align_backward(grad, rois, scale, ph, pw, N, C, H, W, sr, into=None):
     grad, rois = _f32(grad), _f32(rois)
     K = rois.shape[0]
     gin = np.full((N, C, H, W), np.nan, np.float32) if into is None else _f32(into).copy()
-    rc = lib().detops_roi_align_backward_f32(_p(grad), _p(rois), _p(gin), N, C, H, W, K, ph, pw, scale, sr,
-                                             1 if into is None else 0, None)
+    Hs, Ws = (ctypes.c_int * 1)(H), (ctypes.c_int * 1)(W)
+    nbytes = lib().detops_roi_align_backward_workspace_bytes(Hs, Ws, 1, N, C, K, ph, pw)
+    ws = np.full((max(nbytes, 1),), 0xAB, np.uint8)   # poisoned: the pre-pass must write what the kernel reads
+    rc = lib().detops_roi_align_backward_ws_f32(_p(grad), _p(rois), _p(gin), N, C, H, W, K, ph, pw, scale, sr,
+                                                1 if into is None else 0, _p(ws) if nbytes else None, nbytes, None)
     assert rc == 0, rc
     return gin
 
@@ -114,8 +122,11 @@ def roi_align_fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr):
     gins = [np.full(s, np.nan, np.float32) for s in shapes]
     N, C = shapes[0][:2]
     ptrs, Hs, Ws, sc = _host_arrays(gins, scales)
-    rc = lib().detops_roi_align_fpn_backward_f32(_p(grad), _p(rois), _p(levels), ptrs, Hs, Ws, sc, len(shapes), N, C,
-                                                 rois.shape[0], ph, pw, sr, 1, None)
+    nbytes = lib().detops_roi_align_backward_workspace_bytes(Hs, Ws, len(shapes), N, C, rois.shape[0], ph, pw)
+    ws = np.full((max(nbytes, 1),), 0xAB, np.uint8)
+    rc = lib().detops_roi_align_fpn_backward_ws_f32(_p(grad), _p(rois), _p(levels), ptrs, Hs, Ws, sc, len(shapes), N, C,
+                                                    rois.shape[0], ph, pw, sr, 1, _p(ws) if nbytes else None, nbytes,
+                                                    None)
     assert rc == 0, rc
     return gins
 

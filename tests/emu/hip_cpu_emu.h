@@ -44,6 +44,7 @@ struct alignas(8) float2 { float x, y; };
 struct alignas(8) int2 { int x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
@@ -225,6 +226,7 @@ static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 
 template <typename T> static inline T __shfl_down(T v, int off) {
   static_assert(sizeof(T) <= 8, "");

@@ -288,6 +288,74 @@ def test_emu_roi_align_backward_lane_walk(ct, monkeypatch):
         assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("ct,wgs", [("16", None), ("32", None), ("16", "3"), ("16", "1"), ("32", "7")])
+def test_emu_roi_align_backward_binned(ct, wgs, monkeypatch):
+    """binned pixel-owner backward (pre-pass adjoint rows + per-tile hit lists in a poisoned workspace):
+    ragged ROIs / bin shapes, adaptive sampling, channel tails, accumulate mode, both channel chunkings;
+    `wgs` caps the persistent grid so that every workgroup pipelines through many work items."""
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "binned")
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_CT", ct)
+    if wgs:
+        monkeypatch.setenv("DETOPS_ROIALIGN_BWD_WGS", wgs)
+    rng = np.random.RandomState(51)
+    N, C, H, W = 2, 37, 27, 70           # 37 channels: ragged last chunk; 27 x 70: partial edge tiles
+    K = 90
+    x1 = rng.uniform(-20, 270, K)
+    y1 = rng.uniform(-20, 100, K)
+    rois = np.stack([rng.randint(0, N, K), x1, y1, x1 + rng.uniform(0.2, 120, K), y1 + rng.uniform(0.2, 60, K)],
+                    1).astype(np.float32)
+    rois = np.concatenate([rois, _edge_rois()])
+    for (ph, pw, sr) in ((7, 7, 2), (14, 14, 2), (5, 3, 0), (16, 16, 1), (8, 4, 2)):
+        g = rng.randn(rois.shape[0], C, ph, pw).astype(np.float32)
+        ref = oracle.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, acc64=True)
+        emu.stats(reset=True)
+        out = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr)
+        assert emu.stats().get("bwdb.workgroups", 0) > 0, "the binned kernel did not run"
+        tol = 1e-5 * max(1.0, np.abs(ref).max())
+        assert np.abs(out - ref).max() <= tol
+        base = rng.randn(N, C, H, W).astype(np.float32)
+        acc = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, into=base)
+        assert np.abs(acc - (base + ref)).max() <= 2 * tol
+
+
+def test_emu_roi_align_backward_binned_matches_scan_kernel_bitwise_and_handles_crowded_tiles(monkeypatch):
+    """same coefficient arithmetic and visiting order as the scan kernel -> identical bits; a tile hit by more
+    ROIs than one list round (256) and more than one batch; FPN entry point with empty levels."""
+    rng = np.random.RandomState(52)
+    N, C, H, W = 1, 16, 12, 40
+    K = 300
+    x1 = rng.uniform(0, 30, K)
+    y1 = rng.uniform(0, 8, K)
+    rois = np.stack([np.zeros(K), x1, y1, x1 + rng.uniform(1, 10, K), y1 + rng.uniform(1, 4, K)], 1).astype(np.float32)
+    g = rng.randn(K, C, 7, 7).astype(np.float32)
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "gather")
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_GROUPS", "1")   # no ROI-list split: one sequential sum per pixel
+    scan = emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2)
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "binned")
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_WGS", "2")      # two persistent workgroups walk all tiles
+    emu.stats(reset=True)
+    binned = emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2)
+    st = emu.stats()
+    assert st.get("bwdb.rounds", 0) > 0, "expected a tile with more hits than one list round (64)"
+    assert np.array_equal(scan, binned)
+    ref = oracle.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2, acc64=True)
+    assert np.abs(binned - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    # multi-level entry, one level without any ROI
+    shapes = [(2, 8, 50, 84), (2, 8, 25, 42), (2, 8, 13, 21), (2, 8, 7, 11)]
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    rois = synth.fpn_rois(seed=4, per_image=40, smin=8, smax=300)
+    rois[:, 1:] *= 0.25
+    lv = synth.level_map(rois * np.array([1, 4, 4, 4, 4], np.float32))
+    lv[lv == 1] = 2
+    gg = rng.randn(rois.shape[0], 8, 14, 14).astype(np.float32)
+    outs = emu.roi_align_fpn_backward(gg, rois, lv, shapes, scales, 14, 14, 2)
+    for l in range(4):
+        idx = np.nonzero(lv == l)[0]
+        want = oracle.roi_align_backward(gg[idx], rois[idx], scales[l], 14, 14, *shapes[l], 2, acc64=True) \
+            if idx.size else np.zeros(shapes[l], np.float32)
+        assert np.abs(outs[l] - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
 @pytest.mark.parametrize("gi", range(len(DCN_GEOMS)))
 @pytest.mark.parametrize("modulated", [False, True])
 def test_emu_deformable_col2im_ell_variant(gi, modulated):

@@ -140,9 +140,13 @@ def test_forced_ddp_hook_world1_nccl_matches_plain_step():
         m = model.module if force else model
         return [p.detach().clone() for p in m.parameters() if p.requires_grad], opt, model
 
+    det0 = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True   # MIOpen: reproducible solvers only, so a stream race cannot hide in noise
     plain_a, _, _ = run(False)
     plain_b, _, _ = run(False)
     deterministic = all(torch.equal(a, b) for a, b in zip(plain_a, plain_b))
+    # MIOpen's weight-gradient kernels are not run-to-run reproducible: the plain-vs-plain spread is the yardstick
+    noise = max(float((a - b).abs().max()) for a, b in zip(plain_a, plain_b))
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1)
     try:
         ddp_p, opt, model = run(True)
@@ -152,8 +156,10 @@ def test_forced_ddp_hook_world1_nccl_matches_plain_step():
         assert side != torch.cuda.default_stream(_dev()).cuda_stream, "update kernels must run on a side stream"
     finally:
         dist.destroy_process_group()
+        torch.backends.cudnn.deterministic = det0
+    print("forced-DDP test: backward deterministic = %s, plain-vs-plain spread = %.3g" % (deterministic, noise))
     for a, b in zip(plain_a, ddp_p):
         if deterministic:
             assert torch.equal(a, b)
         else:
-            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+            assert float((a - b).abs().max()) <= 4 * noise + 1e-7, (float((a - b).abs().max()), noise)

@@ -101,10 +101,11 @@ def test_roi_align_forward_edge_cases():
 
 
 # ============================================================================ ROIAlign backward
-@pytest.fixture(params=["gather", "tile"])
+@pytest.fixture(params=["binned", "gather", "tile"])
 def bwd_impl(request, monkeypatch):
-    """Both backward kernels behind the same entry points: the default atomic-free pixel-owner
-    kernel and the LDS-scatter tile kernel (DETOPS_ROIALIGN_BWD is read per call)."""
+    """The three backward kernels behind the same entry points: the binned pixel-owner kernel (default for
+    filled launches), the scan pixel-owner kernel (small maps) and the LDS-scatter tile kernel
+    (DETOPS_ROIALIGN_BWD is read per call)."""
     monkeypatch.setenv("DETOPS_ROIALIGN_BWD", request.param)
     return request.param
 
@@ -156,8 +157,13 @@ def test_roi_align_backward_tile_seams_and_accumulate_flag(bwd_impl):
         base = rng.randn(N, C, H, W).astype(np.float32)
         buf = _t(base)
         tg, tr = _t(g), _t(rois)
-        rc = _lib.lib.detops_roi_align_backward_f32(tg.data_ptr(), tr.data_ptr(), buf.data_ptr(), N, C, H, W, K, ph, pw,
-                                                    ctypes.c_float(0.25), sr, 0, torch.cuda.current_stream().cuda_stream)
+        # straight through the C ABI with a caller workspace (the binned kernel needs one; the others ignore it)
+        Hs, Ws = (ctypes.c_int * 1)(H), (ctypes.c_int * 1)(W)
+        nbytes = int(_lib.lib.detops_roi_align_backward_workspace_bytes(Hs, Ws, 1, N, C, K, ph, pw))
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=DEV)
+        rc = _lib.lib.detops_roi_align_backward_ws_f32(tg.data_ptr(), tr.data_ptr(), buf.data_ptr(), N, C, H, W, K, ph, pw,
+                                                       ctypes.c_float(0.25), sr, 0, ws.data_ptr(), nbytes,
+                                                       torch.cuda.current_stream().cuda_stream)
         assert rc == 0
         _close(buf, base + ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()))
     # K = 0 with zero-fill: a pure clear

@@ -104,55 +104,24 @@ def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False, experiment
                 out.append(_entry(f"roi_align_fwd fpn-fused {tag} [LDS {kb} KB, U={u}]", us, alg, {"bit_equal_to_default": same}))
             del os.environ["DETOPS_ROIALIGN_FWD_LDS_KB"], os.environ["DETOPS_ROIALIGN_FWD_U"]
         if "bwd" in which:
-            g = torch.randn(K, Cc, ph, pw, device="cuda")
-            us = dev_time_us(lambda: C.roi_align_backward(g, tr, scale, ph, pw, 1, Cc, 14, 14, sr), iters)
-            out.append(_entry(f"roi_align_bwd cfg1 {ph}x{pw} sr{sr} (gather, ROI list split over 32 groups)", us, alg))
-            for grp in ("1", "16"):
-                os.environ["DETOPS_ROIALIGN_BWD_GROUPS"] = grp
-                us = dev_time_us(lambda: C.roi_align_backward(g, tr, scale, ph, pw, 1, Cc, 14, 14, sr), max(3, iters // 5))
-                out.append(_entry(f"roi_align_bwd cfg1 {ph}x{pw} sr{sr} [groups={grp}]", us, alg))
-            del os.environ["DETOPS_ROIALIGN_BWD_GROUPS"]
-    # cfg-2 box head: 1024 ROIs over P2..P5, 7x7 sr2; cfg-3 mask head: 256 ROIs, 14x14 sr2 ----
-    feats = [torch.randn(2, 256, h, w, device="cuda") for (h, w) in synth.fpn_shapes()[:4]]
-    scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
-    shapes = [tuple(f.shape) for f in feats]
-    feat_bytes = sum(f.numel() * 4 for f in feats)
-    for tag, K, ph in (("box-head 1024x7x7", 1024, 7), ("mask-head 256x14x14", 256, 14)):
-        rois = synth.fpn_rois(per_image=K // 2)
-        tr = _t(rois)
-        alg = 4 * K * 256 * ph * ph + feat_bytes + 20 * K
-        lv = synth.level_map(rois)
-        per = [(l, _t(rois[lv == l])) for l in range(4)]
-
-        def per_level_fwd():
-            for l, r in per:
-                C.roi_align_forward(feats[l], r, scales[l], ph, ph, 2)
-
-        if "fwd" in which:
-            us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
-            out.append(_entry(f"roi_align_fwd fpn-fused {tag}", us, alg))
-            if not fused_only:
-                us = dev_time_us(per_level_fwd, iters)
-                out.append(_entry(f"roi_align_fwd fpn-per-level(4 launches) {tag}", us, alg))
-        if "fwd" in which and not fused_only:
-            base = C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]
-            for kb, u in (("16", "4"), ("16", "8"), ("32", "8"), ("48", "8"), ("8", "8")):
-                os.environ["DETOPS_ROIALIGN_FWD_LDS_KB"], os.environ["DETOPS_ROIALIGN_FWD_U"] = kb, u
-                us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
-                same = bool(torch.equal(base, C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]))
-                out.append(_entry(f"roi_align_fwd fpn-fused {tag} [LDS {kb} KB, U={u}]", us, alg, {"bit_equal_to_default": same}))
-            del os.environ["DETOPS_ROIALIGN_FWD_LDS_KB"], os.environ["DETOPS_ROIALIGN_FWD_U"]
-        if "bwd" in which:
             g = torch.randn(K, 256, ph, ph, device="cuda")
             tl = _t(lv)
             us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
-            out.append(_entry(f"roi_align_bwd fpn-fused gather (atomic-free, incl. zero-fill) {tag}", us, alg))
+            out.append(_entry(f"roi_align_bwd fpn-fused binned pixel-owner (atomic-free, incl. pre-pass + zero-fill) {tag}", us, alg))
             if fused_only:
                 continue
-            os.environ["DETOPS_ROIALIGN_BWD_CT"] = "4"
+            ref_g = C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2)
+            os.environ["DETOPS_ROIALIGN_BWD_CT"] = "32"
             us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
-            out.append(_entry(f"roi_align_bwd fpn-fused gather CT=4 {tag}", us, alg))
+            got = C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2)
             del os.environ["DETOPS_ROIALIGN_BWD_CT"]
+            out.append(_entry(f"roi_align_bwd fpn-fused binned CT=32 {tag}", us, alg,
+                              {"max_abs_diff_vs_default": max(float((a - b).abs().max()) for a, b in zip(ref_g, got))}))
+            os.environ["DETOPS_ROIALIGN_BWD"] = "gather"
+            us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
+            got = C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2)
+            out.append(_entry(f"roi_align_bwd fpn-fused scan pixel-owner (r01 kernel + lane walk) {tag}", us, alg,
+                              {"bit_equal_to_default": all(bool(torch.equal(a, b)) for a, b in zip(ref_g, got))}))
             os.environ["DETOPS_ROIALIGN_BWD"] = "tile"
             us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), max(3, iters // 5))
             del os.environ["DETOPS_ROIALIGN_BWD"]
