@@ -286,6 +286,51 @@ int detops_deform_psroi_pool_backward_f32(const float* out_grad, const float* da
                                           int zero_grads, detops_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training-target assignment on the device (extensions; the reference does these with ATen compositions
+ * and host round trips: SURVEY.md section 8 rows f2 / f3).
+ *
+ * detops_match_boxes_f32 — IoU + Matcher fused (structures/boxlist_ops.py:53-89, modeling/matcher.py:42-112):
+ *   gt_boxes [N, M, 4] xyxy fp32 (padded rows flagged 0 in gt_valid [N, M] uint8), boxes [K, 4] shared by
+ *   the N images (boxes_batched = 0) or [N, K, 4]; matched_idxs [N, K] int64 = arg-max ground truth (first
+ *   index among ties), -1 below low_threshold, -2 between the thresholds; with allow_low_quality_matches every
+ *   box attaining some valid ground truth's maximum IoU keeps its arg-max.  The [M, K] matrix is never stored.
+ *   workspace (only with the low-quality rule): >= detops_match_boxes_workspace_bytes(N, M).
+ *
+ * detops_sample_labels — BalancedPositiveNegativeSampler (modeling/balanced_positive_negative_sampler.py:19-68):
+ *   labels [N, n] (label_dtype: fp32 or int64; >= 1 positive, 0 negative, < 0 ignored); per row a uniformly
+ *   random subset of min(#pos, max_positives) positives and min(#neg, B - that) negatives, as 0/1 masks
+ *   [N, n] and (optional, both or neither) a fixed-length list sampled_idx / sampled_valid [N, B], positives
+ *   first.  Deterministic in (labels, seed); B <= 512.
+ *
+ * detops_mask_targets — mask-head targets (roi_heads/mask_head/loss.py:11-42 via
+ *   structures/segmentation_mask.py:118-158): for ROI p crop instance mask_index[p] of masks [G, H, W] to the
+ *   rounded, clamped box and resize bilinearly (align_corners = False) to M x M; integer masks truncate the
+ *   interpolated value, bool masks map non-zero to 1.  out [P, M, M] fp32.
+ * ---------------------------------------------------------------------------------------- */
+#define DETOPS_LABEL_F32 0
+#define DETOPS_LABEL_I64 1
+#define DETOPS_MASK_U8 0
+#define DETOPS_MASK_F32 1
+#define DETOPS_MASK_BOOL 2
+
+size_t detops_match_boxes_workspace_bytes(int N, int M);
+
+int detops_match_boxes_f32(const float* gt_boxes, const uint8_t* gt_valid, const float* boxes,
+                           int boxes_batched, int N, int M, int K, float high_threshold,
+                           float low_threshold, int allow_low_quality_matches, int64_t* matched_idxs,
+                           void* workspace, size_t workspace_bytes, detops_stream_t stream);
+
+size_t detops_sample_labels_workspace_bytes(int N, int batch_size_per_image);
+
+int detops_sample_labels(const void* labels, int label_dtype, int N, int n, int batch_size_per_image,
+                         int max_positives, uint64_t seed, uint8_t* pos_mask, uint8_t* neg_mask,
+                         int64_t* sampled_idx, uint8_t* sampled_valid, void* workspace,
+                         size_t workspace_bytes, detops_stream_t stream);
+
+int detops_mask_targets(const void* masks, int mask_dtype, const int64_t* mask_index, const float* boxes,
+                        int G, int H, int W, int P, int M, float* out, detops_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused FrozenBatchNorm2d affine (+ residual) (+ ReLU) — the elementwise tail of every backbone
  * convolution: layers/batch_norm.py:19-31 (`x * scale + bias`), then `F.relu_`, and in the
  * bottleneck tail `out += identity; relu` (modeling/backbone/resnet.py:343-366).

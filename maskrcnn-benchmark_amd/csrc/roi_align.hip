@@ -263,12 +263,20 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
     for (int o = tid; o < (cend - c0) * BINS; o += NT) obase[o] = 0.f;
     return;
   }
-  const int ymin = s_bounds[0], xmin = s_bounds[2];
+  const int ymin = s_bounds[0];
   const int rows = s_bounds[1] - ymin + 2;   // (lo range) + the lo+1 row
-  const int ps = (s_bounds[3] - xmin + 2) | 1;  // row stride incl. the lo+1 column; odd -> rows spread over LDS banks
-  const int area = rows * ps;
   const size_t plane = static_cast<size_t>(H) * W;
   const float* base = in + (static_cast<size_t>(g.b) * C + c0) * plane;
+  // Row-vector staging (maps whose rows are 16-byte aligned: W % 4 == 0): the patch starts at a column that is
+  // a multiple of 4 and each row is copied as float4s by a group of 8..64 lanes — one address computation per
+  // 16 bytes instead of ~25 VALU instructions of index arithmetic per staged dword (rocprofv3 PMC of the dword
+  // version, profiles/r02a_pmc_diag.txt: 51 M VALU wave-instructions per launch, 2/3 of them staging index math).
+  const bool vec4 = ((W & 3) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+  const int xmin = vec4 ? (s_bounds[2] & ~3) : s_bounds[2];
+  int ps = s_bounds[3] - xmin + 2;           // columns incl. the lo+1 column
+  if (vec4) { ps = (ps + 3) & ~3; if (!((ps >> 2) & 1)) ps += 4; }   // float4 rows, odd number of float4 per row
+  else ps |= 1;                               // odd -> rows spread over the LDS banks
+  const int area = rows * ps;
 
   if (area > patch_floats) {  // footprint too large for LDS: gather straight from the map
     for (int o = tid; o < (cend - c0) * BINS; o += NT) {
@@ -328,6 +336,38 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
     const float* src = base + static_cast<size_t>(cs - c0) * plane;
     const int total = cn * area;
     if (tid == 0) { DETOPS_STAT("fwd.stage_batches", 1); DETOPS_STAT("fwd.staged_floats", total); }
+    if (vec4) {
+      const int w4 = ps >> 2;
+      int lw = 8;
+      while (lw < w4) lw <<= 1;                 // lanes per patch row (wave-uniform, <= 64: ps <= 256)
+      const int v = tid & (lw - 1), rsub = tid / lw, rpi = NT / lw;
+      const int nrows = cn * rows;
+      const int gx = xmin + 4 * v;
+      for (int rr0 = rsub; rr0 < nrows; rr0 += rpi * U) {
+        float4 val[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int rr = rr0 + u * rpi;
+          val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (rr < nrows && v < w4) {
+            const int c = static_cast<int>((static_cast<float>(rr) + 0.5f) * inv_rows);   // rr / rows
+            const int y = rr - c * rows;
+            const float* rowp = src + static_cast<size_t>(c) * plane + static_cast<size_t>(min(ymin + y, H - 1)) * W;
+            if (gx < W) {
+              val[u] = *reinterpret_cast<const float4*>(rowp + gx);
+            } else {                              // whole float4 beyond the map: the replicated border column
+              const float e = rowp[W - 1];
+              val[u] = make_float4(e, e, e, e);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int rr = rr0 + u * rpi;
+          if (rr < nrows && v < w4) *reinterpret_cast<float4*>(patch + rr * ps + 4 * v) = val[u];
+        }
+      }
+    } else {
     for (int e0 = tid; e0 < total; e0 += NT * U) {
       float v[U];
 #pragma unroll
@@ -347,6 +387,7 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
         const int e = e0 + u * NT;
         if (e < total) patch[e] = v[u];
       }
+    }
     }
     __syncthreads();
     if (csub < G) {

@@ -1,0 +1,414 @@
+// targets.hip — training-target assignment on the device, gfx950.
+//
+//   detops_match_boxes_f32      IoU(gt, boxes) + Matcher, fused: the [M, K] quality matrix of the reference
+//                               (structures/boxlist_ops.py:53-89 -> modeling/matcher.py:42-112) is never
+//                               written — 268,569 RPN anchors x M ground-truth boxes per image are evaluated
+//                               in registers, twice when the low-quality rule is on (per-gt maximum first).
+//   detops_sample_labels        BalancedPositiveNegativeSampler (modeling/balanced_positive_negative_sampler.py
+//                               :19-68) without sorting the anchors: candidates whose hashed key falls under a
+//                               threshold sized for ~8x the quota survive a single filtering pass, one
+//                               workgroup per image sorts the few thousand survivors and keeps the k smallest.
+//   detops_mask_targets         crop + bilinear resize of the matched ground-truth mask to M x M per positive
+//                               ROI (roi_heads/mask_head/loss.py:11-42, structures/segmentation_mask.py:118-158)
+//                               in the operation order of the CPU kernel the reference runs it on.
+//
+// Everything is stream-ordered and sync-free; decisions (IoU thresholds, equality with the per-gt maximum,
+// integer-mask truncation) are evaluated with FP contraction off and IEEE division so that they are the
+// decisions the reference's CPU arithmetic takes.
+#include <algorithm>
+
+#include "detops_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kGtChunk = 256;   // ground-truth boxes staged in LDS per pass
+
+// IoU with the reference's "+1" convention and evaluation order (boxlist_ops.py:72-88):
+//   area = (x2 - x1 + 1) * (y2 - y1 + 1); wh = clamp(rb - lt + 1, 0); inter / (area_a + area_b - inter)
+__device__ __forceinline__ float iou_ref(const float4 g, float area_g, const float4 b, float area_b) {
+#pragma clang fp contract(off)
+  const float ltx = fmaxf(g.x, b.x), lty = fmaxf(g.y, b.y);
+  const float rbx = fminf(g.z, b.z), rby = fminf(g.w, b.w);
+  const float w = fmaxf(rbx - ltx + 1.f, 0.f), h = fmaxf(rby - lty + 1.f, 0.f);
+  const float inter = w * h;
+  return inter / (area_g + area_b - inter);
+}
+
+__device__ __forceinline__ float box_area(const float4 b) {
+#pragma clang fp contract(off)
+  return (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off));
+  return v;
+}
+
+// PASS = 0: per box the best ground truth (first index among ties, like torch.max on the CPU) and its IoU;
+//           with `best_gt` != NULL also the per-gt maximum over the boxes (atomicMax on the non-negative
+//           float's bit pattern; one atomic per wave and gt).
+// PASS = 1: the final Matcher output, low-quality rule included (needs the completed best_gt of pass 0).
+// grid = (ceil(K / 256), N); gt [N, M, 4], valid [N, M], boxes [N or 1, K, 4].
+template <int PASS>
+__global__ void __launch_bounds__(kBlock)
+match_kernel(const float* __restrict__ gt, const uint8_t* __restrict__ valid, const float* __restrict__ boxes,
+             int boxes_batched, int M, int K, float high, float low, int allow_lq,
+             int32_t* __restrict__ best_gt /* [N, M] float bits */, int64_t* __restrict__ matched /* [N, K] */) {
+  __shared__ float4 s_gt[kGtChunk];
+  __shared__ float s_area[kGtChunk];
+  __shared__ int s_ok[kGtChunk];
+  __shared__ int s_best[kGtChunk];
+  const int n = blockIdx.y;
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool live = k < K;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) b = reinterpret_cast<const float4*>(boxes)[(boxes_batched ? static_cast<size_t>(n) * K : 0) + k];
+  const float area_b = box_area(b);
+  float best = -2.f;   // below every quality (invalid rows hold -1)
+  int arg = 0;
+  bool lq = false;
+  for (int m0 = 0; m0 < M; m0 += kGtChunk) {
+    const int mc = min(kGtChunk, M - m0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < mc; t += kBlock) {
+      const float4 g = reinterpret_cast<const float4*>(gt)[static_cast<size_t>(n) * M + m0 + t];
+      s_gt[t] = g;
+      s_area[t] = box_area(g);
+      s_ok[t] = valid[static_cast<size_t>(n) * M + m0 + t] != 0;
+      if (PASS == 1 && allow_lq) s_best[t] = best_gt[static_cast<size_t>(n) * M + m0 + t];
+    }
+    __syncthreads();
+    for (int t = 0; t < mc; ++t) {
+      const float q = s_ok[t] ? iou_ref(s_gt[t], s_area[t], b, area_b) : -1.f;
+      if (q > best) { best = q; arg = m0 + t; }   // strict: the first maximum wins
+      if (PASS == 0 && best_gt != nullptr) {
+        // per-gt maximum over the boxes: most (wave, gt) pairs do not overlap at all (a wave holds 64
+        // neighbouring anchors) — those cost one ballot; the others one wave reduction and at most one atomic,
+        // skipped when the published maximum is already as large (a stale read only costs a redundant atomic)
+        if (__ballot(live && q > 0.f) != 0ull) {
+          const float wm = wave_max(live ? fmaxf(q, 0.f) : 0.f);
+          int32_t* slot = &best_gt[static_cast<size_t>(n) * M + m0 + t];
+          if (lane == 0 && __float_as_int(wm) > *slot) atomicMax(slot, __float_as_int(wm));
+        }
+      }
+      if (PASS == 1 && allow_lq) lq = lq || (s_ok[t] && __float_as_int(q) == s_best[t] && q >= 0.f);
+    }
+  }
+  if (!live) return;
+  if (PASS == 0 && allow_lq) return;   // pass 1 writes the result
+  int64_t out = arg;
+  if (best < low) out = -1;                       // Matcher.BELOW_LOW_THRESHOLD
+  else if (best < high) out = -2;                 // Matcher.BETWEEN_THRESHOLDS
+  if (lq) out = arg;                              // low-quality matches keep their arg-max ground truth
+  matched[static_cast<size_t>(n) * K + k] = out;
+}
+
+// ------------------------------------------------------------------------------------------ sampler
+// 32-bit key of element (row, i) under `seed`: two rounds of a multiply-xorshift mixer (the finaliser of
+// MurmurHash3 — public domain), enough for an unbiased-looking random subset.
+__device__ __forceinline__ unsigned sample_key(unsigned long long seed, int row, int i) {
+  unsigned h = static_cast<unsigned>(seed) ^ (static_cast<unsigned>(row) * 0x9E3779B1u);
+  h ^= static_cast<unsigned>(i) * 0x85EBCA6Bu + static_cast<unsigned>(seed >> 32);
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  h += static_cast<unsigned>(i);
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+
+// label class of an element: 1 positive (label >= 1), 0 negative (label == 0), -1 ignored
+template <typename T>
+__device__ __forceinline__ int label_class(T v) { return v >= static_cast<T>(1) ? 1 : (v == static_cast<T>(0) ? 0 : -1); }
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+sampler_count_kernel(const T* __restrict__ labels, int n, int32_t* __restrict__ counts /* [N, 2] neg, pos */) {
+  const int row = blockIdx.y;
+  int c0 = 0, c1 = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const int c = label_class(labels[static_cast<size_t>(row) * n + i]);
+    c0 += c == 0;
+    c1 += c == 1;
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) { c0 += __shfl_down(c0, off); c1 += __shfl_down(c1, off); }
+  __shared__ int s_c[2][kBlock / kWave];
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_c[0][threadIdx.x / kWave] = c0; s_c[1][threadIdx.x / kWave] = c1; }
+  __syncthreads();
+  if (threadIdx.x < 2) {   // one atomic per block and class (thousands of same-address atomics serialise in L2)
+    int t = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) t += s_c[threadIdx.x][w];
+    if (t) atomicAdd(&counts[row * 2 + threadIdx.x], t);
+  }
+}
+
+struct SamplerPlan {
+  int n, B, max_pos, cap;   // cap = survivor capacity per (row, class)
+  unsigned long long seed;
+};
+
+// key threshold of a class: survivors ~ Binomial(cand, f) with mean mu = quota + 8 sqrt(quota) + 32, i.e. more
+// than 8 standard deviations above the quota (P[fewer than quota] < 1e-14) and far below cap = 16 x B; all
+// candidates when there are at most 2 mu of them.  A short survivor list keeps the per-image sort small.
+__device__ __forceinline__ unsigned class_threshold(int cand, int quota) {
+  if (quota <= 0) return 0u;
+  const double mu = quota + 8.0 * sqrt(static_cast<double>(quota)) + 32.0;
+  if (cand <= 2.0 * mu) return 0xffffffffu;
+  return static_cast<unsigned>(mu / static_cast<double>(cand) * 4294967295.0);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+sampler_filter_kernel(const T* __restrict__ labels, SamplerPlan P, const int32_t* __restrict__ counts,
+                      int32_t* __restrict__ nsurv /* [N, 2] */, unsigned long long* __restrict__ surv /* [N, 2, cap] */) {
+  const int row = blockIdx.y;
+  const int n_neg = counts[row * 2 + 0], n_pos = counts[row * 2 + 1];
+  const int k_pos = min(n_pos, P.max_pos);
+  const int k_neg = min(min(n_neg, P.B), P.B - k_pos);
+  const unsigned thr_pos = class_threshold(n_pos, k_pos), thr_neg = class_threshold(n_neg, k_neg);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int span = gridDim.x * kBlock;
+  for (int i0 = blockIdx.x * kBlock; i0 < P.n; i0 += span) {   // uniform trip count: the ballots need every lane
+    const int i = i0 + threadIdx.x;
+    const int c = (i < P.n) ? label_class(labels[static_cast<size_t>(row) * P.n + i]) : -1;
+    const unsigned key = sample_key(P.seed, row, i);
+    const unsigned thr = c == 1 ? thr_pos : thr_neg;
+    const bool keep = c >= 0 && thr != 0u && key <= thr;
+#pragma unroll
+    for (int cls = 0; cls < 2; ++cls) {   // one atomic per wave and class; lanes take consecutive slots
+      const unsigned long long m = __ballot(keep && c == cls);
+      if (m == 0ull) continue;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&nsurv[row * 2 + cls], __popcll(m));
+      base = __shfl(base, 0);
+      if (keep && c == cls) {
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (slot < P.cap)
+          surv[(static_cast<size_t>(row) * 2 + cls) * P.cap + slot] = (static_cast<unsigned long long>(key) << 32) | static_cast<unsigned>(i);
+      }
+    }
+  }
+}
+
+// one workgroup per row: sort the survivors of each class by (key, index) in LDS, keep the quota
+__global__ void __launch_bounds__(1024)
+sampler_finish_kernel(SamplerPlan P, const int32_t* __restrict__ counts, const int32_t* __restrict__ nsurv,
+                      const unsigned long long* __restrict__ surv, uint8_t* __restrict__ pos_mask,
+                      uint8_t* __restrict__ neg_mask, int64_t* __restrict__ idx /* [N, B] nullable */,
+                      uint8_t* __restrict__ idx_valid /* [N, B] nullable */) {
+  DETOPS_DYNAMIC_LDS(unsigned long long, keys);
+  const int row = blockIdx.x;
+  const int n_neg = counts[row * 2 + 0], n_pos = counts[row * 2 + 1];
+  const int k_pos = min(n_pos, P.max_pos);
+  const int k_neg = min(min(n_neg, P.B), P.B - k_pos);
+  for (int c = 1; c >= 0; --c) {   // positives first
+    const int ns = min(nsurv[row * 2 + c], P.cap);
+    const int k = min(c ? k_pos : k_neg, ns);
+    int npad = 2;
+    while (npad < ns) npad <<= 1;   // the bitonic network only spans the survivors actually present
+    __syncthreads();
+    for (int i = threadIdx.x; i < npad; i += blockDim.x)
+      keys[i] = (i < ns) ? surv[(static_cast<size_t>(row) * 2 + c) * P.cap + i] : ~0ull;
+    __syncthreads();
+    for (int kk = 2; kk <= npad; kk <<= 1) {
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        for (int t = threadIdx.x; t < (npad >> 1); t += blockDim.x) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int p = i | j;
+          const unsigned long long a = keys[i], b = keys[p];
+          const bool up = (i & kk) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+        }
+        __syncthreads();
+      }
+    }
+    uint8_t* mask = c ? pos_mask : neg_mask;
+    const int base = c ? 0 : k_pos;   // fixed-length list: positives first, then negatives
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+      const int e = static_cast<int>(keys[i] & 0xffffffffull);
+      mask[static_cast<size_t>(row) * P.n + e] = 1;
+      if (idx) { idx[static_cast<size_t>(row) * P.B + base + i] = e; idx_valid[static_cast<size_t>(row) * P.B + base + i] = 1; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ mask targets
+struct AxisTap { int i0, i1; float l; };
+
+// torch's bilinear resize (align_corners = False) of a crop [lo, lo + size) to M samples, sample d:
+// src = fma(size / M, d + 0.5, -0.5) clamped at 0 (ONE rounding, as ATen's CPU kernel evaluates it),
+// taps (floor(src), +1) clamped to the crop.
+__device__ __forceinline__ AxisTap axis_tap(int lo, int size, int M, int d) {
+#pragma clang fp contract(off)
+  const float scale = static_cast<float>(size) / static_cast<float>(M);
+  float src = fmaf(scale, static_cast<float>(d) + 0.5f, -0.5f);
+  src = fmaxf(src, 0.f);
+  int i0 = static_cast<int>(floorf(src));
+  i0 = min(i0, size - 1);
+  const int i1 = min(i0 + 1, size - 1);
+  AxisTap t;
+  t.l = src - static_cast<float>(i0);
+  t.i0 = i0 + lo;
+  t.i1 = i1 + lo;
+  return t;
+}
+
+// one workgroup per ROI; masks [G, H, W] of MT (uint8 = integer masks: the interpolated value is truncated,
+// structures/segmentation_mask.py `.type_as(masks)`; float = kept), out [P, M, M] fp32
+// TRUNC: 0 = keep the float value, 1 = integer masks (truncate), 2 = bool masks (non-zero -> 1)
+template <typename MT, int TRUNC>
+__global__ void __launch_bounds__(kBlock)
+mask_targets_kernel(const MT* __restrict__ masks, const int64_t* __restrict__ mask_index, const float* __restrict__ boxes,
+                    int G, int H, int W, int M, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int p = blockIdx.x;
+  const float* bx = boxes + static_cast<size_t>(p) * 4;
+  // box.round() (half to even) -> clamp to the image -> at least one pixel
+  const int bx0 = static_cast<int>(rintf(bx[0])), by0 = static_cast<int>(rintf(bx[1]));
+  const int bx1 = static_cast<int>(rintf(bx[2])), by1 = static_cast<int>(rintf(bx[3]));
+  const int xmin = min(max(bx0, 0), W - 1), ymin = min(max(by0, 0), H - 1);
+  const int xmax = max(min(max(bx1, 0), W), xmin + 1), ymax = max(min(max(by1, 0), H), ymin + 1);
+  int64_t g = mask_index[p];
+  g = g < 0 ? 0 : (g >= G ? G - 1 : g);
+  const MT* m = masks + static_cast<size_t>(g) * H * W;
+  for (int e = threadIdx.x; e < M * M; e += kBlock) {
+    const int dy = e / M, dx = e - dy * M;
+    const AxisTap ty = axis_tap(ymin, ymax - ymin, M, dy);
+    const AxisTap tx = axis_tap(xmin, xmax - xmin, M, dx);
+    const float hy = 1.0f - ty.l, hx = 1.0f - tx.l;
+    const float p00 = static_cast<float>(m[static_cast<size_t>(ty.i0) * W + tx.i0]);
+    const float p01 = static_cast<float>(m[static_cast<size_t>(ty.i0) * W + tx.i1]);
+    const float p10 = static_cast<float>(m[static_cast<size_t>(ty.i1) * W + tx.i0]);
+    const float p11 = static_cast<float>(m[static_cast<size_t>(ty.i1) * W + tx.i1]);
+    // ((h0*w0)*p00 + (h0*w1)*p01) + (h1*w0)*p10 + (h1*w1)*p11, every product and sum rounded to fp32
+    float v = (hy * hx) * p00 + (hy * tx.l) * p01;
+    v = v + (ty.l * hx) * p10;
+    v = v + (ty.l * tx.l) * p11;
+    if (TRUNC == 1) v = static_cast<float>(static_cast<MT>(v));
+    if (TRUNC == 2) v = (v != 0.f) ? 1.f : 0.f;
+    out[static_cast<size_t>(p) * M * M + e] = v;
+  }
+}
+
+inline size_t up256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+struct SamplerLayout { size_t off_counts, off_nsurv, off_surv, total; int cap; };
+
+SamplerLayout sampler_layout(int N, int B) {
+  SamplerLayout l{};
+  l.cap = 16 * std::max(B, 1);
+  size_t o = 0;
+  l.off_counts = o; o = up256(o + sizeof(int32_t) * 2 * N);
+  l.off_nsurv = o;  o = up256(o + sizeof(int32_t) * 2 * N);
+  l.off_surv = o;   o = up256(o + sizeof(unsigned long long) * 2 * static_cast<size_t>(N) * l.cap);
+  l.total = o;
+  return l;
+}
+
+template <typename T>
+int run_sampler(const void* labels, int N, int n, int B, int max_pos, unsigned long long seed, uint8_t* pos_mask,
+                uint8_t* neg_mask, int64_t* idx, uint8_t* idx_valid, void* ws, hipStream_t st) {
+  const SamplerLayout l = sampler_layout(N, B);
+  unsigned char* base = static_cast<unsigned char*>(ws);
+  int32_t* counts = reinterpret_cast<int32_t*>(base + l.off_counts);
+  int32_t* nsurv = reinterpret_cast<int32_t*>(base + l.off_nsurv);
+  unsigned long long* surv = reinterpret_cast<unsigned long long*>(base + l.off_surv);
+  DETOPS_HIP_TRY(hipMemsetAsync(base, 0, l.off_surv, st));
+  DETOPS_HIP_TRY(hipMemsetAsync(pos_mask, 0, static_cast<size_t>(N) * n, st));
+  DETOPS_HIP_TRY(hipMemsetAsync(neg_mask, 0, static_cast<size_t>(N) * n, st));
+  if (idx) {
+    DETOPS_HIP_TRY(hipMemsetAsync(idx, 0, sizeof(int64_t) * static_cast<size_t>(N) * B, st));
+    DETOPS_HIP_TRY(hipMemsetAsync(idx_valid, 0, static_cast<size_t>(N) * B, st));
+  }
+  const SamplerPlan P{n, B, max_pos, l.cap, seed};
+  const int bx = static_cast<int>(std::min<int64_t>(ceil_div64(n, kBlock), 2 * kNumCU));
+  const dim3 grid(static_cast<unsigned>(std::max(bx, 1)), static_cast<unsigned>(N));
+  const T* lab = static_cast<const T*>(labels);
+  hipLaunchKernelGGL(sampler_count_kernel<T>, grid, dim3(kBlock), 0, st, lab, n, counts);
+  hipLaunchKernelGGL(sampler_filter_kernel<T>, grid, dim3(kBlock), 0, st, lab, P, counts, nsurv, surv);
+  int npad = 2;
+  while (npad < l.cap) npad <<= 1;
+  hipLaunchKernelGGL(sampler_finish_kernel, dim3(static_cast<unsigned>(N)), dim3(1024), npad * sizeof(unsigned long long), st,
+                     P, counts, nsurv, surv, pos_mask, neg_mask, idx, idx_valid);
+  return launch_status();
+}
+
+}  // namespace
+
+DETOPS_API size_t detops_match_boxes_workspace_bytes(int N, int M) {
+  if (N <= 0 || M <= 0) return 256;
+  return up256(sizeof(int32_t) * static_cast<size_t>(N) * M);
+}
+
+DETOPS_API int detops_match_boxes_f32(const float* gt_boxes, const uint8_t* gt_valid, const float* boxes,
+                                      int boxes_batched, int N, int M, int K, float high_threshold,
+                                      float low_threshold, int allow_low_quality_matches, int64_t* matched_idxs,
+                                      void* workspace, size_t workspace_bytes, detops_stream_t stream) {
+  if (N < 0 || M <= 0 || K < 0) return DETOPS_EINVAL;
+  if (N == 0 || K == 0) return 0;
+  if (!gt_boxes || !gt_valid || !boxes || !matched_idxs) return DETOPS_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const dim3 grid(static_cast<unsigned>(ceil_div64(K, kBlock)), static_cast<unsigned>(N));
+  int32_t* best = nullptr;
+  if (allow_low_quality_matches) {
+    if (!workspace || workspace_bytes < detops_match_boxes_workspace_bytes(N, M)) return DETOPS_EWORKSPACE;
+    best = static_cast<int32_t*>(workspace);
+    DETOPS_HIP_TRY(hipMemsetAsync(best, 0, sizeof(int32_t) * static_cast<size_t>(N) * M, st));
+  }
+  hipLaunchKernelGGL(match_kernel<0>, grid, dim3(kBlock), 0, st, gt_boxes, gt_valid, boxes, boxes_batched, M, K,
+                     high_threshold, low_threshold, allow_low_quality_matches, best, matched_idxs);
+  if (allow_low_quality_matches)
+    hipLaunchKernelGGL(match_kernel<1>, grid, dim3(kBlock), 0, st, gt_boxes, gt_valid, boxes, boxes_batched, M, K,
+                       high_threshold, low_threshold, allow_low_quality_matches, best, matched_idxs);
+  return launch_status();
+}
+
+DETOPS_API size_t detops_sample_labels_workspace_bytes(int N, int batch_size_per_image) {
+  if (N <= 0) return 256;
+  return sampler_layout(N, batch_size_per_image).total;
+}
+
+DETOPS_API int detops_sample_labels(const void* labels, int label_dtype, int N, int n, int batch_size_per_image,
+                                    int max_positives, uint64_t seed, uint8_t* pos_mask, uint8_t* neg_mask,
+                                    int64_t* sampled_idx, uint8_t* sampled_valid, void* workspace,
+                                    size_t workspace_bytes, detops_stream_t stream) {
+  if (N < 0 || n < 0 || batch_size_per_image <= 0 || max_positives < 0) return DETOPS_EINVAL;
+  if (N == 0 || n == 0) return 0;
+  if (!labels || !pos_mask || !neg_mask || (sampled_idx != nullptr) != (sampled_valid != nullptr)) return DETOPS_EINVAL;
+  if (batch_size_per_image > 512) return DETOPS_EUNSUPPORTED;   // survivor sort: 16 x quota 64-bit keys in <= 64 KiB of LDS
+  if (!workspace || workspace_bytes < detops_sample_labels_workspace_bytes(N, batch_size_per_image)) return DETOPS_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  switch (label_dtype) {
+    case DETOPS_LABEL_F32:
+      return run_sampler<float>(labels, N, n, batch_size_per_image, max_positives, seed, pos_mask, neg_mask, sampled_idx,
+                                sampled_valid, workspace, st);
+    case DETOPS_LABEL_I64:
+      return run_sampler<int64_t>(labels, N, n, batch_size_per_image, max_positives, seed, pos_mask, neg_mask,
+                                  sampled_idx, sampled_valid, workspace, st);
+    default:
+      return DETOPS_EUNSUPPORTED;
+  }
+}
+
+DETOPS_API int detops_mask_targets(const void* masks, int mask_dtype, const int64_t* mask_index, const float* boxes,
+                                   int G, int H, int W, int P, int M, float* out, detops_stream_t stream) {
+  if (G < 0 || H <= 0 || W <= 0 || P < 0 || M <= 0) return DETOPS_EINVAL;
+  if (P == 0) return 0;
+  if (G == 0 || !masks || !mask_index || !boxes || !out) return DETOPS_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const dim3 grid(static_cast<unsigned>(P));
+  if (mask_dtype == DETOPS_MASK_U8)
+    hipLaunchKernelGGL((mask_targets_kernel<uint8_t, 1>), grid, dim3(kBlock), 0, st, static_cast<const uint8_t*>(masks),
+                       mask_index, boxes, G, H, W, M, out);
+  else if (mask_dtype == DETOPS_MASK_BOOL)
+    hipLaunchKernelGGL((mask_targets_kernel<uint8_t, 2>), grid, dim3(kBlock), 0, st, static_cast<const uint8_t*>(masks),
+                       mask_index, boxes, G, H, W, M, out);
+  else if (mask_dtype == DETOPS_MASK_F32)
+    hipLaunchKernelGGL((mask_targets_kernel<float, 0>), grid, dim3(kBlock), 0, st, static_cast<const float*>(masks),
+                       mask_index, boxes, G, H, W, M, out);
+  else
+    return DETOPS_EUNSUPPORTED;
+  return launch_status();
+}

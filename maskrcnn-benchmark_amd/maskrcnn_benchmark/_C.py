@@ -175,6 +175,87 @@ def nms_batched_mask(boxes, scores, seg_offsets, max_n, threshold):
     return mask.view(torch.bool), num
 
 
+# ------------------------------------------------------------------------------------------ target assignment
+def match_boxes(gt_boxes, gt_valid, boxes, high_threshold, low_threshold, allow_low_quality_matches):
+    """Fused IoU + Matcher (extension; reference structures/boxlist_ops.py:53-89 + modeling/matcher.py:42-112):
+    gt_boxes [N,M,4], gt_valid [N,M] bool, boxes [K,4] (shared) or [N,K,4] -> matched_idxs [N,K] int64."""
+    _need_cuda("match_boxes", gt_boxes, gt_valid, boxes)
+    gt_boxes = _f32c("match_boxes", gt_boxes)
+    boxes = _f32c("match_boxes", boxes)
+    valid = gt_valid.to(torch.uint8).contiguous() if gt_valid.dtype != torch.uint8 else gt_valid.contiguous()
+    N, M = gt_boxes.shape[:2]
+    batched = boxes.dim() == 3
+    K = boxes.shape[-2]
+    out = torch.empty((N, K), dtype=torch.int64, device=boxes.device)
+    if N == 0 or K == 0:
+        return out
+    nbytes = int(lib.detops_match_boxes_workspace_bytes(N, M))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=boxes.device)
+    with _on_device(boxes), _timed("match_boxes[N=%d,M=%d,K=%d]" % (N, M, K), boxes):
+        check(lib.detops_match_boxes_f32(ptr(gt_boxes), ptr(valid), ptr(boxes), int(batched), N, M, K,
+                                         float(high_threshold), float(low_threshold), int(bool(allow_low_quality_matches)),
+                                         ptr(out), ptr(ws), nbytes, stream_of(boxes)), "match_boxes")
+    return out
+
+
+_SAMPLER_CALLS = [0]
+
+
+def sample_labels(labels, batch_size_per_image, max_positives, with_list=False, seed=None):
+    """BalancedPositiveNegativeSampler on device (extension; reference
+    modeling/balanced_positive_negative_sampler.py:19-68): labels [N,n] float32 or int64 ->
+    (pos_mask, neg_mask [N,n] bool[, idx [N,B] int64, valid [N,B] bool]).  The random subset is a pure function
+    of (labels, seed); the default seed advances a per-process counter from torch's initial seed (no device op)."""
+    _need_cuda("sample_labels", labels)
+    if labels.dtype not in (torch.float32, torch.int64):
+        labels = labels.to(torch.int64)
+    labels = labels.contiguous()
+    N, n = labels.shape
+    B = int(batch_size_per_image)
+    if seed is None:
+        _SAMPLER_CALLS[0] += 1
+        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SAMPLER_CALLS[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    pos = torch.empty((N, n), dtype=torch.uint8, device=labels.device)
+    neg = torch.empty((N, n), dtype=torch.uint8, device=labels.device)
+    idx = torch.empty((N, B), dtype=torch.int64, device=labels.device) if with_list else None
+    val = torch.empty((N, B), dtype=torch.uint8, device=labels.device) if with_list else None
+    if N and n:
+        nbytes = int(lib.detops_sample_labels_workspace_bytes(N, B))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=labels.device)
+        with _on_device(labels), _timed("sample_labels[N=%d,n=%d,B=%d]" % (N, n, B), labels):
+            check(lib.detops_sample_labels(ptr(labels), 0 if labels.dtype == torch.float32 else 1, N, n, B,
+                                           int(max_positives), ctypes.c_uint64(seed), ptr(pos), ptr(neg), ptr(idx),
+                                           ptr(val), ptr(ws), nbytes, stream_of(labels)), "sample_labels")
+    elif with_list:
+        idx.zero_()
+        val.zero_()
+    if with_list:
+        return pos.view(torch.bool), neg.view(torch.bool), idx, val.view(torch.bool)
+    return pos.view(torch.bool), neg.view(torch.bool)
+
+
+def mask_targets(masks, mask_index, boxes, discretization_size):
+    """Mask-head targets (extension; reference roi_heads/mask_head/loss.py:11-42): masks [G,H,W] uint8 / bool /
+    float32, mask_index [P] int64, boxes [P,4] xyxy -> [P,M,M] float32, bit-equal to the reference's CPU path."""
+    _need_cuda("mask_targets", masks, mask_index, boxes)
+    boxes = _f32c("mask_targets", boxes)
+    if masks.dtype == torch.bool:
+        code, m = 2, masks.contiguous().view(torch.uint8)
+    elif masks.dtype == torch.uint8:
+        code, m = 0, masks.contiguous()
+    else:
+        code, m = 1, masks.to(torch.float32).contiguous()
+    mask_index = mask_index.to(torch.int64).contiguous()
+    G, H, W = m.shape
+    P, M = boxes.size(0), int(discretization_size)
+    out = torch.empty((P, M, M), dtype=torch.float32, device=boxes.device)
+    if P:
+        with _on_device(boxes), _timed("mask_targets[P=%d,M=%d]" % (P, M), boxes):
+            check(lib.detops_mask_targets(ptr(m), code, ptr(mask_index), ptr(boxes), G, H, W, P, M, ptr(out),
+                                          stream_of(boxes)), "mask_targets")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ ROIAlign
 def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
     """reference csrc/ROIAlign.h:11-25 -> [K,C,PH,PW]."""

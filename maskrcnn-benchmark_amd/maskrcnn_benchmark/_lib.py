@@ -29,6 +29,11 @@ SIGNATURES = {
     "detops_roi_align_backward_ws_f32": (
         c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P, c_size_t, _P]),
     "detops_roi_align_backward_workspace_bytes": (c_size_t, [_P, _P] + [c_int] * 6),
+    "detops_match_boxes_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "detops_match_boxes_f32": (c_int, [_P, _P, _P] + [c_int] * 4 + [c_float, c_float, c_int, _P, _P, c_size_t, _P]),
+    "detops_sample_labels_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "detops_sample_labels": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "detops_mask_targets": (c_int, [_P, c_int, _P, _P] + [c_int] * 5 + [_P, _P]),
     "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),
     "detops_roi_pool_backward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "detops_nms_workspace_bytes": (c_size_t, [c_int]),

@@ -42,6 +42,11 @@ def pad_targets(targets, device, fields=()):
 def match_batched(matcher, gt_boxes, row_valid, boxes):
     """IoU + Matcher for a batch: gt_boxes [N,M,4], boxes [N,K,4] (or [K,4] shared) -> matched_idxs
     [N,K] int64 (>= 0 index into the image's gt rows, -1 / -2 as in Matcher)."""
+    if boxes.is_cuda:
+        # fused IoU + Matcher kernel (csrc/targets.hip): the [N, M, K] quality matrix is never materialised
+        from maskrcnn_benchmark import _C
+        return _C.match_boxes(gt_boxes, row_valid, boxes, matcher.high_threshold, matcher.low_threshold,
+                              matcher.allow_low_quality_matches)
     if boxes.dim() == 2:
         boxes = boxes.unsqueeze(0).expand(gt_boxes.shape[0], -1, -1)
     iou = box_iou_matrix(gt_boxes, boxes)

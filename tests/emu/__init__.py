@@ -23,6 +23,12 @@ SIGNATURES = {
     "detops_roi_align_backward_ws_f32": (
         c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P, ctypes.c_size_t, _P]),
     "detops_roi_align_backward_workspace_bytes": (ctypes.c_size_t, [_P, _P] + [c_int] * 6),
+    "detops_match_boxes_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "detops_match_boxes_f32": (c_int, [_P, _P, _P] + [c_int] * 4 + [c_float, c_float, c_int, _P, _P, ctypes.c_size_t, _P]),
+    "detops_sample_labels_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "detops_sample_labels": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, _P, _P, _P, _P, _P,
+                                     ctypes.c_size_t, _P]),
+    "detops_mask_targets": (c_int, [_P, c_int, _P, _P] + [c_int] * 5 + [_P, _P]),
     "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),
     "detops_roi_pool_backward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "detops_nms_workspace_bytes": (ctypes.c_size_t, [c_int]),
@@ -129,6 +135,52 @@ def roi_align_fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr):
                                                     None)
     assert rc == 0, rc
     return gins
+
+
+# ---------------------------------------------------------------------------------- target assignment
+def match_boxes(gt, valid, boxes, high, low, allow_lq):
+    """gt [N,M,4], valid [N,M] bool, boxes [K,4] or [N,K,4] -> matched [N,K] int64"""
+    gt, boxes = _f32(gt), _f32(boxes)
+    valid = np.ascontiguousarray(valid, dtype=np.uint8)
+    N, M = gt.shape[:2]
+    batched = boxes.ndim == 3
+    K = boxes.shape[-2]
+    out = np.full((N, K), -99, np.int64)
+    nbytes = lib().detops_match_boxes_workspace_bytes(N, M)
+    ws = np.full((nbytes,), 0xAB, np.uint8)
+    rc = lib().detops_match_boxes_f32(_p(gt), _p(valid), _p(boxes), int(batched), N, M, K, high, low, int(allow_lq),
+                                      _p(out), _p(ws), nbytes, None)
+    assert rc == 0, rc
+    return out
+
+
+def sample_labels(labels, B, max_pos, seed, with_list=True):
+    labels = np.ascontiguousarray(labels)
+    code = {np.dtype(np.float32): 0, np.dtype(np.int64): 1}[labels.dtype]
+    N, n = labels.shape
+    pos = np.full((N, n), 7, np.uint8)
+    neg = np.full((N, n), 7, np.uint8)
+    idx = np.full((N, B), -5, np.int64)
+    val = np.full((N, B), 7, np.uint8)
+    nbytes = lib().detops_sample_labels_workspace_bytes(N, B)
+    ws = np.full((nbytes,), 0xAB, np.uint8)
+    rc = lib().detops_sample_labels(_p(labels), code, N, n, B, max_pos, seed, _p(pos), _p(neg),
+                                    _p(idx) if with_list else None, _p(val) if with_list else None, _p(ws), nbytes, None)
+    assert rc == 0, rc
+    return pos.astype(bool), neg.astype(bool), idx, val.astype(bool)
+
+
+def mask_targets(masks, mask_index, boxes, M):
+    masks = np.ascontiguousarray(masks)
+    code = {np.dtype(np.uint8): 0, np.dtype(np.float32): 1, np.dtype(np.bool_): 2}[masks.dtype]
+    mask_index = np.ascontiguousarray(mask_index, dtype=np.int64)
+    boxes = _f32(boxes)
+    G, H, W = masks.shape
+    P = boxes.shape[0]
+    out = np.full((P, M, M), np.nan, np.float32)
+    rc = lib().detops_mask_targets(_p(masks), code, _p(mask_index), _p(boxes), G, H, W, P, M, _p(out), None)
+    assert rc == 0, rc
+    return out
 
 
 # ---------------------------------------------------------------------------------- deformable conv

@@ -244,6 +244,13 @@ template <typename T> static inline T __shfl_up(T v, int off) {
   if (src >= 0 && ((live >> src) & 1ull)) { T r; memcpy(&r, &t[src], sizeof(T)); return r; }
   return v;
 }
+template <typename T> static inline T __shfl(T v, int src) {
+  static_assert(sizeof(T) <= 8, "");
+  unsigned long long raw = 0, live = 0; memcpy(&raw, &v, sizeof(T));
+  const unsigned long long* t = emu::exchange(raw, &live);
+  if (src >= 0 && src < emu::kWaveSize && ((live >> src) & 1ull)) { T r; memcpy(&r, &t[src], sizeof(T)); return r; }
+  return v;
+}
 static inline unsigned emu_readlane(unsigned v, int lane) {
   const unsigned long long* t = emu::exchange(v, nullptr);
   return static_cast<unsigned>(t[lane]);

@@ -1,0 +1,116 @@
+"""GPU parity of csrc/targets.hip (fused IoU + Matcher, sampler, mask targets) at the BASELINE sizes: 268,569
+RPN anchors / 201,600 RetinaNet anchors per image, 512-ROI box-head sampling, 28 x 28 mask targets — against the
+torch CPU implementations that tests/test_model_cpu.py pins to the reference-generated fixtures."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from maskrcnn_benchmark.modeling.matcher import Matcher
+from maskrcnn_benchmark.structures.boxlist_ops import box_iou_matrix
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _gt(rng, N, M, W=1344, H=800):
+    cx, cy = rng.uniform(0, W, (N, M)), rng.uniform(0, H, (N, M))
+    w, h = rng.uniform(8, 500, (N, M)), rng.uniform(8, 400, (N, M))
+    return np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], -1).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,hi,lo,lq,strides,sizes,per", [
+    ("rpn", 0.7, 0.3, True, (4, 8, 16, 32, 64), ((32,), (64,), (128,), (256,), (512,)), 3),
+    ("retinanet", 0.5, 0.4, True, (8, 16, 32, 64, 128), None, 9)])
+def test_match_boxes_full_anchor_set_equals_torch_matcher(name, hi, lo, lq, strides, sizes, per):
+    from maskrcnn_benchmark import _C
+    from maskrcnn_benchmark.modeling.rpn.anchor_generator import AnchorGenerator
+    from maskrcnn_benchmark.structures.image_list import ImageList
+    if sizes is None:
+        sizes = tuple(tuple(s * 2 ** (k / 3.0) for k in range(3)) for s in (32, 64, 128, 256, 512))
+    ag = AnchorGenerator(sizes=sizes, anchor_strides=strides, straddle_thresh=-1)
+    feats = [torch.zeros(1, 1, -(-800 // s), -(-1344 // s)) for s in strides]
+    anchors = torch.cat([b.bbox for b in ag(ImageList(torch.zeros(1, 3, 800, 1344), [(800, 1344)]), feats)[0]])
+    K = anchors.shape[0]
+    assert K == {"rpn": 268569, "retinanet": 201600}[name]
+    rng = np.random.RandomState(5)
+    N, M = 2, 23
+    gt = _gt(rng, N, M)
+    valid = np.ones((N, M), bool)
+    valid[1, 9:] = False
+    gt[~valid] = [-1e5, -1e5, -1e5 + 1, -1e5 + 1]
+    gt[0, 4] = anchors[12345].numpy()       # a ground truth identical to an anchor (IoU exactly 1)
+    out = _C.match_boxes(torch.from_numpy(gt).to(DEV), torch.from_numpy(valid).to(DEV), anchors.to(DEV), hi, lo, lq).cpu()
+    iou = box_iou_matrix(torch.from_numpy(gt), anchors.unsqueeze(0).expand(N, -1, -1))
+    iou = torch.where(torch.from_numpy(valid)[:, :, None], iou, iou.new_full((), -1.0))
+    ref = Matcher(hi, lo, allow_low_quality_matches=lq)(iou, torch.from_numpy(valid))
+    assert torch.equal(out, ref)
+    assert int((out >= 0).sum()) > 50 and int((out == -2).sum()) > 50
+
+
+def test_match_boxes_box_head_batched_proposals():
+    from maskrcnn_benchmark import _C
+    rng = np.random.RandomState(6)
+    N, M, K = 2, 40, 2040
+    gt = _gt(rng, N, M)
+    valid = np.ones((N, M), bool)
+    boxes = _gt(rng, N, K)
+    boxes[:, :M] = gt                        # ground truth appended to the proposals (add_gt_proposals)
+    out = _C.match_boxes(torch.from_numpy(gt).to(DEV), torch.from_numpy(valid).to(DEV), torch.from_numpy(boxes).to(DEV),
+                         0.5, 0.5, False).cpu()
+    iou = box_iou_matrix(torch.from_numpy(gt), torch.from_numpy(boxes))
+    ref = Matcher(0.5, 0.5, allow_low_quality_matches=False)(iou, torch.from_numpy(valid))
+    assert torch.equal(out, ref)
+
+
+def test_sample_labels_rpn_and_box_head_sizes():
+    from maskrcnn_benchmark import _C
+    g = torch.Generator().manual_seed(1)
+    N, n = 2, 268569
+    labels = torch.zeros(N, n)
+    labels[torch.rand(N, n, generator=g) < 0.3] = -1
+    labels[0, torch.randperm(n, generator=g)[:57]] = 1
+    labels[1, torch.randperm(n, generator=g)[:900]] = 1
+    lab = labels.to(DEV)
+    pos, neg = _C.sample_labels(lab, 256, 128, seed=7)
+    for i, kp in enumerate((57, 128)):
+        assert int(pos[i].sum()) == kp and int(neg[i].sum()) == 256 - kp
+    assert not (pos & ~(lab >= 1)).any() and not (neg & ~(lab == 0)).any()
+    p2, n2 = _C.sample_labels(lab, 256, 128, seed=7)
+    assert torch.equal(pos, p2) and torch.equal(neg, n2)
+    p3, n3 = _C.sample_labels(lab, 256, 128)            # default seed: advances per call
+    p4, n4 = _C.sample_labels(lab, 256, 128)
+    assert not torch.equal(n3, n4)
+    # each of the 900 positives of row 1 is drawn ~128/900 of the time
+    hits = torch.zeros(n, device=DEV)
+    for s in range(300):
+        hits += _C.sample_labels(lab[1:], 256, 128, seed=100 + s)[0][0]
+    h = hits[lab[1] >= 1]
+    assert abs(float(h.mean()) - 300 * 128 / 900) < 1e-3 and float(h.min()) >= 12 and float(h.max()) <= 80
+    # box head: int64 class labels, fixed-length list, positives first
+    cls = torch.zeros(2, 2040, dtype=torch.int64)
+    cls[0, :300] = torch.randint(1, 81, (300,), generator=g)
+    cls[1, :20] = 5
+    cls[1, 1500:] = -1
+    pos, neg, idx, val = _C.sample_labels(cls.to(DEV), 512, 128, with_list=True, seed=3)
+    idx, val = idx.cpu(), val.cpu()
+    for i, kp in enumerate((128, 20)):
+        assert int(pos[i].sum()) == kp and int(neg[i].sum()) == 512 - kp and bool(val[i].all())
+        assert (cls[i][idx[i][:kp]] >= 1).all() and (cls[i][idx[i][kp:]] == 0).all()
+        assert idx[i].unique().numel() == 512
+
+
+def test_mask_targets_bit_equal_to_the_torch_cpu_path_at_model_size():
+    from maskrcnn_benchmark import _C
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head.loss import project_masks_on_boxes
+    rng = np.random.RandomState(8)
+    G, H, W, P, M = 12, 800, 1344, 256, 28
+    yy, xx = np.mgrid[:H, :W]
+    masks = np.stack([((yy - rng.uniform(100, 700)) ** 2 / rng.uniform(900, 40000) +
+                       (xx - rng.uniform(100, 1200)) ** 2 / rng.uniform(900, 90000)) < 1 for _ in range(G)]).astype(np.uint8)
+    rois = synth.fpn_rois(seed=11, per_image=P, n_images=1)[:, 1:]
+    which = rng.randint(0, G, P).astype(np.int64)
+    for m in (torch.from_numpy(masks), torch.from_numpy(masks).float(), torch.from_numpy(masks).bool()):
+        ref = project_masks_on_boxes(m, torch.from_numpy(which), torch.from_numpy(rois), M)
+        out = _C.mask_targets(m.to(DEV), torch.from_numpy(which).to(DEV), torch.from_numpy(rois).to(DEV), M).cpu()
+        assert torch.equal(out, ref), m.dtype
