@@ -36,6 +36,17 @@ constexpr int kBlock = 256;
 constexpr int kTabBig = 512;    // axis-table entries per axis kept in LDS (adaptive grids);
 constexpr int kTabSmall = 32;   // fixed sampling_ratio: PH*sr, PW*sr <= 32 covers 7x7..14x14 @ sr 2
 
+// 16-byte global load from a 4-byte-aligned address (gfx950 global_load_dwordx4 needs dword alignment only)
+#ifdef DETOPS_CPU_EMU
+__device__ __forceinline__ float4 load_float4_dword_aligned(const float* p) { return make_float4(p[0], p[1], p[2], p[3]); }
+#else
+typedef float float4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float4 load_float4_dword_aligned(const float* p) {
+  const float4_a4 v = *reinterpret_cast<const float4_a4*>(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+#endif
+
 struct __align__(16) Tap {
   int lo, hi;   // y axis: pre-multiplied by W
   float l, h;   // frac, 1-frac (both 0 for a sample outside the map)
@@ -210,12 +221,14 @@ roi_align_fwd_kernel(Levels L, const float* __restrict__ rois, const int32_t* __
 //     reference CPU kernel for finite inputs.
 // Footprints that do not fit the LDS budget fall through to the generic gather loop.
 // ------------------------------------------------------------------------------------------
+constexpr int kFwdWps = 4;   // waves per SIMD of the row-vector forward (register budget 80)
 constexpr int kLdsPatchFloats = 8192 - 64;  // default ~32 KiB dynamic LDS per workgroup -> 4-5 workgroups / CU
 
 // U = staging loads in flight per lane; patch_floats = LDS patch budget (DETOPS_ROIALIGN_FWD_LDS_KB /
 // DETOPS_ROIALIGN_FWD_U select other points of the occupancy / loads-in-flight trade-off at run time)
-template <int PH, int PW, int SR, int G, int U>
-__global__ void __launch_bounds__(((PH * PW * G + 63) / 64) * 64)
+// WPS: waves per SIMD the register allocation must allow (residency hides the stage -> compute latency chain)
+template <int PH, int PW, int SR, int G, int U, int WPS>
+__global__ void __launch_bounds__(((PH * PW * G + 63) / 64) * 64, WPS)
 roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
                          int32_t* __restrict__ levels_out, float* __restrict__ out, int C, int K, int CT,
                          int chunks, int patch_floats) {
@@ -267,15 +280,14 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
   const int rows = s_bounds[1] - ymin + 2;   // (lo range) + the lo+1 row
   const size_t plane = static_cast<size_t>(H) * W;
   const float* base = in + (static_cast<size_t>(g.b) * C + c0) * plane;
-  // Row-vector staging (maps whose rows are 16-byte aligned: W % 4 == 0): the patch starts at a column that is
-  // a multiple of 4 and each row is copied as float4s by a group of 8..64 lanes — one address computation per
-  // 16 bytes instead of ~25 VALU instructions of index arithmetic per staged dword (rocprofv3 PMC of the dword
-  // version, profiles/r02a_pmc_diag.txt: 51 M VALU wave-instructions per launch, 2/3 of them staging index math).
-  const bool vec4 = ((W & 3) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
-  const int xmin = vec4 ? (s_bounds[2] & ~3) : s_bounds[2];
-  int ps = s_bounds[3] - xmin + 2;           // columns incl. the lo+1 column
-  if (vec4) { ps = (ps + 3) & ~3; if (!((ps >> 2) & 1)) ps += 4; }   // float4 rows, odd number of float4 per row
-  else ps |= 1;                               // odd -> rows spread over the LDS banks
+  // Row-vector staging: each patch row is copied as 16-byte pieces by a group of 8..64 lanes — one address
+  // computation per 16 bytes instead of ~25 VALU instructions of index arithmetic per staged dword (rocprofv3
+  // PMC of the dword version, profiles/r02a_pmc_diag.txt: 51 M VALU wave-instructions per launch, 2/3 of them
+  // staging index math).  The global side is only 4-byte aligned (a patch starts at any column of any map
+  // width): gfx950 global_load_dwordx4 takes dword-aligned addresses; the LDS side is 16-byte aligned.
+  const int xmin = s_bounds[2];
+  int ps = (s_bounds[3] - xmin + 2 + 3) & ~3;   // columns incl. the lo+1 column, whole float4s per row
+  if (!((ps >> 2) & 1)) ps += 4;                // odd number of float4 per row: rows spread over the LDS banks
   const int area = rows * ps;
 
   if (area > patch_floats) {  // footprint too large for LDS: gather straight from the map
@@ -329,14 +341,13 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
   // staging: element-linear over the patch (lanes run along a patch row, wrap to the next row), four
   // independent loads in flight per lane before the first LDS store (the loop is latency-bound
   // otherwise: one L2/MALL round trip per iteration)
-  const float inv_ps = 1.f / static_cast<float>(ps), inv_rows = 1.f / static_cast<float>(rows);
+  const float inv_rows = 1.f / static_cast<float>(rows);
   const int ctb = min(cend - c0, patch_floats / area);
   for (int cs = c0; cs < cend; cs += ctb) {
     const int cn = min(ctb, cend - cs);
     const float* src = base + static_cast<size_t>(cs - c0) * plane;
-    const int total = cn * area;
-    if (tid == 0) { DETOPS_STAT("fwd.stage_batches", 1); DETOPS_STAT("fwd.staged_floats", total); }
-    if (vec4) {
+    if (tid == 0) { DETOPS_STAT("fwd.stage_batches", 1); DETOPS_STAT("fwd.staged_floats", cn * area); }
+    {
       const int w4 = ps >> 2;
       int lw = 8;
       while (lw < w4) lw <<= 1;                 // lanes per patch row (wave-uniform, <= 64: ps <= 256)
@@ -350,14 +361,13 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
           const int rr = rr0 + u * rpi;
           val[u] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (rr < nrows && v < w4) {
-            const int c = static_cast<int>((static_cast<float>(rr) + 0.5f) * inv_rows);   // rr / rows
+            const int c = static_cast<int>((static_cast<float>(rr) + 0.5f) * inv_rows);   // rr / rows (exact: rr < 16384)
             const int y = rr - c * rows;
             const float* rowp = src + static_cast<size_t>(c) * plane + static_cast<size_t>(min(ymin + y, H - 1)) * W;
-            if (gx < W) {
-              val[u] = *reinterpret_cast<const float4*>(rowp + gx);
-            } else {                              // whole float4 beyond the map: the replicated border column
-              const float e = rowp[W - 1];
-              val[u] = make_float4(e, e, e, e);
+            if (gx + 3 < W) {
+              val[u] = load_float4_dword_aligned(rowp + gx);
+            } else {                              // piece reaching beyond the row: the replicated border column
+              val[u] = make_float4(rowp[min(gx, W - 1)], rowp[min(gx + 1, W - 1)], rowp[min(gx + 2, W - 1)], rowp[W - 1]);
             }
           }
         }
@@ -367,32 +377,11 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
           if (rr < nrows && v < w4) *reinterpret_cast<float4*>(patch + rr * ps + 4 * v) = val[u];
         }
       }
-    } else {
-    for (int e0 = tid; e0 < total; e0 += NT * U) {
-      float v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * NT;
-        v[u] = 0.f;
-        if (e < total) {
-          const int r = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_ps);   // e / ps  (exact for e < 16384, ps < 2048: brute-forced)
-          const int x = e - r * ps;
-          const int c = static_cast<int>((static_cast<float>(r) + 0.5f) * inv_rows);  // r / rows
-          const int y = r - c * rows;
-          v[u] = src[static_cast<size_t>(c) * plane + static_cast<size_t>(min(ymin + y, H - 1)) * W + min(xmin + x, W - 1)];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * NT;
-        if (e < total) patch[e] = v[u];
-      }
-    }
     }
     __syncthreads();
     if (csub < G) {
       float* o = obase + static_cast<size_t>(cs - c0) * BINS + bin;
-#pragma unroll 2
+#pragma unroll 1
       for (int c = csub; c < cn; c += G) {
 #pragma clang fp contract(off)
         const float* p = patch + c * area;
@@ -888,10 +877,10 @@ void launch_fwd_lds(const Levels& L, const float* rois, const int32_t* levels_in
   if (const char* e = getenv("DETOPS_ROIALIGN_FWD_U")) unroll = atoi(e);
   const dim3 grid(static_cast<unsigned>(K) * chunks);
   const size_t lds = (patch_floats + 64) * sizeof(float);
-#define FWD_LDS_LAUNCH(U_)                                                                                 \
-  hipLaunchKernelGGL((roi_align_fwd_lds_kernel<PH, PW, SR, G, U_>), grid, dim3(NT), lds, st, L, rois,      \
+#define FWD_LDS_LAUNCH(U_)                                                                                       \
+  hipLaunchKernelGGL((roi_align_fwd_lds_kernel<PH, PW, SR, G, U_, kFwdWps>), grid, dim3(NT), lds, st, L, rois,   \
                      levels_in, levels_out, out, C, K, CT, chunks, patch_floats)
-  if (unroll == 8) FWD_LDS_LAUNCH(8); else FWD_LDS_LAUNCH(4);
+  if (unroll == 8) FWD_LDS_LAUNCH(8); else if (unroll == 2) FWD_LDS_LAUNCH(2); else FWD_LDS_LAUNCH(4);
 #undef FWD_LDS_LAUNCH
 }
 
