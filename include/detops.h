@@ -256,6 +256,24 @@ int detops_deformable_col2im_coord(const void* col, const void* im, const void* 
                                    int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
                                    int dil_w, int deformable_group, detops_stream_t stream);
 
+/* Fused deformable-convolution FORWARD: one implicit GEMM on the matrix cores
+ * (v_mfma_f32_32x32x16_{f16,bf16}); the deformed operand tile is built in LDS, `columns` is never written.
+ * Replaces the im2col + GEMM sequence of csrc/cuda/deform_conv_cuda.cu:228-245 / :520-560 for 16-bit storage,
+ * convolution groups == 1 and (C / deformable_group) % 32 == 0; other shapes return DETOPS_EUNSUPPORTED
+ * (workspace_bytes() == 0) and the caller runs detops_deformable_im2col + its GEMM.
+ *   im [B,C,H,W], weight [Cout,C,kh,kw], offset / mask as above (mask NULL = v1), bias [Cout] or NULL,
+ *   out [B,Cout,Ho,Wo]; all of `dtype`.  workspace: NHWC copy of im + tap-major copy of weight. */
+size_t detops_deform_conv_forward_fused_workspace_bytes(int dtype, int B, int C, int H, int W, int Cout,
+                                                        int kh, int kw, int pad_h, int pad_w, int stride_h,
+                                                        int stride_w, int dil_h, int dil_w,
+                                                        int deformable_group);
+
+int detops_deform_conv_forward_fused(const void* im, const void* weight, const void* offset,
+                                     const void* mask, const void* bias, void* out, int dtype, int B, int C,
+                                     int H, int W, int Cout, int kh, int kw, int pad_h, int pad_w,
+                                     int stride_h, int stride_w, int dil_h, int dil_w, int deformable_group,
+                                     void* workspace, size_t workspace_bytes, detops_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Deformable position-sensitive ROI pooling — replaces _C.deform_psroi_pooling_forward /
  * _C.deform_psroi_pooling_backward

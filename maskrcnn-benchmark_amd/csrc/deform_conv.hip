@@ -895,6 +895,304 @@ int coord_t(const void* col, const void* im, const void* offset, const void* mas
   return launch_status();
 }
 
+// ------------------------------------------------------------------------------------ fused forward (MFMA)
+// Deformable convolution forward as ONE implicit GEMM on the matrix cores (fp16 / bf16):
+//     out[co, n] = sum_{tap, c} W[co, c, tap] * column(c, tap, n),      n = (b, ho, wo)
+// The reference (and the unfused path above) materialises `columns` [C*kh*kw, B*Ho*Wo] in HBM — 77 MB at the
+// layer2 shape of cfg-5 — and hands it to a library GEMM (csrc/cuda/deform_conv_cuda.cu:228-245).  Here the
+// deformed B-operand tile is built in LDS and consumed by v_mfma_f32_32x32x16_{f16,bf16} directly:
+//   * pre-pass (one launch, small): the input goes NCHW -> NHWC so that the 4 bilinear taps of a sampling
+//     point read 32 CONTIGUOUS bytes per 16 channels, and the weights go [Cout, C, taps] -> [taps, Cout, C] so
+//     that an A tile of one tap is contiguous in its K dimension (channels);
+//   * main kernel: workgroup tile 128 (Cout) x 64 (pixels), K-step = up to 128 channels of one tap.  The
+//     channels of a sampling point are contiguous in the NHWC copy: 16 adjacent lanes read 256 bytes of one
+//     corner, so a wave-wide gather touches a few full cache lines.  Each thread interpolates 8 channels of its
+//     pixels in fp32, applies the modulation mask, rounds to the storage type (what the im2col kernel would have
+//     stored) and writes 16 bytes of the B tile.  Four waves of 1 x 2 MFMA tiles (32 x 64 outputs each, fp32
+//     accumulators) consume A and B from LDS; rows are 16 bytes longer than the K-step, which makes the
+//     ds_read_b128 fragment reads conflict-free.  The next K-step's gathers and weight tile are issued before
+//     the MFMAs of the current one (register prefetch; LDS-only barriers keep them in flight).
+// Requirements (else the caller uses the unfused path): 16-bit storage, conv groups == 1, (C / dg) % 32 == 0.
+typedef _Float16 dcn_h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 dcn_b8 __attribute__((ext_vector_type(8)));
+typedef float dcn_f16v __attribute__((ext_vector_type(16)));
+typedef unsigned short dcn_u16;
+
+constexpr int kFM = 128, kFN = 64;   // workgroup tile: Cout x pixels
+constexpr int kFK = 32;              // channel granularity of the fused plan ((C / dg) % 32 == 0)
+
+#ifdef DETOPS_CPU_EMU
+#define DCN_MFMA_F16(a, b, c) emu_mfma_f32_32x32x16<dcn_h8, _Float16>(a, b, c)
+#define DCN_MFMA_BF16(a, b, c) emu_mfma_f32_32x32x16<dcn_b8, __bf16>(a, b, c)
+#else
+#define DCN_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define DCN_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+
+// pre-pass: blocks [0, nb_im): input NCHW -> NHWC (32 channels x 64 pixels per block through LDS);
+//           the rest: weights [Cout, C, T] -> [T, Cout, C]
+__global__ void __launch_bounds__(kBlock)
+dcn_fused_prep_kernel(const dcn_u16* __restrict__ im, const dcn_u16* __restrict__ w, dcn_u16* __restrict__ imT,
+                      dcn_u16* __restrict__ wt, int B, int C, int HW, int Cout, int T, int nb_im) {
+  __shared__ dcn_u16 tile[32][66];
+  const int tid = threadIdx.x;
+  if (static_cast<int>(blockIdx.x) < nb_im) {
+    const int pblocks = (HW + 63) / 64, cblocks = (C + 31) / 32;
+    int r = blockIdx.x;
+    const int pb = r % pblocks; r /= pblocks;
+    const int cb = r % cblocks;
+    const int b = r / cblocks;
+    const int p0 = pb * 64, c0 = cb * 32;
+    for (int e = tid; e < 32 * 64; e += kBlock) {   // read: pixels fastest
+      const int c = e >> 6, pp = e & 63;
+      tile[c][pp] = (c0 + c < C && p0 + pp < HW) ? im[(static_cast<size_t>(b) * C + c0 + c) * HW + p0 + pp] : dcn_u16(0);
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * 64; e += kBlock) {   // write: channels fastest
+      const int pp = e >> 5, c = e & 31;
+      if (c0 + c < C && p0 + pp < HW) imT[(static_cast<size_t>(b) * HW + p0 + pp) * C + c0 + c] = tile[c][pp];
+    }
+    return;
+  }
+  const int64_t n = static_cast<int64_t>(Cout) * C * T;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x - nb_im) * kBlock + tid; e < n;
+       e += static_cast<int64_t>(gridDim.x - nb_im) * kBlock) {
+    const int c = static_cast<int>(e % C);      // destination order [t][co][c]: coalesced writes
+    const int64_t r = e / C;
+    const int co = static_cast<int>(r % Cout);
+    const int t = static_cast<int>(r / Cout);
+    wt[e] = w[(static_cast<size_t>(co) * C + c) * T + t];
+  }
+}
+
+template <bool BF16> struct DcnConv;
+template <> struct DcnConv<false> {
+  static __device__ __forceinline__ float to_f(dcn_u16 v) { return __half2float(__ushort_as_half(v)); }
+  static __device__ __forceinline__ dcn_u16 from_f(float f) { return __half_as_ushort(__float2half(f)); }
+};
+template <> struct DcnConv<true> {
+  static __device__ __forceinline__ float to_f(dcn_u16 v) { return __uint_as_float(static_cast<unsigned>(v) << 16); }
+  static __device__ __forceinline__ dcn_u16 from_f(float f) {
+    const __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<const dcn_u16*>(&h);
+  }
+};
+
+// 8 channels of one tap (16 bytes) as a register vector (a struct of 16-bit fields is not promoted to registers:
+// the first version kept these staging arrays in scratch memory with a vmcnt(0) after every load)
+typedef unsigned int DcnRaw8 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dcn_u16 dcn_elem(const DcnRaw8& r, int e) { return static_cast<dcn_u16>((r[e >> 1] >> ((e & 1) * 16)) & 0xffffu); }
+
+// BKC = channels of one tap per K-step (32 / 64 / 128).  Gather mapping: the BKC channels of a sampling
+// point are 2 * BKC CONTIGUOUS bytes of the NHWC copy, read by LPP = BKC / 8 adjacent lanes (16 bytes each) —
+// a wave-wide load touches 64 / LPP pixels x full cache lines instead of 64 different lines (the
+// one-pixel-per-lane mapping of the first version kept the texture addresser busy for 64 line lookups per
+// instruction: 174 us at the layer2 shape).  256 / LPP pixels per pass, kFN / (256 / LPP) passes per step.
+template <bool BF16, typename T, int BKC>
+__global__ void __launch_bounds__(kBlock)
+dcn_fused_fwd_kernel(const dcn_u16* __restrict__ imT, const dcn_u16* __restrict__ wt, const T* __restrict__ offset,
+                     const T* __restrict__ mask, const T* __restrict__ bias, T* __restrict__ out, Geom g, int Cout) {
+  using CV = DcnConv<BF16>;
+  constexpr int LPP = BKC / 8;                 // lanes per pixel
+  constexpr int PPP = kBlock / LPP;            // pixels per pass
+  constexpr int NP = kFN / PPP;                // passes per step (1, 2 or 4)
+  constexpr int LD = BKC + 8;                  // LDS row stride in 16-bit elements: + 16 bytes -> conflict-free b128 reads
+  constexpr int APT = kFM * (BKC / 8) / kBlock;   // 16-byte weight pieces per thread and step
+  DETOPS_DYNAMIC_LDS(DcnRaw8, lds8);
+  dcn_u16* sA = reinterpret_cast<dcn_u16*>(lds8);                 // [kFM][LD]
+  dcn_u16* sB = sA + kFM * LD;                                    // [kFN][LD]
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int co0 = blockIdx.y * kFM;
+  const int64_t npix = static_cast<int64_t>(g.B) * g.Ho * g.Wo;
+  const int64_t pix0 = static_cast<int64_t>(blockIdx.x) * kFN;
+  const int K = g.kh * g.kw, cpg = g.C / g.dg;
+  const size_t HWo = static_cast<size_t>(g.Ho) * g.Wo;
+
+  // ---- B-tile builder role: channel octet cq of pixel (pass * PPP + pg)
+  const int cq = tid % LPP, pg = tid / LPP;
+  int pb[NP], pho[NP], pwo[NP];
+  bool pok[NP];
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    const int64_t n = pix0 + ps * PPP + pg;
+    pok[ps] = n < npix;
+    pb[ps] = 0; pho[ps] = 0; pwo[ps] = 0;
+    if (pok[ps]) {
+      pb[ps] = static_cast<int>(n / static_cast<int64_t>(HWo));
+      const int r = static_cast<int>(n - static_cast<int64_t>(pb[ps]) * HWo);
+      pho[ps] = r / g.Wo; pwo[ps] = r - pho[ps] * g.Wo;
+    }
+  }
+
+  dcn_f16v acc[2];   // wave w: output rows 32 w .. 32 w + 31, two 32-column tiles
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int steps_per_tap = cpg / BKC;
+  const int nsteps = g.dg * K * steps_per_tap;
+  // staged data of the NEXT step
+  DcnRaw8 raw[NP][4];
+  DcnRaw8 araw[APT];
+  float wq[NP][4], mq[NP];   // bilinear weights (0 for a tap outside the map) and modulation of the staged step
+
+  auto issue = [&](int step) {   // global -> registers for K-step `step`
+    const int dgi = step / (K * steps_per_tap);
+    const int rem = step - dgi * K * steps_per_tap;
+    const int tap = rem / steps_per_tap;
+    const int c0 = dgi * cpg + (rem - tap * steps_per_tap) * BKC;
+    const int ti = tap / g.kw, tj = tap - ti * g.kw;
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      float off_h = 0.f, off_w = 0.f;
+      mq[ps] = 1.f;
+      if (pok[ps]) {
+        const T* op = offset + (static_cast<size_t>(pb[ps]) * g.dg + dgi) * 2 * K * HWo + static_cast<size_t>(pho[ps]) * g.Wo + pwo[ps];
+        off_h = ld(op + (2 * tap) * HWo);
+        off_w = ld(op + (2 * tap + 1) * HWo);
+        if (mask) mq[ps] = ld(mask + ((static_cast<size_t>(pb[ps]) * g.dg + dgi) * K + tap) * HWo + static_cast<size_t>(pho[ps]) * g.Wo + pwo[ps]);
+      }
+      const float h_im = static_cast<float>(pho[ps] * g.stride_h - g.pad_h + ti * g.dil_h) + off_h;
+      const float w_im = static_cast<float>(pwo[ps] * g.stride_w - g.pad_w + tj * g.dil_w) + off_w;
+      const Sample sm = make_sample(h_im, w_im, g.H, g.W);
+      const int idx[4] = {sm.i1, sm.i2, sm.i3, sm.i4};
+      const float ws[4] = {sm.w1, sm.w2, sm.w3, sm.w4};
+      const dcn_u16* imb = imT + static_cast<size_t>(pb[ps]) * g.H * g.W * g.C + c0 + 8 * cq;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = pok[ps] && sm.inside && idx[k] >= 0;
+        wq[ps][k] = ok ? ws[k] : 0.f;
+        // a tap outside the map reads element 0 of the image (always valid) with weight 0
+        raw[ps][k] = *reinterpret_cast<const DcnRaw8*>(imb + static_cast<size_t>(ok ? idx[k] : 0) * g.C);
+      }
+    }
+    const dcn_u16* wbase = wt + (static_cast<size_t>(tap) * Cout) * g.C + c0;
+#pragma unroll
+    for (int q = 0; q < APT; ++q) {
+      const int piece = tid + q * kBlock;
+      const int row = piece / (BKC / 8), seg = piece - row * (BKC / 8);
+      if (co0 + row < Cout) araw[q] = *reinterpret_cast<const DcnRaw8*>(wbase + static_cast<size_t>(co0 + row) * g.C + 8 * seg);
+      else araw[q] = DcnRaw8{0u, 0u, 0u, 0u};
+    }
+  };
+  auto commit = [&]() {   // registers -> LDS: interpolate the B tile, copy the A tile
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      DcnRaw8 o = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        // same expression as the im2col kernel: w1*a1 + w2*a2 + w3*a3 + w4*a4 (taps outside contribute 0)
+        const float v = wq[ps][0] * CV::to_f(dcn_elem(raw[ps][0], e)) + wq[ps][1] * CV::to_f(dcn_elem(raw[ps][1], e)) +
+                        wq[ps][2] * CV::to_f(dcn_elem(raw[ps][2], e)) + wq[ps][3] * CV::to_f(dcn_elem(raw[ps][3], e));
+        o[e >> 1] |= static_cast<unsigned>(CV::from_f(mask ? v * mq[ps] : v)) << ((e & 1) * 16);
+      }
+      *reinterpret_cast<DcnRaw8*>(sB + (ps * PPP + pg) * LD + 8 * cq) = o;
+    }
+#pragma unroll
+    for (int q = 0; q < APT; ++q) {
+      const int piece = tid + q * kBlock;
+      const int row = piece / (BKC / 8), seg = piece - row * (BKC / 8);
+      *reinterpret_cast<DcnRaw8*>(sA + row * LD + 8 * seg) = araw[q];
+    }
+  };
+
+  issue(0);
+  for (int step = 0; step < nsteps; ++step) {
+    commit();
+    DETOPS_LDS_BARRIER();   // LDS-only: the prefetch below stays in flight across the barriers
+    if (step + 1 < nsteps) issue(step + 1);
+#pragma unroll
+    for (int ks = 0; ks < BKC / 16; ++ks) {
+      const int koff = ks * 16 + (lane >> 5) * 8;
+      if constexpr (BF16) {
+        const dcn_b8 a = *reinterpret_cast<const dcn_b8*>(sA + (wave * 32 + (lane & 31)) * LD + koff);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const dcn_b8 b = *reinterpret_cast<const dcn_b8*>(sB + (j * 32 + (lane & 31)) * LD + koff);
+          acc[j] = DCN_MFMA_BF16(a, b, acc[j]);
+        }
+      } else {
+        const dcn_h8 a = *reinterpret_cast<const dcn_h8*>(sA + (wave * 32 + (lane & 31)) * LD + koff);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const dcn_h8 b = *reinterpret_cast<const dcn_h8*>(sB + (j * 32 + (lane & 31)) * LD + koff);
+          acc[j] = DCN_MFMA_F16(a, b, acc[j]);
+        }
+      }
+    }
+    DETOPS_LDS_BARRIER();   // the next commit rewrites both tiles
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t n = pix0 + j * 32 + (lane & 31);
+    if (n >= npix) continue;
+    const int b = static_cast<int>(n / static_cast<int64_t>(HWo));
+    const size_t pix = static_cast<size_t>(n - static_cast<int64_t>(b) * HWo);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (co < Cout) {
+        float v = acc[j][r];
+        if (bias) v += ld(bias + co);
+        st(out + (static_cast<size_t>(b) * Cout + co) * HWo + pix, v);
+      }
+    }
+  }
+}
+
+inline size_t dcn_fused_ws_bytes(const Geom& g, int Cout) {
+  const size_t im = (static_cast<size_t>(g.B) * g.C * g.H * g.W * 2 + 255) & ~static_cast<size_t>(255);
+  const size_t w = (static_cast<size_t>(Cout) * g.C * g.kh * g.kw * 2 + 255) & ~static_cast<size_t>(255);
+  return im + w;
+}
+
+inline bool dcn_fused_ok(const Geom& g, int dtype, int Cout) {
+  return (dtype == DETOPS_F16 || dtype == DETOPS_BF16) && Cout > 0 && (g.C / g.dg) % kFK == 0 &&
+         static_cast<int64_t>(g.B) * g.Ho * g.Wo < (1ll << 31) && static_cast<int64_t>(g.H) * g.W < (1ll << 30);
+}
+
+// Is the fused kernel the faster path?  Its grid is (pixels / 64) x (Cout / 128) workgroups and every Cout tile
+// rebuilds the deformed operand, so it wins where pixels are many and Cout tiles few (measured,
+// profiles/r02f_opbench_dcn_fused.log, fused vs im2col + library GEMM: 105 vs 179 us at [2,128,100,168] = 94 TF/s;
+// 108 vs 103 us at [2,256,50,84]; 164 vs 72 us at [2,512,25,42], where 132 workgroups leave half the chip idle).
+// DETOPS_DCN_FUSED=force overrides (tests, measurements).
+inline bool dcn_fused_preferred(const Geom& g, int Cout) {
+  if (const char* e = getenv("DETOPS_DCN_FUSED")) if (e[0] == 'f') return true;
+  const int64_t wgs = ceil_div64(static_cast<int64_t>(g.B) * g.Ho * g.Wo, kFN) * ceil_div64(Cout, kFM);
+  return wgs >= 2 * kNumCU && Cout <= 2 * kFM;
+}
+
+template <bool BF16, typename T>
+int dcn_fused_forward(const void* im, const void* weight, const void* offset, const void* mask, const void* bias,
+                      void* out, const Geom& g, int Cout, void* ws, hipStream_t st_) {
+  unsigned char* base = static_cast<unsigned char*>(ws);
+  const size_t im_bytes = (static_cast<size_t>(g.B) * g.C * g.H * g.W * 2 + 255) & ~static_cast<size_t>(255);
+  dcn_u16* imT = reinterpret_cast<dcn_u16*>(base);
+  dcn_u16* wt = reinterpret_cast<dcn_u16*>(base + im_bytes);
+  const int HW = g.H * g.W, T_ = g.kh * g.kw;
+  const int nb_im = g.B * ((g.C + 31) / 32) * ((HW + 63) / 64);
+  const int nb_w = static_cast<int>(std::min<int64_t>(ceil_div64(static_cast<int64_t>(Cout) * g.C * T_, kBlock), 4 * kNumCU));
+  hipLaunchKernelGGL(dcn_fused_prep_kernel, dim3(static_cast<unsigned>(nb_im + nb_w)), dim3(kBlock), 0, st_,
+                     static_cast<const dcn_u16*>(im), static_cast<const dcn_u16*>(weight), imT, wt, g.B, g.C, HW, Cout, T_,
+                     nb_im);
+  const int64_t npix = static_cast<int64_t>(g.B) * g.Ho * g.Wo;
+  const dim3 grid(static_cast<unsigned>(ceil_div64(npix, kFN)), static_cast<unsigned>(ceil_div64(Cout, kFM)));
+  const int cpg = g.C / g.dg;
+#define DCN_FUSED_LAUNCH(BKC_)                                                                                        \
+  hipLaunchKernelGGL((dcn_fused_fwd_kernel<BF16, T, BKC_>), grid, dim3(kBlock),                                       \
+                     static_cast<size_t>(kFM + kFN) * (BKC_ + 8) * sizeof(dcn_u16), st_, imT, wt,                     \
+                     static_cast<const T*>(offset), static_cast<const T*>(mask), static_cast<const T*>(bias),         \
+                     static_cast<T*>(out), g, Cout)
+  if (cpg % 128 == 0) DCN_FUSED_LAUNCH(128);
+  else if (cpg % 64 == 0) DCN_FUSED_LAUNCH(64);
+  else DCN_FUSED_LAUNCH(32);
+#undef DCN_FUSED_LAUNCH
+  return launch_status();
+}
+
 }  // namespace
 
 #define DETOPS_DTYPE_SWITCH(dtype, CALL)                              \
@@ -1005,4 +1303,36 @@ DETOPS_API int detops_deformable_col2im_coord(const void* col, const void* im, c
 #define CALL(T) coord_t<T>(col, im, offset, mask, grad_offset, grad_mask, g, as_stream(stream))
   DETOPS_DTYPE_SWITCH(dtype, CALL)
 #undef CALL
+}
+
+
+/* Fused deformable-convolution forward (implicit GEMM on MFMA, fp16 / bf16, conv groups == 1): see the kernel
+ * comment above.  Returns DETOPS_EUNSUPPORTED when the shape is outside the fused plan (the caller then runs
+ * im2col + GEMM). */
+DETOPS_API size_t detops_deform_conv_forward_fused_workspace_bytes(int dtype, int B, int C, int H, int W, int Cout,
+                                                                   int kh, int kw, int pad_h, int pad_w, int stride_h,
+                                                                   int stride_w, int dil_h, int dil_w,
+                                                                   int deformable_group) {
+  Geom g;
+  if (make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, deformable_group)) return 0;
+  if (B == 0 || !dcn_fused_ok(g, dtype, Cout) || !dcn_fused_preferred(g, Cout)) return 0;
+  return dcn_fused_ws_bytes(g, Cout);
+}
+
+DETOPS_API int detops_deform_conv_forward_fused(const void* im, const void* weight, const void* offset,
+                                                const void* mask, const void* bias, void* out, int dtype, int B,
+                                                int C, int H, int W, int Cout, int kh, int kw, int pad_h, int pad_w,
+                                                int stride_h, int stride_w, int dil_h, int dil_w,
+                                                int deformable_group, void* workspace, size_t workspace_bytes,
+                                                detops_stream_t stream) {
+  Geom g;
+  if (int rc = make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, deformable_group))
+    return rc;
+  if (B == 0) return 0;
+  if (!im || !weight || !offset || !out) return DETOPS_EINVAL;
+  if (!dcn_fused_ok(g, dtype, Cout)) return DETOPS_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < dcn_fused_ws_bytes(g, Cout)) return DETOPS_EWORKSPACE;
+  if (dtype == DETOPS_F16)
+    return dcn_fused_forward<false, __half>(im, weight, offset, mask, bias, out, g, Cout, workspace, as_stream(stream));
+  return dcn_fused_forward<true, __hip_bfloat16>(im, weight, offset, mask, bias, out, g, Cout, workspace, as_stream(stream));
 }

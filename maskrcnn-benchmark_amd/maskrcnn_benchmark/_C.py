@@ -598,6 +598,28 @@ def deformable_col2im_coord(col, im, offset, mask, grad_offset, grad_mask, kH, k
               "deformable_col2im_coord")
 
 
+def _fused_dcn_forward(input, weight, offset, mask, bias, out, kH, kW, padH, padW, dH, dW, dilH, dilW, group, dg):
+    """Fused implicit-GEMM forward on the matrix cores (csrc/deform_conv.hip: the deformed operand tile is built
+    in LDS, `columns` is never written).  Returns False when the shape is outside the fused plan (fp32 storage,
+    grouped convolution, channels per deformable group not a multiple of 32) or DETOPS_DCN_FUSED=0."""
+    if group != 1 or input.dtype not in (torch.float16, torch.bfloat16) or os.environ.get("DETOPS_DCN_FUSED", "1") == "0":
+        return False
+    B, C, H, W = input.shape
+    Cout = weight.size(0)
+    code = 1 if input.dtype == torch.float16 else 2
+    geo = (code, B, C, H, W, Cout, kH, kW, padH, padW, dH, dW, dilH, dilW, dg)
+    nbytes = int(lib.detops_deform_conv_forward_fused_workspace_bytes(*geo))
+    if nbytes == 0:
+        return False
+    with _on_device(input):
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=input.device)
+        with _timed("dcn_fused_fwd[B=%d,C=%d,%dx%d,Cout=%d]" % (B, C, H, W, Cout), input):
+            check(lib.detops_deform_conv_forward_fused(ptr(input), ptr(weight), ptr(offset), ptr(mask), ptr(bias),
+                                                       ptr(out), *geo, ptr(ws), nbytes, stream_of(input)),
+                  "deform_conv_forward_fused")
+    return True
+
+
 def _grouped_weight_times_cols(weight, col, group, out):
     """out[g] (+)= W[g] @ col[g]; out is [Cout, ncol] (written), fp32/half via rocBLAS/hipBLASLt."""
     Cout = weight.size(0)
@@ -621,6 +643,9 @@ def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW
     if B % im2col_step != 0:
         raise RuntimeError("im2col step must divide batchsize")
     out = output.view(B, Cout, Ho, Wo)
+    if out.is_contiguous() and _fused_dcn_forward(input, weight, offset, None, None, out, kH, kW, padH, padW, dH, dW,
+                                                  dilationH, dilationW, group, deformable_group):
+        return 1
     for b0 in range(0, B, im2col_step):
         sl = slice(b0, b0 + im2col_step)
         col = deformable_im2col(input[sl], offset[sl], None, kH, kW, padH, padW, dH, dW, dilationH,
@@ -702,6 +727,11 @@ def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, outpu
         raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (C, Cker * group))
     Ho, Wo = _out_hw(H, W, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w)
     offset, mask = offset.contiguous(), mask.contiguous()
+    out = output.view(B, Cout, Ho, Wo)
+    if out.is_contiguous() and _fused_dcn_forward(input, weight, offset, mask, bias.contiguous() if with_bias else None,
+                                                  out, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w,
+                                                  dilation_h, dilation_w, group, deformable_group):
+        return
     col = deformable_im2col(input, offset, mask, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w,
                             dilation_h, dilation_w, deformable_group)
     buf = torch.empty((Cout, B * Ho * Wo), dtype=input.dtype, device=input.device)

@@ -66,7 +66,9 @@ class PostProcessor(nn.Module):
         det_labels = sel // n
         det_boxes = cb[sel]
         if 0 < self.detections_per_img < sel.numel():
-            top = det_scores.topk(self.detections_per_img).indices
+            # the reference thresholds at the k-th value (inference.py:139-146): ties at the threshold all stay
+            thr = det_scores.topk(self.detections_per_img).values[-1]
+            top = (det_scores >= thr).nonzero().squeeze(1)
             det_scores, det_labels, det_boxes = det_scores[top], det_labels[top], det_boxes[top]
         out = BoxList(det_boxes, image_shape, mode="xyxy")
         out.add_field("scores", det_scores)

@@ -60,7 +60,9 @@ class RetinaNetPostProcessor(torch.nn.Module):
                 keep, _ = _C.nms_batched_mask(b, s, seg, max_n, self.nms_thresh)
                 b, s, l = b[keep], s[keep], l[keep]
             if 0 < self.fpn_post_nms_top_n < s.numel():
-                top = s.topk(self.fpn_post_nms_top_n).indices
+                # k-th value threshold like the reference (inference.py:160-168): ties at the threshold all stay
+                thr = s.topk(self.fpn_post_nms_top_n).values[-1]
+                top = (s >= thr).nonzero().squeeze(1)
                 b, s, l = b[top], s[top], l[top]
             out = BoxList(b, (w, h), mode="xyxy")
             out.add_field("scores", s)

@@ -51,6 +51,8 @@ SIGNATURES = {
     "detops_deformable_col2im": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),
     "detops_deformable_col2im_workspace_bytes": (ctypes.c_size_t, [c_int] * 13),
     "detops_deformable_col2im_ws": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P, ctypes.c_size_t, _P]),
+    "detops_deform_conv_forward_fused_workspace_bytes": (ctypes.c_size_t, [c_int] * 15),
+    "detops_deform_conv_forward_fused": (c_int, [_P] * 6 + [c_int] * 15 + [_P, ctypes.c_size_t, _P]),
     "detops_deformable_col2im_coord": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 14 + [_P]),
 }
 
@@ -185,6 +187,31 @@ def mask_targets(masks, mask_index, boxes, M):
 
 # ---------------------------------------------------------------------------------- deformable conv
 _DT = {np.dtype(np.float32): 0, np.dtype(np.float16): 1}
+
+
+def deform_conv_forward_fused(im, weight, offset, mask, bias, pad, stride, dil, dg):
+    """fp16 im [B,C,H,W], weight [Cout,C,kh,kw] -> out [B,Cout,Ho,Wo] fp16 through the fused MFMA kernel
+    (the host emulation runs the same fragment-layout arithmetic); None when the shape is outside its plan."""
+    im, weight, offset = (np.ascontiguousarray(a, dtype=np.float16) for a in (im, weight, offset))
+    mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.float16)
+    bias = None if bias is None else np.ascontiguousarray(bias, dtype=np.float16)
+    B, C, H, W = im.shape
+    Cout, _, kh, kw = weight.shape
+    Ho, Wo = _out_hw(H, W, kh, kw, pad, stride, dil)
+    geo = (1, B, C, H, W, Cout, kh, kw, pad[0], pad[1], stride[0], stride[1], dil[0], dil[1], dg)
+    os.environ["DETOPS_DCN_FUSED"] = "force"   # small test shapes: bypass the "is it faster" dispatch rule
+    try:
+        nbytes = lib().detops_deform_conv_forward_fused_workspace_bytes(*geo)
+    finally:
+        del os.environ["DETOPS_DCN_FUSED"]
+    if nbytes == 0:
+        return None
+    ws = np.full((nbytes,), 0xAB, np.uint8)
+    out = np.full((B, Cout, Ho, Wo), np.nan, np.float16)
+    rc = lib().detops_deform_conv_forward_fused(_p(im), _p(weight), _p(offset), None if mask is None else _p(mask),
+                                                None if bias is None else _p(bias), _p(out), *geo, _p(ws), nbytes, None)
+    assert rc == 0, rc
+    return out
 
 
 def _geom(B, C, H, W, kh, kw, pad, stride, dil, dg):

@@ -251,6 +251,33 @@ template <typename T> static inline T __shfl(T v, int src) {
   if (src >= 0 && src < emu::kWaveSize && ((live >> src) & 1ull)) { T r; memcpy(&r, &t[src], sizeof(T)); return r; }
   return v;
 }
+// v_mfma_f32_32x32x16_{f16,bf16}: D = A (32x16) * B (16x32) + C.  Fragment layout (the documented gfx950 one):
+// lane l holds A[l & 31][8 * (l >> 5) + 0..7] and B[8 * (l >> 5) + 0..7][l & 31]; C/D element `reg` of lane l is
+// row (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5), column l & 31.  All 64 lanes must execute it.
+template <typename V8, typename E>
+static inline __attribute__((ext_vector_type(16))) float emu_mfma_f32_32x32x16(V8 a, V8 b,
+                                                                                 __attribute__((ext_vector_type(16))) float c) {
+  static_assert(sizeof(V8) == 16, "");
+  unsigned long long ta[2][emu::kWaveSize], tb[2][emu::kWaveSize], raw[2];
+  memcpy(raw, &a, 16);
+  for (int h = 0; h < 2; ++h) { const unsigned long long* t = emu::exchange(raw[h], nullptr); memcpy(ta[h], t, sizeof(ta[h])); }
+  memcpy(raw, &b, 16);
+  for (int h = 0; h < 2; ++h) { const unsigned long long* t = emu::exchange(raw[h], nullptr); memcpy(tb[h], t, sizeof(tb[h])); }
+  const int lane = emu::lane_id(), j = lane & 31;
+  for (int reg = 0; reg < 16; ++reg) {
+    const int i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    float sum = c[reg];
+    for (int k = 0; k < 16; ++k) {
+      E ea[8], eb[8];
+      unsigned long long pa[2] = {ta[0][i + 32 * (k / 8)], ta[1][i + 32 * (k / 8)]};
+      unsigned long long pb[2] = {tb[0][j + 32 * (k / 8)], tb[1][j + 32 * (k / 8)]};
+      memcpy(ea, pa, 16); memcpy(eb, pb, 16);
+      sum += static_cast<float>(ea[k % 8]) * static_cast<float>(eb[k % 8]);
+    }
+    c[reg] = sum;
+  }
+  return c;
+}
 static inline unsigned emu_readlane(unsigned v, int lane) {
   const unsigned long long* t = emu::exchange(v, nullptr);
   return static_cast<unsigned>(t[lane]);

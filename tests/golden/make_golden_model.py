@@ -16,6 +16,10 @@ Captured (inputs + the reference's outputs), all seeded:
   model_masks.npz        project_masks_on_boxes on BinaryMaskList targets (mask_head/loss.py:11-42)
   model_proposals.npz    RPNPostProcessor.forward (train + test settings) on random head outputs
   model_solver.npz       WarmupMultiStepLR factors, smooth_l1_loss values
+  model_postprocess.npz  evaluation post-processing: PostProcessor.forward (roi_heads/box_head/inference.py:
+                         softmax, decode, clip, score threshold, per-class NMS, detections-per-image kthvalue)
+                         and RetinaNetPostProcessor.forward (rpn/retinanet/inference.py: per-level threshold +
+                         top-n, decode, per-class NMS over levels, detections-per-image)
 
 Run:  python tests/golden/make_golden_model.py      (this script never runs on the GPU box)
 """
@@ -315,6 +319,65 @@ def gen_proposals():
     save("model_proposals.npz", **out)
 
 
+# ------------------------------------------------------------------ evaluation post-processing
+def _canon(r):
+    """detections of one image in a canonical order: label ascending, score descending"""
+    s, l = r.get_field("scores"), r.get_field("labels")
+    order = np.lexsort((-t2n(s).astype(np.float64), t2n(l)))
+    return t2n(r.bbox)[order], t2n(s)[order], t2n(l)[order]
+
+
+def gen_postprocess():
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.inference import PostProcessor
+    from maskrcnn_benchmark.modeling.rpn.retinanet.inference import RetinaNetPostProcessor
+    out = {}
+    # ---- Fast R-CNN box head: two images, C = 9 classes (8 + background)
+    torch.manual_seed(6)
+    rng = np.random.RandomState(6)
+    C = 9
+    sizes = [(320, 240), (300, 200)]                       # (W, H)
+    counts = [150, 90]
+    props = [torch.from_numpy(rand_boxes(rng, n, w, h, smin=10, smax=150)) for n, (w, h) in zip(counts, sizes)]
+    logits = torch.randn(sum(counts), C) * 2.5
+    reg = torch.randn(sum(counts), 4 * C) * 0.6
+    for tag, kw in {"a": dict(score_thresh=0.05, nms=0.5, detections_per_img=100),
+                    "b": dict(score_thresh=0.01, nms=0.3, detections_per_img=25)}.items():
+        pp = PostProcessor(box_coder=BoxCoder((10., 10., 5., 5.)), **kw)
+        res = pp((logits, reg), [BoxList(p, s, mode="xyxy") for p, s in zip(props, sizes)])
+        for i, r in enumerate(res):
+            b, sc, lb = _canon(r)
+            out["box_%s_boxes_%d" % (tag, i)], out["box_%s_scores_%d" % (tag, i)], out["box_%s_labels_%d" % (tag, i)] = b, sc, lb
+        out["box_%s_cfg" % tag] = np.array([kw["score_thresh"], kw["nms"], kw["detections_per_img"]])
+    out["box_logits"], out["box_reg"] = t2n(logits), t2n(reg)
+    out["box_sizes"], out["box_counts"] = np.array(sizes), np.array(counts)
+    for i, p in enumerate(props):
+        out["box_props_%d" % i] = t2n(p)
+    # ---- RetinaNet: 3 levels, A = 9 anchors, 5 classes (+ background)
+    W, H = 224, 160
+    nc = 6
+    sz = tuple(tuple(s * 2 ** (k / 3.0) for k in range(3)) for s in (32, 64, 128))
+    ag = AnchorGenerator(sizes=sz, aspect_ratios=(0.5, 1.0, 2.0), anchor_strides=(8, 16, 32), straddle_thresh=-1)
+    feats = [torch.zeros(2, 1, H // s, W // s) for s in (8, 16, 32)]
+    il = ImageList(torch.zeros(2, 3, H, W), [(H, W), (150, 200)])
+    anchors = ag(il, feats)
+    A = 9
+    box_cls = [torch.randn(2, A * (nc - 1), f.shape[2], f.shape[3]) * 2 - 3 for f in feats]
+    box_reg = [torch.randn(2, A * 4, f.shape[2], f.shape[3]) * 0.4 for f in feats]
+    for l in range(3):
+        out["ret_cls_%d" % l], out["ret_reg_%d" % l] = t2n(box_cls[l]), t2n(box_reg[l])
+    out["ret_image_sizes"], out["ret_canvas"] = np.array(il.image_sizes), np.array([H, W])
+    for tag, kw in {"a": dict(pre_nms_thresh=0.05, pre_nms_top_n=60, nms_thresh=0.4, fpn_post_nms_top_n=40, min_size=0),
+                    "b": dict(pre_nms_thresh=0.2, pre_nms_top_n=1000, nms_thresh=0.5, fpn_post_nms_top_n=100, min_size=0)}.items():
+        pp = RetinaNetPostProcessor(num_classes=nc, box_coder=BoxCoder((10., 10., 5., 5.)), **kw)
+        pp.eval()
+        res = pp(anchors, box_cls, box_reg)
+        for i, r in enumerate(res):
+            b, sc, lb = _canon(r)
+            out["ret_%s_boxes_%d" % (tag, i)], out["ret_%s_scores_%d" % (tag, i)], out["ret_%s_labels_%d" % (tag, i)] = b, sc, lb
+        out["ret_%s_cfg" % tag] = np.array([kw["pre_nms_thresh"], kw["pre_nms_top_n"], kw["nms_thresh"], kw["fpn_post_nms_top_n"]])
+    save("model_postprocess.npz", **out)
+
+
 # ------------------------------------------------------------------ solver bits
 def gen_solver():
     from maskrcnn_benchmark.layers import smooth_l1_loss
@@ -341,4 +404,5 @@ if __name__ == "__main__":
     gen_targets()
     gen_masks()
     gen_proposals()
+    gen_postprocess()
     gen_solver()

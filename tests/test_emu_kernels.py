@@ -392,3 +392,29 @@ def test_emu_deformable_col2im_ell_overflow():
     for mode in ("ell", "gather", "scatter"):
         out = emu.deformable_col2im(gcol, off, None, B, C, H, W, mode=mode, **geo)
         np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()), err_msg=mode)
+
+
+# ================================================================================ fused deformable conv (MFMA)
+@pytest.mark.parametrize("geom", [dict(B=2, C=32, H=9, W=11, Cout=40, k=3, pad=1, stride=1, dil=1, dg=1),
+                                  dict(B=1, C=64, H=12, W=10, Cout=130, k=3, pad=2, stride=2, dil=2, dg=2),
+                                  dict(B=1, C=64, H=7, W=9, Cout=32, k=3, pad=1, stride=1, dil=1, dg=1),      # 64-channel K-steps
+                                  dict(B=1, C=256, H=6, W=7, Cout=64, k=3, pad=1, stride=1, dil=1, dg=1)])    # 128-channel K-steps
+@pytest.mark.parametrize("modulated", [False, True])
+def test_emu_deform_conv_forward_fused_mfma(geom, modulated):
+    """implicit-GEMM forward (B tile interpolated in LDS, v_mfma_f32_32x32x16_f16 fragment arithmetic emulated lane
+    by lane): ragged Cout / pixel tiles, two deformable groups, stride / dilation, bias; vs the oracle's
+    im2col + GEMM on the same fp16-rounded inputs."""
+    g = geom
+    x, off, mask, wgt = synth.dcn_inputs(g["B"], g["C"], g["H"], g["W"], g["Cout"], g["k"], g["dg"], modulated, seed=21)
+    Ho = (g["H"] + 2 * g["pad"] - (g["dil"] * (g["k"] - 1) + 1)) // g["stride"] + 1
+    Wo = (g["W"] + 2 * g["pad"] - (g["dil"] * (g["k"] - 1) + 1)) // g["stride"] + 1
+    off = np.ascontiguousarray(off[:, :, :Ho, :Wo])
+    mask = None if mask is None else np.ascontiguousarray(mask[:, :, :Ho, :Wo])
+    bias = np.random.RandomState(2).randn(g["Cout"]).astype(np.float32) if modulated else None
+    h = lambda a: None if a is None else a.astype(np.float16)  # noqa: E731
+    geo = dict(pad=(g["pad"],) * 2, stride=(g["stride"],) * 2, dil=(g["dil"],) * 2)
+    out = emu.deform_conv_forward_fused(h(x), h(wgt), h(off), h(mask), h(bias), dg=g["dg"], **geo)
+    assert out is not None and out.shape == (g["B"], g["Cout"], Ho, Wo)
+    f = lambda a: None if a is None else a.astype(np.float16).astype(np.float32)  # noqa: E731
+    ref = oracle.deform_conv_forward(f(x), f(off), f(mask), f(wgt), f(bias), group=1, dg=g["dg"], **geo)
+    assert np.abs(out.astype(np.float32) - ref).max() <= 2e-2 * np.abs(ref).max()

@@ -318,6 +318,58 @@ def test_rpn_proposal_selection_matches_reference(tag, dev):
         np.testing.assert_allclose(N_(b[order]), g["%s_boxes_%d" % (tag, i)], rtol=1e-5, atol=1e-4)
 
 
+# ------------------------------------------------------------------ evaluation post-processing
+def _canon(r):
+    s, l = N_(r.get_field("scores")), N_(r.get_field("labels"))
+    order = np.lexsort((-s.astype(np.float64), l))
+    return N_(r.bbox)[order], s[order], l[order]
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_box_head_postprocessor_matches_reference(tag, dev):
+    """PostProcessor.forward (reference roi_heads/box_head/inference.py:42-149): the per-class NMS problems run
+    as one segmented launch; detections equal the reference's per-class loop (set-wise, scores to 1e-6)."""
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.inference import PostProcessor
+    g = load("model_postprocess.npz")
+    thr, nms, dets = g["box_%s_cfg" % tag]
+    pp = PostProcessor(float(thr), float(nms), int(dets), BoxCoder((10., 10., 5., 5.)))
+    sizes = [tuple(int(v) for v in s) for s in g["box_sizes"]]
+    props = [BoxList(T(g["box_props_%d" % i], dev), sizes[i], mode="xyxy") for i in range(2)]
+    with _shim(dev):
+        res = pp((T(g["box_logits"], dev), T(g["box_reg"], dev)), props)
+    for i, r in enumerate(res):
+        b, s, l = _canon(r)
+        np.testing.assert_array_equal(l, g["box_%s_labels_%d" % (tag, i)])
+        np.testing.assert_allclose(s, g["box_%s_scores_%d" % (tag, i)], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(b, g["box_%s_boxes_%d" % (tag, i)], rtol=1e-5, atol=1e-3)
+    empty = pp.filter_results(torch.zeros(0, 36, device=dev), torch.zeros(0, 9, device=dev), (32, 32))
+    assert len(empty) == 0 and empty.has_field("scores") and empty.has_field("labels")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_retinanet_postprocessor_matches_reference(tag, dev):
+    """RetinaNetPostProcessor.forward (reference rpn/retinanet/inference.py:64-173)."""
+    from maskrcnn_benchmark.modeling.rpn.retinanet.inference import RetinaNetPostProcessor
+    g = load("model_postprocess.npz")
+    H, W = (int(v) for v in g["ret_canvas"])
+    sz = tuple(tuple(s * 2 ** (k / 3.0) for k in range(3)) for s in (32, 64, 128))
+    ag = AnchorGenerator(sizes=sz, aspect_ratios=(0.5, 1.0, 2.0), anchor_strides=(8, 16, 32), straddle_thresh=-1).to(dev)
+    feats = [torch.zeros(2, 1, H // s, W // s, device=dev) for s in (8, 16, 32)]
+    il = ImageList(torch.zeros(2, 3, H, W, device=dev), [tuple(int(v) for v in s) for s in g["ret_image_sizes"]])
+    anchors = ag(il, feats)
+    thr, topn, nms, post = g["ret_%s_cfg" % tag]
+    pp = RetinaNetPostProcessor(float(thr), int(topn), float(nms), int(post), 0, 6, BoxCoder((10., 10., 5., 5.)))
+    cls = [T(g["ret_cls_%d" % l], dev) for l in range(3)]
+    reg = [T(g["ret_reg_%d" % l], dev) for l in range(3)]
+    with _shim(dev):
+        res = pp(anchors, cls, reg)
+    for i, r in enumerate(res):
+        b, s, l = _canon(r)
+        np.testing.assert_array_equal(l, g["ret_%s_labels_%d" % (tag, i)])
+        np.testing.assert_allclose(s, g["ret_%s_scores_%d" % (tag, i)], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(b, g["ret_%s_boxes_%d" % (tag, i)], rtol=1e-5, atol=1e-3)
+
+
 # ------------------------------------------------------------------ solver
 def test_lr_schedule_and_smooth_l1_match_reference():
     from maskrcnn_benchmark.layers import smooth_l1_loss

@@ -761,3 +761,40 @@ def test_frozen_bn_fused_half(dtype):
     ref = torch.relu(bn(x) + r)
     out = bn.fused(x.to(dtype), relu=True, residual=r.to(dtype)).float()
     assert (out - ref).abs().max() <= 2e-2 * ref.abs().max()
+
+
+@pytest.mark.parametrize("shape", CFG5_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("modulated", [False, True])
+def test_deform_conv_fused_mfma_forward_cfg5_shapes(shape, dtype, modulated, monkeypatch):
+    """the fused implicit-GEMM forward (v_mfma_f32_32x32x16_{f16,bf16}, columns never written) at the cfg-5 layer
+    shapes: <= 2e-2 of the output scale against the fp32 oracle on the same rounded inputs, and within half-precision
+    accumulation noise of the unfused im2col + GEMM path."""
+    from maskrcnn_benchmark.layers import deform_conv, modulated_deform_conv
+    Cc, H, W = shape
+    x, off, mask, wgt = synth.dcn_inputs(2, Cc, H, W, Cc, 3, 1, modulated, seed=31)
+    wgt = wgt * 0.5
+    hx, hoff, hw = (_t(a).to(dtype) for a in (x, off, wgt))
+    hmask = _t(mask).to(dtype) if modulated else None
+    hb = _t(np.random.RandomState(3).randn(Cc).astype(np.float32)).to(dtype) if modulated else None
+
+    def run():
+        if modulated:
+            return modulated_deform_conv(hx, hoff, hmask, hw, hb, 1, 1, 1, 1, 1)
+        return deform_conv(hx, hoff, hw, 1, 1, 1, 1, 1)
+
+    monkeypatch.setenv("DETOPS_DCN_FUSED", "force")   # also where the dispatch rule prefers im2col + GEMM
+    from maskrcnn_benchmark import _C
+    timer = _C.KernelTimer()
+    _C.KERNEL_TIMER = timer
+    y = run()
+    _C.KERNEL_TIMER = None
+    torch.cuda.synchronize()
+    assert any(k.startswith("dcn_fused_fwd") for k in timer.results()), "the fused kernel did not run"
+    monkeypatch.setenv("DETOPS_DCN_FUSED", "0")
+    y0 = run()
+    f = lambda t: None if t is None else t.float().cpu().numpy()  # noqa: E731
+    ref = oracle.deform_conv_forward(f(hx), f(hoff), f(hmask), f(hw), f(hb), **_OG)
+    scale = np.abs(ref).max()
+    assert y.dtype == dtype and np.abs(f(y) - ref).max() <= 2e-2 * scale
+    assert np.abs(f(y) - f(y0)).max() <= 2e-2 * scale

@@ -189,6 +189,39 @@ def bench_focal(C, iters):
     return out
 
 
+def bench_dcn_fused(C, iters):
+    """deformable conv forward at the cfg-5 layer shapes, fp16 / bf16: fused implicit GEMM on MFMA (columns never
+    written) vs im2col kernel + library GEMM; TFLOP/s against the 2.5 PF dense matrix peak and the bytes the
+    unfused path moves through HBM for `columns` (write + read)."""
+    out = []
+    for (Cc, H, W) in [(128, 100, 168), (256, 50, 84), (512, 25, 42)]:
+        for dt in (torch.float16, torch.bfloat16):
+            x = torch.randn(2, Cc, H, W, device="cuda").to(dt)
+            off = (torch.randn(2, 18, H, W, device="cuda") * 2).to(dt)
+            msk = torch.rand(2, 9, H, W, device="cuda").to(dt)
+            w = (torch.randn(Cc, Cc, 3, 3, device="cuda") / (3 * Cc ** 0.5)).to(dt)
+            y = torch.empty(2, Cc, H, W, device="cuda", dtype=dt)
+            bufs = [torch.empty(0, device="cuda", dtype=dt), torch.empty(0, device="cuda", dtype=dt)]
+            flops = 2.0 * Cc * Cc * 9 * 2 * H * W
+            col_bytes = 2 * Cc * 9 * 2 * H * W * 2
+
+            def run():
+                C.modulated_deform_conv_forward(x, w, None, bufs[0], off, msk, y, bufs[1], 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, False)
+
+            res = {}
+            for tag, env in (("fused MFMA", "force"), ("im2col + GEMM", "0")):
+                os.environ["DETOPS_DCN_FUSED"] = env
+                us = dev_time_us(run, iters)
+                res[tag] = y.float().clone()
+                e = _entry(f"dcn_fwd {tag} C={Cc} {H}x{W} {str(dt)[6:]}", us, 2 * (x.numel() + off.numel() + msk.numel() + y.numel()),
+                           {"TFLOPs": round(flops / us / 1e6, 1), "frac_of_2.5PF": round(flops / us / 1e6 / 2500.0, 4),
+                            "columns_bytes_unfused": col_bytes})
+                out.append(e)
+            del os.environ["DETOPS_DCN_FUSED"]
+            out[-1]["max_abs_diff_fused_vs_unfused"] = float((res["fused MFMA"] - res["im2col + GEMM"]).abs().max())
+    return out
+
+
 def bench_dcn(C, iters, experimental=False):
     out = []
     for (Cc, H, W, smooth) in [(128, 100, 168, False), (256, 50, 84, False), (512, 25, 42, False), (128, 100, 168, True)]:
@@ -271,6 +304,8 @@ def main():
         res += bench_focal(C, args.iters)
     if not only or "dcn" in only:
         res += bench_dcn(C, args.iters, experimental=args.experimental)
+    if not only or "dcn_fused" in only:
+        res += bench_dcn_fused(C, args.iters)
     for r in res:
         print("%-70s %10.2f us  %9.1f GB/s  (%.1f%% of 8 TB/s) %s" % (
             r["op"], r["us"], r["gbs"], 100 * r["frac_of_8TBs"],
