@@ -116,8 +116,8 @@ def measured_traffic(kernel_name, impl_hint=None):
             continue
         for key, v in table.items():
             if v.get("tag") == kernel_name and (impl_hint is None or impl_hint in key):
-                return v["hbm_bytes"]
-    return None
+                return v["hbm_bytes"], os.path.relpath(path, ROOT) + " :: " + key
+    return None, None
 
 
 def cpu_baseline(sample_rois=1024, min_seconds=8.0):
@@ -151,6 +151,10 @@ def cpu_baseline(sample_rois=1024, min_seconds=8.0):
             break
     dt = (time.perf_counter() - t0) / reps
     extra = cpu_baseline_extras(ref)
+    try:
+        extra["all_cores"] = cpu_baseline_all_cores()
+    except Exception as e:  # noqa: BLE001
+        extra["all_cores"] = {"error": repr(e)}
     # scale the sample to the full launch: per-ROI cost dominates; bytes per §8d for the full launch
     full_bytes = 4 * 1024 * 256 * 49 + sum(f.nbytes for f in rng_feats) + 20 * 1024
     est_full_s = dt * 1024.0 / sample_rois
@@ -162,6 +166,52 @@ def cpu_baseline(sample_rois=1024, min_seconds=8.0):
                           "reference csrc/cpu/ROIAlign_cpu.cpp compiled in oracle/_ref" if ref is not None
                           else "C restatement oracle/detops_oracle.c"),
             "roi_align_fwd_ms_est": round(est_full_s * 1e3, 2), **extra}
+
+
+def _roi_worker(args):
+    """one host core's share of the box-head ROIAlign forward through the reference's CPU kernel (oracle/_ref)"""
+    import numpy as np
+    import torch
+
+    import oracle
+    import synth
+
+    lo, hi, reps = args
+    torch.set_num_threads(1)
+    ref = oracle.ref()
+    feats = [((torch.arange(2 * 256 * h * w, dtype=torch.float32) % 251.0) * 0.01).view(2, 256, h, w)   # cheap fill
+             for (h, w) in synth.fpn_shapes()[:4]]
+    rois = synth.fpn_rois(seed=3, per_image=512, n_images=2)
+    lv = synth.level_map(rois)
+    mine = np.arange(lo, hi)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for l in range(4):
+            sel = mine[lv[mine] == l]
+            if sel.size:
+                if ref is not None:
+                    ref.roi_align_forward(feats[l], torch.from_numpy(rois[sel]), 1.0 / (4 << l), 7, 7, 2)
+                else:
+                    oracle.roi_align_forward(feats[l].numpy(), rois[sel], 1.0 / (4 << l), 7, 7, 2)
+    return (time.perf_counter() - t0) / reps
+
+
+def cpu_baseline_all_cores(max_workers=None):
+    """the node figure — one single-threaded worker per host core, the 1024 box-head ROIs
+    split evenly (what a CPU data-parallel run of the reference does); wall time = the slowest worker."""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = max(1, min(cores, max_workers or 32))   # each worker holds its own 183 MB copy of the pyramid: capped at 32
+    per = -(-1024 // n)
+    jobs = [(i * per, min(1024, (i + 1) * per), 2) for i in range(n) if i * per < 1024]
+    ctx = mp.get_context("spawn")   # CUDA is initialised in the parent: no fork
+    t0 = time.perf_counter()
+    with ctx.Pool(len(jobs)) as pool:
+        times = pool.map_async(_roi_worker, jobs).get(timeout=120)
+    wall = time.perf_counter() - t0
+    full_bytes = 4 * 1024 * 256 * 49 + sum(4 * 2 * 256 * h * w for (h, w) in [(200, 336), (100, 168), (50, 84), (25, 42)]) + 20 * 1024
+    return {"workers": len(jobs), "host_cores": cores, "slowest_worker_s": round(max(times), 4),
+            "GBs": round(full_bytes / max(times) / 1e9, 3), "pool_wall_s_incl_startup": round(wall, 2)}
 
 
 def cpu_baseline_extras(ref, budget_s=6.0):
@@ -196,10 +246,27 @@ def cpu_baseline_extras(ref, budget_s=6.0):
         t0 = time.perf_counter()
         oracle.roi_align_backward(g, rois[sel], 1.0 / 16, 7, 7, 2, 256, 50, 84, 2)
         out["roi_align_bwd_ms_est_port"] = round((time.perf_counter() - t0) * 1024.0 / max(len(sel), 1) * 1e3, 1)
-        # SigmoidFocalLoss forward (C restatement of the .cu formula), 20,000 of the 403,200 rows
-        logits, targets = synth.focal_inputs(20000, 80)
+        # SigmoidFocalLoss: the reference's own CPU path is the Python composite `sigmoid_focal_loss_cpu`
+        # (layers/sigmoid_focal_loss.py:40-50), restated here line by line on torch CPU tensors and timed on the
+        # FULL RetinaNet shape (R = 403,200 rows x 80 classes, all host threads torch gives it); the C restatement
+        # of the CUDA formula on a 20,000-row sample is kept beside it
+        logits, targets = synth.focal_inputs(403200, 80)
+        tl, tt = torch.from_numpy(logits), torch.from_numpy(targets.astype(np.int64))
+        torch.set_num_threads(max(1, os.cpu_count() or 1))
         t0 = time.perf_counter()
-        oracle.sigmoid_focal_loss_forward(logits, targets, 2.0, 0.25)
+        num_classes = tl.shape[1]
+        class_range = torch.arange(1, num_classes + 1, dtype=tt.dtype).unsqueeze(0)
+        t = tt.unsqueeze(1)
+        p = torch.sigmoid(tl)
+        term1 = (1 - p) ** 2.0 * torch.log(p)
+        term2 = p ** 2.0 * torch.log(1 - p)
+        loss = -(t == class_range).float() * term1 * 0.25 - ((t != class_range) * (t >= 0)).float() * term2 * (1 - 0.25)
+        float(loss.sum())
+        out["focal_fwd_ms_reference_python_cpu"] = round((time.perf_counter() - t0) * 1e3, 1)
+        out["focal_cpu_threads"] = torch.get_num_threads()
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
+        oracle.sigmoid_focal_loss_forward(logits[:20000], targets[:20000], 2.0, 0.25)
         out["focal_fwd_ms_est_port"] = round((time.perf_counter() - t0) * 403200.0 / 20000.0 * 1e3, 1)
     except Exception as e:  # extras never cost the main figure
         out["extras_error"] = repr(e)
@@ -343,9 +410,12 @@ def main():
             line["kernels"] = kernels
             if dominant is not None:
                 name, _, e = dominant
+                traffic, source = measured_traffic(name)
                 line["roofline"] = {"kernel": name, "bound": "hbm", "achieved": e["achieved_GBs"], "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": round(e["achieved_GBs"] / HBM_PEAK_GBS, 4),
-                                    "traffic": measured_traffic(name, "bwd_gather" if "_bwd[" in name and os.environ.get("DETOPS_ROIALIGN_BWD", "g")[0] != "t" else None),
+                                    "traffic": traffic,
+                                    # the PMC passes are separate rocprofv3 runs (committed table), not this run
+                                    "traffic_source": source,
                                     "alg_bytes_per_launch": e["alg_bytes"], "mean_us": e["mean_us"]}
         if world == 1 and not args.no_cpu_baseline:
             try:
