@@ -63,6 +63,18 @@ int detops_roi_align_backward_f32(const float* grad_out, const float* rois, floa
                                   float spatial_scale, int sampling_ratio, int zero_grad_in,
                                   detops_stream_t stream);
 
+/* Forward with a caller-provided workspace (`detops_roi_align_forward_workspace_bytes(K)` bytes; 0 = not used for
+ * this K): a pre-pass launch ranks the ROIs by (level, image, position) and the main launch visits them in that
+ * order, so that overlapping footprints are fetched while they are still in the XCD's L2.  The output is identical,
+ * bit for bit, to the workspace-free call (what detops_roi_align_forward_f32 / detops_roi_align_fpn_forward_f32
+ * do); workspace == NULL or too small selects that path. */
+size_t detops_roi_align_forward_workspace_bytes(int K);
+
+int detops_roi_align_forward_ws_f32(const float* input, const float* rois, float* output,
+                                    int N, int C, int H, int W, int K, int PH, int PW,
+                                    float spatial_scale, int sampling_ratio, void* workspace,
+                                    size_t workspace_bytes, detops_stream_t stream);
+
 /* Backward with a caller-provided workspace: selects the binned pixel-owner kernel (a pre-pass launch
  * builds per-ROI adjoint rows and per-tile hit lists in the workspace, the main launch only gathers).
  * `detops_roi_align_backward_workspace_bytes` returns the size for a set of maps (H_host/W_host:
@@ -96,6 +108,15 @@ int detops_roi_align_fpn_forward_f32(const float* const* inputs_host, const int*
                                      int sampling_ratio, int k_min, int k_max,
                                      float canonical_scale, float canonical_level, float eps,
                                      detops_stream_t stream);
+
+int detops_roi_align_fpn_forward_ws_f32(const float* const* inputs_host, const int* H_host,
+                                        const int* W_host, const float* scale_host,
+                                        int num_levels, const float* rois, float* output,
+                                        int32_t* levels_out, int N, int C, int K, int PH, int PW,
+                                        int sampling_ratio, int k_min, int k_max,
+                                        float canonical_scale, float canonical_level, float eps,
+                                        void* workspace, size_t workspace_bytes,
+                                        detops_stream_t stream);
 
 int detops_roi_align_fpn_backward_ws_f32(const float* grad_out, const float* rois,
                                          const int32_t* levels, float* const* grad_inputs_host,

@@ -61,6 +61,15 @@ static inline int launch_status() { return static_cast<int>(hipGetLastError()); 
 #define DETOPS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// Scheduling pin: the four values must be in registers here, so every load that produces them has been ISSUED
+// before this point (hipcc's scheduler otherwise serialises LDS reads one `s_waitcnt lgkmcnt(0)` at a time to
+// save registers).  No instruction is emitted.
+#ifdef DETOPS_CPU_EMU
+#define DETOPS_PIN4(a, b, c, d) ((void)0)
+#else
+#define DETOPS_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#endif
+
 constexpr int kWave = 64;        // CDNA4 wavefront
 constexpr int kNumCU = 256;      // MI355X
 constexpr int kNumXCD = 8;

@@ -221,6 +221,7 @@ roi_align_fwd_kernel(Levels L, const float* __restrict__ rois, const int32_t* __
 //     reference CPU kernel for finite inputs.
 // Footprints that do not fit the LDS budget fall through to the generic gather loop.
 // ------------------------------------------------------------------------------------------
+constexpr int kFwdDmaWps = 5;  // LDS-DMA forward: no staging registers
 constexpr int kFwdWps = 4;   // waves per SIMD of the row-vector forward (register budget 80)
 constexpr int kLdsPatchFloats = 8192 - 64;  // default ~32 KiB dynamic LDS per workgroup -> 4-5 workgroups / CU
 
@@ -395,6 +396,271 @@ roi_align_fwd_lds_kernel(Levels L, const float* __restrict__ rois, const int32_t
       }
     }
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, LDS-DMA variant of the fast path: the footprint is copied global -> LDS by
+// `global_load_lds_dwordx4` (gfx950: 16 bytes per lane, no staging registers), the whole batch issued
+// back to back (one memory round trip per batch instead of one per U loads), and the NEXT batch is
+// issued before the current one is consumed (two LDS buffers, one barrier per batch).  LDS-DMA writes
+// wave-uniform base + lane * 16, so the patch is lane-linear: float4 index = (channel * rows + y) * w4 + v.
+// Pieces that reach beyond a map row (replicated border column) go through registers.
+// Arithmetic and operation order are those of roi_align_fwd_lds_kernel: bit-identical output.
+// ------------------------------------------------------------------------------------------
+// Visiting order for the forward: ROIs sorted by (level, image, 8-row band, column) of their centre.  ROIs arrive
+// in score / sampling order, i.e. spatially random; the forward is bound by the fabric traffic of re-fetching
+// overlapping footprints (rocprofv3: L2 hit 40 %, TCC misses x 128 B = 600 MB for 342 MB of staged footprints,
+// 183 MB of maps).  With neighbours adjacent in the launch — workgroup b runs on XCD b % 8, so the 4 channel chunks
+// of ROIs k and k + 2 share an XCD and its L2 — the box-head launch drops from 128 to 96-100 us
+// (tools/probe_fwd_order.py).  Rank sort: 8 lanes per ROI count the keys below their own in LDS.  The order is a
+// locality heuristic only: ANY permutation gives the same output, bit for bit.
+constexpr int kOrderMaxK = 4096;
+constexpr int kOrderMinK = 384;
+constexpr int kOrderLanes = 16;     // lanes that share one ROI's count
+constexpr int kOrderBlock = 1024;   // 16 waves: enough to hide the LDS read latency of the count loop
+
+__device__ __forceinline__ unsigned long long roi_order_key(const Levels& L, const float* __restrict__ rois,
+                                                            const int32_t* __restrict__ levels_in, int i) {
+  const float* roi = rois + static_cast<size_t>(i) * 5;
+  int lvl = 0;
+  if (L.num > 1) lvl = levels_in ? levels_in[i] : fpn_level(roi, L);
+  float scale = L.lv[0].scale;
+#pragma unroll
+  for (int l = 1; l < DETOPS_MAX_LEVELS; ++l)
+    if (l == lvl) scale = L.lv[l].scale;
+  const int b = static_cast<int>(roi[0]);
+  const int xc = static_cast<int>((roi[1] + roi[3]) * 0.5f * scale);
+  const int yc = static_cast<int>((roi[2] + roi[4]) * 0.0625f * scale);
+  const unsigned key = (static_cast<unsigned>(lvl & 7) << 29) | (static_cast<unsigned>(min(max(b, 0), 127)) << 22) |
+                       (static_cast<unsigned>(min(max(yc, 0), 1023)) << 12) | static_cast<unsigned>(min(max(xc, 0), 4095));
+  return (static_cast<unsigned long long>(key) << 32) | static_cast<unsigned>(i);
+}
+
+__global__ void __launch_bounds__(kOrderBlock)
+roi_order_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in, int K,
+                 int32_t* __restrict__ order) {
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[kOrderMaxK + 2 * kOrderLanes];
+  const int tid = threadIdx.x;
+  const int Kp = (K + 2 * kOrderLanes - 1) / (2 * kOrderLanes) * (2 * kOrderLanes);   // padded with +inf keys
+  for (int i = tid; i < Kp; i += kOrderBlock)
+    keys[i] = i < K ? roi_order_key(L, rois, levels_in, i) : ~0ull;
+  __syncthreads();
+  const int r = (blockIdx.x * kOrderBlock + tid) / kOrderLanes;
+  const int sub = tid & (kOrderLanes - 1);
+  int cnt = 0;
+  if (r < K) {
+    const unsigned long long mine = keys[r];
+#pragma unroll 8
+    for (int j = 2 * sub; j < Kp; j += 2 * kOrderLanes) {   // one 16-byte LDS read = two keys; same address across ROIs: broadcast
+      const unsigned long long k0 = keys[j], k1 = keys[j + 1];
+      cnt += (k0 < mine ? 1 : 0) + (k1 < mine ? 1 : 0);
+    }
+  }
+  cnt += __shfl_down(cnt, 8);
+  cnt += __shfl_down(cnt, 4);
+  cnt += __shfl_down(cnt, 2);
+  cnt += __shfl_down(cnt, 1);
+  if (r < K && sub == 0) { order[cnt] = r; DETOPS_STAT("fwd.ranked_rois", 1); }
+}
+
+#ifdef DETOPS_CPU_EMU
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+  float* d = lds_wave_base + 4 * (threadIdx.x & 63);
+  d[0] = g[0]; d[1] = g[1]; d[2] = g[2]; d[3] = g[3];
+}
+#else
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+#endif
+
+template <int PH, int PW, int SR, int G, int WPS>
+__global__ void __launch_bounds__(((PH * PW * G + 63) / 64) * 64, WPS)
+roi_align_fwd_dma_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
+                         int32_t* __restrict__ levels_out, float* __restrict__ out, int C, int K, int CT,
+                         int chunks, int buf_floats, const int32_t* __restrict__ order) {
+  constexpr int BINS = PH * PW;
+  constexpr int NS = SR * SR;
+  constexpr int NT = ((BINS * G + 63) / 64) * 64;
+  DETOPS_DYNAMIC_LDS(float, patch);          // two buffers of buf_floats (multiple of 256 floats = one wave-instruction)
+  __shared__ Tap tabY[PH * SR];
+  __shared__ Tap tabX[PW * SR];
+  __shared__ int s_bounds[4];
+
+  const int tid = threadIdx.x;
+  const int bid = blockIdx.x;
+  const int kk = bid / chunks;
+  const int chunk = bid - kk * chunks;
+  const int k = order ? order[kk] : kk;
+  const float* roi = rois + static_cast<size_t>(k) * 5;
+  int lvl = 0;
+  if (L.num > 1) lvl = levels_in ? levels_in[k] : fpn_level(roi, L);
+  if (levels_out && chunk == 0 && tid == 0) levels_out[k] = lvl;
+  const float* in = L.lv[0].in; int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
+#pragma unroll
+  for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+    if (i == lvl) { in = L.lv[i].in; H = L.lv[i].H; W = L.lv[i].W; scale = L.lv[i].scale; }
+
+  const RoiGeom g = roi_geometry(roi, scale, PH, PW, SR);
+  if (tid == 0) { s_bounds[0] = 0x7fffffff; s_bounds[1] = -1; s_bounds[2] = 0x7fffffff; s_bounds[3] = -1; }
+  __syncthreads();
+  if (tid < PH * SR + PW * SR) {
+    if (tid < PH * SR) {
+      const Tap e = axis_entry(g.start_h, g.bin_h, tid / SR, tid % SR, SR, H, 1);
+      tabY[tid] = e;
+      if (e.l != 0.f || e.h != 0.f) { atomicMin(&s_bounds[0], e.lo); atomicMax(&s_bounds[1], e.lo); }
+    } else {
+      const int u = tid - PH * SR;
+      const Tap e = axis_entry(g.start_w, g.bin_w, u / SR, u % SR, SR, W, 1);
+      tabX[u] = e;
+      if (e.l != 0.f || e.h != 0.f) { atomicMin(&s_bounds[2], e.lo); atomicMax(&s_bounds[3], e.lo); }
+    }
+  }
+  __syncthreads();
+  const int c0 = chunk * CT;
+  const int cend = min(C, c0 + CT);
+  float* obase = out + (static_cast<size_t>(k) * C + c0) * BINS;
+  if (s_bounds[1] < 0 || s_bounds[3] < 0) {  // every sample falls outside the map: all-zero output
+    for (int o = tid; o < (cend - c0) * BINS; o += NT) obase[o] = 0.f;
+    return;
+  }
+  const int ymin = s_bounds[0];
+  const int rows = s_bounds[1] - ymin + 2;   // (lo range) + the lo+1 row
+  const size_t plane = static_cast<size_t>(H) * W;
+  const float* base = in + (static_cast<size_t>(g.b) * C + c0) * plane;
+  const int xmin = s_bounds[2];
+  int w4 = (s_bounds[3] - xmin + 2 + 3) >> 2;   // float4 pieces per patch row incl. the lo+1 column
+  w4 |= 1;                                       // odd: rows spread over the LDS banks
+  const int ps = 4 * w4;
+  const int a4 = rows * w4;                      // float4 pieces per channel
+  const int area = 4 * a4;
+
+  if (area > buf_floats) {  // footprint too large for LDS: gather straight from the map
+    for (int o = tid; o < (cend - c0) * BINS; o += NT) {
+#pragma clang fp contract(off)
+      const int cl = o / BINS;
+      const int bin = o - cl * BINS;
+      const int ph = bin / PW, pw = bin - ph * PW;
+      const float* d = base + static_cast<size_t>(cl) * plane;
+      float acc = 0.f;
+      for (int iy = 0; iy < SR; ++iy) {
+        const Tap ty = tabY[ph * SR + iy];
+        const float* r0 = d + ty.lo * W;
+        const float* r1 = d + ty.hi * W;
+        for (int ix = 0; ix < SR; ++ix) {
+          const Tap tx = tabX[pw * SR + ix];
+          const float w1 = ty.h * tx.h, w2 = ty.h * tx.l, w3 = ty.l * tx.h, w4_ = ty.l * tx.l;
+          acc += w1 * r0[tx.lo] + w2 * r0[tx.hi] + w3 * r1[tx.lo] + w4_ * r1[tx.hi];
+        }
+      }
+      obase[o] = acc / g.count;
+    }
+    return;
+  }
+
+  // this lane's piece of a staging pass: piece index tid -> (channel, row, column piece); a pass advances by NT
+  const float inv_a4 = 1.f / static_cast<float>(a4), inv_w4 = 1.f / static_cast<float>(w4);
+  const int pc0 = static_cast<int>((static_cast<float>(tid) + 0.5f) * inv_a4);
+  const int prem = tid - pc0 * a4;
+  const int py0 = static_cast<int>((static_cast<float>(prem) + 0.5f) * inv_w4);
+  const int pv0 = prem - py0 * w4;
+  const int dc = static_cast<int>((static_cast<float>(NT) + 0.5f) * inv_a4);
+  const int drem = NT - dc * a4;
+  const int dy = static_cast<int>((static_cast<float>(drem) + 0.5f) * inv_w4);
+  const int dv = drem - dy * w4;
+  const int wave_off = __builtin_amdgcn_readfirstlane(tid >> 6) * 256;   // floats
+
+  // channels per batch: as many as fit a buffer, then evened out over the batches (a short last batch costs a full
+  // barrier + memory round trip: 2 x 13 KB buffers measured 93 us where the evenly filled 2 x 11 KB took 84)
+  const int ctb_max = min(cend - c0, buf_floats / area);
+  const int nbatch = (cend - c0 + ctb_max - 1) / ctb_max;
+  const int ctb = (cend - c0 + nbatch - 1) / nbatch;
+  // element offset of this lane's piece inside the batch's source planes, advanced incrementally per pass (the
+  // from-scratch form costs ~25 VALU instructions per 16 bytes: 64-bit multiplies for channel and row)
+  const int go0 = pc0 * static_cast<int>(plane) + (ymin + py0) * W + xmin + 4 * pv0;
+  const int dgo = dc * static_cast<int>(plane) + dy * W + 4 * dv;
+  const int wrap_v = W - 4 * w4;                          // (y + 1, v - w4)
+  const int wrap_y = static_cast<int>(plane) - rows * W;  // (c + 1, y - rows)
+  const bool planes_fit = static_cast<size_t>(ctb + 1) * plane < 0x7fffffffu;
+  auto issue = [&](int cs, int cn, float* buf) {
+    const float* src = base + static_cast<size_t>(cs - c0) * plane;
+    const int total = cn * a4;
+    int y = py0, v = pv0, go = go0;
+    int c = pc0;
+#pragma unroll 1
+    for (int i0 = 0; i0 < total; i0 += NT) {
+      if (i0 + tid < total) {
+        const int gx = xmin + 4 * v;
+        if (gx + 3 < W && ymin + y < H && planes_fit) {
+          glds16(src + go, buf + 4 * i0 + wave_off);
+        } else {                              // piece reaching beyond the map: replicated border column / row
+          const float* rowp = src + static_cast<size_t>(c) * plane + static_cast<size_t>(min(ymin + y, H - 1)) * W;
+          *reinterpret_cast<float4*>(buf + 4 * (i0 + tid)) =
+              make_float4(rowp[min(gx, W - 1)], rowp[min(gx + 1, W - 1)], rowp[min(gx + 2, W - 1)], rowp[min(gx + 3, W - 1)]);
+        }
+      }
+      go += dgo; v += dv; y += dy; c += dc;
+      if (v >= w4) { v -= w4; ++y; go += wrap_v; }
+      if (y >= rows) { y -= rows; ++c; go += wrap_y; }
+    }
+  };
+
+  // per-thread sample geometry (registers)
+  const int bin = tid % BINS;
+  const int csub = tid / BINS;  // >= G: idle lane of the last wave
+  const int ph = bin / PW, pw = bin - ph * PW;
+  int off[NS];
+  float w1[NS], w2[NS], w3[NS], w4s[NS];
+#pragma unroll
+  for (int iy = 0; iy < SR; ++iy) {
+    const Tap ty = tabY[ph * SR + iy];
+    const bool vy = (ty.l != 0.f || ty.h != 0.f);
+#pragma unroll
+    for (int ix = 0; ix < SR; ++ix) {
+#pragma clang fp contract(off)
+      const Tap tx = tabX[pw * SR + ix];
+      const bool vv = vy && (tx.l != 0.f || tx.h != 0.f);
+      const int s = iy * SR + ix;
+      off[s] = vv ? (ty.lo - ymin) * ps + (tx.lo - xmin) : 0;
+      w1[s] = vv ? ty.h * tx.h : 0.f;
+      w2[s] = vv ? ty.h * tx.l : 0.f;
+      w3[s] = vv ? ty.l * tx.h : 0.f;
+      w4s[s] = vv ? ty.l * tx.l : 0.f;
+    }
+  }
+  const float inv_count = 1.f / static_cast<float>(NS);  // NS in {1,4}: exact reciprocal
+
+  issue(c0, min(ctb, cend - c0), patch);
+  int n = 0;
+  for (int cs = c0; cs < cend; cs += ctb, ++n) {
+    const int cn = min(ctb, cend - cs);
+    if (tid == 0) { DETOPS_STAT("fwd.stage_batches", 1); DETOPS_STAT("fwd.staged_floats", cn * area); }
+    __syncthreads();   // batch n has landed (vmcnt(0) + barrier); every wave is done reading the other buffer
+    const float* cur = patch + (n & 1) * buf_floats;
+    if (cs + ctb < cend) issue(cs + ctb, min(ctb, cend - cs - ctb), patch + ((n + 1) & 1) * buf_floats);
+    if (csub < G) {
+      float* o = obase + static_cast<size_t>(cs - c0) * BINS + bin;
+#pragma unroll 1
+      for (int c = csub; c < cn; c += G) {
+#pragma clang fp contract(off)
+        const float* p = cur + c * area;
+        float t0[NS], t1[NS], t2[NS], t3[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {     // all taps of the bin in flight before the first use
+          const float* q = p + off[s];
+          t0[s] = q[0]; t1[s] = q[1]; t2[s] = q[ps]; t3[s] = q[ps + 1];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) DETOPS_PIN4(t0[s], t1[s], t2[s], t3[s]);
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc += w1[s] * t0[s] + w2[s] * t1[s] + w3[s] * t2[s] + w4s[s] * t3[s];
+        o[static_cast<size_t>(c) * BINS] = acc * inv_count;
+      }
+    }
   }
 }
 
@@ -860,10 +1126,19 @@ inline void dispatch_shape(int PH, int PW, int sr, F&& f) {
 
 template <int PH, int PW, int SR, int G>
 void launch_fwd_lds(const Levels& L, const float* rois, const int32_t* levels_in, int32_t* levels_out,
-                    float* out, int C, int K, hipStream_t st) {
+                    float* out, int C, int K, hipStream_t st, int32_t* order_ws) {
   constexpr int NT = ((PH * PW * G + 63) / 64) * 64;
-  int CT = 64;  // channels per workgroup: >= 4 x 256 workgroups when the problem allows it
+  // channels per workgroup.  32: with C = 256 the 8 chunks of a ROI land on the 8 XCDs (workgroup b runs on XCD
+  // b % 8), so every L2 caches ONE 32-channel slice of the maps and sees all ROIs in ranked order; and 8 K short
+  // workgroups balance better over 256 x 7 slots than 4 K long ones (tools/probe_fwd_knobs.py: 84 vs 100 us)
+  const char* fwd_env = getenv("DETOPS_ROIALIGN_FWD");
+  const bool reg_staged = fwd_env && fwd_env[0] == 'l';   // DETOPS_ROIALIGN_FWD=lds: register-staged kernel (A/B runs)
+  int64_t map_pixels = 0;
+  for (int i = 0; i < L.num; ++i) map_pixels += static_cast<int64_t>(L.lv[i].H) * L.lv[i].W;
+  // small maps = small footprints: the per-workgroup setup dominates, fewer and fatter workgroups win (cfg-1: 63 vs 86 us)
+  int CT = (reg_staged || map_pixels < 16384) ? 64 : 32;
   while (CT > 16 && static_cast<int64_t>(K) * ceil_div64(C, CT) < 4 * kNumCU) CT >>= 1;
+  if (const char* e = getenv("DETOPS_ROIALIGN_FWD_CT")) CT = max(1, atoi(e));   // A/B runs
   if (CT > C) CT = C;
   const int chunks = static_cast<int>(ceil_div64(C, CT));
   // measured (profiles/r01d_opbench.log): 7x7 bins are fastest at 32 KiB / 4 loads in flight (142 us box
@@ -876,6 +1151,34 @@ void launch_fwd_lds(const Levels& L, const float* rois, const int32_t* levels_in
   }
   if (const char* e = getenv("DETOPS_ROIALIGN_FWD_U")) unroll = atoi(e);
   const dim3 grid(static_cast<unsigned>(K) * chunks);
+  if (!reg_staged) {
+    // two buffers, each a whole number of 1 KiB wave-instructions, sized so that LDS allows as many workgroups per
+    // CU as the registers do (68 VGPRs -> 7 waves / SIMD = 28 waves / CU): 7 x (2 x 11 KB) for the 4-wave 7x7
+    // kernel, 4 x (2 x 19 KB) for the 7-wave 14x14 kernel — the measured optimum of both sweeps
+    const int wgs = max(1, 28 / (NT / 64));
+    int buf_floats = max(4, (160 * 1024 / wgs - 768) / 2048) * 256;
+    if (const char* e = getenv("DETOPS_ROIALIGN_FWD_BUF_KB")) {
+      const int kb = atoi(e);
+      if (kb >= 2 && kb <= 64) buf_floats = kb * 256;
+    }
+    const size_t lds2 = 2 * static_cast<size_t>(buf_floats) * sizeof(float);
+    int wps = kFwdDmaWps;
+    if (const char* e = getenv("DETOPS_ROIALIGN_FWD_WPS")) wps = atoi(e);
+    const int32_t* order = nullptr;
+    // order_ws != nullptr implies K >= order_min_k(); maps that fit an L2 slice several times over need no ranking
+    const char* oe = getenv("DETOPS_ROIALIGN_FWD_ORDER");          // "force": rank even for small maps (tests)
+    if (order_ws && K <= kOrderMaxK && (map_pixels * C * 4 > (2 << 20) || (oe && oe[0] == 'f'))) {
+      const unsigned og = static_cast<unsigned>(ceil_div64(static_cast<int64_t>(K) * kOrderLanes, kOrderBlock));
+      hipLaunchKernelGGL(roi_order_kernel, dim3(og), dim3(kOrderBlock), 0, st, L, rois, levels_in, K, order_ws);
+      order = order_ws;
+    }
+#define FWD_DMA_LAUNCH(W_)                                                                                        \
+  hipLaunchKernelGGL((roi_align_fwd_dma_kernel<PH, PW, SR, G, W_>), grid, dim3(NT), lds2, st, L, rois, levels_in, \
+                     levels_out, out, C, K, CT, chunks, buf_floats, order)
+    if (wps == 8) FWD_DMA_LAUNCH(8); else if (wps == 6) FWD_DMA_LAUNCH(6); else if (wps == 4) FWD_DMA_LAUNCH(4); else FWD_DMA_LAUNCH(5);
+#undef FWD_DMA_LAUNCH
+    return;
+  }
   const size_t lds = (patch_floats + 64) * sizeof(float);
 #define FWD_LDS_LAUNCH(U_)                                                                                       \
   hipLaunchKernelGGL((roi_align_fwd_lds_kernel<PH, PW, SR, G, U_, kFwdWps>), grid, dim3(NT), lds, st, L, rois,   \
@@ -885,7 +1188,9 @@ void launch_fwd_lds(const Levels& L, const float* rois, const int32_t* levels_in
 }
 
 int run_forward(const Levels& L, const float* rois, const int32_t* levels_in, int32_t* levels_out,
-                float* out, int C, int K, int PH, int PW, int sr, hipStream_t st) {
+                float* out, int C, int K, int PH, int PW, int sr, hipStream_t st, int32_t* order_ws = nullptr) {
+  if (const char* e = getenv("DETOPS_ROIALIGN_FWD_ORDER"))
+    if (e[0] == '0') order_ws = nullptr;            // A/B runs: launch order = ROI order
   if (K == 0 || C == 0) return 0;
   // DETOPS_ROIALIGN_FWD=generic forces the gather kernel (A/B measurements; default: LDS fast path)
   static const bool force_generic = [] {
@@ -894,15 +1199,15 @@ int run_forward(const Levels& L, const float* rois, const int32_t* levels_in, in
   }();
   if (force_generic) {
   } else if (PH == 7 && PW == 7 && sr == 2) {
-    launch_fwd_lds<7, 7, 2, 5>(L, rois, levels_in, levels_out, out, C, K, st);
+    launch_fwd_lds<7, 7, 2, 5>(L, rois, levels_in, levels_out, out, C, K, st, order_ws);
     return launch_status();
   }
   else if (PH == 14 && PW == 14 && sr == 2) {
-    launch_fwd_lds<14, 14, 2, 2>(L, rois, levels_in, levels_out, out, C, K, st);
+    launch_fwd_lds<14, 14, 2, 2>(L, rois, levels_in, levels_out, out, C, K, st, order_ws);
     return launch_status();
   }
   else if (PH == 7 && PW == 7 && sr == 1) {
-    launch_fwd_lds<7, 7, 1, 5>(L, rois, levels_in, levels_out, out, C, K, st);
+    launch_fwd_lds<7, 7, 1, 5>(L, rois, levels_in, levels_out, out, C, K, st, order_ws);
     return launch_status();
   }
   const int CT = pick_chunk(C, K);
@@ -1574,10 +1879,25 @@ inline bool bad_dims(int N, int C, int K, int PH, int PW) {
 
 }  // namespace
 
-DETOPS_API int detops_roi_align_forward_f32(const float* input, const float* rois, float* output,
-                                            int N, int C, int H, int W, int K, int PH, int PW,
-                                            float spatial_scale, int sampling_ratio,
-                                            detops_stream_t stream) {
+static int order_min_k() {
+  if (const char* e = getenv("DETOPS_ROIALIGN_FWD_ORDER_MINK")) return max(2, atoi(e));   // A/B runs
+  return kOrderMinK;
+}
+
+DETOPS_API size_t detops_roi_align_forward_workspace_bytes(int K) {
+  if (K < order_min_k() || K > kOrderMaxK) return 0;
+  return (sizeof(int32_t) * static_cast<size_t>(K) + 255) & ~static_cast<size_t>(255);
+}
+
+static int32_t* order_workspace(int K, void* workspace, size_t workspace_bytes) {
+  const size_t need = detops_roi_align_forward_workspace_bytes(K);
+  return (workspace && need && workspace_bytes >= need) ? static_cast<int32_t*>(workspace) : nullptr;
+}
+
+DETOPS_API int detops_roi_align_forward_ws_f32(const float* input, const float* rois, float* output,
+                                               int N, int C, int H, int W, int K, int PH, int PW,
+                                               float spatial_scale, int sampling_ratio, void* workspace,
+                                               size_t workspace_bytes, detops_stream_t stream) {
   if (bad_dims(N, C, K, PH, PW) || H < 0 || W < 0) return DETOPS_EINVAL;
   if (K == 0 || C == 0) return 0;
   if (!input || !rois || !output || H == 0 || W == 0 || N == 0) return DETOPS_EINVAL;
@@ -1585,7 +1905,15 @@ DETOPS_API int detops_roi_align_forward_f32(const float* input, const float* roi
   L.num = 1;
   L.lv[0] = Level{input, nullptr, H, W, spatial_scale};
   return run_forward(L, rois, nullptr, nullptr, output, C, K, PH, PW, sampling_ratio,
-                     as_stream(stream));
+                     as_stream(stream), order_workspace(K, workspace, workspace_bytes));
+}
+
+DETOPS_API int detops_roi_align_forward_f32(const float* input, const float* rois, float* output,
+                                            int N, int C, int H, int W, int K, int PH, int PW,
+                                            float spatial_scale, int sampling_ratio,
+                                            detops_stream_t stream) {
+  return detops_roi_align_forward_ws_f32(input, rois, output, N, C, H, W, K, PH, PW, spatial_scale,
+                                         sampling_ratio, nullptr, 0, stream);
 }
 
 DETOPS_API int detops_roi_align_backward_ws_f32(const float* grad_out, const float* rois,
@@ -1632,11 +1960,11 @@ DETOPS_API size_t detops_roi_align_backward_workspace_bytes(const int* H_host, c
   return lay.total;
 }
 
-DETOPS_API int detops_roi_align_fpn_forward_f32(
+DETOPS_API int detops_roi_align_fpn_forward_ws_f32(
     const float* const* inputs_host, const int* H_host, const int* W_host, const float* scale_host,
     int num_levels, const float* rois, float* output, int32_t* levels_out, int N, int C, int K,
     int PH, int PW, int sampling_ratio, int k_min, int k_max, float canonical_scale,
-    float canonical_level, float eps, detops_stream_t stream) {
+    float canonical_level, float eps, void* workspace, size_t workspace_bytes, detops_stream_t stream) {
   if (bad_dims(N, C, K, PH, PW) || num_levels < 1 || num_levels > DETOPS_MAX_LEVELS ||
       !inputs_host || !H_host || !W_host || !scale_host)
     return DETOPS_EINVAL;
@@ -1652,7 +1980,18 @@ DETOPS_API int detops_roi_align_fpn_forward_f32(
   }
   hipStream_t st = as_stream(stream);
   if (num_levels == 1 && levels_out) DETOPS_HIP_TRY(hipMemsetAsync(levels_out, 0, sizeof(int32_t) * K, st));
-  return run_forward(L, rois, nullptr, levels_out, output, C, K, PH, PW, sampling_ratio, st);
+  return run_forward(L, rois, nullptr, levels_out, output, C, K, PH, PW, sampling_ratio, st,
+                     order_workspace(K, workspace, workspace_bytes));
+}
+
+DETOPS_API int detops_roi_align_fpn_forward_f32(
+    const float* const* inputs_host, const int* H_host, const int* W_host, const float* scale_host,
+    int num_levels, const float* rois, float* output, int32_t* levels_out, int N, int C, int K,
+    int PH, int PW, int sampling_ratio, int k_min, int k_max, float canonical_scale,
+    float canonical_level, float eps, detops_stream_t stream) {
+  return detops_roi_align_fpn_forward_ws_f32(inputs_host, H_host, W_host, scale_host, num_levels, rois, output,
+                                             levels_out, N, C, K, PH, PW, sampling_ratio, k_min, k_max,
+                                             canonical_scale, canonical_level, eps, nullptr, 0, stream);
 }
 
 DETOPS_API int detops_roi_align_fpn_backward_ws_f32(

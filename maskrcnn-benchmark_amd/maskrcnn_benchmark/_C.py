@@ -268,11 +268,21 @@ def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, s
     if out.numel() == 0:
         return out
     with _on_device(input):
-        check(lib.detops_roi_align_forward_f32(ptr(input), ptr(rois), ptr(out), N, C, H, W, K,
-                                               pooled_height, pooled_width, float(spatial_scale),
-                                               int(sampling_ratio), stream_of(input)),
+        ws, nbytes = _fwd_workspace(input.device, K)
+        check(lib.detops_roi_align_forward_ws_f32(ptr(input), ptr(rois), ptr(out), N, C, H, W, K,
+                                                  pooled_height, pooled_width, float(spatial_scale),
+                                                  int(sampling_ratio), ptr(ws), nbytes, stream_of(input)),
               "roi_align_forward")
     return out
+
+
+def _fwd_workspace(device, K):
+    """Scratch for the forward's ROI visiting order (one int32 per ROI), from torch's stream-ordered caching
+    allocator; (None, 0) when this ROI count is served without a pre-pass."""
+    nbytes = int(lib.detops_roi_align_forward_workspace_bytes(int(K)))
+    if nbytes <= 0:
+        return None, 0
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device), nbytes
 
 
 def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
@@ -326,10 +336,11 @@ def roi_align_fpn_forward(inputs, rois, scales, pooled_height, pooled_width, sam
         return out, levels
     ptrs, Hs, Ws, sc = _host_arrays(inputs, scales)
     with _on_device(rois), _timed("roi_align_fpn_fwd[K=%d,C=%d,%dx%d]" % (K, C, pooled_height, pooled_width), rois):
-        check(lib.detops_roi_align_fpn_forward_f32(
+        ws, nbytes = _fwd_workspace(rois.device, K)
+        check(lib.detops_roi_align_fpn_forward_ws_f32(
             ptrs, Hs, Ws, sc, len(inputs), ptr(rois), ptr(out), ptr(levels), N, C, K, pooled_height,
             pooled_width, int(sampling_ratio), int(k_min), int(k_max), float(canonical_scale),
-            float(canonical_level), float(eps), stream_of(rois)), "roi_align_fpn_forward")
+            float(canonical_level), float(eps), ptr(ws), nbytes, stream_of(rois)), "roi_align_fpn_forward")
     return out, levels
 
 

@@ -23,6 +23,10 @@ SIGNATURES = {
     "detops_roi_align_backward_ws_f32": (
         c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P, ctypes.c_size_t, _P]),
     "detops_roi_align_backward_workspace_bytes": (ctypes.c_size_t, [_P, _P] + [c_int] * 6),
+    "detops_roi_align_forward_workspace_bytes": (ctypes.c_size_t, [c_int]),
+    "detops_roi_align_forward_ws_f32": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, _P, ctypes.c_size_t, _P]),
+    "detops_roi_align_fpn_forward_ws_f32": (
+        c_int, [_P, _P, _P, _P, c_int, _P, _P, _P] + [c_int] * 8 + [c_float, c_float, c_float, _P, ctypes.c_size_t, _P]),
     "detops_match_boxes_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "detops_match_boxes_f32": (c_int, [_P, _P, _P] + [c_int] * 4 + [c_float, c_float, c_int, _P, _P, ctypes.c_size_t, _P]),
     "detops_sample_labels_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
@@ -81,7 +85,10 @@ def roi_align_forward(inp, rois, scale, ph, pw, sr):
     N, C, H, W = inp.shape
     K = rois.shape[0]
     out = np.full((K, C, ph, pw), np.nan, np.float32)
-    rc = lib().detops_roi_align_forward_f32(_p(inp), _p(rois), _p(out), N, C, H, W, K, ph, pw, scale, sr, None)
+    nbytes = lib().detops_roi_align_forward_workspace_bytes(K)
+    ws = np.full((max(nbytes, 1),), 0xAB, np.uint8)   # poisoned: the order pre-pass must write every slot
+    rc = lib().detops_roi_align_forward_ws_f32(_p(inp), _p(rois), _p(out), N, C, H, W, K, ph, pw, scale, sr,
+                                               _p(ws) if nbytes else None, nbytes, None)
     assert rc == 0, rc
     return out
 
@@ -118,8 +125,11 @@ def roi_align_fpn_forward(feats, rois, scales, ph, pw, sr, k_min, k_max):
     out = np.full((K, C, ph, pw), np.nan, np.float32)
     levels = np.full((K,), -1, np.int32)
     ptrs, Hs, Ws, sc = _host_arrays(feats, scales)
-    rc = lib().detops_roi_align_fpn_forward_f32(ptrs, Hs, Ws, sc, len(feats), _p(rois), _p(out), _p(levels), N, C, K,
-                                                ph, pw, sr, k_min, k_max, 224.0, 4.0, 1e-6, None)
+    nbytes = lib().detops_roi_align_forward_workspace_bytes(K)
+    ws = np.full((max(nbytes, 1),), 0xAB, np.uint8)
+    rc = lib().detops_roi_align_fpn_forward_ws_f32(ptrs, Hs, Ws, sc, len(feats), _p(rois), _p(out), _p(levels), N, C, K,
+                                                   ph, pw, sr, k_min, k_max, 224.0, 4.0, 1e-6,
+                                                   _p(ws) if nbytes else None, nbytes, None)
     assert rc == 0, rc
     return out, levels
 

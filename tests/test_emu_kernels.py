@@ -91,6 +91,37 @@ def test_emu_roi_align_fpn_fused_levels(bwd_impl):
         assert np.abs(gins[l] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("impl", ["dma+order", "dma", "lds"])
+def test_emu_roi_align_fpn_forward_visiting_order_and_staging_variants(impl, monkeypatch):
+    """K >= 384 switches the ROI ranking pre-pass on (poisoned workspace: every order slot must be written, and
+    the order must be a permutation — a lost or duplicated ROI leaves NaN rows); the LDS-DMA and the
+    register-staged kernels are bit-equal to the oracle, border pieces (replicated column / row) included."""
+    if impl == "lds":
+        monkeypatch.setenv("DETOPS_ROIALIGN_FWD", "lds")
+    monkeypatch.setenv("DETOPS_ROIALIGN_FWD_ORDER", "0" if impl == "dma" else "force")   # force: rank although the maps are tiny
+    rng = np.random.RandomState(11)
+    shapes = [(2, 3, 50, 84), (2, 3, 25, 42), (2, 3, 13, 21), (2, 3, 7, 11)]
+    feats = [rng.randn(*s).astype(np.float32) for s in shapes]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    rois = synth.fpn_rois(seed=5, per_image=200, smin=8, smax=300)
+    rois[:, 1:] *= 0.25
+    rois[:7, 3] = 335.0                      # touching the right / bottom border: replicated border pieces
+    rois[7:14, 4] = 199.0
+    rois[14] = rois[15]                      # identical ROIs: equal keys, ranks must stay distinct
+    assert emu.lib().detops_roi_align_forward_workspace_bytes(rois.shape[0]) > 0
+    lv = synth.level_map(rois)
+    emu.stats(reset=True)
+    out, levels = emu.roi_align_fpn_forward(feats, rois, scales, 7, 7, 2, 2, 5)
+    assert emu.stats().get("fwd.ranked_rois", 0) == (rois.shape[0] if impl == "dma+order" else 0)
+    assert np.array_equal(levels, lv)
+    for l in range(4):
+        sel = lv == l
+        assert np.array_equal(out[sel], oracle.roi_align_forward(feats[l], rois[sel], scales[l], 7, 7, 2))
+    # single-level entry, 14x14 bins
+    out1 = emu.roi_align_forward(feats[1], rois, scales[1], 14, 14, 2)
+    assert np.array_equal(out1, oracle.roi_align_forward(feats[1], rois, scales[1], 14, 14, 2))
+
+
 # ================================================================================ deformable conv
 DCN_GEOMS = [dict(B=2, C=8, H=13, W=17, k=3, stride=1, pad=1, dil=1, dg=1),
              dict(B=2, C=8, H=14, W=15, k=3, stride=2, pad=2, dil=2, dg=2),

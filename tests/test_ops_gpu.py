@@ -82,6 +82,25 @@ def test_roi_align_forward_fpn_full_size_and_fused():
     assert np.array_equal(out.cpu().numpy(), expected)
 
 
+def test_roi_align_forward_variants_bit_equal(monkeypatch):
+    """The ROI ranking pre-pass only changes the order workgroups visit the ROIs in, the LDS-DMA kernel only how
+    the footprint reaches LDS: every variant gives the same bits (cfg-2 box head and cfg-3 mask head, full size)."""
+    feats = [torch.randn(2, 256, h, w, device=DEV) for (h, w) in synth.fpn_shapes()[:4]]
+    scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
+    for K, ph in ((1024, 7), (256, 14)):
+        rois = _t(synth.fpn_rois(per_image=K // 2))
+        base, lv = _C().roi_align_fpn_forward(feats, rois, scales, ph, ph, 2, 2, 5)
+        assert torch.isfinite(base).all()
+        for env in ({"DETOPS_ROIALIGN_FWD_ORDER": "0"}, {"DETOPS_ROIALIGN_FWD_ORDER": "force", "DETOPS_ROIALIGN_FWD_ORDER_MINK": "64"},
+                    {"DETOPS_ROIALIGN_FWD": "lds"}, {"DETOPS_ROIALIGN_FWD": "generic"},
+                    {"DETOPS_ROIALIGN_FWD_CT": "64", "DETOPS_ROIALIGN_FWD_BUF_KB": "5"}):
+            with monkeypatch.context() as m:
+                for k, v in env.items():
+                    m.setenv(k, v)
+                out, lv2 = _C().roi_align_fpn_forward(feats, rois, scales, ph, ph, 2, 2, 5)
+            assert torch.equal(out, base) and torch.equal(lv, lv2), env
+
+
 def test_roi_align_forward_edge_cases():
     C = _C()
     x = torch.randn(2, 3, 10, 12, device=DEV)

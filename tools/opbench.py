@@ -51,6 +51,10 @@ def _entry(name, us, alg_bytes, extra=None):
     return e
 
 
+FWD_SWEEP_KB = os.environ.get("OPBENCH_FWD_KB", "16").split(",")
+FWD_SWEEP_WPS = os.environ.get("OPBENCH_FWD_WPS", "5").split(",")
+
+
 def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False, experimental=False):
     """fused_only: just the FPN-fused launches with the model's shapes (the PMC traffic passes use this,
     so every ROIAlign kernel in their trace is the box-head / mask-head launch bench.py times)."""
@@ -97,12 +101,25 @@ def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False, experiment
                 out.append(_entry(f"roi_align_fwd fpn-per-level(4 launches) {tag}", us, alg))
         if "fwd" in which and not fused_only:
             base = C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]
-            for kb, u in (("16", "4"), ("16", "8"), ("32", "8"), ("48", "8"), ("8", "8")):
-                os.environ["DETOPS_ROIALIGN_FWD_LDS_KB"], os.environ["DETOPS_ROIALIGN_FWD_U"] = kb, u
-                us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
-                same = bool(torch.equal(base, C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]))
-                out.append(_entry(f"roi_align_fwd fpn-fused {tag} [LDS {kb} KB, U={u}]", us, alg, {"bit_equal_to_default": same}))
-            del os.environ["DETOPS_ROIALIGN_FWD_LDS_KB"], os.environ["DETOPS_ROIALIGN_FWD_U"]
+            os.environ["DETOPS_ROIALIGN_FWD_ORDER"] = "0"
+            us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
+            same = bool(torch.equal(base, C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]))
+            del os.environ["DETOPS_ROIALIGN_FWD_ORDER"]
+            out.append(_entry(f"roi_align_fwd fpn-fused {tag} [LDS-DMA, ROIs in caller order (no ranking pre-pass)]", us, alg,
+                              {"bit_equal_to_default": same}))
+            os.environ["DETOPS_ROIALIGN_FWD"] = "lds"
+            us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
+            same = bool(torch.equal(base, C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]))
+            del os.environ["DETOPS_ROIALIGN_FWD"]
+            out.append(_entry(f"roi_align_fwd fpn-fused {tag} [register-staged r01 kernel]", us, alg, {"bit_equal_to_default": same}))
+            for kb in FWD_SWEEP_KB:
+                for wps in FWD_SWEEP_WPS:
+                    os.environ["DETOPS_ROIALIGN_FWD_BUF_KB"], os.environ["DETOPS_ROIALIGN_FWD_WPS"] = kb, wps
+                    us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
+                    same = bool(torch.equal(base, C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]))
+                    out.append(_entry(f"roi_align_fwd fpn-fused {tag} [LDS-DMA 2x{kb} KB, {wps} waves/SIMD budget]", us, alg,
+                                      {"bit_equal_to_default": same}))
+                    del os.environ["DETOPS_ROIALIGN_FWD_BUF_KB"], os.environ["DETOPS_ROIALIGN_FWD_WPS"]
         if "bwd" in which:
             g = torch.randn(K, 256, ph, ph, device="cuda")
             tl = _t(lv)
@@ -296,6 +313,8 @@ def main():
         res += bench_roi_align(C, args.iters, experimental=args.experimental)
     if "roi_align_fpn" in only:
         res += bench_roi_align(C, args.iters, fused_only=True)
+    if "roi_align_fwd" in only:
+        res += bench_roi_align(C, args.iters, which=("fwd",))
     if not only or "nms" in only:
         res += bench_nms(C, args.iters)
     if not only or "frozen_bn" in only:
