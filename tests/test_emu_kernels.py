@@ -176,6 +176,25 @@ def test_emu_nms_bit_exact(n):
         assert np.array_equal(emu.nms(b, s, thr), oracle.nms(b, s, thr))
 
 
+def _nms_chain(n, step):
+    """boxes marching along x: each overlaps only its near neighbours, scores descending with the index — the
+    greedy choice is a dependency chain (0 kept -> 1 dropped -> 2 kept ...) as long as the row block."""
+    x0 = np.arange(n, dtype=np.float32) * step
+    b = np.stack([x0, np.zeros(n, np.float32), x0 + 99, np.full(n, 49, np.float32)], 1)
+    return b, np.linspace(1.0, 0.1, n).astype(np.float32)
+
+
+@pytest.mark.parametrize("step,thr", [(10, 0.8), (25, 0.55), (34, 0.45), (50, 0.3)])
+def test_emu_nms_dependency_chains(step, thr):
+    """worst case of the scan's fixed-point resolve: chains of depth 64 inside a row block, across blocks, and
+    the 4097-box case that takes the shared-memory scan"""
+    for n in (64, 200, 4097):
+        b, s = _nms_chain(n, step)
+        ref = oracle.nms(b, s, thr)
+        assert 1 < len(ref) < n
+        assert np.array_equal(emu.nms(b, s, thr), ref)
+
+
 def test_emu_nms_ties_large_n_and_batched():
     b, s = synth.nms_boxes(300, seed=4)
     s[::3] = s[0]          # score ties: stable (ascending index) order like the CPU sort

@@ -436,6 +436,20 @@ def test_nms_edge_cases():
         np.testing.assert_array_equal(_nms(b, s, thr), oracle.nms(b, s, thr))
 
 
+@pytest.mark.parametrize("step,thr", [(10, 0.8), (25, 0.55), (34, 0.45), (50, 0.3)])
+def test_nms_dependency_chains(step, thr):
+    """boxes marching along x with descending scores: the greedy choice is a dependency chain through every row
+    block (worst case of the one-wave scan's fixed-point resolve); n = 4097 takes the shared-memory scan."""
+    for n in (64, 200, 2000, 4096, 4097):
+        x0 = np.arange(n, dtype=np.float32) * step
+        b = np.stack([x0, np.zeros(n, np.float32), x0 + 99, np.full(n, 49, np.float32)], 1)
+        sc = np.linspace(1.0, 0.1, n).astype(np.float32)
+        ref = oracle.nms(b, sc, thr)
+        assert 1 < len(ref) < n
+        keep = _C().nms(_t(b), _t(sc), thr).cpu().numpy()
+        assert np.array_equal(keep, ref), (n, step, thr)
+
+
 def test_nms_idempotent_and_sorted_full_size():
     b, s = synth.nms_boxes(2000, seed=8)
     keep = _nms(b, s, 0.7)
