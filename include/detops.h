@@ -227,6 +227,15 @@ int detops_sigmoid_focal_loss_forward_partial_sums_f32(const float* logits, cons
                                                        int C, float gamma, float alpha,
                                                        detops_stream_t stream);
 
+/* Two-stage, atomic-free form of _forward_sum: stage 1 leaves one sum per workgroup in `workspace`
+ * (`detops_sigmoid_focal_loss_sum_workspace_bytes()` bytes, need not be initialised), stage 2 adds them in a fixed
+ * order and OVERWRITES loss_sum[0] — no zero-fill launch, no host-side reduction, bit-reproducible run to run. */
+size_t detops_sigmoid_focal_loss_sum_workspace_bytes(void);
+int detops_sigmoid_focal_loss_forward_sum_ws_f32(const float* logits, const int32_t* targets,
+                                                 float* losses, float* loss_sum, int R, int C,
+                                                 float gamma, float alpha, void* workspace,
+                                                 size_t workspace_bytes, detops_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Deformable convolution building blocks — the kernels behind _C.deform_conv_forward,
  * _backward_input, _backward_parameters, _C.modulated_deform_conv_forward/_backward

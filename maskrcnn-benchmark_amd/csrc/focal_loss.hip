@@ -22,8 +22,9 @@ namespace {
 constexpr int kBlock = 256;
 constexpr float kLogFltMin = -87.33654475f;  // logf(FLT_MIN)
 
+template <bool G2>
 __device__ __forceinline__ float pow_gamma(float v, float gamma) {
-  if (gamma == 2.f) return v * v;
+  if (G2 || gamma == 2.f) return v * v;
   if (gamma == 1.f) return v;
   if (gamma == 0.f) return 1.f;
   return powf(v, gamma);
@@ -33,41 +34,63 @@ struct Terms {
   float p, q, logp, nsp;  // sigmoid, 1-sigmoid, log p (clamped), -max(x,0) - L = log(1-p)
 };
 
+// Transcendentals: the hardware's v_exp_f32 / v_log_f32 (base 2, ~1 ulp) with the base change folded into one
+// multiply each.  e = exp(-|x|) <= 1 and L = log(1 + e) <= log 2, so the absolute error of every term stays
+// below 2e-7 — the kernels are VALU-bound on this math, not HBM-bound, when they do not also write [R, C]
+// (rocprofv3: the sum-forward read 129 MB in 51 us with the libm-accurate expf / logf, ~75 instructions / element).
+__device__ __forceinline__ float fast_exp(float x) {
+#ifdef DETOPS_CPU_EMU
+  return expf(x);
+#else
+  return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#endif
+}
+__device__ __forceinline__ float fast_log(float x) {   // x in [1, 2]
+#ifdef DETOPS_CPU_EMU
+  return logf(x);
+#else
+  return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
+#endif
+}
+
 __device__ __forceinline__ Terms terms(float x) {
   Terms t;
-  const float e = expf(-fabsf(x));
-  const float L = logf(1.f + e);
+  const float e = fast_exp(-fabsf(x));
+  const float L = fast_log(1.f + e);
   const float inv = __builtin_amdgcn_rcpf(1.f + e);
   const float ei = e * inv;
   const bool pos = x >= 0.f;
   t.p = pos ? inv : ei;
   t.q = pos ? ei : inv;
-  t.logp = fmaxf(fminf(x, 0.f) - L, kLogFltMin);
-  t.nsp = -fmaxf(x, 0.f) - L;
+  t.nsp = -(pos ? x : 0.f) - L;                 // -max(x,0) - L
+  t.logp = fmaxf(x + t.nsp, kLogFltMin);        // min(x,0) - L = x - max(x,0) - L
   return t;
 }
 
+template <bool G2>
 __device__ __forceinline__ float fwd_elem(float x, int t, int d, float gamma, float alpha) {
   const float c1 = (t == d + 1) ? 1.f : 0.f;
   const float c2 = (t >= 0 && t != d + 1) ? 1.f : 0.f;
   const Terms k = terms(x);
-  const float term1 = pow_gamma(k.q, gamma) * k.logp;
-  const float term2 = pow_gamma(k.p, gamma) * k.nsp;
+  const float term1 = pow_gamma<G2>(k.q, gamma) * k.logp;
+  const float term2 = pow_gamma<G2>(k.p, gamma) * k.nsp;
   return -c1 * term1 * alpha - c2 * term2 * (1.f - alpha);
 }
 
+template <bool G2>
 __device__ __forceinline__ float bwd_elem(float x, int t, int d, float gamma, float alpha, float dl) {
   const float c1 = (t == d + 1) ? 1.f : 0.f;
   const float c2 = (t >= 0 && t != d + 1) ? 1.f : 0.f;
   const Terms k = terms(x);
-  const float term1 = pow_gamma(k.q, gamma) * (k.q - k.p * gamma * k.logp);
-  const float term2 = pow_gamma(k.p, gamma) * (k.nsp * k.q * gamma - k.p);
+  const float term1 = pow_gamma<G2>(k.q, gamma) * (k.q - k.p * gamma * k.logp);
+  const float term2 = pow_gamma<G2>(k.p, gamma) * (k.nsp * k.q * gamma - k.p);
   return (-c1 * term1 * alpha - c2 * term2 * (1.f - alpha)) * dl;
 }
 
-// MODE 0: forward, 1: backward, 2: forward + sum (losses may be null),
-//      3: backward with ONE upstream gradient for all elements (dloss points to a device scalar)
-template <int MODE, bool VEC4>
+// MODE 0: forward, 1: backward, 2: forward + sum (losses may be null; atomics into `nslots` words),
+//      3: backward with ONE upstream gradient for all elements (dloss points to a device scalar),
+//      4: forward + sum, stage 1 of the two-stage form: sum_out[blockIdx.x] = this workgroup's sum (no atomics)
+template <int MODE, bool VEC4, bool G2>
 __global__ void __launch_bounds__(kBlock)
 focal_kernel(const float* __restrict__ logits, const int32_t* __restrict__ targets,
              const float* __restrict__ dloss, float* __restrict__ out, float* __restrict__ sum_out,
@@ -78,31 +101,37 @@ focal_kernel(const float* __restrict__ logits, const int32_t* __restrict__ targe
   if (VEC4) {
     const int64_t total4 = total >> 2;
     const int C4 = C >> 2;
-    for (int64_t v = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; v < total4; v += stride) {
-      const int n = static_cast<int>(v / C4);
-      const int d = static_cast<int>(v - static_cast<int64_t>(n) * C4) << 2;
+    // (row, column group) advanced incrementally: the grid stride is a fixed (rows, groups) step — a 64-bit
+    // division per float4 was a fifth of the instruction stream
+    int64_t v = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    int n = static_cast<int>(v / C4);
+    int d4 = static_cast<int>(v - static_cast<int64_t>(n) * C4);
+    const int sn = static_cast<int>(stride / C4), sd = static_cast<int>(stride - static_cast<int64_t>(sn) * C4);
+    for (; v < total4; v += stride, n += sn, d4 += sd) {
+      if (d4 >= C4) { d4 -= C4; ++n; }
+      const int d = d4 << 2;
       const int t = targets[n];
       const float4 x = reinterpret_cast<const float4*>(logits)[v];
       float4 r;
       if (MODE == 3) {
-        r.x = bwd_elem(x.x, t, d, gamma, alpha, gscalar);
-        r.y = bwd_elem(x.y, t, d + 1, gamma, alpha, gscalar);
-        r.z = bwd_elem(x.z, t, d + 2, gamma, alpha, gscalar);
-        r.w = bwd_elem(x.w, t, d + 3, gamma, alpha, gscalar);
+        r.x = bwd_elem<G2>(x.x, t, d, gamma, alpha, gscalar);
+        r.y = bwd_elem<G2>(x.y, t, d + 1, gamma, alpha, gscalar);
+        r.z = bwd_elem<G2>(x.z, t, d + 2, gamma, alpha, gscalar);
+        r.w = bwd_elem<G2>(x.w, t, d + 3, gamma, alpha, gscalar);
       } else if (MODE == 1) {
         const float4 g = reinterpret_cast<const float4*>(dloss)[v];
-        r.x = bwd_elem(x.x, t, d, gamma, alpha, g.x);
-        r.y = bwd_elem(x.y, t, d + 1, gamma, alpha, g.y);
-        r.z = bwd_elem(x.z, t, d + 2, gamma, alpha, g.z);
-        r.w = bwd_elem(x.w, t, d + 3, gamma, alpha, g.w);
+        r.x = bwd_elem<G2>(x.x, t, d, gamma, alpha, g.x);
+        r.y = bwd_elem<G2>(x.y, t, d + 1, gamma, alpha, g.y);
+        r.z = bwd_elem<G2>(x.z, t, d + 2, gamma, alpha, g.z);
+        r.w = bwd_elem<G2>(x.w, t, d + 3, gamma, alpha, g.w);
       } else {
-        r.x = fwd_elem(x.x, t, d, gamma, alpha);
-        r.y = fwd_elem(x.y, t, d + 1, gamma, alpha);
-        r.z = fwd_elem(x.z, t, d + 2, gamma, alpha);
-        r.w = fwd_elem(x.w, t, d + 3, gamma, alpha);
-        if (MODE == 2) lsum += (r.x + r.y) + (r.z + r.w);
+        r.x = fwd_elem<G2>(x.x, t, d, gamma, alpha);
+        r.y = fwd_elem<G2>(x.y, t, d + 1, gamma, alpha);
+        r.z = fwd_elem<G2>(x.z, t, d + 2, gamma, alpha);
+        r.w = fwd_elem<G2>(x.w, t, d + 3, gamma, alpha);
+        if (MODE == 2 || MODE == 4) lsum += (r.x + r.y) + (r.z + r.w);
       }
-      if (MODE != 2 || out) reinterpret_cast<float4*>(out)[v] = r;
+      if ((MODE != 2 && MODE != 4) || out) reinterpret_cast<float4*>(out)[v] = r;
     }
   } else {
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += stride) {
@@ -110,14 +139,14 @@ focal_kernel(const float* __restrict__ logits, const int32_t* __restrict__ targe
       const int d = static_cast<int>(i - static_cast<int64_t>(n) * C);
       const int t = targets[n];
       float r;
-      if (MODE == 3) r = bwd_elem(logits[i], t, d, gamma, alpha, gscalar);
-      else if (MODE == 1) r = bwd_elem(logits[i], t, d, gamma, alpha, dloss[i]);
-      else r = fwd_elem(logits[i], t, d, gamma, alpha);
-      if (MODE == 2) lsum += r;
-      if (MODE != 2 || out) out[i] = r;
+      if (MODE == 3) r = bwd_elem<G2>(logits[i], t, d, gamma, alpha, gscalar);
+      else if (MODE == 1) r = bwd_elem<G2>(logits[i], t, d, gamma, alpha, dloss[i]);
+      else r = fwd_elem<G2>(logits[i], t, d, gamma, alpha);
+      if (MODE == 2 || MODE == 4) lsum += r;
+      if ((MODE != 2 && MODE != 4) || out) out[i] = r;
     }
   }
-  if (MODE == 2) {
+  if (MODE == 2 || MODE == 4) {
     __shared__ float wsum[kBlock / kWave];
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) lsum += __shfl_down(lsum, off);
@@ -128,27 +157,52 @@ focal_kernel(const float* __restrict__ logits, const int32_t* __restrict__ targe
       for (int j = 0; j < kBlock / kWave; ++j) s += wsum[j];
       // one atomic per workgroup, spread over `nslots` words: ~2000 workgroups finishing together on
       // ONE word serialise in L2 (~12 ns each = a 25 us tail on a 50 us kernel)
-      atomicAdd(sum_out + (blockIdx.x % nslots), s);
+      if (MODE == 4) sum_out[blockIdx.x] = s;
+      else atomicAdd(sum_out + (blockIdx.x % nslots), s);
     }
   }
 }
 
+// Stage 2 of the two-stage sum: one workgroup adds the per-workgroup sums in a fixed order (thread t takes
+// partial[t], partial[t + 256], ...; then a fixed shuffle tree) — the result is bit-reproducible run to run, which
+// the atomic form is not.
+__global__ void __launch_bounds__(kBlock)
+focal_sum_reduce_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  __shared__ float wsum[kBlock / kWave];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += kBlock) s += partial[i];
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int j = 0; j < kBlock / kWave; ++j) t += wsum[j];
+    out[0] = t;
+  }
+}
+
+constexpr int kMaxBlocks = kNumCU * 8;
+
 template <int MODE>
 int launch(const float* logits, const int32_t* targets, const float* dloss, float* out,
-           float* sum_out, int R, int C, float gamma, float alpha, hipStream_t st, int nslots = 1) {
+           float* sum_out, int R, int C, float gamma, float alpha, hipStream_t st, int nslots = 1,
+           int* blocks_out = nullptr) {
   const int64_t total = static_cast<int64_t>(R) * C;
   if (total == 0) return 0;
   const bool vec = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                    (MODE == 3 || (reinterpret_cast<uintptr_t>(dloss) & 15) == 0);
   const int64_t work = vec ? (total >> 2) : total;
-  const int blocks = static_cast<int>(std::min<int64_t>(ceil_div64(work, kBlock), kNumCU * 8));
-  if (vec)
-    hipLaunchKernelGGL((focal_kernel<MODE, true>), dim3(blocks), dim3(kBlock), 0, st, logits, targets,
-                       dloss, out, sum_out, total, C, gamma, alpha, nslots);
-  else
-    hipLaunchKernelGGL((focal_kernel<MODE, false>), dim3(blocks), dim3(kBlock), 0, st, logits,
-                       targets, dloss, out, sum_out, total, C, gamma, alpha, nslots);
+  const int blocks = static_cast<int>(std::min<int64_t>(ceil_div64(work, kBlock), kMaxBlocks));
+  if (blocks_out) *blocks_out = blocks;
+#define FOCAL_LAUNCH(VEC_, G2_)                                                                             \
+  hipLaunchKernelGGL((focal_kernel<MODE, VEC_, G2_>), dim3(blocks), dim3(kBlock), 0, st, logits, targets, dloss, \
+                     out, sum_out, total, C, gamma, alpha, nslots)
+  if (vec && gamma == 2.f) FOCAL_LAUNCH(true, true);      // the configured value (RETINANET.LOSS_GAMMA): no powf code
+  else if (vec) FOCAL_LAUNCH(true, false);
+  else FOCAL_LAUNCH(false, false);
+#undef FOCAL_LAUNCH
   return launch_status();
 }
 
@@ -209,4 +263,26 @@ DETOPS_API int detops_sigmoid_focal_loss_backward_scalar_f32(const float* logits
   if (!logits || !targets || !d_loss_scalar || !d_logits) return DETOPS_EINVAL;
   return launch<3>(logits, targets, d_loss_scalar, d_logits, nullptr, R, C, gamma, alpha,
                    as_stream(stream));
+}
+
+DETOPS_API size_t detops_sigmoid_focal_loss_sum_workspace_bytes(void) { return sizeof(float) * kMaxBlocks; }
+
+DETOPS_API int detops_sigmoid_focal_loss_forward_sum_ws_f32(const float* logits, const int32_t* targets,
+                                                            float* losses, float* loss_sum, int R, int C,
+                                                            float gamma, float alpha, void* workspace,
+                                                            size_t workspace_bytes, detops_stream_t stream) {
+  if (R < 0 || C < 0 || !loss_sum) return DETOPS_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (static_cast<int64_t>(R) * C == 0) {
+    DETOPS_HIP_TRY(hipMemsetAsync(loss_sum, 0, sizeof(float), st));
+    return 0;
+  }
+  if (!logits || !targets) return DETOPS_EINVAL;
+  if (!workspace || workspace_bytes < detops_sigmoid_focal_loss_sum_workspace_bytes()) return DETOPS_EWORKSPACE;
+  float* partial = static_cast<float*>(workspace);
+  int blocks = 0;
+  const int rc = launch<4>(logits, targets, nullptr, losses, partial, R, C, gamma, alpha, st, 1, &blocks);
+  if (rc) return rc;
+  hipLaunchKernelGGL(focal_sum_reduce_kernel, dim3(1), dim3(kBlock), 0, st, partial, blocks, loss_sum);
+  return launch_status();
 }

@@ -441,18 +441,18 @@ def sigmoid_focalloss_backward(logits, targets, d_losses, num_classes, gamma, al
     return d_logits
 
 
-_FOCAL_SUM_SLOTS = 64  # workgroup partial sums are spread over this many words (L2 atomic fan-in)
-
-
 def sigmoid_focalloss_forward_sum(logits, targets, num_classes, gamma, alpha):
-    """Extension: sum(losses) without materialising [R,C] (what SigmoidFocalLoss.forward needs)."""
+    """Extension: sum(losses) without materialising [R,C] (what SigmoidFocalLoss.forward needs).  Two launches
+    (per-workgroup sums, then one fixed-order reduction) and nothing else: no zero-fill, no torch reduction."""
     logits, targets = _focal_args("sigmoid_focalloss_forward_sum", logits, targets, num_classes)
-    partial = torch.zeros((_FOCAL_SUM_SLOTS,), dtype=torch.float32, device=logits.device)
+    nbytes = int(lib.detops_sigmoid_focal_loss_sum_workspace_bytes())
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=logits.device)
+    total = torch.empty((), dtype=torch.float32, device=logits.device)
     with _on_device(logits), _timed("focal_fwd_sum[R=%d,C=%d]" % (logits.size(0), num_classes), logits):
-        check(lib.detops_sigmoid_focal_loss_forward_partial_sums_f32(
-            ptr(logits), ptr(targets), None, ptr(partial), _FOCAL_SUM_SLOTS, logits.size(0), num_classes,
-            float(gamma), float(alpha), stream_of(logits)), "sigmoid_focalloss_forward_sum")
-    return partial.sum()
+        check(lib.detops_sigmoid_focal_loss_forward_sum_ws_f32(
+            ptr(logits), ptr(targets), None, ptr(total), logits.size(0), num_classes, float(gamma), float(alpha),
+            ptr(ws), nbytes, stream_of(logits)), "sigmoid_focalloss_forward_sum")
+    return total
 
 
 def sigmoid_focalloss_backward_scalar(logits, targets, d_loss, num_classes, gamma, alpha):

@@ -54,6 +54,9 @@ SIGNATURES = {
         c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     "detops_sigmoid_focal_loss_forward_partial_sums_f32": (
         c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
+    "detops_sigmoid_focal_loss_sum_workspace_bytes": (c_size_t, []),
+    "detops_sigmoid_focal_loss_forward_sum_ws_f32": (
+        c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
     "detops_frozen_bn_act_forward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
     "detops_frozen_bn_act_backward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
     "detops_deformable_im2col": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),

@@ -44,6 +44,9 @@ SIGNATURES = {
     "detops_sigmoid_focal_loss_backward_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     "detops_sigmoid_focal_loss_backward_scalar_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     "detops_sigmoid_focal_loss_forward_sum_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_sigmoid_focal_loss_sum_workspace_bytes": (ctypes.c_size_t, []),
+    "detops_sigmoid_focal_loss_forward_sum_ws_f32": (
+        c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, ctypes.c_size_t, _P]),
     "detops_sigmoid_focal_loss_forward_partial_sums_f32": (
         c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
     "detops_frozen_bn_act_forward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
@@ -336,7 +339,19 @@ def focal_forward(logits, targets, gamma, alpha, with_sum=False):
                                                                       gamma, alpha, None)
         assert rc == 0, rc
         assert abs(float(part.sum()) - float(tot[0])) <= 1e-5 * max(1.0, abs(float(tot[0])))
-        return out, float(tot[0])
+        # two-stage form: poisoned workspace and result word, must be overwritten; bit-reproducible
+        nbytes = lib().detops_sigmoid_focal_loss_sum_workspace_bytes()
+        two = []
+        for fill in (0xAB, 0x7F):
+            ws = np.full((nbytes,), fill, np.uint8)
+            t2 = np.full((1,), np.nan, np.float32)
+            rc = lib().detops_sigmoid_focal_loss_forward_sum_ws_f32(_p(logits), _p(targets), None, _p(t2), R, C, gamma,
+                                                                    alpha, _p(ws), nbytes, None)
+            assert rc == 0, rc
+            two.append(t2[0])
+        assert two[0] == two[1]
+        assert abs(float(two[0]) - float(tot[0])) <= 1e-5 * max(1.0, abs(float(tot[0])))
+        return out, float(two[0])
     rc = lib().detops_sigmoid_focal_loss_forward_f32(_p(logits), _p(targets), _p(out), R, C, gamma, alpha, None)
     assert rc == 0, rc
     return out
