@@ -396,6 +396,20 @@ int detops_frozen_bn_act_backward(const void* grad_y, const void* y, const float
                                   void* grad_x, void* grad_residual, int dtype, int N, int C,
                                   int HW, int relu, detops_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------
+ * CPU branch — HOST pointers, no stream.  The reference `_C` serves exactly two operators for CPU tensors
+ * (csrc/nms.h:19-27 -> csrc/cpu/nms_cpu.cpp, csrc/ROIAlign.h:19-24 -> csrc/cpu/ROIAlign_cpu.cpp) and raises
+ * "Not implemented on the CPU" for the rest; so does this library.  These are NOT a fallback of the device entry
+ * points (which never call them and fail when there is no GPU); they exist so that a caller holding CPU tensors
+ * gets the reference's behaviour from the drop-in.
+ *   detops_nms_cpu_f32: keep[n] receives the kept ORIGINAL indices in ascending order, *num_keep their count.
+ * ---------------------------------------------------------------------------------------- */
+int detops_nms_cpu_f32(const float* boxes, const float* scores, int n, float iou_threshold,
+                       int64_t* keep, int32_t* num_keep);
+int detops_roi_align_forward_cpu_f32(const float* input, const float* rois, float* output, int N, int C,
+                                     int H, int W, int K, int PH, int PW, float spatial_scale,
+                                     int sampling_ratio);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

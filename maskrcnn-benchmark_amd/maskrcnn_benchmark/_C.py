@@ -112,14 +112,21 @@ def _timed(name, t):
 def nms(dets, scores, threshold):
     """reference csrc/nms.h:10-28: dets [n,4] xyxy, scores [n] -> int64 kept indices, ascending.
     CPU semantics (IoU >= threshold suppresses; csrc/cpu/nms_cpu.cpp:60)."""
-    _need_cuda("nms", dets, scores)
     if dets.numel() == 0:  # nms.h:17-18 returns an empty CPU long tensor
         return torch.empty((0,), dtype=torch.long, device="cpu")
+    on_cpu = not dets.is_cuda and not scores.is_cuda
+    if not on_cpu:
+        _need_cuda("nms", dets, scores)
     dets = _f32c("nms", dets)
     scores = _f32c("nms", scores)
     n = dets.size(0)
     if dets.dim() != 2 or dets.size(1) != 4 or scores.numel() != n:
         raise RuntimeError("nms: expected dets [n,4] and scores [n]")
+    if on_cpu:  # the reference dispatches CPU tensors to nms_cpu (csrc/nms.h:26-27); host code of the same library
+        keep = torch.empty((n,), dtype=torch.long)
+        num = torch.zeros((1,), dtype=torch.int32)
+        check(lib.detops_nms_cpu_f32(ptr(dets), ptr(scores), n, float(threshold), ptr(keep), ptr(num)), "nms(cpu)")
+        return keep[: int(num.item())]
     keep = torch.empty((n,), dtype=torch.long, device=dets.device)
     num = torch.empty((1,), dtype=torch.int32, device=dets.device)
     ws_bytes = lib.detops_nms_workspace_bytes(n)
@@ -259,6 +266,8 @@ def mask_targets(masks, mask_index, boxes, discretization_size):
 # ------------------------------------------------------------------------------------------ ROIAlign
 def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
     """reference csrc/ROIAlign.h:11-25 -> [K,C,PH,PW]."""
+    if not input.is_cuda and not rois.is_cuda:
+        return _roi_align_forward_cpu(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio)
     _need_cuda("roi_align_forward", input, rois)
     input = _f32c("roi_align_forward", input)
     rois = _f32c("roi_align_forward", rois)
@@ -273,6 +282,22 @@ def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, s
                                                   pooled_height, pooled_width, float(spatial_scale),
                                                   int(sampling_ratio), ptr(ws), nbytes, stream_of(input)),
               "roi_align_forward")
+    return out
+
+
+def _roi_align_forward_cpu(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
+    """CPU tensors: the reference dispatches to ROIAlign_forward_cpu (csrc/ROIAlign.h:19-24); host code of the
+    same library (csrc/cpu_branch.hip).  Not a fallback of the device path: CUDA tensors never come here."""
+    input = _f32c("roi_align_forward", input)
+    rois = _f32c("roi_align_forward", rois)
+    N, C, H, W = input.shape
+    K = rois.size(0)
+    out = torch.empty((K, C, pooled_height, pooled_width), dtype=torch.float32)
+    if out.numel() == 0:
+        return out
+    check(lib.detops_roi_align_forward_cpu_f32(ptr(input), ptr(rois), ptr(out), N, C, H, W, K, pooled_height,
+                                               pooled_width, float(spatial_scale), int(sampling_ratio)),
+          "roi_align_forward(cpu)")
     return out
 
 

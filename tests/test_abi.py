@@ -76,14 +76,21 @@ def test_layers_api_names_match_reference():
 
 
 def test_no_cpu_fallback_ops_fail_loudly():
-    """The product path has no CPU implementation: CPU tensors raise instead of silently computing."""
+    """CPU tensors raise instead of silently computing — except for the two operators the reference itself serves
+    on the CPU (nms, ROIAlign_forward: tests/test_cpu_branch.py); their backward and every other operator raise,
+    and mixing devices raises."""
     from maskrcnn_benchmark import _C
     from maskrcnn_benchmark.layers import ROIAlign, SigmoidFocalLoss, deform_conv
 
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
-        _C.nms(torch.zeros(2, 4), torch.zeros(2), 0.5)
+        _C.roi_align_backward(torch.zeros(1, 2, 7, 7), torch.zeros(1, 5), 0.25, 7, 7, 1, 2, 8, 8, 2)
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
-        ROIAlign((7, 7), 0.25, 2)(torch.zeros(1, 2, 8, 8), torch.zeros(1, 5))
+        x = torch.zeros(1, 2, 8, 8, requires_grad=True)
+        ROIAlign((7, 7), 0.25, 2)(x, torch.zeros(1, 5)).sum().backward()
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        _C.nms_batched_mask(torch.zeros(2, 4), torch.zeros(2), torch.tensor([0, 2], dtype=torch.int32), 2, 0.5)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        _C.roi_pool_forward(torch.zeros(1, 2, 8, 8), torch.zeros(1, 5), 0.25, 7, 7)
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         SigmoidFocalLoss(2.0, 0.25)(torch.zeros(4, 3), torch.zeros(4, dtype=torch.int32))
     with pytest.raises(NotImplementedError):

@@ -115,8 +115,10 @@ def test_roi_align_forward_edge_cases():
         out = C.roi_align_forward(x, _t(rois), 1.0, 4, 6, sr).cpu().numpy()
         assert np.array_equal(out, ref), sr
         assert not out[0].any()
-    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
-        C.roi_align_forward(x.cpu(), _t(rois).cpu(), 1.0, 4, 6, 2)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):     # mixed devices: no silent copies
+        C.roi_align_forward(x, _t(rois).cpu(), 1.0, 4, 6, 2)
+    assert np.array_equal(C.roi_align_forward(x.cpu(), _t(rois).cpu(), 1.0, 4, 6, 2).numpy(),   # CPU branch = device
+                          C.roi_align_forward(x, _t(rois), 1.0, 4, 6, 2).cpu().numpy())
 
 
 # ============================================================================ ROIAlign backward
