@@ -70,6 +70,15 @@ static inline int launch_status() { return static_cast<int>(hipGetLastError()); 
 #define DETOPS_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 #endif
 
+// Ordering point for LDS data handed from some lanes of a wave to other lanes of the SAME wave (no other wave
+// touches the region): the hardware executes a wave's LDS operations in order, so only the compiler must be kept
+// from moving the reads above the writes.  The emulation runs lanes as fibers and needs a real rendezvous.
+#ifdef DETOPS_CPU_EMU
+#define DETOPS_WAVE_SYNC() ((void)__ballot(1))
+#else
+#define DETOPS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
+
 constexpr int kWave = 64;        // CDNA4 wavefront
 constexpr int kNumCU = 256;      // MI355X
 constexpr int kNumXCD = 8;

@@ -1555,10 +1555,20 @@ roi_align_bwd_binned_kernel(Levels L, BinPlan P, BinWs ws, const float* __restri
   const int PXS = PPW + 1;                                 // AX rows in LDS: odd stride, 32 columns -> 32 banks
   const int slots = P.batch * bins;                        // (hit, bin) slots per float4 channel group
 
+  // Separable walk (7 bin columns): grad_in[y, x] += sum_b AX[x, b] * (sum_a AY[y, a] * g[a, b]).  Pass 1: lane =
+  // (row of the wave, bin column, channel group) builds T[row][bin column] = sum_a AY * g for its channels and parks
+  // it in a per-wave LDS strip; pass 2: lane = pixel sums <= 3 strip entries.  3 + 3 multiply-adds per pixel and
+  // channel where the direct form has up to 9, and a third of its LDS reads.
+  constexpr bool kSep = (PW_ == 7);   // measured: box head 117 -> 110 us; 14 columns (16-wide strip, one hit per batch) 85 -> 88 us, not used
+  constexpr int PWP = (PW_ <= 8) ? 8 : 16;                 // strip columns
+  constexpr int LPC = 32 / PWP;                            // pass-1 lanes side by side on one (row, bin column)
+  constexpr int CPL = (CG + LPC - 1) / LPC;                // channel groups per pass-1 lane
+
   DETOPS_DYNAMIC_LDS(float, g_lds);
   float4* gs4 = reinterpret_cast<float4*>(g_lds);          // [CG][slots] float4
   float* ayt = g_lds + slots * CT;                         // [batch][kGTH][PPH]
   float* axt = ayt + P.batch * kGTH * PPH;                 // [batch][kGTW][PXS]
+  float4* tb4 = reinterpret_cast<float4*>(axt + P.batch * kGTW * PXS);   // [wave][2][PWP][CG] float4 (kSep only)
   __shared__ int4 s_ent[kBinRound];
 
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -1649,7 +1659,48 @@ roi_align_bwd_binned_kernel(Levels L, BinPlan P, BinWs ws, const float* __restri
         while (__ballot(na < ny) != 0ull) ++na;
         while (__ballot(nb_ < nx) != 0ull) ++nb_;
         if (lane == 0) DETOPS_STAT("bwdb.bodies", na * nb_);
-        if (na <= 3 && nb_ <= 3) {
+        if (kSep && na <= 3 && nb_ <= 3 && !(P.debug & 32)) {
+          // ---- pass 1
+          const int r1 = lane >> 5, pw1 = (lane & 31) / LPC, cgl = (lane & 31) % LPC;
+          const float4 hy1 = *reinterpret_cast<const float4*>(ayt + (j * kGTH + 2 * wave + r1) * PPH);
+          const int ylo1 = __float_as_int(hy1.x) & 0xffff;
+          float4 t[CPL];
+#pragma unroll
+          for (int k = 0; k < CPL; ++k) t[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4* gc = gj + min(pw1, PW - 1) + cgl * slots;
+          for (int a = 0; a < na; ++a) {   // wave-uniform trip count
+            const float wya = (a == 0) ? hy1.y : (a == 1) ? hy1.z : hy1.w;   // zero beyond the row's own range
+            const float4* gr = gc + min(ylo1 + a, PH - 1) * PW;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+              if (cgl + k * LPC < CG) {
+                const float4 g4 = gr[k * LPC * slots];
+                t[k].x = fmaf(wya, g4.x, t[k].x); t[k].y = fmaf(wya, g4.y, t[k].y);
+                t[k].z = fmaf(wya, g4.z, t[k].z); t[k].w = fmaf(wya, g4.w, t[k].w);
+              }
+            }
+          }
+          float4* tw = tb4 + wave * (2 * PWP * CG);
+          DETOPS_WAVE_SYNC();              // the previous hit's pass-2 reads of the strip are done
+#pragma unroll
+          for (int k = 0; k < CPL; ++k)
+            if (cgl + k * LPC < CG) tw[(r1 * PWP + pw1) * CG + cgl + k * LPC] = t[k];
+          DETOPS_WAVE_SYNC();
+          // ---- pass 2
+          const float4* tr = tw + (lane >> 5) * PWP * CG;
+          for (int b2 = 0; b2 < nb_; ++b2) {   // wave-uniform trip count
+            const float wxb = (b2 == 0) ? hx1 : (b2 == 1) ? hx2 : hx3;       // zero beyond the column's own range
+            const float4* tp = tr + min(xlo + b2, PW - 1) * CG;
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) {
+              const float4 t4 = tp[cg];
+              acc[4 * cg + 0] = fmaf(wxb, t4.x, acc[4 * cg + 0]);
+              acc[4 * cg + 1] = fmaf(wxb, t4.y, acc[4 * cg + 1]);
+              acc[4 * cg + 2] = fmaf(wxb, t4.z, acc[4 * cg + 2]);
+              acc[4 * cg + 3] = fmaf(wxb, t4.w, acc[4 * cg + 3]);
+            }
+          }
+        } else if (na <= 3 && nb_ <= 3) {
           const float wx[3] = {hx1, hx2, hx3};
           for (int a = 0; a < na; ++a) {   // wave-uniform trip count; one LDS round trip per bin row
             const float wya = (a == 0) ? hy.y : (a == 1) ? hy.z : hy.w;   // zero beyond the lane's own range
@@ -1711,6 +1762,12 @@ roi_align_bwd_binned_kernel(Levels L, BinPlan P, BinWs ws, const float* __restri
   }
 }
 
+// per-wave LDS strips of the separable walk (7 bin columns): [waves][2 rows][8 | 16 columns][CT] floats
+inline int bin_strip_floats(int PW, int CT) {
+  if (PW != 7) return 0;
+  return (kBlock / kWave) * 2 * (PW <= 8 ? 8 : 16) * CT;
+}
+
 // Plan + workspace carve of the binned backward.  Returns false when the shape is outside its plan
 // (bins > 256, coefficient rows beyond the prefetch registers, maps wider than the packed fields).
 struct BinLayout { size_t off_counts, off_lists, off_tabs, total; };
@@ -1725,6 +1782,10 @@ bool bin_plan(const Levels& L, int N, int C, int K, int PH, int PW, int CT, BinP
   if (const char* e = getenv("DETOPS_ROIALIGN_BWD_BATCH")) P.batch = max(1, min(P.batch, atoi(e)));   // tuning knob
   // LDS plan: gradients of a batch (16 x bins floats per hit at CT = 16) + its adjoint rows, <= 48 KiB
   while (P.batch > 1 && static_cast<int64_t>(P.batch) * (bins * 32 + kGTH * P.PPH + kGTW * (P.PPW + 1)) * 4 > 48 * 1024) --P.batch;
+  // shapes with the separable walk carry a per-wave strip (bin_strip_floats); keep 6 workgroups per CU (<= 26 KiB)
+  while (P.batch > 2 && bin_strip_floats(PW, CT) > 0 &&
+         (static_cast<int64_t>(P.batch) * (bins * CT + kGTH * P.PPH + kGTW * (P.PPW + 1)) + bin_strip_floats(PW, CT)) * 4 > 25 * 1024)
+    --P.batch;
   if (static_cast<int64_t>(bins * 32 + kGTH * P.PPH + kGTW * (P.PPW + 1)) * 4 > 60 * 1024) return false;
   P.cap = K;
   P.chunks = static_cast<int>(ceil_div64(C, CT));
@@ -1777,7 +1838,8 @@ int run_backward_binned(const Levels& L, const float* rois, const int32_t* level
   hipLaunchKernelGGL(roi_bwd_prep_kernel, dim3(static_cast<unsigned>(P.tab_blocks + ceil_div64(P.num_tiles, kPrepTiles))), dim3(kBlock), 0, st,
                      L, P, ws, rois, levels_in, K, PH, PW, sr);
   const size_t lds = sizeof(float) * (static_cast<size_t>(P.batch) * PH * PW * CT +
-                                      static_cast<size_t>(P.batch) * (kGTH * P.PPH + kGTW * (P.PPW + 1)));
+                                      static_cast<size_t>(P.batch) * (kGTH * P.PPH + kGTW * (P.PPW + 1)) +
+                                      ((PH == PW) ? bin_strip_floats(PW, CT) : 0));
   const dim3 grid(static_cast<unsigned>(static_cast<int64_t>(P.num_tiles) * P.chunks));
 #define BINNED_LAUNCH(PH_, PW_, CT_)                                                                              \
   hipLaunchKernelGGL((roi_align_bwd_binned_kernel<PH_, PW_, CT_>), grid, dim3(kBlock), lds, st, L, P, ws, gout, \

@@ -382,7 +382,7 @@ def test_emu_roi_align_backward_binned_matches_scan_kernel_bitwise_and_handles_c
     monkeypatch.setenv("DETOPS_ROIALIGN_BWD_GROUPS", "1")   # no ROI-list split: one sequential sum per pixel
     scan = emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2)
     monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "binned")
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_WGS", "2")      # two persistent workgroups walk all tiles
+    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_DEBUG", "32")   # direct walk: the scan kernel's summation order
     emu.stats(reset=True)
     binned = emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2)
     st = emu.stats()
@@ -390,6 +390,11 @@ def test_emu_roi_align_backward_binned_matches_scan_kernel_bitwise_and_handles_c
     assert np.array_equal(scan, binned)
     ref = oracle.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2, acc64=True)
     assert np.abs(binned - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    monkeypatch.delenv("DETOPS_ROIALIGN_BWD_DEBUG")         # default: the separable two-pass walk (7 bin columns)
+    sep = emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2)
+    assert not np.array_equal(sep, binned), "expected the two-pass walk to round differently from the direct one"
+    assert np.abs(sep - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(sep, emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2))   # run-to-run identical
     # multi-level entry, one level without any ROI
     shapes = [(2, 8, 50, 84), (2, 8, 25, 42), (2, 8, 13, 21), (2, 8, 7, 11)]
     scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
