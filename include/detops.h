@@ -396,6 +396,29 @@ int detops_frozen_bn_act_backward(const void* grad_y, const void* y, const float
                                   void* grad_x, void* grad_residual, int dtype, int N, int C,
                                   int HW, int relu, detops_stream_t stream);
 
+/* RPN loss in one pass over the head outputs (reference modeling/rpn/loss.py:92-127 with
+ * modeling/box_coder.py:27-51 and modeling/rpn/utils.py:9-45): objectness = BCE-with-logits over the sampled
+ * anchors, box = smooth-L1(beta) against BoxCoder.encode(matched gt, anchor) over the sampled positives, both
+ * divided by max(#sampled, 1).
+ *   objectness[l] [N, A, H_l, W_l], box_regression[l] [N, 4A, H_l, W_l]: the per-level head outputs as written by
+ *   the heads (HOST arrays of device pointers); anchors [T, 4], T = A * sum_l H_l W_l, ordered level, y, x, a;
+ *   matched_idxs [N, T] (Matcher output), pos_mask / neg_mask [N, T] (sampler output), gt_boxes [N, M, 4].
+ *   grad_*[l]: same shapes as the inputs, OVERWRITTEN with d(sum of the per-anchor losses) / d(input);
+ *   losses3 (device, 3 floats) = {objectness loss, box loss, 1 / max(#sampled, 1)}.
+ * detops_rpn_loss_backward_f32 scales the stored gradients in place by upstream * losses3[2] (device scalars). */
+size_t detops_rpn_loss_workspace_bytes(void);
+int detops_rpn_loss_f32(const float* const* objectness_host, const float* const* box_regression_host,
+                        const int* H_host, const int* W_host, int num_levels, int anchors_per_location,
+                        const float* anchors, const int64_t* matched_idxs, const uint8_t* pos_mask,
+                        const uint8_t* neg_mask, const float* gt_boxes, int N, int M, int T, float beta,
+                        const float* weights4_host, float* const* grad_objectness_host,
+                        float* const* grad_box_regression_host, float* losses3, void* workspace,
+                        size_t workspace_bytes, detops_stream_t stream);
+int detops_rpn_loss_backward_f32(float* const* grad_objectness_host, float* const* grad_box_regression_host,
+                                 const int* H_host, const int* W_host, int num_levels, int anchors_per_location,
+                                 int N, int T, const float* upstream_objectness, const float* upstream_box,
+                                 const float* inv_count, detops_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------
  * CPU branch — HOST pointers, no stream.  The reference `_C` serves exactly two operators for CPU tensors
  * (csrc/nms.h:19-27 -> csrc/cpu/nms_cpu.cpp, csrc/ROIAlign.h:19-24 -> csrc/cpu/ROIAlign_cpu.cpp) and raises

@@ -335,6 +335,148 @@ int run_sampler(const void* labels, int N, int n, int B, int max_pos, unsigned l
   return launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// RPN loss (reference modeling/rpn/loss.py:92-127): objectness = BCE-with-logits over the sampled anchors,
+// box = smooth-L1 (beta 1/9) between the regression output and BoxCoder.encode(matched gt, anchor) over the
+// sampled positives, both divided by the number of sampled anchors.  The reference builds both from ~120
+// elementwise / indexing launches over [N, 268,569] anchors (permute + cat of the per-level head outputs,
+// encode, masks, two reductions, and the autograd mirror of each).  Here ONE launch reads the head outputs in
+// the layout the heads wrote them ([N, A, H, W] / [N, 4A, H, W] per level), evaluates both losses per anchor,
+// and writes d(loss sum)/d(logit) in the same layout; a second launch finishes the two fixed-order sums.  The
+// backward is one scaling launch.  Anchor t = level offset + (y * W + x) * A + a, i.e. the order of
+// AnchorGenerator.grid_anchors and of concat_box_prediction_layers (modeling/rpn/utils.py:9-45).
+// ---------------------------------------------------------------------------------------------------------
+struct RpnLevels {
+  const float* obj[DETOPS_MAX_LEVELS];
+  const float* box[DETOPS_MAX_LEVELS];
+  float* gobj[DETOPS_MAX_LEVELS];
+  float* gbox[DETOPS_MAX_LEVELS];
+  int plane[DETOPS_MAX_LEVELS];       // H * W
+  int first[DETOPS_MAX_LEVELS + 1];   // first anchor index of the level; first[num] = T
+  int num;
+};
+
+constexpr int kRpnMaxBlocks = 2048;
+
+__global__ void __launch_bounds__(kBlock)
+rpn_loss_kernel(RpnLevels L, int A, const float* __restrict__ anchors, const int64_t* __restrict__ matched,
+                const uint8_t* __restrict__ pos, const uint8_t* __restrict__ neg, const float* __restrict__ gt,
+                int N, int M, int T, float beta, float wx, float wy, float ww, float wh,
+                float* __restrict__ partial /* [gridDim.x][3] */) {
+#pragma clang fp contract(off)
+  float s_obj = 0.f, s_box = 0.f, s_cnt = 0.f;
+  const int64_t total = static_cast<int64_t>(N) * T;
+  const float inv_beta = 1.f / beta, half_beta = 0.5f * beta;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int n = static_cast<int>(i / T);
+    const int t = static_cast<int>(i - static_cast<int64_t>(n) * T);
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < DETOPS_MAX_LEVELS; ++k)
+      if (k < L.num && t >= L.first[k]) l = k;
+    const float* obj = L.obj[0]; const float* box = L.box[0]; float* gobj = L.gobj[0]; float* gbox = L.gbox[0];
+    int plane = L.plane[0], first = L.first[0];
+#pragma unroll
+    for (int k = 1; k < DETOPS_MAX_LEVELS; ++k)
+      if (k == l) { obj = L.obj[k]; box = L.box[k]; gobj = L.gobj[k]; gbox = L.gbox[k]; plane = L.plane[k]; first = L.first[k]; }
+    const int rem = t - first;
+    const int loc = rem / A, a = rem - loc * A;
+    const size_t o1 = (static_cast<size_t>(n) * A + a) * plane + loc;
+    const size_t o4 = (static_cast<size_t>(n) * A + a) * 4 * plane + loc;
+    const bool p = pos[i] != 0, q = neg[i] != 0;
+    // objectness: binary_cross_entropy_with_logits(x, z), z = 1 for sampled positives, 0 for sampled negatives
+    float g1 = 0.f;
+    if (p || q) {
+      const float x = obj[o1], z = p ? 1.f : 0.f;
+      const float e = expf(-fabsf(x));
+      s_obj += fmaxf(x, 0.f) - x * z + log1pf(e);
+      const float sig = (x >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e);
+      g1 = sig - z;
+      s_cnt += 1.f;
+    }
+    gobj[o1] = g1;
+    float g4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p) {
+      const int64_t m = matched[i];
+      const float4 gb = reinterpret_cast<const float4*>(gt)[static_cast<size_t>(n) * M + (m < 0 ? 0 : m)];
+      const float4 an = reinterpret_cast<const float4*>(anchors)[t];
+      // BoxCoder.encode (modeling/box_coder.py:27-51), "+1" widths
+      const float ew = an.z - an.x + 1.f, eh = an.w - an.y + 1.f;
+      const float ex = an.x + 0.5f * ew, ey = an.y + 0.5f * eh;
+      const float gw = gb.z - gb.x + 1.f, gh = gb.w - gb.y + 1.f;
+      const float gx = gb.x + 0.5f * gw, gy = gb.y + 0.5f * gh;
+      const float tg[4] = {wx * (gx - ex) / ew, wy * (gy - ey) / eh, ww * logf(gw / ew), wh * logf(gh / eh)};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = box[o4 + static_cast<size_t>(k) * plane] - tg[k];
+        const float ad = fabsf(d);
+        if (ad < beta) { s_box += 0.5f * ad * ad * inv_beta; g4[k] = d * inv_beta; }
+        else { s_box += ad - half_beta; g4[k] = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f); }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gbox[o4 + static_cast<size_t>(k) * plane] = g4[k];
+  }
+  __shared__ float red[3][kBlock / kWave];
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    s_obj += __shfl_down(s_obj, off); s_box += __shfl_down(s_box, off); s_cnt += __shfl_down(s_cnt, off);
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    red[0][threadIdx.x / kWave] = s_obj; red[1][threadIdx.x / kWave] = s_box; red[2][threadIdx.x / kWave] = s_cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float v = 0.f;
+    for (int j = 0; j < kBlock / kWave; ++j) v += red[threadIdx.x][j];
+    partial[blockIdx.x * 3 + threadIdx.x] = v;
+  }
+}
+
+// fixed-order sum of the per-workgroup partials -> {objectness loss, box loss, 1 / max(#sampled, 1)}
+__global__ void __launch_bounds__(kBlock)
+rpn_loss_finish_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ out3) {
+  __shared__ float red[3][kBlock / kWave];
+  float v[3] = {0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < nblocks; i += kBlock) {
+    v[0] += partial[i * 3]; v[1] += partial[i * 3 + 1]; v[2] += partial[i * 3 + 2];
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    v[0] += __shfl_down(v[0], off); v[1] += __shfl_down(v[1], off); v[2] += __shfl_down(v[2], off);
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0)
+    for (int k = 0; k < 3; ++k) red[k][threadIdx.x / kWave] = v[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[3] = {0.f, 0.f, 0.f};
+    for (int j = 0; j < kBlock / kWave; ++j)
+      for (int k = 0; k < 3; ++k) t[k] += red[k][j];
+    const float inv = 1.f / fmaxf(t[2], 1.f);
+    out3[0] = t[0] * inv;
+    out3[1] = t[1] * inv;
+    out3[2] = inv;
+  }
+}
+
+// backward: grad *= upstream gradient of the loss * 1 / #sampled, in place, every level in one launch
+__global__ void __launch_bounds__(kBlock)
+rpn_loss_scale_kernel(RpnLevels L, int A, int N, const float* __restrict__ up_obj, const float* __restrict__ up_box,
+                      const float* __restrict__ inv_count) {
+  const float so = up_obj[0] * inv_count[0], sb = up_box[0] * inv_count[0];
+  for (int l = 0; l < L.num; ++l) {
+    const int64_t n1 = static_cast<int64_t>(N) * A * L.plane[l];
+    float* go = L.gobj[l];
+    float* gb = L.gbox[l];
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < 5 * n1;
+         i += static_cast<int64_t>(gridDim.x) * kBlock) {
+      if (i < n1) go[i] *= so; else gb[i - n1] *= sb;
+    }
+  }
+}
+
 }  // namespace
 
 DETOPS_API size_t detops_match_boxes_workspace_bytes(int N, int M) {
@@ -410,5 +552,67 @@ DETOPS_API int detops_mask_targets(const void* masks, int mask_dtype, const int6
                        mask_index, boxes, G, H, W, M, out);
   else
     return DETOPS_EUNSUPPORTED;
+  return launch_status();
+}
+
+static int rpn_levels(RpnLevels& L, const float* const* obj, const float* const* box, float* const* gobj,
+                      float* const* gbox, const int* H, const int* W, int num_levels, int A, int T, bool need_inputs) {
+  if (num_levels < 1 || num_levels > DETOPS_MAX_LEVELS || A <= 0 || !gobj || !gbox || !H || !W) return DETOPS_EINVAL;
+  if (need_inputs && (!obj || !box)) return DETOPS_EINVAL;
+  L = RpnLevels{};
+  L.num = num_levels;
+  int64_t first = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    if (H[l] <= 0 || W[l] <= 0 || !gobj[l] || !gbox[l] || (need_inputs && (!obj[l] || !box[l]))) return DETOPS_EINVAL;
+    L.obj[l] = need_inputs ? obj[l] : nullptr; L.box[l] = need_inputs ? box[l] : nullptr;
+    L.gobj[l] = gobj[l]; L.gbox[l] = gbox[l];
+    L.plane[l] = H[l] * W[l];
+    L.first[l] = static_cast<int>(first);
+    first += static_cast<int64_t>(H[l]) * W[l] * A;
+  }
+  if (first != T) return DETOPS_EINVAL;   // the anchor list must be exactly the concatenation of the level grids
+  for (int l = num_levels; l <= DETOPS_MAX_LEVELS; ++l) L.first[l] = T;
+  return 0;
+}
+
+DETOPS_API size_t detops_rpn_loss_workspace_bytes(void) { return up256(sizeof(float) * 3 * kRpnMaxBlocks); }
+
+DETOPS_API int detops_rpn_loss_f32(const float* const* objectness_host, const float* const* box_regression_host,
+                                   const int* H_host, const int* W_host, int num_levels, int anchors_per_location,
+                                   const float* anchors, const int64_t* matched_idxs, const uint8_t* pos_mask,
+                                   const uint8_t* neg_mask, const float* gt_boxes, int N, int M, int T, float beta,
+                                   const float* weights4_host, float* const* grad_objectness_host,
+                                   float* const* grad_box_regression_host, float* losses3, void* workspace,
+                                   size_t workspace_bytes, detops_stream_t stream) {
+  if (N <= 0 || M <= 0 || T <= 0 || !(beta > 0.f) || !weights4_host) return DETOPS_EINVAL;
+  if (!anchors || !matched_idxs || !pos_mask || !neg_mask || !gt_boxes || !losses3) return DETOPS_EINVAL;
+  if (!workspace || workspace_bytes < detops_rpn_loss_workspace_bytes()) return DETOPS_EWORKSPACE;
+  RpnLevels L;
+  if (const int rc = rpn_levels(L, objectness_host, box_regression_host, grad_objectness_host, grad_box_regression_host,
+                                H_host, W_host, num_levels, anchors_per_location, T, true))
+    return rc;
+  hipStream_t st = as_stream(stream);
+  const int blocks = static_cast<int>(std::min<int64_t>(ceil_div64(static_cast<int64_t>(N) * T, kBlock), kRpnMaxBlocks));
+  float* partial = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(rpn_loss_kernel, dim3(blocks), dim3(kBlock), 0, st, L, anchors_per_location, anchors, matched_idxs,
+                     pos_mask, neg_mask, gt_boxes, N, M, T, beta, weights4_host[0], weights4_host[1], weights4_host[2],
+                     weights4_host[3], partial);
+  hipLaunchKernelGGL(rpn_loss_finish_kernel, dim3(1), dim3(kBlock), 0, st, partial, blocks, losses3);
+  return launch_status();
+}
+
+DETOPS_API int detops_rpn_loss_backward_f32(float* const* grad_objectness_host, float* const* grad_box_regression_host,
+                                            const int* H_host, const int* W_host, int num_levels,
+                                            int anchors_per_location, int N, int T, const float* upstream_objectness,
+                                            const float* upstream_box, const float* inv_count,
+                                            detops_stream_t stream) {
+  if (N <= 0 || T <= 0 || !upstream_objectness || !upstream_box || !inv_count) return DETOPS_EINVAL;
+  RpnLevels L;
+  if (const int rc = rpn_levels(L, nullptr, nullptr, grad_objectness_host, grad_box_regression_host, H_host, W_host,
+                                num_levels, anchors_per_location, T, false))
+    return rc;
+  const int blocks = static_cast<int>(std::min<int64_t>(ceil_div64(static_cast<int64_t>(N) * T * 5, kBlock * 4), kRpnMaxBlocks));
+  hipLaunchKernelGGL(rpn_loss_scale_kernel, dim3(std::max(blocks, 1)), dim3(kBlock), 0, as_stream(stream), L,
+                     anchors_per_location, N, upstream_objectness, upstream_box, inv_count);
   return launch_status();
 }

@@ -182,6 +182,62 @@ def nms_batched_mask(boxes, scores, seg_offsets, max_n, threshold):
     return mask.view(torch.bool), num
 
 
+# ------------------------------------------------------------------------------------------ RPN loss
+class _RpnLoss(torch.autograd.Function):
+    """Fused RPN loss (extension; reference modeling/rpn/loss.py:92-127): one launch evaluates both losses from the
+    per-level head outputs and stores d(loss sum)/d(logit) in the same layouts; backward = one scaling launch."""
+
+    @staticmethod
+    def forward(ctx, anchors, matched, pos, neg, gt, beta, weights, A, L, *heads):
+        obj, box = list(heads[:L]), list(heads[L:])
+        N = obj[0].size(0)
+        T, M = anchors.size(0), gt.size(1)
+        gobj = [torch.empty_like(t) for t in obj]
+        gbox = [torch.empty_like(t) for t in box]
+        out3 = torch.empty((3,), dtype=torch.float32, device=anchors.device)
+        nbytes = int(lib.detops_rpn_loss_workspace_bytes())
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=anchors.device)
+        Hs = (ctypes.c_int * L)(*[t.size(2) for t in obj])
+        Ws = (ctypes.c_int * L)(*[t.size(3) for t in obj])
+        arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
+        w4 = (ctypes.c_float * 4)(*[float(w) for w in weights])
+        with _on_device(anchors), _timed("rpn_loss[N=%d,T=%d]" % (N, T), anchors):
+            check(lib.detops_rpn_loss_f32(arr(obj), arr(box), Hs, Ws, L, int(A), ptr(anchors), ptr(matched), ptr(pos),
+                                          ptr(neg), ptr(gt), N, M, T, float(beta), w4, arr(gobj), arr(gbox), ptr(out3),
+                                          ptr(ws), nbytes, stream_of(anchors)), "rpn_loss")
+        ctx.grads, ctx.out3, ctx.meta = (gobj, gbox), out3, (L, int(A), N, T, Hs, Ws)
+        ctx.mark_non_differentiable(out3)
+        return out3[0], out3[1], out3
+
+    @staticmethod
+    def backward(ctx, g_obj, g_box, _unused):
+        gobj, gbox = ctx.grads
+        L, A, N, T, Hs, Ws = ctx.meta
+        if gobj is None:
+            raise RuntimeError("rpn_loss: backward called twice (the stored gradients are scaled in place)")
+        up_o = (g_obj if g_obj is not None else torch.zeros((), device=ctx.out3.device)).reshape(1).float().contiguous()
+        up_b = (g_box if g_box is not None else torch.zeros((), device=ctx.out3.device)).reshape(1).float().contiguous()
+        arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
+        with _on_device(ctx.out3):
+            check(lib.detops_rpn_loss_backward_f32(arr(gobj), arr(gbox), Hs, Ws, L, A, N, T, ptr(up_o), ptr(up_b),
+                                                   ptr(ctx.out3[2:]), stream_of(ctx.out3)), "rpn_loss_backward")
+        ctx.grads = (None, None)
+        return (None,) * 9 + tuple(gobj) + tuple(gbox)
+
+
+def rpn_loss(objectness, box_regression, anchors, matched_idxs, pos_mask, neg_mask, gt_boxes, beta, weights):
+    """objectness / box_regression: per-level lists [N, A, H, W] / [N, 4A, H, W] (fp32, contiguous); anchors [T, 4];
+    matched_idxs [N, T] int64; pos_mask / neg_mask [N, T] bool; gt_boxes [N, M, 4] -> (objectness_loss, box_loss)."""
+    _need_cuda("rpn_loss", anchors, matched_idxs, pos_mask, neg_mask, gt_boxes, *objectness, *box_regression)
+    L = len(objectness)
+    A = box_regression[0].size(1) // 4
+    heads = [_f32c("rpn_loss", t) for t in list(objectness) + list(box_regression)]
+    as_u8 = lambda m: (m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)).contiguous()
+    lo, lb, _ = _RpnLoss.apply(_f32c("rpn_loss", anchors), matched_idxs.to(torch.int64).contiguous(), as_u8(pos_mask),
+                               as_u8(neg_mask), _f32c("rpn_loss", gt_boxes), float(beta), tuple(weights), A, L, *heads)
+    return lo, lb
+
+
 # ------------------------------------------------------------------------------------------ target assignment
 def match_boxes(gt_boxes, gt_valid, boxes, high_threshold, low_threshold, allow_low_quality_matches):
     """Fused IoU + Matcher (extension; reference structures/boxlist_ops.py:53-89 + modeling/matcher.py:42-112):

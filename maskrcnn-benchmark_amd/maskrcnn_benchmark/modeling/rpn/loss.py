@@ -9,6 +9,8 @@ Batched over images (ground truth padded to the largest count with a row mask) a
 `nonzero`: sampled subsets are boolean masks and the losses are masked sums, so the values equal
 the reference's indexed forms while nothing is synchronised with the host.
 """
+import os
+
 import torch
 from torch.nn import functional as F
 
@@ -17,6 +19,9 @@ from maskrcnn_benchmark.structures.boxlist_ops import box_iou_matrix
 
 from ..balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
 from .utils import concat_box_prediction_layers
+
+
+_FUSED = os.environ.get("DETOPS_RPN_LOSS", "fused") != "torch"   # A/B switch: the PyTorch composite on the GPU
 
 
 def pad_targets(targets, device, fields=()):
@@ -68,9 +73,8 @@ class RPNLossComputation(object):
         self.generate_labels_func = generate_labels_func
         self.discard_cases = ["not_visibility", "between_thresholds"]
 
-    def prepare_targets(self, anchors, targets):
-        """anchors: list (image) of list (level) of BoxList.  -> labels [N,A] float (1/0/-1),
-        regression_targets [N,A,4]."""
+    def _match(self, anchors, targets):
+        """-> (labels [N,A] float 1/0/-1, matched_idxs [N,A] int64, padded gt [N,M,4], all anchors [A,4])."""
         all_anchors = torch.cat([b.bbox for b in anchors[0]], dim=0)
         dev = all_anchors.device
         gt, row_valid, extra = pad_targets(targets, dev, self.copied_fields)
@@ -83,11 +87,27 @@ class RPNLossComputation(object):
             labels = torch.where(vis, labels, labels.new_full((), -1.0))
         if "between_thresholds" in self.discard_cases:
             labels = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, labels.new_full((), -1.0), labels)
+        return labels, matched, gt, all_anchors
+
+    def prepare_targets(self, anchors, targets):
+        """anchors: list (image) of list (level) of BoxList.  -> labels [N,A] float (1/0/-1),
+        regression_targets [N,A,4]."""
+        labels, matched, gt, all_anchors = self._match(anchors, targets)
         matched_gt = torch.gather(gt, 1, matched.clamp(min=0)[:, :, None].expand(-1, -1, 4))
         regression_targets = self.box_coder.encode(matched_gt, all_anchors.unsqueeze(0))
         return labels, regression_targets
 
     def __call__(self, anchors, objectness, box_regression, targets):
+        if (objectness[0].is_cuda and all(t.dtype == torch.float32 for t in list(objectness) + list(box_regression))
+                and len(objectness) <= 8 and _FUSED):
+            # one launch over the head outputs in their own layout (csrc/targets.hip::rpn_loss_kernel): no permute /
+            # cat of the 5 levels, no [N, A, 4] regression targets, no masked reductions — and none of their
+            # autograd mirrors
+            from maskrcnn_benchmark import _C
+            labels, matched, gt, all_anchors = self._match(anchors, targets)
+            pos, neg = self.fg_bg_sampler._masks(labels)
+            return _C.rpn_loss(objectness, box_regression, all_anchors, matched, pos, neg, gt, 1.0 / 9,
+                               self.box_coder.weights)
         labels, regression_targets = self.prepare_targets(anchors, targets)
         pos, neg = self.fg_bg_sampler._masks(labels)
         sampled = pos | neg

@@ -33,6 +33,10 @@ SIGNATURES = {
     "detops_sample_labels": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, _P, _P, _P, _P, _P,
                                      ctypes.c_size_t, _P]),
     "detops_mask_targets": (c_int, [_P, c_int, _P, _P] + [c_int] * 5 + [_P, _P]),
+    "detops_rpn_loss_workspace_bytes": (ctypes.c_size_t, []),
+    "detops_rpn_loss_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
+                                    _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "detops_rpn_loss_backward_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),
     "detops_roi_pool_backward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "detops_nms_workspace_bytes": (ctypes.c_size_t, [c_int]),
@@ -446,3 +450,32 @@ def stats(reset=True):
         k, v = line.split("=")
         out[k] = float(v)
     return out
+
+
+def rpn_loss(objectness, box_regression, anchors, matched, pos, neg, gt, beta, weights, upstream=(1.0, 1.0)):
+    """-> (objectness loss, box loss, grads wrt the objectness levels, grads wrt the box-regression levels) with the
+    backward scaling applied for the given upstream gradients."""
+    obj = [_f32(t) for t in objectness]
+    box = [_f32(t) for t in box_regression]
+    anchors, gt = _f32(anchors), _f32(gt)
+    matched = np.ascontiguousarray(matched, dtype=np.int64)
+    pos = np.ascontiguousarray(pos, dtype=np.uint8)
+    neg = np.ascontiguousarray(neg, dtype=np.uint8)
+    L, N, A = len(obj), obj[0].shape[0], obj[0].shape[1]
+    T, M = anchors.shape[0], gt.shape[1]
+    gobj = [np.full(t.shape, np.nan, np.float32) for t in obj]
+    gbox = [np.full(t.shape, np.nan, np.float32) for t in box]
+    arr = lambda ts: (ctypes.c_void_p * L)(*[t.ctypes.data for t in ts])
+    Hs = (ctypes.c_int * L)(*[t.shape[2] for t in obj])
+    Ws = (ctypes.c_int * L)(*[t.shape[3] for t in obj])
+    w4 = (ctypes.c_float * 4)(*[float(w) for w in weights])
+    out3 = np.full((3,), np.nan, np.float32)
+    nbytes = lib().detops_rpn_loss_workspace_bytes()
+    ws = np.full((nbytes,), 0xAB, np.uint8)
+    rc = lib().detops_rpn_loss_f32(arr(obj), arr(box), Hs, Ws, L, A, _p(anchors), _p(matched), _p(pos), _p(neg), _p(gt),
+                                   N, M, T, beta, w4, arr(gobj), arr(gbox), _p(out3), _p(ws), nbytes, None)
+    assert rc == 0, rc
+    uo, ub = np.full((1,), upstream[0], np.float32), np.full((1,), upstream[1], np.float32)
+    rc = lib().detops_rpn_loss_backward_f32(arr(gobj), arr(gbox), Hs, Ws, L, A, N, T, _p(uo), _p(ub), _p(out3[2:]), None)
+    assert rc == 0, rc
+    return float(out3[0]), float(out3[1]), gobj, gbox
