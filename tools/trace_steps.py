@@ -29,6 +29,22 @@ def main(path, steps=4, top=40):
     print("%10s %10s %10s  kernel" % ("ms/step", "calls/step", "avg_us"))
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
         print("%10.3f %10.1f %10.1f  %s" % (v[0] / 1e6 / steps, v[1] / steps, v[0] / v[1] / 1e3, k))
+    # idle time of the device inside the window: gaps between the end of everything launched so far and the next start
+    gaps, end = [], int(sel[0]["End_Timestamp"])
+    for prev, r in zip(sel, sel[1:]):
+        st = int(r["Start_Timestamp"])
+        if st > end:
+            gaps.append((st - end, prev["Kernel_Name"][:60], r["Kernel_Name"][:60]))
+        end = max(end, int(r["End_Timestamp"]))
+    tot = sum(g[0] for g in gaps)
+    hist = collections.Counter(min(int(g[0] / 1000) // 5 * 5, 50) for g in gaps)
+    print("\ndevice idle inside the window: %.2f ms/step in %d gaps/step; > 20 us: %.2f ms/step in %d gaps/step" % (
+        tot / 1e6 / steps, len(gaps) / steps, sum(g[0] for g in gaps if g[0] > 20000) / 1e6 / steps,
+        sum(1 for g in gaps if g[0] > 20000) / steps))
+    print("gap histogram (us bucket: count/step): " + ", ".join("%d+: %.0f" % (k, v / steps) for k, v in sorted(hist.items())))
+    print("largest gaps (us, after kernel -> before kernel):")
+    for g in sorted(gaps, reverse=True)[:12]:
+        print("%9.1f  %s  ->  %s" % (g[0] / 1e3, g[1], g[2]))
 
 
 if __name__ == "__main__":
