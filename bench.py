@@ -357,8 +357,12 @@ def main():
         timer = _C.KernelTimer()
         _C.KERNEL_TIMER = timer
     t0 = time.perf_counter()
+    host_pad = float(os.environ.get("BENCH_HOST_PAD_MS", "0")) / 1000.0   # diagnosis: is the host or the device the limiter?
     for i in range(args.steps):
         losses = step(*batches[i % len(batches)])
+        if host_pad:
+            time.sleep(host_pad)
+    host_elapsed = time.perf_counter() - t0      # everything enqueued; the device may still be running
     sync()
     elapsed = time.perf_counter() - t0
     _C.KERNEL_TIMER = None
@@ -394,6 +398,8 @@ def main():
             "max_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
             "miopen": {"search": bool(torch.backends.cudnn.benchmark), "db": miopen_db},
             "ddp": ddp_mode,
+            # host time to ENQUEUE the timed steps (rank 0): close to ms_per_step = the host is the limiter
+            "host_enqueue_ms_per_step": round(1000.0 * host_elapsed / args.steps, 3),
         }
         if timer is not None:
             kernels, dominant = {}, None
