@@ -51,13 +51,19 @@ def _worker(rank, world, port, steps, out_dir, bucket_mb):
     ddp = wrap_data_parallel(model, opt, device_ids=None, bucket_cap_mb=bucket_mb)
     assert opt.deferred and isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
     reduced = None
+    used_bucket_zeroing = 0
     for it in range(steps):
         x, y = _data(rank, it)
         loss = ((ddp(x) - y) ** 2).mean()
-        opt.zero_grad(set_to_none=False)
+        if opt.zero_buckets():          # what TrainStep does: one multi-tensor zero of DDP's flat bucket buffers
+            used_bucket_zeroing += 1
+            assert all(float(p.grad.abs().sum()) == 0.0 for p in model.parameters())
+        else:
+            opt.zero_grad(set_to_none=False)
         loss.backward()   # all-reduce + SGD update happen inside, bucket by bucket
         opt.step()        # no-op in deferred mode
         reduced = reduce_dict({"loss": loss.detach(), "twice": 2 * loss.detach()})
+    assert used_bucket_zeroing >= steps - 3, used_bucket_zeroing   # active once the (rebuilt) buckets have been seen
     torch.save({"params": [p.detach().clone() for p in model.parameters()],
                 "reduced": {k: float(v) for k, v in reduced.items()}, "loss": float(loss)},
                os.path.join(out_dir, "rank%d.pt" % rank))
@@ -68,7 +74,7 @@ def _worker(rank, world, port, steps, out_dir, bucket_mb):
 @pytest.mark.parametrize("bucket_mb", [25, 0.001])  # one bucket / one bucket per parameter
 def test_overlapped_sgd_ddp_matches_single_process_sgd(tmp_path, bucket_mb):
     sys.path.insert(0, PKG)
-    steps, world = 4, 2
+    steps, world = 6, 2
     mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), bucket_mb), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
