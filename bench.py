@@ -303,6 +303,13 @@ def main():
         opts = opts[1:]
     if args.dtype:
         opts += ["DTYPE", args.dtype]
+    # The yaml's BASE_LR (0.02) is for the reference's 16-image global batch (8 GPUs x 2).  For other batch sizes the
+    # reference's own recipe is the linear scaling rule (README.md "Single GPU Training": IMS_PER_BATCH 2 -> BASE_LR
+    # 0.0025); at 0.02 with 2 images the random-init detector diverges in some runs.  No effect on the work per step.
+    global_batch = args.images_per_gpu * world
+    if "SOLVER.BASE_LR" not in opts:
+        base = load_cfg(args.config, []).SOLVER.BASE_LR
+        opts += ["SOLVER.BASE_LR", base * global_batch / 16.0, "SOLVER.IMS_PER_BATCH", global_batch]
     cfg = load_cfg(args.config, opts)
     torch.manual_seed(1234 + rank)
     # MIOpen: immediate mode by default (see --miopen-search)
@@ -392,7 +399,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: fwd+bwd+allreduce+SGD, %d img/GPU of synthetic 1333x800 (padded %dx%d), "
                                    "random-init weights" % (os.path.basename(args.config), args.images_per_gpu, H, W),
-                       "global_batch": args.images_per_gpu * world, "parallelism": "dp%d" % world},
+                       "global_batch": args.images_per_gpu * world, "parallelism": "dp%d" % world,
+                       "base_lr": cfg.SOLVER.BASE_LR},
             "loss_finite": all(v == v and abs(v) != float("inf") for v in loss_vals.values()),
             "losses": {k: round(v, 4) for k, v in loss_vals.items()},
             "max_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),

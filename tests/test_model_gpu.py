@@ -9,6 +9,7 @@ import oracle
 import synth
 
 pytestmark = pytest.mark.gpu
+DEV = "cuda"
 
 
 def _dev():
@@ -163,3 +164,34 @@ def test_forced_ddp_hook_world1_nccl_matches_plain_step():
             assert torch.equal(a, b)
         else:
             assert float((a - b).abs().max()) <= 4 * noise + 1e-7, (float((a - b).abs().max()), noise)
+
+
+def test_overlapped_sgd_fused_kernel_equals_torch_sgd_on_device():
+    """the one-pass multi-tensor update (torch._fused_sgd_) used on CUDA parameters follows torch.optim.SGD
+    (momentum 0.9, the reference's weight / bias param-group rule) step for step, first step included"""
+    from maskrcnn_benchmark.engine import ddp_step
+    assert ddp_step._FUSED_SGD
+
+    class Cfg:
+        class SOLVER:
+            BASE_LR, MOMENTUM, WEIGHT_DECAY, BIAS_LR_FACTOR, WEIGHT_DECAY_BIAS = 0.05, 0.9, 0.01, 2, 0.0
+
+    def toy():
+        torch.manual_seed(3)
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1)).to(DEV)
+
+    m1, m2 = toy(), toy()
+    o1 = ddp_step.make_overlapped_sgd(Cfg, m1)
+    w = [p for n, p in m2.named_parameters() if "bias" not in n]
+    b = [p for n, p in m2.named_parameters() if "bias" in n]
+    o2 = torch.optim.SGD([{"params": w, "lr": 0.05, "weight_decay": 0.01}, {"params": b, "lr": 0.1, "weight_decay": 0.0}],
+                         lr=0.05, momentum=0.9)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for it in range(5):
+        x = torch.randn(2, 3, 9, 11, generator=g).to(DEV)
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad()
+            (m(x) ** 2).mean().backward()
+            o.step()
+    for a, c in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(a, c, rtol=1e-6, atol=1e-7)
