@@ -122,6 +122,31 @@ def test_emu_roi_align_fpn_forward_visiting_order_and_staging_variants(impl, mon
     assert np.array_equal(out1, oracle.roi_align_forward(feats[1], rois, scales[1], 14, 14, 2))
 
 
+@pytest.mark.parametrize("K", [384, 385, 415, 1025, 4096])
+def test_emu_roi_order_prepass_is_a_permutation_at_its_size_limits(K, monkeypatch):
+    """ranking pre-pass at the smallest / largest ROI counts it serves and at counts that are not a multiple of
+    its 32-key LDS padding; duplicate ROIs and ROIs with NaN / huge coordinates (the key only has to be SOME
+    number: any permutation is correct, a lost ROI would leave its output rows NaN-poisoned)"""
+    monkeypatch.setenv("DETOPS_ROIALIGN_FWD_ORDER", "force")
+    rng = np.random.RandomState(K)
+    feats = [rng.randn(1, 2, 20, 30).astype(np.float32), rng.randn(1, 2, 10, 15).astype(np.float32)]
+    scales = [0.25, 0.125]
+    rois = synth.fpn_rois(seed=K, per_image=K, n_images=1, smin=8, smax=200)
+    rois[:, 1:] *= 0.09
+    rois[5] = rois[6]
+    rois[7, 1:] = [1e30, 1e30, 1e30, 1e30]       # far outside: all-zero output rows
+    emu.stats(reset=True)
+    out, levels = emu.roi_align_fpn_forward(feats, rois, scales, 7, 7, 2, 2, 3)
+    assert emu.stats().get("fwd.ranked_rois", 0) == K
+    lv = np.clip(levels, 0, 1)
+    assert not np.isnan(out).any()
+    for l in range(2):
+        sel = levels == l
+        if sel.any():
+            assert np.array_equal(out[sel], oracle.roi_align_forward(feats[l], rois[sel], scales[l], 7, 7, 2))
+    assert not out[7].any()
+
+
 # ================================================================================ deformable conv
 DCN_GEOMS = [dict(B=2, C=8, H=13, W=17, k=3, stride=1, pad=1, dil=1, dg=1),
              dict(B=2, C=8, H=14, W=15, k=3, stride=2, pad=2, dil=2, dg=2),

@@ -101,6 +101,24 @@ def test_roi_align_forward_variants_bit_equal(monkeypatch):
             assert torch.equal(out, base) and torch.equal(lv, lv2), env
 
 
+@pytest.mark.parametrize("K", [384, 415, 4096, 4097])
+def test_roi_align_forward_ranking_prepass_size_limits(K, monkeypatch):
+    """ROI counts at the edges of the ranking pre-pass (384 .. 4096; 4097 runs unranked), not multiples of its
+    LDS padding, duplicates included: bit-equal to the oracle either way"""
+    monkeypatch.setenv("DETOPS_ROIALIGN_FWD_ORDER", "force")
+    rng = np.random.RandomState(K)
+    feats = [rng.randn(2, 8, 50, 84).astype(np.float32), rng.randn(2, 8, 25, 42).astype(np.float32)]
+    scales = [0.25, 0.125]
+    rois = synth.fpn_rois(seed=K, per_image=(K + 1) // 2, n_images=2, smin=8, smax=300)[:K]
+    rois[:, 1:] *= 0.25
+    rois[5] = rois[6]
+    out, levels = _C().roi_align_fpn_forward([_t(f) for f in feats], _t(rois), scales, 7, 7, 2, 2, 3)
+    out, levels = out.cpu().numpy(), levels.cpu().numpy()
+    for l in range(2):
+        sel = levels == l
+        assert np.array_equal(out[sel], oracle.roi_align_forward(feats[l], rois[sel], scales[l], 7, 7, 2))
+
+
 def test_roi_align_forward_edge_cases():
     C = _C()
     x = torch.randn(2, 3, 10, 12, device=DEV)
