@@ -225,6 +225,7 @@ constexpr int kFwdDmaWps = 5;  // LDS-DMA forward: no staging registers
 constexpr int kFwdWps = 4;   // waves per SIMD of the row-vector forward (register budget 80)
 constexpr int kLdsPatchFloats = 8192 - 64;  // default ~32 KiB dynamic LDS per workgroup -> 4-5 workgroups / CU
 
+// Register-staged variant (round 1; kept behind DETOPS_ROIALIGN_FWD=lds for A/B runs against the LDS-DMA kernel below).
 // U = staging loads in flight per lane; patch_floats = LDS patch budget (DETOPS_ROIALIGN_FWD_LDS_KB /
 // DETOPS_ROIALIGN_FWD_U select other points of the occupancy / loads-in-flight trade-off at run time)
 // WPS: waves per SIMD the register allocation must allow (residency hides the stage -> compute latency chain)

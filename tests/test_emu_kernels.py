@@ -363,15 +363,15 @@ def test_emu_roi_align_backward_lane_walk(ct, monkeypatch):
         assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("ct,wgs", [("16", None), ("32", None), ("16", "3"), ("16", "1"), ("32", "7")])
-def test_emu_roi_align_backward_binned(ct, wgs, monkeypatch):
+@pytest.mark.parametrize("ct,batch", [("16", None), ("32", None), ("16", "1"), ("16", "2"), ("32", "3")])
+def test_emu_roi_align_backward_binned(ct, batch, monkeypatch):
     """binned pixel-owner backward (pre-pass adjoint rows + per-tile hit lists in a poisoned workspace):
     ragged ROIs / bin shapes, adaptive sampling, channel tails, accumulate mode, both channel chunkings;
-    `wgs` caps the persistent grid so that every workgroup pipelines through many work items."""
+    `batch` caps the hits staged per batch so that every workgroup runs through several stage / walk rounds."""
     monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "binned")
     monkeypatch.setenv("DETOPS_ROIALIGN_BWD_CT", ct)
-    if wgs:
-        monkeypatch.setenv("DETOPS_ROIALIGN_BWD_WGS", wgs)
+    if batch:
+        monkeypatch.setenv("DETOPS_ROIALIGN_BWD_BATCH", batch)
     rng = np.random.RandomState(51)
     N, C, H, W = 2, 37, 27, 70           # 37 channels: ragged last chunk; 27 x 70: partial edge tiles
     K = 90
