@@ -1308,6 +1308,7 @@ struct BinWs {
   float* tabs;       // [K][Hmax * PPH + Wmax * PPW]
   int4* heads;       // [num_tiles] {hit count, level | image << 8, y0, x0}
   int4* lists;       // [num_tiles][cap]
+  unsigned long long* prof;   // DETOPS_ROIALIGN_BWD_DEBUG & 128: per-phase shader-clock sums (diagnosis only), else NULL
 };
 
 struct RoiExtent {
@@ -1589,6 +1590,15 @@ roi_align_bwd_binned_kernel(Levels L, BinPlan P, BinWs ws, const float* __restri
   float acc[CT];
 #pragma unroll
   for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+#ifndef DETOPS_CPU_EMU
+  // phase clocks of wave 0 (diagnosis build path: ws.prof != NULL only under DETOPS_ROIALIGN_BWD_DEBUG & 128)
+  const bool prof = ws.prof != nullptr && tid == 0;
+  long long pt0 = 0, pt = 0, p_stage = 0, p_walk = 0, p_list = 0;
+  if (prof) pt0 = pt = clock64();
+#define BIN_PROF(acc_) do { if (prof) { const long long n_ = clock64(); acc_ += n_ - pt; pt = n_; } } while (0)
+#else
+#define BIN_PROF(acc_) do { } while (0)
+#endif
 
   // staging roles (no divisions inside the loops): gradients — thread t owns slot t = (hit, bin) of every
   // channel group (t < batch * bins <= 256); adjoint rows — float4 unit u = tid + i * 256 of the batch
@@ -1600,6 +1610,7 @@ roi_align_bwd_binned_kernel(Levels L, BinPlan P, BinWs ws, const float* __restri
     const int nr = min(kBinRound, total - r0);
     if (tid < nr) s_ent[tid] = list[r0 + tid];
     __syncthreads();
+    BIN_PROF(p_list);
     if (tid == 0) { DETOPS_STAT("bwdb.rounds", r0 > 0); if (r0 == 0) DETOPS_STAT("bwdb.hits", total); }
     for (int h0 = 0; h0 < nr; h0 += P.batch) {
       const int nb = min(P.batch, nr - h0);
@@ -1643,6 +1654,7 @@ roi_align_bwd_binned_kernel(Levels L, BinPlan P, BinWs ws, const float* __restri
         }
       }
       __syncthreads();
+      BIN_PROF(p_stage);
       // ---- walk: every pixel gathers from the bins of this batch's hits that reach it
       for (int j = 0; j < ((P.debug & 1) ? 0 : nb); ++j) {
         const int4 en = s_ent[h0 + j];
@@ -1733,6 +1745,7 @@ roi_align_bwd_binned_kernel(Levels L, BinPlan P, BinWs ws, const float* __restri
         }
       }
       __syncthreads();  // the next batch / round rewrites the staging region
+      BIN_PROF(p_walk);
     }
   }
 
@@ -1761,6 +1774,21 @@ roi_align_bwd_binned_kernel(Levels L, BinPlan P, BinWs ws, const float* __restri
       }
     }
   }
+#ifndef DETOPS_CPU_EMU
+  if (prof) {
+    const long long end = clock64();
+    const int cls = total == 0 ? 0 : (total <= 4 ? 1 : (total <= 16 ? 2 : 3));   // workgroups by hit count
+    unsigned long long* o = ws.prof + cls * 8;
+    atomicAdd(o + 0, 1ull);
+    atomicAdd(o + 1, static_cast<unsigned long long>(end - pt0));
+    atomicAdd(o + 2, static_cast<unsigned long long>(p_list));
+    atomicAdd(o + 3, static_cast<unsigned long long>(p_stage));
+    atomicAdd(o + 4, static_cast<unsigned long long>(p_walk));
+    atomicAdd(o + 5, static_cast<unsigned long long>(end - pt));          // store tail
+    atomicAdd(o + 6, static_cast<unsigned long long>(total));
+  }
+#endif
+#undef BIN_PROF
 }
 
 // per-wave LDS strips of the separable walk (7 bin columns): [waves][2 rows][8 | 16 columns][CT] floats
@@ -1835,7 +1863,15 @@ int run_backward_binned(const Levels& L, const float* rois, const int32_t* level
   if (const char* e = getenv("DETOPS_ROIALIGN_BWD_DEBUG")) P.debug = atoi(e);
   unsigned char* base = static_cast<unsigned char*>(workspace);
   BinWs ws{reinterpret_cast<float*>(base + lay.off_tabs), reinterpret_cast<int4*>(base + lay.off_counts),
-           reinterpret_cast<int4*>(base + lay.off_lists)};
+           reinterpret_cast<int4*>(base + lay.off_lists), nullptr};
+#ifndef DETOPS_CPU_EMU
+  if (P.debug & 128) {   // diagnosis only: phase clocks of every workgroup's wave 0, printed after a device sync
+    static unsigned long long* prof_buf = nullptr;
+    if (!prof_buf) DETOPS_HIP_TRY(hipMalloc(&prof_buf, 32 * sizeof(unsigned long long)));
+    DETOPS_HIP_TRY(hipMemsetAsync(prof_buf, 0, 32 * sizeof(unsigned long long), st));
+    ws.prof = prof_buf;
+  }
+#endif
   hipLaunchKernelGGL(roi_bwd_prep_kernel, dim3(static_cast<unsigned>(P.tab_blocks + ceil_div64(P.num_tiles, kPrepTiles))), dim3(kBlock), 0, st,
                      L, P, ws, rois, levels_in, K, PH, PW, sr);
   const size_t lds = sizeof(float) * (static_cast<size_t>(P.batch) * PH * PW * CT +
@@ -1849,6 +1885,19 @@ int run_backward_binned(const Levels& L, const float* rois, const int32_t* level
   else if (PH == 14 && PW == 14) { if (CT == 32) BINNED_LAUNCH(14, 14, 32); else BINNED_LAUNCH(14, 14, 16); }
   else { if (CT == 32) BINNED_LAUNCH(0, 0, 32); else BINNED_LAUNCH(0, 0, 16); }
 #undef BINNED_LAUNCH
+#ifndef DETOPS_CPU_EMU
+  if (ws.prof) {
+    unsigned long long h[32];
+    DETOPS_HIP_TRY(hipStreamSynchronize(st));
+    DETOPS_HIP_TRY(hipMemcpy(h, ws.prof, sizeof(h), hipMemcpyDeviceToHost));
+    static const char* cls[4] = {"0 hits", "1-4 hits", "5-16 hits", ">16 hits"};
+    for (int c = 0; c < 4; ++c) {
+      const double n = h[c * 8] ? static_cast<double>(h[c * 8]) : 1.0;
+      fprintf(stderr, "[bwd-binned %dx%d] %-9s workgroups %6llu  hits/wg %6.1f  cycles/wg: total %8.0f  list %7.0f  stage %8.0f  walk %8.0f  store %7.0f\n",
+              PH, PW, cls[c], h[c * 8], h[c * 8 + 6] / n, h[c * 8 + 1] / n, h[c * 8 + 2] / n, h[c * 8 + 3] / n, h[c * 8 + 4] / n, h[c * 8 + 5] / n);
+    }
+  }
+#endif
   return launch_status();
 }
 
