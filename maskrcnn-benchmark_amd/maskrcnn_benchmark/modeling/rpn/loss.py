@@ -98,14 +98,16 @@ class RPNLossComputation(object):
         return labels, regression_targets
 
     def __call__(self, anchors, objectness, box_regression, targets):
-        if (objectness[0].is_cuda and all(t.dtype == torch.float32 for t in list(objectness) + list(box_regression))
-                and len(objectness) <= 8 and _FUSED):
+        if objectness[0].is_cuda and len(objectness) <= 8 and _FUSED:
             # one launch over the head outputs in their own layout (csrc/targets.hip::rpn_loss_kernel): no permute /
             # cat of the 5 levels, no [N, A, 4] regression targets, no masked reductions — and none of their
             # autograd mirrors
             from maskrcnn_benchmark import _C
             labels, matched, gt, all_anchors = self._match(anchors, targets)
             pos, neg = self.fg_bg_sampler._masks(labels)
+            # half-precision head outputs (autocast): the loss is evaluated in fp32 like the composite below
+            objectness = [t.float() for t in objectness]
+            box_regression = [t.float() for t in box_regression]
             return _C.rpn_loss(objectness, box_regression, all_anchors, matched, pos, neg, gt, 1.0 / 9,
                                self.box_coder.weights)
         labels, regression_targets = self.prepare_targets(anchors, targets)
