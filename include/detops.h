@@ -43,6 +43,20 @@ typedef void* detops_stream_t; /* hipStream_t */
  * string naming the ISA the device code was built for ("gfx950"). */
 int detops_version(const char** arch);
 
+/* Tuning / test switches (all default 0 = automatic).  Read once at library load from the environment variable
+ * DETOPS_TUNING="key=value,key=value"; this call changes one at run time (tests, A/B measurements — process-wide,
+ * not thread-safe against concurrent launches).  The launch paths never read the environment.  Keys:
+ *   roi_bwd_impl      1 ring (needs a workspace) | 2 scan | 3 atomic scatter
+ *   roi_bwd_seg       ring: hits per hit-list segment (default 32, >= 8)
+ *   roi_bwd_groups    scan: ROI-list split        roi_bwd_scan_ct   scan: channels per workgroup (4 | 16)
+ *   roi_bwd_debug     ablation bits (1 = skip the walk)
+ *   roi_fwd_impl      1 generic gather kernel    roi_fwd_order     1 never rank | 2 rank even tiny maps
+ *   roi_fwd_order_mink  smallest K that gets the ranking pre-pass
+ *   dcn_col2im        1 gather | 2 scatter | 3 ell    dcn_fused  1 force | 2 off    dcn_gather_xcd  1 plain block order
+ * Returns 0, or DETOPS_EINVAL for an unknown key. */
+int detops_tuning_set(const char* key, int value);
+int detops_tuning_get(const char* key, int* value);
+
 /* ------------------------------------------------------------------------------------------
  * ROIAlign  — replaces _C.roi_align_forward / _C.roi_align_backward
  *   reference: csrc/ROIAlign.h:11-25 (forward), :27-45 (backward);

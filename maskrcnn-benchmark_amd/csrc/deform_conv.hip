@@ -785,8 +785,7 @@ int col2im_ell_t(const void* col, const void* offset, const void* mask, void* gr
   int cc = cpg;
   while (cc > kGatherCC && pix_blocks * g.dg * ceil_div64(cpg, cc) < 4 * kNumCU) cc = max(kGatherCC, cc / 2);
   cc = static_cast<int>(ceil_div64(cc, kGatherCC)) * kGatherCC;
-  const char* sw = getenv("DETOPS_DCN_GATHER_XCD");
-  const int xcd_remap = !(sw && sw[0] == '0');
+  const int xcd_remap = detops_tuning().dcn_gather_xcd != 1;
   const dim3 ggrid(static_cast<unsigned>(ceil_div64(static_cast<int64_t>(g.H) * g.W, kBlock)),
                    static_cast<unsigned>(g.dg * ceil_div64(cpg, cc)), static_cast<unsigned>(g.B));
   hipLaunchKernelGGL(col2im_ell_gather_kernel<T>, ggrid, dim3(kBlock), 0, st_, static_cast<const T*>(col),
@@ -863,8 +862,7 @@ int col2im_gather_t(const void* col, const void* offset, const void* mask, void*
   int cc = cpg;  // channels per workgroup: whole passes of kGatherCC, enough workgroups to fill the chip
   while (cc > kGatherCC && pix_blocks * g.dg * ceil_div64(cpg, cc) < 4 * kNumCU) cc = max(kGatherCC, cc / 2);
   cc = static_cast<int>(ceil_div64(cc, kGatherCC)) * kGatherCC;
-  const char* sw = getenv("DETOPS_DCN_GATHER_XCD");  // "0": plain block order (A/B measurements)
-  const int xcd_remap = !(sw && sw[0] == '0');
+  const int xcd_remap = detops_tuning().dcn_gather_xcd != 1;   // 1: plain block order (A/B measurements)
   const dim3 ggrid(static_cast<unsigned>(ceil_div64(static_cast<int64_t>(g.H) * g.W, kBlock)),
                    static_cast<unsigned>(g.dg * ceil_div64(cpg, cc)), static_cast<unsigned>(g.B));
   hipLaunchKernelGGL(col2im_gather_kernel<T>, ggrid, dim3(kBlock), 0, st_, static_cast<const T*>(col),
@@ -1158,9 +1156,9 @@ inline bool dcn_fused_ok(const Geom& g, int dtype, int Cout) {
 // rebuilds the deformed operand, so it wins where pixels are many and Cout tiles few (measured,
 // profiles/r02f_opbench_dcn_fused.log, fused vs im2col + library GEMM: 105 vs 179 us at [2,128,100,168] = 94 TF/s;
 // 108 vs 103 us at [2,256,50,84]; 164 vs 72 us at [2,512,25,42], where 132 workgroups leave half the chip idle).
-// DETOPS_DCN_FUSED=force overrides (tests, measurements).
+// Tuning dcn_fused = 1 overrides (tests, measurements).
 inline bool dcn_fused_preferred(const Geom& g, int Cout) {
-  if (const char* e = getenv("DETOPS_DCN_FUSED")) if (e[0] == 'f') return true;
+  if (detops_tuning().dcn_fused == 1) return true;
   const int64_t wgs = ceil_div64(static_cast<int64_t>(g.B) * g.Ho * g.Wo, kFN) * ceil_div64(Cout, kFM);
   return wgs >= 2 * kNumCU && Cout <= 2 * kFM;
 }
@@ -1263,12 +1261,12 @@ DETOPS_API int detops_deformable_col2im_ws(const void* col, const void* offset, 
   // Default: the fixed-width (ELL) inverted index for fp32 and for large maps, the CSR index + gather
   // otherwise (profiles/r02a_opbench_experimental_ab.log, ELL vs CSR: fp32 448 vs 785 / 281 vs 355 /
   // 231 vs 235 us at layer2/3/4; fp16 401 vs 592 / 264 vs 264 / 212 vs 152 us).  Both are free of data
-  // atomics except ELL's overflow list.  DETOPS_DCN_COL2IM = "scatter" | "gather" | "ell" forces one
+  // atomics except ELL's overflow list.  tuning dcn_col2im = 1 gather | 2 scatter | 3 ell forces one
   // (A/B measurements, tests).
-  const char* e = getenv("DETOPS_DCN_COL2IM");
-  const bool want_gather = !(e && e[0] == 's');
+  const int e = detops_tuning().dcn_col2im;
+  const bool want_gather = e != 2;
   const bool big = static_cast<int64_t>(g.B) * g.H * g.W >= 16384;
-  const bool want_ell = e ? e[0] == 'e' : (dtype == DETOPS_F32 || big);
+  const bool want_ell = e ? e == 3 : (dtype == DETOPS_F32 || big);
   if (want_ell && workspace) {
     EllPlan E;
     if (ell_plan(g, E) && workspace_bytes >= E.total) {

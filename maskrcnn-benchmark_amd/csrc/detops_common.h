@@ -79,6 +79,97 @@ static inline int launch_status() { return static_cast<int>(hipGetLastError()); 
 #define DETOPS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 
+// ---- LDS-DMA (gfx950 global_load_lds_dwordx4): 16 bytes per lane, global (per-lane, dword-aligned address) ->
+// LDS (wave-uniform base + lane * 16).
+//   glds16        compiler-visible builtin: hipcc counts it and waits vmcnt(0) before any LDS read that may alias
+//                 (right for a one-batch-ahead double buffer: roi_align_fwd.hip);
+//   glds16_async  hidden in inline asm (cdna_hip_programming.md section 5.7): hipcc emits NO wait for it — the kernel
+//                 counts completion itself with DETOPS_VMCNT_WAIT(n) (at most n of this wave's vector-memory
+//                 operations still outstanding; they retire in issue order) and orders other waves' reads with a
+//                 barrier.  This is what lets several stagings stay in flight across barriers (a ring of LDS slots).
+//                 `active` lanes transfer; the instruction is issued by the wave either way (call it in wave-uniform
+//                 control flow so that every wave's count is known).
+// Host emulation: glds16 copies at once; glds16_async QUEUES the copy and DETOPS_VMCNT_WAIT applies all but the
+// newest n instructions' copies — a read that is not covered by a wait sees stale LDS, as on the device.
+#ifdef DETOPS_CPU_EMU
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+  float* d = lds_wave_base + 4 * (threadIdx.x & 63);
+  d[0] = g[0]; d[1] = g[1]; d[2] = g[2]; d[3] = g[3];
+}
+__device__ __forceinline__ void glds16_async(bool active, const float* g, float* lds_wave_base) {
+  emu::dma_issue(active, g, lds_wave_base + 4 * (threadIdx.x & 63));
+}
+__device__ __forceinline__ void glds16_async_so(bool active, const float* sbase, unsigned voff_bytes, float* lds_wave_base) {
+  emu::dma_issue(active, reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase) + voff_bytes),
+                 lds_wave_base + 4 * (threadIdx.x & 63));
+}
+#define DETOPS_VMCNT_WAIT(n) emu::dma_wait(n)
+#else
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds16_async(bool active, const float* g, float* lds_wave_base) {
+  typedef __attribute__((address_space(3))) float* lds_fptr_t;
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_fptr_t)lds_wave_base)));
+  unsigned keep;
+  if (active)   // M0 is compiler-reserved: saved, written and restored inside the one statement that reads it
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+// scalar base (wave-uniform 64-bit pointer) + per-lane unsigned 32-bit byte offset: the address arithmetic of a
+// homogeneous instruction stays on the scalar unit
+__device__ __forceinline__ void glds16_async_so(bool active, const float* sbase, unsigned voff_bytes, float* lds_wave_base) {
+  typedef __attribute__((address_space(3))) float* lds_fptr_t;
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_fptr_t)lds_wave_base)));
+  unsigned keep;
+  if (active)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(dst) : "memory");
+}
+#define DETOPS_VMCNT_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+#endif
+
+// ---- write-through (sc1) 16-byte global store and its matching load: partial results handed to ANOTHER workgroup
+// inside one launch (cdna_hip_programming.md Guideline 16, "sc1 slab stores"): the store bypasses the XCD's
+// non-coherent L2, DETOPS_VMCNT_WAIT(0) + a barrier + a relaxed agent-scope atomic then publishes it.
+#ifdef DETOPS_CPU_EMU
+__device__ __forceinline__ void store_f4_wt(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+#else
+__device__ __forceinline__ void store_f4_wt(float* p, float4 v) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
+}
+#endif
+
+// Acquire at agent scope (buffer_inv sc1: drops this CU's L1 lines) — executed by ONE lane of the workgroup that
+// is about to read another workgroup's published partial results, followed by a barrier.
+#ifdef DETOPS_CPU_EMU
+#define DETOPS_ACQUIRE_AGENT() ((void)0)
+#else
+#define DETOPS_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#endif
+
+// ---- tuning / test switches (read once at library load from DETOPS_TUNING="key=value,...", or set through
+// detops_tuning_set(); never read from the environment on the launch path)
+struct DetopsTuning {
+  int roi_bwd_impl;        // 0 auto | 1 ring (needs a workspace) | 2 scan | 3 atomic scatter
+  int roi_bwd_seg;         // ring: hits per segment before a tile's hit list is split over workgroups (0 = default)
+  int roi_bwd_ring;        // ring: LDS slots (hits in flight) of the 7x7 kernel, 2 | 3 | 4 (0 = default)
+  int roi_bwd_groups;      // scan: ROI-list split over blockIdx.y (0 = auto)
+  int roi_bwd_scan_ct;     // scan: channels per workgroup, 4 | 16 (0 = auto)
+  int roi_bwd_debug;       // ablation bits (diagnosis only)
+  int roi_fwd_impl;        // 0 auto | 1 generic gather kernel
+  int roi_fwd_order;       // 0 auto | 1 never rank | 2 rank even for tiny maps
+  int roi_fwd_order_mink;  // smallest K that gets the ranking pre-pass (0 = default)
+  int dcn_col2im;          // 0 auto | 1 gather | 2 scatter | 3 ell
+  int dcn_fused;           // 0 auto | 1 force | 2 off
+  int dcn_gather_xcd;      // 0 auto (XCD-contiguous block order) | 1 plain block order
+};
+DetopsTuning& detops_tuning();
+
 constexpr int kWave = 64;        // CDNA4 wavefront
 constexpr int kNumCU = 256;      // MI355X
 constexpr int kNumXCD = 8;

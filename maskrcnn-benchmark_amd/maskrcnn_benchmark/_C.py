@@ -693,8 +693,8 @@ def deformable_col2im_coord(col, im, offset, mask, grad_offset, grad_mask, kH, k
 def _fused_dcn_forward(input, weight, offset, mask, bias, out, kH, kW, padH, padW, dH, dW, dilH, dilW, group, dg):
     """Fused implicit-GEMM forward on the matrix cores (csrc/deform_conv.hip: the deformed operand tile is built
     in LDS, `columns` is never written).  Returns False when the shape is outside the fused plan (fp32 storage,
-    grouped convolution, channels per deformable group not a multiple of 32) or DETOPS_DCN_FUSED=0."""
-    if group != 1 or input.dtype not in (torch.float16, torch.bfloat16) or os.environ.get("DETOPS_DCN_FUSED", "1") == "0":
+    grouped convolution, channels per deformable group not a multiple of 32) or tuning dcn_fused = 2."""
+    if group != 1 or input.dtype not in (torch.float16, torch.bfloat16) or _lib.tuning_get("dcn_fused") == 2:
         return False
     B, C, H, W = input.shape
     Cout = weight.size(0)

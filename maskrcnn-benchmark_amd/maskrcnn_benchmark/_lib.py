@@ -18,6 +18,8 @@ c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void
 _P = c_void_p
 SIGNATURES = {
     "detops_version": (c_int, [_P]),
+    "detops_tuning_set": (c_int, [ctypes.c_char_p, c_int]),
+    "detops_tuning_get": (c_int, [ctypes.c_char_p, _P]),
     "detops_roi_align_forward_f32": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, _P]),
     "detops_roi_align_backward_f32": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P]),
     "detops_roi_align_fpn_forward_f32": (
@@ -118,3 +120,14 @@ def stream_of(t):
 
 
 DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def tuning_set(key, value):
+    """Tuning / test switch of the library (include/detops.h: detops_tuning_set)."""
+    check(lib.detops_tuning_set(key.encode(), int(value)), "detops_tuning_set(%s)" % key)
+
+
+def tuning_get(key):
+    v = ctypes.c_int(0)
+    check(lib.detops_tuning_get(key.encode(), ctypes.byref(v)), "detops_tuning_get(%s)" % key)
+    return v.value

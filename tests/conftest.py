@@ -34,3 +34,17 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _reset_library_tuning():
+    """the libraries' tuning switches (detops_tuning_set) are process-wide: every test starts from the defaults"""
+    yield
+    emu_mod = sys.modules.get("emu")
+    if emu_mod is not None:
+        emu_mod.tuning_reset()
+    lib_mod = sys.modules.get("maskrcnn_benchmark._lib")
+    if lib_mod is not None and hasattr(lib_mod, "tuning_set"):
+        import emu as _e  # key list only
+        for k in _e.TUNING_KEYS:
+            lib_mod.lib.detops_tuning_set(k.encode(), 0)

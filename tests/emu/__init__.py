@@ -13,6 +13,8 @@ _LIB = None
 
 c_int, c_float, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 SIGNATURES = {
+    "detops_tuning_set": (c_int, [ctypes.c_char_p, c_int]),
+    "detops_tuning_get": (c_int, [ctypes.c_char_p, _P]),
     "detops_roi_align_forward_f32": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, _P]),
     "detops_roi_align_backward_f32": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P]),
     "detops_roi_align_fpn_forward_f32": (
@@ -77,6 +79,22 @@ def lib():
             fn = getattr(_LIB, name)
             fn.restype, fn.argtypes = res, args
     return _LIB
+
+
+TUNING_KEYS = ("roi_bwd_impl", "roi_bwd_seg", "roi_bwd_ring", "roi_bwd_groups", "roi_bwd_scan_ct", "roi_bwd_debug", "roi_fwd_impl",
+               "roi_fwd_order", "roi_fwd_order_mink", "dcn_col2im", "dcn_fused", "dcn_gather_xcd")
+
+
+def tuning_set(key, value):
+    """tuning / test switch of the emulated library (include/detops.h: detops_tuning_set)"""
+    rc = lib().detops_tuning_set(key.encode(), int(value))
+    assert rc == 0, (key, rc)
+
+
+def tuning_reset():
+    if _LIB is not None:
+        for k in TUNING_KEYS:
+            _LIB.detops_tuning_set(k.encode(), 0)
 
 
 def _f32(a):
@@ -216,11 +234,11 @@ def deform_conv_forward_fused(im, weight, offset, mask, bias, pad, stride, dil, 
     Cout, _, kh, kw = weight.shape
     Ho, Wo = _out_hw(H, W, kh, kw, pad, stride, dil)
     geo = (1, B, C, H, W, Cout, kh, kw, pad[0], pad[1], stride[0], stride[1], dil[0], dil[1], dg)
-    os.environ["DETOPS_DCN_FUSED"] = "force"   # small test shapes: bypass the "is it faster" dispatch rule
+    tuning_set("dcn_fused", 1)   # small test shapes: bypass the "is it faster" dispatch rule
     try:
         nbytes = lib().detops_deform_conv_forward_fused_workspace_bytes(*geo)
     finally:
-        del os.environ["DETOPS_DCN_FUSED"]
+        tuning_set("dcn_fused", 0)
     if nbytes == 0:
         return None
     ws = np.full((nbytes,), 0xAB, np.uint8)
@@ -267,12 +285,12 @@ def deformable_col2im(col, offset, mask, B, C, H, W, kh, kw, pad, stride, dil, d
     g = _geom(B, C, H, W, kh, kw, pad, stride, dil, dg)
     mp = None if mask is None else _p(mask)
     if gather:
-        os.environ["DETOPS_DCN_COL2IM"] = mode
+        tuning_set("dcn_col2im", {"gather": 1, "scatter": 2, "ell": 3}[mode])
         nbytes = lib().detops_deformable_col2im_workspace_bytes(*g)
         assert nbytes > 0
         ws = np.full((nbytes,), 0xAB, np.uint8)  # arbitrary contents
         rc = lib().detops_deformable_col2im_ws(_p(col), _p(offset), mp, _p(gim), _DT[dt], *g, _p(ws), nbytes, None)
-        del os.environ["DETOPS_DCN_COL2IM"]
+        tuning_set("dcn_col2im", 0)
     else:
         rc = lib().detops_deformable_col2im(_p(col), _p(offset), mp, _p(gim), _DT[dt], *g, None)
     assert rc == 0, rc

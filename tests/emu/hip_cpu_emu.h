@@ -161,6 +161,29 @@ inline const unsigned long long* exchange(unsigned long long v, unsigned long lo
 }
 inline int lane_id() { return cur_fiber()->linear % kWaveSize; }
 
+// Asynchronous LDS-DMA model (glds16_async / DETOPS_VMCNT_WAIT in detops_common.h): every thread keeps the queue
+// of the copies it has issued (one entry per INSTRUCTION, a null entry for a lane that was masked off); a wait for
+// "at most n outstanding" lands everything but the newest n entries, oldest first.  Data therefore reaches LDS only at
+// a covering wait — a kernel that reads a slot too early sees stale bytes here exactly as it would on the device.
+struct DmaOp { const float* src; float* dst; };
+inline std::vector<std::vector<DmaOp>>& dma_queues() { static std::vector<std::vector<DmaOp>> q; return q; }
+inline void dma_issue(bool active, const float* src, float* dst) {
+  auto& q = dma_queues();
+  const size_t t = static_cast<size_t>(cur_fiber()->linear);
+  if (q.size() <= t) q.resize(t + 1);
+  q[t].push_back(active ? DmaOp{src, dst} : DmaOp{nullptr, nullptr});
+}
+inline void dma_wait(int n) {
+  auto& q = dma_queues();
+  const size_t t = static_cast<size_t>(cur_fiber()->linear);
+  if (q.size() <= t) return;
+  auto& mine = q[t];
+  while (static_cast<int>(mine.size()) > n) {
+    if (mine.front().src) memcpy(mine.front().dst, mine.front().src, 16);
+    mine.erase(mine.begin());
+  }
+}
+
 inline void launch(const std::function<void()>& kernel_body, dim3 grid, dim3 block, size_t lds_bytes) {
   if (lds_bytes > kDynLdsBytes) { fprintf(stderr, "emu: dynamic LDS %zu too large\n", lds_bytes); abort(); }
   const int nthreads = static_cast<int>(block.x * block.y * block.z);
@@ -180,6 +203,7 @@ inline void launch(const std::function<void()>& kernel_body, dim3 grid, dim3 blo
         blk.bid = dim3(bx, by, bz);
         blk.alive = nthreads; blk.arrived = 0; blk.gen = 0;
         blk.waves.assign((nthreads + kWaveSize - 1) / kWaveSize, Wave());
+        for (auto& dq : dma_queues()) dq.clear();
         for (int t = 0; t < nthreads; ++t) {
           Fiber& f = fibers[t];
           f.done = false;

@@ -23,7 +23,7 @@ def _rois(rng, K, N, H, W, scale):
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_emu_fuzz_roi_align(seed, monkeypatch):
+def test_emu_fuzz_roi_align(seed):
     rng = np.random.RandomState(1000 + seed)
     N = int(rng.randint(1, 3))
     C = int(rng.choice([1, 3, 4, 5, 16, 17, 33]))
@@ -39,13 +39,16 @@ def test_emu_fuzz_roi_align(seed, monkeypatch):
     g = rng.randn(K, C, ph, pw).astype(np.float32)
     ref = oracle.roi_align_backward(g, rois, scale, ph, pw, N, C, H, W, sr, acc64=True)
     tol = 2e-5 * max(1.0, np.abs(ref).max())
-    for impl in ("gather", "tile"):
-        monkeypatch.setenv("DETOPS_ROIALIGN_BWD", impl)
+    impls = [("scan", 2), ("atomic", 3)] + ([("ring", 1)] if (ph, pw) in ((7, 7), (14, 14)) else [])
+    for name, impl in impls:
+        emu.tuning_set("roi_bwd_impl", impl)
+        if impl == 1:
+            emu.tuning_set("roi_bwd_seg", 8 + seed % 3)        # split whatever is crowded
         got = emu.roi_align_backward(g, rois, scale, ph, pw, N, C, H, W, sr)
-        assert np.abs(got - ref).max() <= tol, impl
+        assert np.abs(got - ref).max() <= tol, name
     if seed % 3 == 0:
-        monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "gather")
-        monkeypatch.setenv("DETOPS_ROIALIGN_BWD_GROUPS", "5")
+        emu.tuning_set("roi_bwd_impl", 2)
+        emu.tuning_set("roi_bwd_groups", 5)
         got = emu.roi_align_backward(g, rois, scale, ph, pw, N, C, H, W, sr)
         assert np.abs(got - ref).max() <= tol, "ROI-list split"
 

@@ -18,9 +18,9 @@ def _edge_rois():
                      [0, 100, 100, 100, 100], [0, 223, 223, 224, 224], [0, -17, 5, 3, 40]], np.float32)
 
 
-@pytest.fixture(params=["gather", "tile"])
-def bwd_impl(request, monkeypatch):
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", request.param)
+@pytest.fixture(params=["scan", "atomic"])
+def bwd_impl(request):
+    emu.tuning_set("roi_bwd_impl", {"scan": 2, "atomic": 3}[request.param])
     return request.param
 
 
@@ -43,11 +43,11 @@ def test_emu_roi_align_backward_small_map(ph, pw, sr, bwd_impl):
 
 
 @pytest.mark.parametrize("ct", ["4", "16"])
-def test_emu_roi_align_backward_tile_seams_accumulate_and_chunking(ct, monkeypatch):
+def test_emu_roi_align_backward_tile_seams_accumulate_and_chunking(ct):
     """multi-tile odd-sized maps, 2 images, channel count not a multiple of the chunk, > 256 ROIs
     (two scan rounds), the accumulate flag, K = 0."""
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "gather")
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_CT", ct)
+    emu.tuning_set("roi_bwd_impl", 2)
+    emu.tuning_set("roi_bwd_scan_ct", int(ct))
     rng = np.random.RandomState(11)
     N, C, H, W = 2, 6 if ct == "4" else 21, 27, 70
     K = 300
@@ -91,14 +91,14 @@ def test_emu_roi_align_fpn_fused_levels(bwd_impl):
         assert np.abs(gins[l] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("impl", ["dma+order", "dma", "lds"])
-def test_emu_roi_align_fpn_forward_visiting_order_and_staging_variants(impl, monkeypatch):
+@pytest.mark.parametrize("impl", ["dma+order", "dma", "generic"])
+def test_emu_roi_align_fpn_forward_visiting_order_and_staging_variants(impl):
     """K >= 384 switches the ROI ranking pre-pass on (poisoned workspace: every order slot must be written, and
-    the order must be a permutation — a lost or duplicated ROI leaves NaN rows); the LDS-DMA and the
-    register-staged kernels are bit-equal to the oracle, border pieces (replicated column / row) included."""
-    if impl == "lds":
-        monkeypatch.setenv("DETOPS_ROIALIGN_FWD", "lds")
-    monkeypatch.setenv("DETOPS_ROIALIGN_FWD_ORDER", "0" if impl == "dma" else "force")   # force: rank although the maps are tiny
+    the order must be a permutation — a lost or duplicated ROI leaves NaN rows); the LDS-DMA and the generic
+    gather kernels are bit-equal to the oracle, border pieces (replicated column / row) included."""
+    if impl == "generic":
+        emu.tuning_set("roi_fwd_impl", 1)
+    emu.tuning_set("roi_fwd_order", 1 if impl != "dma+order" else 2)   # 2: rank although the maps are tiny
     rng = np.random.RandomState(11)
     shapes = [(2, 3, 50, 84), (2, 3, 25, 42), (2, 3, 13, 21), (2, 3, 7, 11)]
     feats = [rng.randn(*s).astype(np.float32) for s in shapes]
@@ -123,11 +123,11 @@ def test_emu_roi_align_fpn_forward_visiting_order_and_staging_variants(impl, mon
 
 
 @pytest.mark.parametrize("K", [384, 385, 415, 1025, 4096])
-def test_emu_roi_order_prepass_is_a_permutation_at_its_size_limits(K, monkeypatch):
+def test_emu_roi_order_prepass_is_a_permutation_at_its_size_limits(K):
     """ranking pre-pass at the smallest / largest ROI counts it serves and at counts that are not a multiple of
     its 32-key LDS padding; duplicate ROIs and ROIs with NaN / huge coordinates (the key only has to be SOME
     number: any permutation is correct, a lost ROI would leave its output rows NaN-poisoned)"""
-    monkeypatch.setenv("DETOPS_ROIALIGN_FWD_ORDER", "force")
+    emu.tuning_set("roi_fwd_order", 2)
     rng = np.random.RandomState(K)
     feats = [rng.randn(1, 2, 20, 30).astype(np.float32), rng.randn(1, 2, 10, 15).astype(np.float32)]
     scales = [0.25, 0.125]
@@ -324,13 +324,13 @@ def test_emu_deform_psroi_pool(no_trans, ncls, D, G, P, part, S, std):
 
 
 @pytest.mark.parametrize("groups", [None, "3", "7"])
-def test_emu_roi_align_backward_roi_list_split(groups, monkeypatch):
+def test_emu_roi_align_backward_roi_list_split(groups):
     """small maps split the ROI list over blockIdx.y (partials combined with atomics on the
     pre-zeroed map): automatic (K = 100 on a 14x14 map -> 4 groups) and forced group counts,
     with and without the accumulate flag."""
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "gather")
+    emu.tuning_set("roi_bwd_impl", 2)
     if groups:
-        monkeypatch.setenv("DETOPS_ROIALIGN_BWD_GROUPS", groups)
+        emu.tuning_set("roi_bwd_groups", int(groups))
     inp, rois, scale = synth.cfg1_roi_align(K=100, C=6)
     rois = np.concatenate([rois, _edge_rois()])
     for (ph, pw, sr) in ((7, 7, 2), (14, 14, 2), (3, 5, 0)):
@@ -344,10 +344,10 @@ def test_emu_roi_align_backward_roi_list_split(groups, monkeypatch):
 
 
 @pytest.mark.parametrize("ct", ["4", "16"])
-def test_emu_roi_align_backward_lane_walk(ct, monkeypatch):
-    """per-lane bin-range walk of the pixel-owner kernel on ragged ROIs / bin shapes, both channel chunkings."""
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "gather")
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_CT", ct)
+def test_emu_roi_align_backward_lane_walk(ct):
+    """per-lane bin-range walk of the scan pixel-owner kernel on ragged ROIs / bin shapes, both channel chunkings."""
+    emu.tuning_set("roi_bwd_impl", 2)
+    emu.tuning_set("roi_bwd_scan_ct", int(ct))
     rng = np.random.RandomState(31)
     N, C, H, W = 2, 9, 27, 70
     K = 90
@@ -363,15 +363,15 @@ def test_emu_roi_align_backward_lane_walk(ct, monkeypatch):
         assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("ct,batch", [("16", None), ("32", None), ("16", "1"), ("16", "2"), ("32", "3")])
-def test_emu_roi_align_backward_binned(ct, batch, monkeypatch):
-    """binned pixel-owner backward (pre-pass adjoint rows + per-tile hit lists in a poisoned workspace):
-    ragged ROIs / bin shapes, adaptive sampling, channel tails, accumulate mode, both channel chunkings;
-    `batch` caps the hits staged per batch so that every workgroup runs through several stage / walk rounds."""
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "binned")
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_CT", ct)
-    if batch:
-        monkeypatch.setenv("DETOPS_ROIALIGN_BWD_BATCH", batch)
+@pytest.mark.parametrize("seg", [None, 8, 9])
+def test_emu_roi_align_backward_ring(seg):
+    """ring pixel-owner backward (pre-pass adjoint rows + per-tile hit lists in a poisoned workspace, LDS-DMA ring
+    with counted waits — the emulation lands a staged piece only at a covering wait): ragged ROIs, slivers (bin
+    ranges longer than 3), channel tails, accumulate mode; `seg` = 8 / 9 splits the crowded tiles into segments
+    whose partial sums the last arriver combines."""
+    emu.tuning_set("roi_bwd_impl", 1)
+    if seg:
+        emu.tuning_set("roi_bwd_seg", seg)
     rng = np.random.RandomState(51)
     N, C, H, W = 2, 37, 27, 70           # 37 channels: ragged last chunk; 27 x 70: partial edge tiles
     K = 90
@@ -380,46 +380,53 @@ def test_emu_roi_align_backward_binned(ct, batch, monkeypatch):
     rois = np.stack([rng.randint(0, N, K), x1, y1, x1 + rng.uniform(0.2, 120, K), y1 + rng.uniform(0.2, 60, K)],
                     1).astype(np.float32)
     rois = np.concatenate([rois, _edge_rois()])
-    for (ph, pw, sr) in ((7, 7, 2), (14, 14, 2), (5, 3, 0), (16, 16, 1), (8, 4, 2)):
+    for (ph, pw, sr) in ((7, 7, 2), (14, 14, 2), (7, 7, 0), (14, 14, 1)):
         g = rng.randn(rois.shape[0], C, ph, pw).astype(np.float32)
         ref = oracle.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, acc64=True)
         emu.stats(reset=True)
         out = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr)
-        assert emu.stats().get("bwdb.workgroups", 0) > 0, "the binned kernel did not run"
+        st = emu.stats()
+        assert st.get("bwdr.units", 0) > 0, "the ring kernel did not run"
+        if seg:
+            assert st.get("bwdr.combines", 0) > 0, "expected split tiles"
         tol = 1e-5 * max(1.0, np.abs(ref).max())
         assert np.abs(out - ref).max() <= tol
+        assert np.array_equal(out, emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr))   # run-to-run identical
         base = rng.randn(N, C, H, W).astype(np.float32)
         acc = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, into=base)
         assert np.abs(acc - (base + ref)).max() <= 2 * tol
 
 
-def test_emu_roi_align_backward_binned_matches_scan_kernel_bitwise_and_handles_crowded_tiles(monkeypatch):
-    """same coefficient arithmetic and visiting order as the scan kernel -> identical bits; a tile hit by more
-    ROIs than one list round (256) and more than one batch; FPN entry point with empty levels."""
+def test_emu_roi_align_backward_ring_crowded_tiles_and_fpn_levels():
+    """a tile hit by hundreds of ROIs: the split is capped at 8 segments, each longer than one LDS round of hit
+    entries (64); a refused split (more crowded tiles than partial-sum slots) leaves long unsplit lists; the FPN
+    entry point with an empty level."""
     rng = np.random.RandomState(52)
     N, C, H, W = 1, 16, 12, 40
-    K = 300
+    K = 700
     x1 = rng.uniform(0, 30, K)
     y1 = rng.uniform(0, 8, K)
     rois = np.stack([np.zeros(K), x1, y1, x1 + rng.uniform(1, 10, K), y1 + rng.uniform(1, 4, K)], 1).astype(np.float32)
     g = rng.randn(K, C, 7, 7).astype(np.float32)
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "gather")
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_GROUPS", "1")   # no ROI-list split: one sequential sum per pixel
-    scan = emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2)
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", "binned")
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD_DEBUG", "32")   # direct walk: the scan kernel's summation order
-    emu.stats(reset=True)
-    binned = emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2)
-    st = emu.stats()
-    assert st.get("bwdb.rounds", 0) > 0, "expected a tile with more hits than one list round (64)"
-    assert np.array_equal(scan, binned)
     ref = oracle.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2, acc64=True)
-    assert np.abs(binned - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
-    monkeypatch.delenv("DETOPS_ROIALIGN_BWD_DEBUG")         # default: the separable two-pass walk (7 bin columns)
-    sep = emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2)
-    assert not np.array_equal(sep, binned), "expected the two-pass walk to round differently from the direct one"
-    assert np.abs(sep - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
-    assert np.array_equal(sep, emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2))   # run-to-run identical
+    tol = 2e-5 * max(1.0, np.abs(ref).max())
+    emu.tuning_set("roi_bwd_impl", 1)
+    emu.tuning_set("roi_bwd_seg", 8)
+    emu.stats(reset=True)
+    out = emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2)
+    st = emu.stats()
+    assert st.get("bwdr.combines", 0) > 0 and st.get("bwdr.rounds", 0) > 0, st
+    assert np.abs(out - ref).max() <= tol
+    emu.tuning_set("roi_bwd_seg", 0)
+    out = emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2)
+    assert np.abs(out - ref).max() <= tol
+    emu.tuning_set("roi_bwd_impl", 2)
+    emu.tuning_set("roi_bwd_groups", 1)
+    scan = emu.roi_align_backward(g, rois, 1.0, 7, 7, N, C, H, W, 2)
+    assert np.abs(scan - ref).max() <= tol
+    emu.tuning_set("roi_bwd_impl", 1)
+    emu.tuning_set("roi_bwd_groups", 0)
+    rng = np.random.RandomState(53)
     # multi-level entry, one level without any ROI
     shapes = [(2, 8, 50, 84), (2, 8, 25, 42), (2, 8, 13, 21), (2, 8, 7, 11)]
     scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]

@@ -33,6 +33,11 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name), allow_pickle=False)
 
 
+def _tune(key, value):
+    from maskrcnn_benchmark import _lib
+    _lib.tuning_set(key, value)
+
+
 def _close(a, b, rtol=1e-4, atol=1e-5):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
@@ -82,7 +87,7 @@ def test_roi_align_forward_fpn_full_size_and_fused():
     assert np.array_equal(out.cpu().numpy(), expected)
 
 
-def test_roi_align_forward_variants_bit_equal(monkeypatch):
+def test_roi_align_forward_variants_bit_equal():
     """The ROI ranking pre-pass only changes the order workgroups visit the ROIs in, the LDS-DMA kernel only how
     the footprint reaches LDS: every variant gives the same bits (cfg-2 box head and cfg-3 mask head, full size)."""
     feats = [torch.randn(2, 256, h, w, device=DEV) for (h, w) in synth.fpn_shapes()[:4]]
@@ -91,21 +96,22 @@ def test_roi_align_forward_variants_bit_equal(monkeypatch):
         rois = _t(synth.fpn_rois(per_image=K // 2))
         base, lv = _C().roi_align_fpn_forward(feats, rois, scales, ph, ph, 2, 2, 5)
         assert torch.isfinite(base).all()
-        for env in ({"DETOPS_ROIALIGN_FWD_ORDER": "0"}, {"DETOPS_ROIALIGN_FWD_ORDER": "force", "DETOPS_ROIALIGN_FWD_ORDER_MINK": "64"},
-                    {"DETOPS_ROIALIGN_FWD": "lds"}, {"DETOPS_ROIALIGN_FWD": "generic"},
-                    {"DETOPS_ROIALIGN_FWD_CT": "64", "DETOPS_ROIALIGN_FWD_BUF_KB": "5"}):
-            with monkeypatch.context() as m:
-                for k, v in env.items():
-                    m.setenv(k, v)
-                out, lv2 = _C().roi_align_fpn_forward(feats, rois, scales, ph, ph, 2, 2, 5)
+        from maskrcnn_benchmark import _lib
+        for env in ({"roi_fwd_order": 1}, {"roi_fwd_order": 2, "roi_fwd_order_mink": 64}, {"roi_fwd_impl": 1}):
+            for k, v in env.items():
+                _lib.tuning_set(k, v)
+            out, lv2 = _C().roi_align_fpn_forward(feats, rois, scales, ph, ph, 2, 2, 5)
+            for k in env:
+                _lib.tuning_set(k, 0)
             assert torch.equal(out, base) and torch.equal(lv, lv2), env
 
 
 @pytest.mark.parametrize("K", [384, 415, 4096, 4097])
-def test_roi_align_forward_ranking_prepass_size_limits(K, monkeypatch):
+def test_roi_align_forward_ranking_prepass_size_limits(K):
     """ROI counts at the edges of the ranking pre-pass (384 .. 4096; 4097 runs unranked), not multiples of its
     LDS padding, duplicates included: bit-equal to the oracle either way"""
-    monkeypatch.setenv("DETOPS_ROIALIGN_FWD_ORDER", "force")
+    from maskrcnn_benchmark import _lib
+    _lib.tuning_set("roi_fwd_order", 2)
     rng = np.random.RandomState(K)
     feats = [rng.randn(2, 8, 50, 84).astype(np.float32), rng.randn(2, 8, 25, 42).astype(np.float32)]
     scales = [0.25, 0.125]
@@ -140,12 +146,13 @@ def test_roi_align_forward_edge_cases():
 
 
 # ============================================================================ ROIAlign backward
-@pytest.fixture(params=["binned", "gather", "tile"])
-def bwd_impl(request, monkeypatch):
-    """The three backward kernels behind the same entry points: the binned pixel-owner kernel (default for
-    filled launches), the scan pixel-owner kernel (small maps) and the LDS-scatter tile kernel
-    (DETOPS_ROIALIGN_BWD is read per call)."""
-    monkeypatch.setenv("DETOPS_ROIALIGN_BWD", request.param)
+@pytest.fixture(params=["ring", "scan", "atomic"])
+def bwd_impl(request):
+    """The three backward kernels behind the same entry points: the ring pixel-owner kernel (default for filled
+    launches of the model's bin shapes; forced here also for under-filled ones), the scan pixel-owner kernel (small
+    maps, other shapes) and the atomic scatter kernel (universal fallback).  tests/conftest.py resets the switch."""
+    from maskrcnn_benchmark import _lib
+    _lib.tuning_set("roi_bwd_impl", {"ring": 1, "scan": 2, "atomic": 3}[request.param])
     return request.param
 
 
@@ -584,7 +591,7 @@ def _dcn_case(g, modulated, seed=3):
 
 @pytest.mark.parametrize("gi", range(len(GEOMS)))
 @pytest.mark.parametrize("modulated", [False, True])
-def test_deformable_kernels_vs_oracle_fp32(gi, modulated, monkeypatch):
+def test_deformable_kernels_vs_oracle_fp32(gi, modulated):
     C = _C()
     g = GEOMS[gi]
     x, off, mask, _ = _dcn_case(g, modulated)
@@ -597,22 +604,22 @@ def test_deformable_kernels_vs_oracle_fp32(gi, modulated, monkeypatch):
     _close(col, ref_col, rtol=1e-5, atol=1e-5)
     gcol = np.random.RandomState(9).randn(*ref_col.shape).astype(np.float32)
     gim = torch.zeros(*x.shape, device=DEV)
-    monkeypatch.setenv("DETOPS_DCN_COL2IM", "gather")       # inverted-index gather (no data atomics)
+    _tune("dcn_col2im", 1)      # inverted-index gather (no data atomics)
     C.deformable_col2im(_t(gcol), _t(off), tm, gim, *geo)
     ref_gim = oracle.deformable_col2im(gcol, off, mask, *x.shape, **ogeo)
     _close(gim, ref_gim, rtol=1e-4, atol=1e-4)
     gim2 = torch.zeros(*x.shape, device=DEV)
     C.deformable_col2im(_t(gcol), _t(off), tm, gim2, *geo)
     assert torch.equal(gim, gim2), "gather col2im must be deterministic"
-    monkeypatch.setenv("DETOPS_DCN_COL2IM", "scatter")      # the atomic LDS-window kernel
+    _tune("dcn_col2im", 2)      # the atomic LDS-window kernel
     gim3 = torch.zeros(*x.shape, device=DEV)
     C.deformable_col2im(_t(gcol), _t(off), tm, gim3, *geo)
     _close(gim3, ref_gim, rtol=1e-4, atol=1e-4)
-    monkeypatch.setenv("DETOPS_DCN_COL2IM", "ell")          # fixed-width inverted index
+    _tune("dcn_col2im", 3)      # fixed-width inverted index
     gim5 = torch.zeros(*x.shape, device=DEV)
     C.deformable_col2im(_t(gcol), _t(off), tm, gim5, *geo)
     _close(gim5, ref_gim, rtol=1e-4, atol=1e-4)
-    monkeypatch.delenv("DETOPS_DCN_COL2IM")                 # default: chosen by dtype / map size
+    _tune("dcn_col2im", 0)      # default: chosen by dtype / map size
     gim4 = torch.zeros(*x.shape, device=DEV)
     C.deformable_col2im(_t(gcol), _t(off), tm, gim4, *geo)
     _close(gim4, ref_gim, rtol=1e-4, atol=1e-4)
@@ -819,7 +826,7 @@ def test_frozen_bn_fused_half(dtype):
 @pytest.mark.parametrize("shape", CFG5_SHAPES)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("modulated", [False, True])
-def test_deform_conv_fused_mfma_forward_cfg5_shapes(shape, dtype, modulated, monkeypatch):
+def test_deform_conv_fused_mfma_forward_cfg5_shapes(shape, dtype, modulated):
     """the fused implicit-GEMM forward (v_mfma_f32_32x32x16_{f16,bf16}, columns never written) at the cfg-5 layer
     shapes: <= 2e-2 of the output scale against the fp32 oracle on the same rounded inputs, and within half-precision
     accumulation noise of the unfused im2col + GEMM path."""
@@ -836,7 +843,7 @@ def test_deform_conv_fused_mfma_forward_cfg5_shapes(shape, dtype, modulated, mon
             return modulated_deform_conv(hx, hoff, hmask, hw, hb, 1, 1, 1, 1, 1)
         return deform_conv(hx, hoff, hw, 1, 1, 1, 1, 1)
 
-    monkeypatch.setenv("DETOPS_DCN_FUSED", "force")   # also where the dispatch rule prefers im2col + GEMM
+    _tune("dcn_fused", 1)   # also where the dispatch rule prefers im2col + GEMM
     from maskrcnn_benchmark import _C
     timer = _C.KernelTimer()
     _C.KERNEL_TIMER = timer
@@ -844,7 +851,7 @@ def test_deform_conv_fused_mfma_forward_cfg5_shapes(shape, dtype, modulated, mon
     _C.KERNEL_TIMER = None
     torch.cuda.synchronize()
     assert any(k.startswith("dcn_fused_fwd") for k in timer.results()), "the fused kernel did not run"
-    monkeypatch.setenv("DETOPS_DCN_FUSED", "0")
+    _tune("dcn_fused", 2)
     y0 = run()
     f = lambda t: None if t is None else t.float().cpu().numpy()  # noqa: E731
     ref = oracle.deform_conv_forward(f(hx), f(hoff), f(hmask), f(hw), f(hb), **_OG)

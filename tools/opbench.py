@@ -51,8 +51,11 @@ def _entry(name, us, alg_bytes, extra=None):
     return e
 
 
-FWD_SWEEP_KB = os.environ.get("OPBENCH_FWD_KB", "16").split(",")
-FWD_SWEEP_WPS = os.environ.get("OPBENCH_FWD_WPS", "5").split(",")
+def tune(key, value):
+    """library tuning / test switch (include/detops.h: detops_tuning_set)"""
+    from maskrcnn_benchmark import _lib
+    _lib.tuning_set(key, value)
+
 
 
 def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False, experimental=False):
@@ -72,11 +75,11 @@ def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False, experiment
             g = torch.randn(K, Cc, ph, pw, device="cuda")
             us = dev_time_us(lambda: C.roi_align_backward(g, tr, scale, ph, pw, 1, Cc, 14, 14, sr), iters)
             out.append(_entry(f"roi_align_bwd cfg1 {ph}x{pw} sr{sr} (gather, ROI list split over 32 groups)", us, alg))
-            for grp in ("1", "16"):
-                os.environ["DETOPS_ROIALIGN_BWD_GROUPS"] = grp
+            for grp in (1, 16):
+                tune("roi_bwd_groups", grp)
                 us = dev_time_us(lambda: C.roi_align_backward(g, tr, scale, ph, pw, 1, Cc, 14, 14, sr), max(3, iters // 5))
                 out.append(_entry(f"roi_align_bwd cfg1 {ph}x{pw} sr{sr} [groups={grp}]", us, alg))
-            del os.environ["DETOPS_ROIALIGN_BWD_GROUPS"]
+            tune("roi_bwd_groups", 0)
     # cfg-2 box head: 1024 ROIs over P2..P5, 7x7 sr2; cfg-3 mask head: 256 ROIs, 14x14 sr2 ----
     feats = [torch.randn(2, 256, h, w, device="cuda") for (h, w) in synth.fpn_shapes()[:4]]
     scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
@@ -101,48 +104,60 @@ def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False, experiment
                 out.append(_entry(f"roi_align_fwd fpn-per-level(4 launches) {tag}", us, alg))
         if "fwd" in which and not fused_only:
             base = C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]
-            os.environ["DETOPS_ROIALIGN_FWD_ORDER"] = "0"
-            us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
-            same = bool(torch.equal(base, C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]))
-            del os.environ["DETOPS_ROIALIGN_FWD_ORDER"]
-            out.append(_entry(f"roi_align_fwd fpn-fused {tag} [LDS-DMA, ROIs in caller order (no ranking pre-pass)]", us, alg,
-                              {"bit_equal_to_default": same}))
-            os.environ["DETOPS_ROIALIGN_FWD"] = "lds"
-            us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
-            same = bool(torch.equal(base, C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]))
-            del os.environ["DETOPS_ROIALIGN_FWD"]
-            out.append(_entry(f"roi_align_fwd fpn-fused {tag} [register-staged r01 kernel]", us, alg, {"bit_equal_to_default": same}))
-            for kb in FWD_SWEEP_KB:
-                for wps in FWD_SWEEP_WPS:
-                    os.environ["DETOPS_ROIALIGN_FWD_BUF_KB"], os.environ["DETOPS_ROIALIGN_FWD_WPS"] = kb, wps
-                    us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
-                    same = bool(torch.equal(base, C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]))
-                    out.append(_entry(f"roi_align_fwd fpn-fused {tag} [LDS-DMA 2x{kb} KB, {wps} waves/SIMD budget]", us, alg,
-                                      {"bit_equal_to_default": same}))
-                    del os.environ["DETOPS_ROIALIGN_FWD_BUF_KB"], os.environ["DETOPS_ROIALIGN_FWD_WPS"]
+            for label, key, val in (("LDS-DMA, ROIs in caller order (no ranking pre-pass)", "roi_fwd_order", 1),
+                                    ("generic gather kernel", "roi_fwd_impl", 1)):
+                tune(key, val)
+                us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
+                same = bool(torch.equal(base, C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5)[0]))
+                tune(key, 0)
+                out.append(_entry(f"roi_align_fwd fpn-fused {tag} [{label}]", us, alg, {"bit_equal_to_default": same}))
         if "bwd" in which:
             g = torch.randn(K, 256, ph, ph, device="cuda")
             tl = _t(lv)
             us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
-            out.append(_entry(f"roi_align_bwd fpn-fused binned pixel-owner (atomic-free, incl. pre-pass + zero-fill) {tag}", us, alg))
+            out.append(_entry(f"roi_align_bwd fpn-fused ring pixel-owner (atomic-free, incl. pre-pass + zero-fill) {tag}", us, alg))
             if fused_only:
                 continue
             ref_g = C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2)
-            os.environ["DETOPS_ROIALIGN_BWD_CT"] = "32"
-            us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
-            got = C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2)
-            del os.environ["DETOPS_ROIALIGN_BWD_CT"]
-            out.append(_entry(f"roi_align_bwd fpn-fused binned CT=32 {tag}", us, alg,
-                              {"max_abs_diff_vs_default": max(float((a - b).abs().max()) for a, b in zip(ref_g, got))}))
-            os.environ["DETOPS_ROIALIGN_BWD"] = "gather"
-            us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
-            got = C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2)
-            out.append(_entry(f"roi_align_bwd fpn-fused scan pixel-owner (r01 kernel + lane walk) {tag}", us, alg,
-                              {"bit_equal_to_default": all(bool(torch.equal(a, b)) for a, b in zip(ref_g, got))}))
-            os.environ["DETOPS_ROIALIGN_BWD"] = "tile"
-            us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), max(3, iters // 5))
-            del os.environ["DETOPS_ROIALIGN_BWD"]
-            out.append(_entry(f"roi_align_bwd fpn-fused tile (LDS atomics) {tag}", us, alg))
+            for label, key, val in (("ring, hit lists never split", "roi_bwd_seg", 1 << 20), ("ring, segments of 16 hits", "roi_bwd_seg", 16),
+                                    ("scan pixel-owner (no pre-pass)", "roi_bwd_impl", 2), ("atomic scatter", "roi_bwd_impl", 3)):
+                tune(key, val)
+                us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), max(3, iters // 5))
+                got = C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2)
+                tune(key, 0)
+                out.append(_entry(f"roi_align_bwd fpn-fused [{label}] {tag}", us, alg,
+                                  {"max_abs_diff_vs_default": max(float((a - b).abs().max()) for a, b in zip(ref_g, got))}))
+    return out
+
+
+def bench_roi_sets(C, iters, model_npz=None, only_sets=None, only_heads=None, which=("fwd", "bwd")):
+    """FPN-fused ROIAlign forward / backward on every ROI set of synth.roi_sets(): the SURVEY 8d log-uniform set, the
+    trained-like set and the sets the detector itself produced (tools/dump_model_rois.py) - VERDICT r02 item 1a."""
+    out = []
+    feats = [torch.randn(2, 256, h, w, device="cuda") for (h, w) in synth.fpn_shapes()[:4]]
+    scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
+    shapes = [tuple(f.shape) for f in feats]
+    feat_bytes = sum(f.numel() * 4 for f in feats)
+    for name, sets in synth.roi_sets(model_npz).items():
+        if only_sets and name not in only_sets:
+            continue
+        for head, ph in (("box", 7), ("mask", 14)):
+            if only_heads and head not in only_heads:
+                continue
+            rois = sets[head]
+            K = rois.shape[0]
+            tr = _t(rois)
+            lv = synth.level_map(rois)
+            tl = _t(lv)
+            alg = 4 * K * 256 * ph * ph + feat_bytes + 20 * K
+            g = torch.randn(K, 256, ph, ph, device="cuda")
+            extra = {"rois_per_level": np.bincount(lv, minlength=4).tolist()}
+            if "fwd" in which:
+                us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
+                out.append(_entry(f"roi_align_fwd fpn-fused {head}-head K={K} {ph}x{ph} [{name}]", us, alg, extra))
+            if "bwd" in which:
+                us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
+                out.append(_entry(f"roi_align_bwd fpn-fused {head}-head K={K} {ph}x{ph} [{name}]", us, alg, extra))
     return out
 
 
@@ -226,15 +241,15 @@ def bench_dcn_fused(C, iters):
                 C.modulated_deform_conv_forward(x, w, None, bufs[0], off, msk, y, bufs[1], 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, False)
 
             res = {}
-            for tag, env in (("fused MFMA", "force"), ("im2col + GEMM", "0")):
-                os.environ["DETOPS_DCN_FUSED"] = env
+            for tag, env in (("fused MFMA", 1), ("im2col + GEMM", 2)):
+                tune("dcn_fused", env)
                 us = dev_time_us(run, iters)
                 res[tag] = y.float().clone()
                 e = _entry(f"dcn_fwd {tag} C={Cc} {H}x{W} {str(dt)[6:]}", us, 2 * (x.numel() + off.numel() + msk.numel() + y.numel()),
                            {"TFLOPs": round(flops / us / 1e6, 1), "frac_of_2.5PF": round(flops / us / 1e6 / 2500.0, 4),
                             "columns_bytes_unfused": col_bytes})
                 out.append(e)
-            del os.environ["DETOPS_DCN_FUSED"]
+            tune("dcn_fused", 0)
             out[-1]["max_abs_diff_fused_vs_unfused"] = float((res["fused MFMA"] - res["im2col + GEMM"]).abs().max())
     return out
 
@@ -259,25 +274,25 @@ def bench_dcn(C, iters, experimental=False):
             gim = torch.zeros_like(x)
             us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), iters)
             out.append(_entry(f"dcn_col2im default C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg))
-            os.environ["DETOPS_DCN_COL2IM"] = "gather"
+            tune("dcn_col2im", 1)
             us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), max(3, iters // 5))
             out.append(_entry(f"dcn_col2im gather (index+sort+gather, XCD-contiguous) C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg))
-            os.environ["DETOPS_DCN_GATHER_XCD"] = "0"
+            tune("dcn_gather_xcd", 1)
             us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), max(3, iters // 5))
-            del os.environ["DETOPS_DCN_GATHER_XCD"]
+            tune("dcn_gather_xcd", 0)
             out.append(_entry(f"dcn_col2im gather (plain block order) C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg))
-            os.environ["DETOPS_DCN_COL2IM"] = "scatter"
+            tune("dcn_col2im", 2)
             us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), max(3, iters // 5))
-            del os.environ["DETOPS_DCN_COL2IM"]
+            tune("dcn_col2im", 0)
             out.append(_entry(f"dcn_col2im scatter (LDS atomics) C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg))
             if True:
                 ref_g = torch.zeros_like(x)
                 C.deformable_col2im(col, off, None, ref_g, *geo)
-                os.environ["DETOPS_DCN_COL2IM"] = "ell"
+                tune("dcn_col2im", 3)
                 us = dev_time_us(lambda: C.deformable_col2im(col, off, None, gim, *geo), max(3, iters // 5))
                 got = torch.zeros_like(x)
                 C.deformable_col2im(col, off, None, got, *geo)
-                del os.environ["DETOPS_DCN_COL2IM"]
+                tune("dcn_col2im", 0)
                 err = float((got.float() - ref_g.float()).abs().max())
                 out.append(_entry(f"dcn_col2im ELL index C={Cc} {H}x{W} {str(dt)[6:]}{tagx}", us, alg,
                                   {"max_abs_diff_vs_default": err}))
@@ -299,6 +314,10 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--json", default=None)
     ap.add_argument("--only", default="")
+    ap.add_argument("--sets", default="", help="roi_sets: comma list of ROI-set names (default all)")
+    ap.add_argument("--heads", default="", help="roi_sets: box,mask (default both)")
+    ap.add_argument("--dir", default="", help="roi_sets: fwd,bwd (default both)")
+    ap.add_argument("--model-rois", default=None, help="npz of tools/dump_model_rois.py (default: tests/golden/model_rois.npz)")
     ap.add_argument("--experimental", action="store_true",
                     help="also time the opt-in, not-yet-measured kernel variants (DESIGN.md section 7)")
     args = ap.parse_args()
@@ -313,6 +332,9 @@ def main():
         res += bench_roi_align(C, args.iters, experimental=args.experimental)
     if "roi_align_fpn" in only:
         res += bench_roi_align(C, args.iters, fused_only=True)
+    if not only or "roi_sets" in only:
+        res += bench_roi_sets(C, args.iters, args.model_rois, set(filter(None, args.sets.split(","))),
+                              set(filter(None, args.heads.split(","))), tuple(filter(None, args.dir.split(","))) or ("fwd", "bwd"))
     if "roi_align_fwd" in only:
         res += bench_roi_align(C, args.iters, which=("fwd",))
     if not only or "nms" in only:

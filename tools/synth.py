@@ -51,6 +51,53 @@ def fpn_rois(seed=3, per_image=512, n_images=2, smin=16.0, smax=800.0):
     return np.concatenate(out, 0).astype(np.float32)
 
 
+def fpn_rois_trained_like(seed=7, per_image=512, n_images=2, fg_fraction=0.25, n_gt=(8, 20)):
+    """[K,5] rois shaped like the box head's input late in training: per image 8-20 ground-truth boxes
+    (the synthetic COCO-shaped generator's size range), `fg_fraction` of the ROIs are jitters of a
+    ground-truth box (IoU >~ 0.5: centre +-10 % of the side, log-size N(0, 0.15)), the rest are
+    proposal-like boxes clustered AROUND the objects (centre within 1.5 sides, log-size N(0, 0.5)) —
+    what an RPN that has learnt objectness emits — positives first per image, like the sampler."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for b in range(n_images):
+        m = rng.randint(n_gt[0], n_gt[1] + 1)
+        gs = np.exp(rng.uniform(math.log(32), math.log(480), m))
+        gar = rng.uniform(0.5, 2.0, m)
+        gw, gh = gs * np.sqrt(gar), gs / np.sqrt(gar)
+        gcx = rng.uniform(0.1 * IMG_W, 0.9 * IMG_W, m)
+        gcy = rng.uniform(0.1 * IMG_H, 0.9 * IMG_H, m)
+        n_fg = int(round(per_image * fg_fraction))
+        which = rng.randint(0, m, per_image)
+        fg = np.arange(per_image) < n_fg
+        cj = np.where(fg, 0.1, 1.5)
+        sj = np.where(fg, 0.15, 0.5)
+        cx = gcx[which] + rng.uniform(-1, 1, per_image) * cj * gw[which]
+        cy = gcy[which] + rng.uniform(-1, 1, per_image) * cj * gh[which]
+        w = gw[which] * np.exp(rng.randn(per_image) * sj)
+        h = gh[which] * np.exp(rng.randn(per_image) * sj)
+        x1 = np.clip(cx - w / 2, 0, IMG_W - 1)
+        y1 = np.clip(cy - h / 2, 0, IMG_H - 1)
+        x2 = np.clip(cx + w / 2, 0, IMG_W - 1)
+        y2 = np.clip(cy + h / 2, 0, IMG_H - 1)
+        out.append(np.stack([np.full(per_image, b), x1, y1, np.maximum(x2, x1), np.maximum(y2, y1)], 1))
+    return np.concatenate(out, 0).astype(np.float32)
+
+
+def roi_sets(model_npz=None):
+    """name -> {"box": [K,5], "mask": [K',5]} ROI sets for tools/opbench.py: the log-uniform set of SURVEY.md 8d,
+    the trained-like set, and (when the file exists) the sets the detector itself produced in a training step
+    (tools/dump_model_rois.py, committed under tests/golden/model_rois.npz)."""
+    import os
+    sets = {"synthetic-loguniform": {"box": fpn_rois(per_image=512), "mask": fpn_rois(per_image=128)},
+            "trained-like": {"box": fpn_rois_trained_like(per_image=512),
+                             "mask": fpn_rois_trained_like(per_image=128, fg_fraction=1.0)}}
+    path = model_npz or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "model_rois.npz")
+    if os.path.exists(path):
+        z = np.load(path)
+        sets["model-random-init"] = {"box": z["box_rois"].astype(np.float32), "mask": z["mask_rois"].astype(np.float32)}
+    return sets
+
+
 def level_map(rois, k_min=2, k_max=5, s0=224.0, lvl0=4.0, eps=1e-6):
     """LevelMapper (reference modeling/poolers.py:33-42) in fp32, 0-based level index."""
     r = rois.astype(np.float32)
