@@ -88,8 +88,11 @@ def setup_miopen_db(export_dir=None):
 
 
 def algorithmic_bytes(name, feat_bytes):
-    """SURVEY.md §8(d): ROIAlign fwd/bwd = pooled tensor + every pooled feature map once + rois;
-    focal fwd(sum) = logits + targets (+ nothing written), bwd = logits + targets + d_logits."""
+    """SURVEY.md §8(d) per-launch ALGORITHMIC bytes of a hand-written entry point, from the shape in its timer name:
+    ROIAlign fwd/bwd = pooled tensor + every pooled feature map once + rois; focal fwd(sum) = logits + targets, bwd =
+    logits + targets + d_logits; FrozenBN = the activation read once + written once (+ residual / mask reads);
+    deformable im2col / col2im / coord-gradient = input (or gradient) map + offsets (+ mask) + the column matrix;
+    fused deformable forward = input + offsets (+ mask) + output + weights (no columns term)."""
     import re
     m = re.match(r"roi_align_fpn_(fwd|bwd)\[K=(\d+),C=(\d+),(\d+)x(\d+)\]", name)
     if m:
@@ -99,6 +102,46 @@ def algorithmic_bytes(name, feat_bytes):
     if m:
         R, C = int(m.group(2)), int(m.group(3))
         return (4 * R * C + 4 * R) if m.group(1) == "fwd_sum" else (8 * R * C + 4 * R)
+    m = re.match(r"frozen_bn_fwd\[n=(\d+),e=(\d+),res=(\d)\]", name)
+    if m:
+        n, e, res = (int(g) for g in m.groups())
+        return e * n * (2 + res)
+    m = re.match(r"frozen_bn_bwd\[n=(\d+),e=(\d+),res=(\d),relu=(\d)\]", name)
+    if m:
+        n, e, res, relu = (int(g) for g in m.groups())
+        return e * n * (2 + res + relu)
+    m = re.match(r"dcn_(im2col|col2im|col2im_coord)\[B=(\d+),C=(\d+),(\d+)x(\d+),k=(\d+),e=(\d+),m=(\d)\]", name)
+    if m:
+        B, C, H, W, k, e, msk = (int(g) for g in m.groups()[1:])
+        pix = B * H * W        # 3x3 / stride 1 / pad 1 in every model config: Ho x Wo = H x W
+        return e * (B * C * H * W + 2 * k * k * pix + msk * k * k * pix + C * k * k * pix)
+    m = re.match(r"dcn_fused_fwd\[B=(\d+),C=(\d+),(\d+)x(\d+),Cout=(\d+),k=(\d+),e=(\d+),m=(\d)\]", name)
+    if m:
+        B, C, H, W, Co, k, e, msk = (int(g) for g in m.groups())
+        pix = B * H * W
+        return e * (B * C * H * W + 2 * k * k * pix + msk * k * k * pix + B * Co * H * W + Co * C * k * k)
+    return None
+
+
+def rocprof_kernel_us(entry_name):
+    """Average duration of the entry point's main kernel in the newest committed rocprofv3 kernel-trace summary
+    (profiles/*kernel_times*.txt, written by tools/kernel_times.py from `rocprofv3 --kernel-trace` of the same
+    workload) — printed beside the live HIP-event figure so that both can be compared."""
+    import glob
+    import re
+    key = {"roi_align_fpn_bwd": "roi_align_bwd_ring_kernel", "roi_align_fpn_fwd": "roi_align_fwd_dma_kernel",
+           "focal_fwd_sum": "focal_kernel", "focal_bwd_scalar": "focal_kernel", "frozen_bn_fwd": "frozen_bn",
+           "frozen_bn_bwd": "frozen_bn", "dcn_col2im": "col2im", "dcn_im2col": "im2col_kernel",
+           "dcn_col2im_coord": "col2im_coord", "dcn_fused_fwd": "dcn_fused_fwd"}.get(entry_name.split("[")[0])
+    if key is None:
+        return None
+    bins = re.search(r",(\d+)x(\d+)\]", entry_name)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*kernel_times*.txt")), reverse=True):
+        for line in open(path):
+            if key in line and "mean=" in line and (not bins or "roi_align" not in key or ("<%s, %s" % bins.groups()) in line):
+                m = re.search(r"mean=\s*([0-9.]+) us", line)
+                if m:
+                    return {"us": float(m.group(1)), "source": os.path.relpath(path, ROOT)}
     return None
 
 
@@ -411,26 +454,39 @@ def main():
         }
         if timer is not None:
             kernels, dominant = {}, None
-            for name, (count, total_ms) in sorted(timer.results().items()):
+            for name, (calls, timed, total_ms) in sorted(timer.results().items()):
                 b = algorithmic_bytes(name, feat_bytes)
-                mean_us = total_ms / max(count, 1) * 1e3
-                entry = {"launches": count, "mean_us": round(mean_us, 2), "ms_per_step": round(total_ms / args.steps, 4)}
+                mean_us = total_ms / max(timed, 1) * 1e3
+                # sampled entry points (FrozenBN): the per-step figure scales the sampled mean to every call
+                entry = {"launches": calls, "timed": timed, "mean_us": round(mean_us, 2),
+                         "ms_per_step": round(mean_us * calls / args.steps / 1e3, 4)}
                 if b is not None:
                     entry["alg_bytes"] = b
                     entry["achieved_GBs"] = round(b / (mean_us * 1e-6) / 1e9, 1)
-                    if dominant is None or total_ms > dominant[1]:
-                        dominant = (name, total_ms, entry)
                 kernels[name] = entry
+            # one `roofline` entry point: the hand-written kernel FAMILY (name before the shape) with the largest time per
+            # step, represented by its member with the largest time per step
+            fam = {}
+            for name, e in kernels.items():
+                if "alg_bytes" in e:
+                    fam.setdefault(name.split("[")[0], []).append((e["ms_per_step"], name))
+            if fam:
+                best = max(fam.values(), key=lambda members: sum(m[0] for m in members))
+                name = max(best)[1]
+                dominant = (name, kernels[name])
             line["kernels"] = kernels
+            line["kernel_families_ms_per_step"] = {k: round(sum(m[0] for m in v), 4) for k, v in sorted(fam.items())}
             if dominant is not None:
-                name, _, e = dominant
+                name, e = dominant
                 traffic, source = measured_traffic(name)
                 line["roofline"] = {"kernel": name, "bound": "hbm", "achieved": e["achieved_GBs"], "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": round(e["achieved_GBs"] / HBM_PEAK_GBS, 4),
                                     "traffic": traffic,
                                     # the PMC passes are separate rocprofv3 runs (committed table), not this run
                                     "traffic_source": source,
-                                    "alg_bytes_per_launch": e["alg_bytes"], "mean_us": e["mean_us"]}
+                                    "alg_bytes_per_launch": e["alg_bytes"], "mean_us": e["mean_us"],
+                                    "family_ms_per_step": round(sum(m[0] for m in fam[name.split("[")[0]]), 4),
+                                    "rocprof_us": rocprof_kernel_us(name)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()

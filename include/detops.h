@@ -53,6 +53,7 @@ int detops_version(const char** arch);
  *   roi_fwd_impl      1 generic gather kernel    roi_fwd_order     1 never rank | 2 rank even tiny maps
  *   roi_fwd_order_mink  smallest K that gets the ranking pre-pass
  *   dcn_col2im        1 gather | 2 scatter | 3 ell    dcn_fused  1 force | 2 off    dcn_gather_xcd  1 plain block order
+ *   dcn_nhwc          2 = never use the channels-last pipeline (the layers then run the reference-layout kernels)
  * Returns 0, or DETOPS_EINVAL for an unknown key. */
 int detops_tuning_set(const char* key, int value);
 int detops_tuning_get(const char* key, int* value);
@@ -446,6 +447,35 @@ int detops_nms_cpu_f32(const float* boxes, const float* scores, int n, float iou
 int detops_roi_align_forward_cpu_f32(const float* input, const float* rois, float* output, int N, int C,
                                      int H, int W, int K, int PH, int PW, float spatial_scale,
                                      int sampling_ratio);
+
+/* ------------------------------------------------------------------------------------------
+ * Deformable convolution, channels-last pipeline (extension; what the layers use for the model's shapes).
+ *   reference: the same operators as above (csrc/cuda/deform_conv_cuda.cu:158-691), restructured so that every
+ *   per-sampling-point operand is channel-fastest and the GEMMs are plain library GEMMs on those layouts:
+ *     xT [B, H*W, C] = NHWC copy of the input                       detops_nchw_to_nhwc
+ *     colT [B*Ho*Wo, kh*kw, C] deformed (and modulated) columns     detops_deformable_im2col_nhwc
+ *     offset / mask gradients from colsG_T [B*Ho*Wo, kh*kw, C]      detops_deformable_coord_nhwc
+ *     S_T [B*H*W, kh*kw, Cout] = transposed sampling of gT [B, Ho*Wo, Cout] (the NHWC output gradient):
+ *     grad_input[b] = W2T [C, kh*kw*Cout] x S_T[b]^T                 detops_deformable_transposed_sample
+ *   detops_deformable_nhwc_supported: 1 when these kernels serve the shape (deformable_group == 1, C and Cout
+ *   16-byte-vector counts that are powers of two in [16, 256]); otherwise use the reference-layout entry points.
+ *   dtype: DETOPS_F32 / F16 / BF16; offset [B, 2*kh*kw, Ho, Wo] and mask [B, kh*kw, Ho, Wo] (NULL = v1) as above.
+ * ---------------------------------------------------------------------------------------- */
+int detops_nchw_to_nhwc(const void* in, void* out, int dtype, int B, int C, int HW, detops_stream_t stream);
+int detops_deformable_nhwc_supported(int dtype, int C, int Cout, int deformable_group);
+int detops_deformable_im2col_nhwc(const void* xT, const void* offset, const void* mask, void* colT, int dtype,
+                                  int B, int C, int H, int W, int kh, int kw, int pad_h, int pad_w, int stride_h,
+                                  int stride_w, int dil_h, int dil_w, int deformable_group, detops_stream_t stream);
+int detops_deformable_coord_nhwc(const void* colsG_T, const void* xT, const void* offset, const void* mask,
+                                 void* grad_offset, void* grad_mask, int dtype, int B, int C, int H, int W, int kh,
+                                 int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w,
+                                 int deformable_group, detops_stream_t stream);
+size_t detops_deformable_transposed_sample_workspace_bytes(int B, int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
+                                                 int stride_h, int stride_w, int dil_h, int dil_w, int deformable_group);
+int detops_deformable_transposed_sample(const void* gT, const void* offset, const void* mask, void* S_T, int dtype, int B, int C,
+                              int H, int W, int Cout, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                              int dil_h, int dil_w, int deformable_group, void* workspace, size_t workspace_bytes,
+                              detops_stream_t stream);
 
 #ifdef __cplusplus
 } /* extern "C" */

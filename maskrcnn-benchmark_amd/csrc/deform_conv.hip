@@ -1191,6 +1191,353 @@ int dcn_fused_forward(const void* im, const void* weight, const void* offset, co
   return launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------ channels-last pipeline
+// The reference's column matrix is [C * kh * kw, B * Ho * Wo] with the PIXEL index fastest, so one sampling point's
+// channels are B * Ho * Wo elements apart: the im2col store, the col2im gather and the coordinate-gradient reduction
+// all move 2-byte (fp16) elements with a lane stride of a whole row — 1.8 .. 8 % of the HBM peak at the cfg-5 shapes
+// (profiles/r02h_opbench.log).  The kernels below keep every per-sampling-point operand CHANNEL-fastest instead:
+//     xT    [B, H * W, C]                 input, NHWC                       (nchw_to_nhwc_kernel)
+//     colT  [B * Ho * Wo, kh * kw, C]     deformed columns                   (im2col_nhwc_kernel)
+//     gT    [B, Ho * Wo, Cout]            output gradient, NHWC
+//     S_T   [B * H * W, kh * kw, Cout]    "transposed sampling" of gT        (sampleT_gather_kernel)
+// A group of SUB = min(C / V, 64) adjacent lanes owns one pixel and moves its channels as 16-byte vectors (V = 4 fp32 or
+// 8 half elements), so the four bilinear corners of a sampling point are four contiguous runs.  The GEMMs around them
+// are plain library GEMMs on these layouts (the host side: maskrcnn_benchmark/_C.py):
+//     forward        out[b]        = W2 [Cout, K C]  x colT[b]^T
+//     weight grad    dW2           = gT^T [Cout, B HW] x colT [B HW, K C]
+//     column grad    colsG_T       = gT [B HW, Cout] x W2 [Cout, K C]           -> coord_nhwc_kernel (offset / mask gradients)
+//     input grad     grad_in[b]    = W2T [C, K Cout] x S_T[b]^T
+// The input gradient uses the TRANSPOSED sampling operator instead of the reference's scatter (col2im): pixel p of
+// the gradient map gathers, per tap, the output-gradient vectors of the sampling points that touch it (the same
+// fixed-width inverted index as col2im_ell above), and the channel mixing W^T is applied afterwards by the GEMM —
+// the gather moves contiguous Cout-vectors instead of single column elements.  Requires deformable_group == 1, conv
+// groups == 1 and C / V, Cout / V powers of two in [16, 256] (every model shape); anything else stays on the
+// reference-layout kernels above.
+template <typename T> struct VecT;
+template <> struct VecT<float> { static constexpr int N = 4; };
+template <> struct VecT<__half> { static constexpr int N = 8; };
+template <> struct VecT<__hip_bfloat16> { static constexpr int N = 8; };
+
+typedef unsigned int RawV4 __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ void vec_load(const T* p, float* v);
+template <> __device__ __forceinline__ void vec_load<float>(const float* p, float* v) {
+  const float4 r = *reinterpret_cast<const float4*>(p);
+  v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+}
+template <> __device__ __forceinline__ void vec_load<__half>(const __half* p, float* v) {
+  const RawV4 r = *reinterpret_cast<const RawV4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __half2float(__ushort_as_half(static_cast<unsigned short>(r[i] & 0xffffu)));
+    v[2 * i + 1] = __half2float(__ushort_as_half(static_cast<unsigned short>(r[i] >> 16)));
+  }
+}
+template <> __device__ __forceinline__ void vec_load<__hip_bfloat16>(const __hip_bfloat16* p, float* v) {
+  const RawV4 r = *reinterpret_cast<const RawV4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(r[i] << 16);
+    v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ void vec_store(T* p, const float* v);
+template <> __device__ __forceinline__ void vec_store<float>(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void vec_store<__half>(__half* p, const float* v) {
+  RawV4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    r[i] = static_cast<unsigned>(__half_as_ushort(__float2half(v[2 * i]))) |
+           (static_cast<unsigned>(__half_as_ushort(__float2half(v[2 * i + 1]))) << 16);
+  *reinterpret_cast<RawV4*>(p) = r;
+}
+template <> __device__ __forceinline__ void vec_store<__hip_bfloat16>(__hip_bfloat16* p, const float* v) {
+  RawV4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __hip_bfloat16 a = __float2bfloat16(v[2 * i]), b = __float2bfloat16(v[2 * i + 1]);
+    r[i] = static_cast<unsigned>(*reinterpret_cast<const unsigned short*>(&a)) |
+           (static_cast<unsigned>(*reinterpret_cast<const unsigned short*>(&b)) << 16);
+  }
+  *reinterpret_cast<RawV4*>(p) = r;
+}
+
+// [B, C, HW] -> [B, HW, C] through a 32-channel x 64-pixel LDS tile (element size 2 or 4 bytes)
+template <typename U>
+__global__ void __launch_bounds__(kBlock)
+nchw_to_nhwc_kernel(const U* __restrict__ in, U* __restrict__ out, int C, int HW) {
+  __shared__ U tile[32][64 + 4 / sizeof(U)];
+  const int tid = threadIdx.x;
+  const int pblocks = (HW + 63) / 64, cblocks = (C + 31) / 32;
+  int r = blockIdx.x;
+  const int pb = r % pblocks; r /= pblocks;
+  const int cb = r % cblocks;
+  const int b = r / cblocks;
+  const int p0 = pb * 64, c0 = cb * 32;
+  for (int e = tid; e < 32 * 64; e += kBlock) {   // read: pixels fastest
+    const int c = e >> 6, pp = e & 63;
+    tile[c][pp] = (c0 + c < C && p0 + pp < HW) ? in[(static_cast<size_t>(b) * C + c0 + c) * HW + p0 + pp] : U(0);
+  }
+  __syncthreads();
+  for (int e = tid; e < 32 * 64; e += kBlock) {   // write: channels fastest
+    const int pp = e >> 5, c = e & 31;
+    if (c0 + c < C && p0 + pp < HW) out[(static_cast<size_t>(b) * HW + p0 + pp) * C + c0 + c] = tile[c][pp];
+  }
+}
+
+// lanes per pixel / vectors per lane of a channel count (CV = channels / V, a power of two in [16, 256])
+struct NhwcMap { int sub, nv, ppb; };   // ppb = pixels per 256-thread block
+inline bool nhwc_map(int channels, int V, NhwcMap& m) {
+  if (channels % V) return false;
+  const int cv = channels / V;
+  if (cv < 16 || cv > 256 || (cv & (cv - 1))) return false;
+  m.sub = cv < 64 ? cv : 64;
+  m.nv = cv / m.sub;
+  m.ppb = kBlock / m.sub;
+  return true;
+}
+
+// the sampling point (b, tap, ho, wo) of deformable group 0
+template <typename T>
+__device__ __forceinline__ Sample tap_sample(const Geom& g, int b, int tap, int ho, int wo, int pix,
+                                             const T* __restrict__ offset, const T* __restrict__ mask, float& m) {
+  const int K = g.kh * g.kw;
+  const int i = tap / g.kw, j = tap - i * g.kw;
+  const size_t HWo = static_cast<size_t>(g.Ho) * g.Wo;
+  const T* op = offset + static_cast<size_t>(b) * 2 * K * HWo;
+  const float off_h = ld(op + (2 * tap) * HWo + pix), off_w = ld(op + (2 * tap + 1) * HWo + pix);
+  m = mask ? ld(mask + (static_cast<size_t>(b) * K + tap) * HWo + pix) : 1.f;
+  return make_sample(static_cast<float>(ho * g.stride_h - g.pad_h + i * g.dil_h) + off_h,
+                     static_cast<float>(wo * g.stride_w - g.pad_w + j * g.dil_w) + off_w, g.H, g.W);
+}
+
+// colT[q, tap, c] = mask * bilinear(xT[b, :, c]; sampling point (q, tap)), q = b * Ho * Wo + pix
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+im2col_nhwc_kernel(const T* __restrict__ xT, const T* __restrict__ offset, const T* __restrict__ mask,
+                   T* __restrict__ colT, Geom g, int sub, int nv, int64_t npix) {
+  constexpr int V = VecT<T>::N;
+  const int ls = threadIdx.x % sub;
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * (kBlock / sub) + threadIdx.x / sub;
+  if (q >= npix) return;
+  const int HWo = g.Ho * g.Wo, K = g.kh * g.kw;
+  const int b = static_cast<int>(q / HWo), pix = static_cast<int>(q - static_cast<int64_t>(b) * HWo);
+  const int ho = pix / g.Wo, wo = pix - ho * g.Wo;
+  const T* xb = xT + static_cast<size_t>(b) * g.H * g.W * g.C;
+  for (int tap = 0; tap < K; ++tap) {
+    float m;
+    const Sample s = tap_sample(g, b, tap, ho, wo, pix, offset, mask, m);
+    const int idx[4] = {s.i1, s.i2, s.i3, s.i4};
+    const float wgt[4] = {s.w1 * m, s.w2 * m, s.w3 * m, s.w4 * m};
+    T* dst = colT + (static_cast<size_t>(q) * K + tap) * g.C;
+    for (int k = 0; k < nv; ++k) {
+      const int c = (k * sub + ls) * V;
+      float acc[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (idx[t] >= 0) {     // wave-uniform per pixel group only: exec-masked
+          float v[V];
+          vec_load(xb + static_cast<size_t>(idx[t]) * g.C + c, v);
+#pragma unroll
+          for (int e = 0; e < V; ++e) acc[e] = fmaf(wgt[t], v[e], acc[e]);
+        }
+      }
+      vec_store(dst + c, acc);
+    }
+  }
+}
+
+// offset / mask gradients from the column gradient colsG_T [q, tap, c] (channel-fastest) and the NHWC input:
+// get_coordinate_weight / mask gradient of deform_conv_kernel_cuda.cu:152-195, :738-772, summed over the channels
+// by the lanes of a pixel group (butterfly over `sub` adjacent lanes) — the same sums in a different order
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+coord_nhwc_kernel(const T* __restrict__ colsG, const T* __restrict__ xT, const T* __restrict__ offset,
+                  const T* __restrict__ mask, T* __restrict__ grad_offset, T* __restrict__ grad_mask, Geom g,
+                  int sub, int nv, int64_t npix) {
+  constexpr int V = VecT<T>::N;
+  const int ls = threadIdx.x % sub;
+  const int64_t q0 = static_cast<int64_t>(blockIdx.x) * (kBlock / sub) + threadIdx.x / sub;
+  const bool live = q0 < npix;                 // dead groups stay for the wave-wide shuffles
+  const int64_t q = live ? q0 : npix - 1;
+  const int HWo = g.Ho * g.Wo, K = g.kh * g.kw;
+  const int b = static_cast<int>(q / HWo), pix = static_cast<int>(q - static_cast<int64_t>(b) * HWo);
+  const int ho = pix / g.Wo, wo = pix - ho * g.Wo;
+  const T* xb = xT + static_cast<size_t>(b) * g.H * g.W * g.C;
+  const int lane = threadIdx.x & (kWave - 1);
+  for (int tap = 0; tap < K; ++tap) {
+    float m;
+    const Sample s = tap_sample(g, b, tap, ho, wo, pix, offset, mask, m);
+    const int idx[4] = {s.i1, s.i2, s.i3, s.i4};
+    const float hw = 1.f - s.lw, hh = 1.f - s.lh;
+    const float ch[4] = {-hw, -s.lw, hw, s.lw};          // d/dh weights of the four corners
+    const float cw[4] = {-hh, hh, -s.lh, s.lh};          // d/dw
+    const float cm[4] = {s.w1, s.w2, s.w3, s.w4};
+    float gh = 0.f, gw = 0.f, gm = 0.f;
+    if (s.inside) {
+      const T* gp = colsG + (static_cast<size_t>(q) * K + tap) * g.C;
+      for (int k = 0; k < nv; ++k) {
+        const int c = (k * sub + ls) * V;
+        float gv[V];
+        vec_load(gp + c, gv);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (idx[t] >= 0) {
+            float v[V];
+            vec_load(xb + static_cast<size_t>(idx[t]) * g.C + c, v);
+            float dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < V; ++e) dot = fmaf(gv[e], v[e], dot);
+            gh = fmaf(ch[t], dot, gh); gw = fmaf(cw[t], dot, gw); gm = fmaf(cm[t], dot, gm);
+          }
+        }
+      }
+    }
+    for (int o = sub >> 1; o >= 1; o >>= 1) {
+      gh += __shfl(gh, lane ^ o); gw += __shfl(gw, lane ^ o); gm += __shfl(gm, lane ^ o);
+    }
+    if (live && ls == 0) {
+      const size_t HWo_ = static_cast<size_t>(HWo);
+      T* gop = grad_offset + static_cast<size_t>(b) * 2 * K * HWo_;
+      st(gop + (2 * tap) * HWo_ + pix, gh * m);
+      st(gop + (2 * tap + 1) * HWo_ + pix, gw * m);
+      if (mask && grad_mask) st(grad_mask + (static_cast<size_t>(b) * K + tap) * HWo_ + pix, gm);
+    }
+  }
+}
+
+// S_T[p, tap, co] = sum over the sampling points (q, tap) whose bilinear footprint contains gradient-map pixel p of
+// weight * gT[q, co]  (weight = bilinear corner weight x modulation mask, from the fixed-width inverted index)
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+sampleT_gather_kernel(const T* __restrict__ gT, const int32_t* __restrict__ counter, const int32_t* __restrict__ ent_idx,
+                      const float* __restrict__ ent_w, T* __restrict__ S_T, Geom g, int Cout, int sub, int nv, int64_t npix) {
+  constexpr int V = VecT<T>::N;
+  const int ls = threadIdx.x % sub;
+  const int64_t gp = static_cast<int64_t>(blockIdx.x) * (kBlock / sub) + threadIdx.x / sub;   // b * H * W + pixel
+  if (gp >= npix) return;
+  const int HW = g.H * g.W, HWo = g.Ho * g.Wo, K = g.kh * g.kw;
+  const int b = static_cast<int>(gp / HW), p = static_cast<int>(gp - static_cast<int64_t>(b) * HW);
+  for (int tap = 0; tap < K; ++tap) {
+    const size_t col = (static_cast<size_t>(b) * K + tap) * HW + p;             // counter: [img][tap][pixel]
+    const int n = min(counter[col], kEllCap);
+    const int32_t* ei = ent_idx + (static_cast<size_t>(b) * K + tap) * kEllCap * HW + p;
+    const float* ew = ent_w + (static_cast<size_t>(b) * K + tap) * kEllCap * HW + p;
+    int32_t qi[kEllCap];
+    float wi[kEllCap];
+#pragma unroll
+    for (int j = 0; j < kEllCap; ++j) {            // the (<= 8) entries: same addresses across the pixel group
+      qi[j] = j < n ? ei[static_cast<size_t>(j) * HW] - tap * (g.B * HWo) : 0;   // column index -> b * Ho * Wo + pix
+      wi[j] = j < n ? ew[static_cast<size_t>(j) * HW] : 0.f;
+    }
+    T* dst = S_T + (static_cast<size_t>(gp) * K + tap) * Cout;
+    for (int k = 0; k < nv; ++k) {
+      const int co = (k * sub + ls) * V;
+      float acc[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < kEllCap; ++j) {
+        if (j < n) {
+          float v[V];
+          vec_load(gT + static_cast<size_t>(qi[j]) * Cout + co, v);
+#pragma unroll
+          for (int e = 0; e < V; ++e) acc[e] = fmaf(wi[j], v[e], acc[e]);
+        }
+      }
+      vec_store(dst + co, acc);
+    }
+  }
+}
+
+// contributions beyond kEllCap per (pixel, tap): added with atomics after the gather (rare)
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+sampleT_overflow_kernel(const T* __restrict__ gT, const int32_t* __restrict__ ovf_count, const EllOverflow* __restrict__ ovf,
+                        int ovf_cap, T* __restrict__ S_T, Geom g, int Cout) {
+  const int n = min(*ovf_count, ovf_cap);
+  const int HWo = g.Ho * g.Wo, K = g.kh * g.kw;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < static_cast<int64_t>(n) * Cout;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int e = static_cast<int>(i / Cout);
+    const int co = static_cast<int>(i - static_cast<int64_t>(e) * Cout);
+    const EllOverflow o = ovf[e];                 // li = b * H * W + pixel (dg == 1), colidx = tap * B * HWo + q
+    const int tap = o.colidx / (g.B * HWo), q = o.colidx - tap * (g.B * HWo);
+    atomic_add_t(S_T + (static_cast<size_t>(o.li) * K + tap) * Cout + co, o.w * ld(gT + static_cast<size_t>(q) * Cout + co));
+  }
+}
+
+template <typename T>
+int nchw_to_nhwc_t(const void* in, void* out, int B, int C, int HW, hipStream_t st_) {
+  if (static_cast<int64_t>(B) * ((HW + 63) / 64) * ((C + 31) / 32) > 0x7fffffff) return DETOPS_EUNSUPPORTED;
+  const dim3 grid(static_cast<unsigned>(B * ((HW + 63) / 64) * ((C + 31) / 32)));
+  if (sizeof(T) == 4)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<unsigned int>, grid, dim3(kBlock), 0, st_, static_cast<const unsigned int*>(in),
+                       static_cast<unsigned int*>(out), C, HW);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<unsigned short>, grid, dim3(kBlock), 0, st_, static_cast<const unsigned short*>(in),
+                       static_cast<unsigned short*>(out), C, HW);
+  return launch_status();
+}
+
+template <typename T>
+int im2col_nhwc_t(const void* xT, const void* offset, const void* mask, void* colT, const Geom& g, hipStream_t st_) {
+  NhwcMap m;
+  if (g.dg != 1 || !nhwc_map(g.C, VecT<T>::N, m)) return DETOPS_EUNSUPPORTED;
+  const int64_t npix = static_cast<int64_t>(g.B) * g.Ho * g.Wo;
+  if (npix == 0) return 0;
+  hipLaunchKernelGGL(im2col_nhwc_kernel<T>, dim3(static_cast<unsigned>(ceil_div64(npix, m.ppb))), dim3(kBlock), 0, st_,
+                     static_cast<const T*>(xT), static_cast<const T*>(offset), static_cast<const T*>(mask),
+                     static_cast<T*>(colT), g, m.sub, m.nv, npix);
+  return launch_status();
+}
+
+template <typename T>
+int coord_nhwc_t(const void* colsG, const void* xT, const void* offset, const void* mask, void* goff, void* gmask,
+                 const Geom& g, hipStream_t st_) {
+  NhwcMap m;
+  if (g.dg != 1 || !nhwc_map(g.C, VecT<T>::N, m)) return DETOPS_EUNSUPPORTED;
+  const int64_t npix = static_cast<int64_t>(g.B) * g.Ho * g.Wo;
+  if (npix == 0) return 0;
+  hipLaunchKernelGGL(coord_nhwc_kernel<T>, dim3(static_cast<unsigned>(ceil_div64(npix, m.ppb))), dim3(kBlock), 0, st_,
+                     static_cast<const T*>(colsG), static_cast<const T*>(xT), static_cast<const T*>(offset),
+                     static_cast<const T*>(mask), static_cast<T*>(goff), static_cast<T*>(gmask), g, m.sub, m.nv, npix);
+  return launch_status();
+}
+
+template <typename T>
+int sampleT_t(const void* gT, const void* offset, const void* mask, void* S_T, const Geom& g, int Cout, const EllPlan& P,
+              void* ws, hipStream_t st_) {
+  NhwcMap m;
+  if (g.dg != 1 || !nhwc_map(Cout, VecT<T>::N, m)) return DETOPS_EUNSUPPORTED;
+  const int64_t npix = static_cast<int64_t>(g.B) * g.H * g.W;
+  if (npix == 0 || P.npoints_per_dg == 0) return 0;
+  char* w = static_cast<char*>(ws);
+  int32_t* count = reinterpret_cast<int32_t*>(w + P.off_count);
+  int32_t* ovf_count = reinterpret_cast<int32_t*>(w + P.off_ovf_count);
+  int32_t* ent_idx = reinterpret_cast<int32_t*>(w + P.off_idx);
+  float* ent_w = reinterpret_cast<float*>(w + P.off_w);
+  EllOverflow* ovf = reinterpret_cast<EllOverflow*>(w + P.off_ovf);
+  DETOPS_HIP_TRY(hipMemsetAsync(count, 0, P.off_idx - P.off_count, st_));   // counters + overflow counter
+  hipLaunchKernelGGL(col2im_ell_fill_kernel<T>, dim3(static_cast<unsigned>(ceil_div64(P.npoints_per_dg, kBlock)), 1u), dim3(kBlock),
+                     0, st_, static_cast<const T*>(offset), static_cast<const T*>(mask), g, P.npoints_per_dg, count, ent_idx,
+                     ent_w, ovf_count, ovf, P.ovf_cap);
+  hipLaunchKernelGGL(col2im_ell_sort_kernel, dim3(static_cast<unsigned>(ceil_div64(P.ncols, kBlock))), dim3(kBlock), 0, st_,
+                     static_cast<const int32_t*>(count), P.ncols, g.H * g.W, ent_idx, ent_w);
+  hipLaunchKernelGGL(sampleT_gather_kernel<T>, dim3(static_cast<unsigned>(ceil_div64(npix, m.ppb))), dim3(kBlock), 0, st_,
+                     static_cast<const T*>(gT), static_cast<const int32_t*>(count), static_cast<const int32_t*>(ent_idx),
+                     static_cast<const float*>(ent_w), static_cast<T*>(S_T), g, Cout, m.sub, m.nv, npix);
+  hipLaunchKernelGGL(sampleT_overflow_kernel<T>, dim3(kNumCU), dim3(kBlock), 0, st_, static_cast<const T*>(gT),
+                     static_cast<const int32_t*>(ovf_count), static_cast<const EllOverflow*>(ovf), P.ovf_cap,
+                     static_cast<T*>(S_T), g, Cout);
+  return launch_status();
+}
+
 }  // namespace
 
 #define DETOPS_DTYPE_SWITCH(dtype, CALL)                              \
@@ -1333,4 +1680,75 @@ DETOPS_API int detops_deform_conv_forward_fused(const void* im, const void* weig
   if (dtype == DETOPS_F16)
     return dcn_fused_forward<false, __half>(im, weight, offset, mask, bias, out, g, Cout, workspace, as_stream(stream));
   return dcn_fused_forward<true, __hip_bfloat16>(im, weight, offset, mask, bias, out, g, Cout, workspace, as_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------ channels-last pipeline: C ABI
+DETOPS_API int detops_nchw_to_nhwc(const void* in, void* out, int dtype, int B, int C, int HW, detops_stream_t stream) {
+  if (B < 0 || C < 0 || HW < 0) return DETOPS_EINVAL;
+  if (B == 0 || C == 0 || HW == 0) return 0;
+  if (!in || !out) return DETOPS_EINVAL;
+#define CALL(T) nchw_to_nhwc_t<T>(in, out, B, C, HW, as_stream(stream))
+  DETOPS_DTYPE_SWITCH(dtype, CALL)
+#undef CALL
+}
+
+// 1 when the channels-last kernels serve this shape (deformable_group == 1, channels / (16 bytes of elements) a power of
+// two in [16, 256] for both channel counts), else 0: the caller then uses the reference-layout entry points
+DETOPS_API int detops_deformable_nhwc_supported(int dtype, int C, int Cout, int deformable_group) {
+  const int V = dtype == DETOPS_F32 ? 4 : 8;
+  NhwcMap m;
+  return (dtype == DETOPS_F32 || dtype == DETOPS_F16 || dtype == DETOPS_BF16) && deformable_group == 1 &&
+         nhwc_map(C, V, m) && nhwc_map(Cout, V, m);
+}
+
+DETOPS_API int detops_deformable_im2col_nhwc(const void* xT, const void* offset, const void* mask, void* colT, int dtype,
+                                             int B, int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
+                                             int stride_h, int stride_w, int dil_h, int dil_w, int deformable_group,
+                                             detops_stream_t stream) {
+  Geom g;
+  if (int rc = make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, deformable_group)) return rc;
+  if (B == 0) return 0;
+  if (!xT || !offset || !colT) return DETOPS_EINVAL;
+#define CALL(T) im2col_nhwc_t<T>(xT, offset, mask, colT, g, as_stream(stream))
+  DETOPS_DTYPE_SWITCH(dtype, CALL)
+#undef CALL
+}
+
+DETOPS_API int detops_deformable_coord_nhwc(const void* colsG_T, const void* xT, const void* offset, const void* mask,
+                                            void* grad_offset, void* grad_mask, int dtype, int B, int C, int H, int W,
+                                            int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                                            int dil_w, int deformable_group, detops_stream_t stream) {
+  Geom g;
+  if (int rc = make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, deformable_group)) return rc;
+  if (B == 0) return 0;
+  if (!colsG_T || !xT || !offset || !grad_offset) return DETOPS_EINVAL;
+#define CALL(T) coord_nhwc_t<T>(colsG_T, xT, offset, mask, grad_offset, grad_mask, g, as_stream(stream))
+  DETOPS_DTYPE_SWITCH(dtype, CALL)
+#undef CALL
+}
+
+DETOPS_API size_t detops_deformable_transposed_sample_workspace_bytes(int B, int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
+                                                             int stride_h, int stride_w, int dil_h, int dil_w,
+                                                             int deformable_group) {
+  Geom g;
+  if (make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, deformable_group)) return 0;
+  EllPlan P;
+  if (B == 0 || g.dg != 1 || !ell_plan(g, P)) return 0;
+  return P.total;
+}
+
+DETOPS_API int detops_deformable_transposed_sample(const void* gT, const void* offset, const void* mask, void* S_T, int dtype, int B,
+                                         int C, int H, int W, int Cout, int kh, int kw, int pad_h, int pad_w, int stride_h,
+                                         int stride_w, int dil_h, int dil_w, int deformable_group, void* workspace,
+                                         size_t workspace_bytes, detops_stream_t stream) {
+  Geom g;
+  if (int rc = make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, deformable_group)) return rc;
+  if (B == 0) return 0;
+  if (!gT || !offset || !S_T || Cout <= 0) return DETOPS_EINVAL;
+  EllPlan P;
+  if (g.dg != 1 || !ell_plan(g, P)) return DETOPS_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < P.total) return DETOPS_EWORKSPACE;
+#define CALL(T) sampleT_t<T>(gT, offset, mask, S_T, g, Cout, P, workspace, as_stream(stream))
+  DETOPS_DTYPE_SWITCH(dtype, CALL)
+#undef CALL
 }

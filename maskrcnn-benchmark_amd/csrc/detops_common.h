@@ -167,6 +167,7 @@ struct DetopsTuning {
   int dcn_col2im;          // 0 auto | 1 gather | 2 scatter | 3 ell
   int dcn_fused;           // 0 auto | 1 force | 2 off
   int dcn_gather_xcd;      // 0 auto (XCD-contiguous block order) | 1 plain block order
+  int dcn_nhwc;            // 0 auto (channels-last pipeline where supported) | 2 off (reference-layout kernels)
 };
 DetopsTuning& detops_tuning();
 

@@ -17,6 +17,8 @@
 // decisions the reference's CPU arithmetic takes.
 #include <algorithm>
 
+#include <cmath>
+
 #include "detops_common.h"
 
 namespace {
@@ -298,7 +300,9 @@ struct SamplerLayout { size_t off_counts, off_nsurv, off_surv, total; int cap; }
 
 SamplerLayout sampler_layout(int N, int B) {
   SamplerLayout l{};
-  l.cap = 16 * std::max(B, 1);
+  // survivors are at most 2 mu = 2 (k + 8 sqrt(k) + 32) per class (class_threshold), k <= B: 16 B covers that for
+  // B >= 8; tiny batch sizes (unit tests) need the explicit bound or the filter would drop survivors in arrival order
+  l.cap = std::max(16 * std::max(B, 1), 2 * (std::max(B, 1) + 8 * static_cast<int>(std::ceil(std::sqrt(static_cast<double>(std::max(B, 1))))) + 32) + 8);
   size_t o = 0;
   l.off_counts = o; o = up256(o + sizeof(int32_t) * 2 * N);
   l.off_nsurv = o;  o = up256(o + sizeof(int32_t) * 2 * N);

@@ -62,19 +62,24 @@ class _on_device:
 class KernelTimer(object):
     """Optional per-entry-point timing with HIP events recorded on the launch stream (the current
     torch stream of the tensor's device).  bench.py installs one to measure the hand-written
-    kernels live inside the timed region; `results()` must be called after a device sync."""
+    kernels live inside the timed region; `results()` must be called after a device sync.
+    High-frequency entry points (FrozenBN: ~100 launches per step) are SAMPLED — every `every`-th call of a name
+    gets an event pair, all calls are counted — so that the timer's own host cost stays out of the step."""
 
     def __init__(self):
         self.pairs = {}
+        self.calls = {}
 
-    def span(self, name, t):
-        return _Span(self, name, t)
+    def span(self, name, t, every=1):
+        n = self.calls.get(name, 0)
+        self.calls[name] = n + 1
+        return _Span(self, name, t) if n % every == 0 else _NOSPAN
 
     def results(self):
-        """name -> (launches, total_ms)"""
+        """name -> (calls, timed launches, total_ms of the timed launches)"""
         out = {}
         for name, pairs in self.pairs.items():
-            out[name] = (len(pairs), sum(a.elapsed_time(b) for a, b in pairs))
+            out[name] = (self.calls.get(name, len(pairs)), len(pairs), sum(a.elapsed_time(b) for a, b in pairs))
         return out
 
 
@@ -104,8 +109,11 @@ _NOSPAN = _NoSpan()
 KERNEL_TIMER = None  # set to a KernelTimer to collect timings
 
 
-def _timed(name, t):
-    return _NOSPAN if KERNEL_TIMER is None else KERNEL_TIMER.span(name, t)
+def _timed(name, t, every=1):
+    return _NOSPAN if KERNEL_TIMER is None else KERNEL_TIMER.span(name, t, every)
+
+
+_ESIZE = {torch.float32: 4, torch.float16: 2, torch.bfloat16: 2}
 
 
 # ------------------------------------------------------------------------------------------ NMS
@@ -264,11 +272,26 @@ def match_boxes(gt_boxes, gt_valid, boxes, high_threshold, low_threshold, allow_
 _SAMPLER_CALLS = [0]
 
 
+def _next_sampler_seed(device):
+    """64-bit seed of the next sampler call, drawn from the DEVICE generator's (seed, Philox offset) — host-side state,
+    no device op: the stream follows torch.cuda.manual_seed and is saved / restored with the generator state
+    (torch.cuda.get_rng_state in a checkpoint), like the `torch.randperm` the reference's sampler draws from the same
+    generator.  The offset is advanced by 4 per call (one Philox block)."""
+    try:
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        base, off = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(off + 4)
+    except (AttributeError, RuntimeError, IndexError):   # a torch without generator offsets: per-process counter
+        _SAMPLER_CALLS[0] += 1
+        base, off = torch.initial_seed(), _SAMPLER_CALLS[0]
+    return (base * 0x9E3779B97F4A7C15 + off * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
 def sample_labels(labels, batch_size_per_image, max_positives, with_list=False, seed=None):
     """BalancedPositiveNegativeSampler on device (extension; reference
     modeling/balanced_positive_negative_sampler.py:19-68): labels [N,n] float32 or int64 ->
     (pos_mask, neg_mask [N,n] bool[, idx [N,B] int64, valid [N,B] bool]).  The random subset is a pure function
-    of (labels, seed); the default seed advances a per-process counter from torch's initial seed (no device op)."""
+    of (labels, seed); the default seed is drawn from the device generator's seed and Philox offset (no device op)."""
     _need_cuda("sample_labels", labels)
     if labels.dtype not in (torch.float32, torch.int64):
         labels = labels.to(torch.int64)
@@ -276,8 +299,7 @@ def sample_labels(labels, batch_size_per_image, max_positives, with_list=False, 
     N, n = labels.shape
     B = int(batch_size_per_image)
     if seed is None:
-        _SAMPLER_CALLS[0] += 1
-        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SAMPLER_CALLS[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        seed = _next_sampler_seed(labels.device)
     pos = torch.empty((N, n), dtype=torch.uint8, device=labels.device)
     neg = torch.empty((N, n), dtype=torch.uint8, device=labels.device)
     idx = torch.empty((N, B), dtype=torch.int64, device=labels.device) if with_list else None
@@ -306,6 +328,10 @@ def mask_targets(masks, mask_index, boxes, discretization_size):
         code, m = 2, masks.contiguous().view(torch.uint8)
     elif masks.dtype == torch.uint8:
         code, m = 0, masks.contiguous()
+    elif not masks.dtype.is_floating_point:
+        # any other integer dtype: the reference's `.type_as(self.masks)` truncates the interpolated value for every
+        # non-floating mask (segmentation_mask.py:111-158); binary masks are 0 / 1, so uint8 is the same computation
+        code, m = 0, masks.to(torch.uint8).contiguous()
     else:
         code, m = 1, masks.to(torch.float32).contiguous()
     mask_index = mask_index.to(torch.int64).contiguous()
@@ -562,7 +588,7 @@ def frozen_bn_act_forward(x, scale, bias, residual, relu):
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // max(N * C, 1)
     y = torch.empty_like(x)
-    with _on_device(x):
+    with _on_device(x), _timed("frozen_bn_fwd[n=%d,e=%d,res=%d]" % (x.numel(), _ESIZE[x.dtype], residual is not None), x, every=16):
         check(lib.detops_frozen_bn_act_forward(ptr(x), ptr(scale), ptr(bias), ptr(residual), ptr(y), code, N, C, HW,
                                                int(bool(relu)), stream_of(x)), "frozen_bn_act_forward")
     return y
@@ -577,7 +603,8 @@ def frozen_bn_act_backward(grad_y, y, scale, relu, need_residual):
     HW = grad_y.numel() // max(N * C, 1)
     gx = torch.empty_like(grad_y)
     gres = torch.empty_like(grad_y) if need_residual else None
-    with _on_device(grad_y):
+    with _on_device(grad_y), _timed("frozen_bn_bwd[n=%d,e=%d,res=%d,relu=%d]" % (grad_y.numel(), _ESIZE[grad_y.dtype], bool(need_residual), bool(relu)),
+                                     grad_y, every=16):
         check(lib.detops_frozen_bn_act_backward(ptr(grad_y), ptr(y) if relu else None, ptr(scale), ptr(gx), ptr(gres),
                                                 code, N, C, HW, int(bool(relu)), stream_of(grad_y)),
               "frozen_bn_act_backward")
@@ -656,7 +683,7 @@ def deformable_im2col(im, offset, mask, kH, kW, padH, padW, dH, dW, dilH, dilW, 
     B, C, H, W = im.shape
     Ho, Wo = _out_hw(H, W, kH, kW, padH, padW, dH, dW, dilH, dilW)
     col = torch.empty((C * kH * kW, B * Ho * Wo), dtype=im.dtype, device=im.device)
-    with _on_device(im):
+    with _on_device(im), _timed("dcn_im2col[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]" % (B, C, H, W, kH, _ESIZE[im.dtype], mask is not None), im):
         check(lib.detops_deformable_im2col(ptr(im), ptr(offset), ptr(mask), ptr(col), code,
                                            *_geom_args(B, C, H, W, kH, kW, padH, padW, dH, dW, dilH,
                                                        dilW, dg), stream_of(im)), "deformable_im2col")
@@ -673,8 +700,9 @@ def deformable_col2im(col, offset, mask, grad_im, kH, kW, padH, padW, dH, dW, di
         # stream-ordered reuse, no hipMalloc per call); 0 bytes = shape outside the index plan
         nbytes = int(lib.detops_deformable_col2im_workspace_bytes(*geom))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=col.device) if nbytes > 0 else None
-        check(lib.detops_deformable_col2im_ws(ptr(col), ptr(offset), ptr(mask), ptr(grad_im), code, *geom,
-                                              ptr(ws), nbytes, stream_of(col)), "deformable_col2im")
+        with _timed("dcn_col2im[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]" % (B, C, H, W, kH, _ESIZE[col.dtype], mask is not None), col):
+            check(lib.detops_deformable_col2im_ws(ptr(col), ptr(offset), ptr(mask), ptr(grad_im), code, *geom,
+                                                  ptr(ws), nbytes, stream_of(col)), "deformable_col2im")
 
 
 def deformable_col2im_coord(col, im, offset, mask, grad_offset, grad_mask, kH, kW, padH, padW, dH,
@@ -682,7 +710,7 @@ def deformable_col2im_coord(col, im, offset, mask, grad_offset, grad_mask, kH, k
     """overwrites grad_offset (and grad_mask) (deform_conv_kernel_cuda.cu:380-443 / :702-774)."""
     code = _dcn_check("deformable_col2im_coord", col, im, offset, mask, grad_offset, grad_mask)
     B, C, H, W = im.shape
-    with _on_device(col):
+    with _on_device(col), _timed("dcn_col2im_coord[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]" % (B, C, H, W, kH, _ESIZE[col.dtype], mask is not None), col):
         check(lib.detops_deformable_col2im_coord(ptr(col), ptr(im), ptr(offset), ptr(mask),
                                                  ptr(grad_offset), ptr(grad_mask), code,
                                                  *_geom_args(B, C, H, W, kH, kW, padH, padW, dH, dW,
@@ -705,11 +733,108 @@ def _fused_dcn_forward(input, weight, offset, mask, bias, out, kH, kW, padH, pad
         return False
     with _on_device(input):
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=input.device)
-        with _timed("dcn_fused_fwd[B=%d,C=%d,%dx%d,Cout=%d]" % (B, C, H, W, Cout), input):
+        with _timed("dcn_fused_fwd[B=%d,C=%d,%dx%d,Cout=%d,k=%d,e=2,m=%d]" % (B, C, H, W, Cout, kH, mask is not None), input):
             check(lib.detops_deform_conv_forward_fused(ptr(input), ptr(weight), ptr(offset), ptr(mask), ptr(bias),
                                                        ptr(out), *geo, ptr(ws), nbytes, stream_of(input)),
                   "deform_conv_forward_fused")
     return True
+
+
+# ---- channels-last pipeline (csrc/deform_conv.hip, "channels-last pipeline"): every per-sampling-point operand is
+# channel-fastest, the GEMMs are plain library GEMMs on those layouts, the input gradient uses the transposed
+# sampling operator + a GEMM instead of the col2im scatter.  Served shapes: conv groups == 1, deformable_group == 1,
+# channel counts that are power-of-two multiples of a 16-byte vector (all model shapes).
+def _nhwc_ok(input, weight, group, dg):
+    if group != 1 or dg != 1 or input.dtype not in _lib.DTYPE_CODE or _lib.tuning_get("dcn_nhwc") == 2:
+        return False
+    return bool(lib.detops_deformable_nhwc_supported(_lib.DTYPE_CODE[input.dtype], input.size(1), weight.size(0), dg))
+
+
+def _to_nhwc(x):
+    """[B, C, H, W] -> [B, H*W, C] (contiguous)."""
+    B, C, H, W = x.shape
+    x = x.contiguous()
+    out = torch.empty((B, H * W, C), dtype=x.dtype, device=x.device)
+    if out.numel():
+        with _on_device(x), _timed("dcn_to_nhwc[n=%d,e=%d]" % (x.numel(), _ESIZE[x.dtype]), x, every=4):
+            check(lib.detops_nchw_to_nhwc(ptr(x), ptr(out), _lib.DTYPE_CODE[x.dtype], B, C, H * W, stream_of(x)), "nchw_to_nhwc")
+    return out
+
+
+def _im2col_nhwc(xT, offset, mask, B, C, H, W, geom):
+    kH, kW = geom[0], geom[1]
+    Ho, Wo = _out_hw(H, W, *geom[:8])
+    colT = torch.empty((B * Ho * Wo, kH * kW * C), dtype=xT.dtype, device=xT.device)
+    if colT.numel():
+        with _on_device(xT), _timed("dcn_im2col_nhwc[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]" % (B, C, H, W, kH, _ESIZE[xT.dtype], mask is not None), xT):
+            check(lib.detops_deformable_im2col_nhwc(ptr(xT), ptr(offset), ptr(mask), ptr(colT), _lib.DTYPE_CODE[xT.dtype],
+                                                    B, C, H, W, *geom, stream_of(xT)), "deformable_im2col_nhwc")
+    return colT
+
+
+def _coord_nhwc(colsG, xT, offset, mask, grad_offset, grad_mask, B, C, H, W, geom):
+    with _on_device(xT), _timed("dcn_coord_nhwc[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]" % (B, C, H, W, geom[0], _ESIZE[xT.dtype], mask is not None), xT):
+        check(lib.detops_deformable_coord_nhwc(ptr(colsG), ptr(xT), ptr(offset), ptr(mask), ptr(grad_offset), ptr(grad_mask),
+                                               _lib.DTYPE_CODE[xT.dtype], B, C, H, W, *geom, stream_of(xT)), "deformable_coord_nhwc")
+
+
+def _transposed_sample(gT, offset, mask, B, C, H, W, Cout, geom):
+    """S_T [B*H*W, kh*kw*Cout]: per gradient-map pixel and tap, the weighted sum of the output-gradient vectors of the
+    sampling points that touch the pixel."""
+    kH, kW = geom[0], geom[1]
+    S_T = torch.empty((B * H * W, kH * kW * Cout), dtype=gT.dtype, device=gT.device)
+    nbytes = int(lib.detops_deformable_transposed_sample_workspace_bytes(B, C, H, W, *geom))
+    if nbytes == 0:
+        raise RuntimeError("deformable_transposed_sample: shape outside the index plan")
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=gT.device)
+    with _on_device(gT), _timed("dcn_transposed_sample[B=%d,Cout=%d,%dx%d,k=%d,e=%d,m=%d]" % (B, Cout, H, W, kH, _ESIZE[gT.dtype], mask is not None), gT):
+        check(lib.detops_deformable_transposed_sample(ptr(gT), ptr(offset), ptr(mask), ptr(S_T), _lib.DTYPE_CODE[gT.dtype],
+                                                      B, C, H, W, Cout, *geom, ptr(ws), nbytes, stream_of(gT)),
+              "deformable_transposed_sample")
+    return S_T
+
+
+def _w_tap_major(weight):
+    """[Cout, C, kh, kw] -> W2 [Cout, kh*kw*C] (tap-major, channel-fastest: the column order of colT)"""
+    Cout = weight.size(0)
+    return weight.permute(0, 2, 3, 1).reshape(Cout, -1)
+
+
+def _nhwc_forward(input, weight, offset, mask, bias, out, geom):
+    B, C, H, W = input.shape
+    Cout = weight.size(0)
+    xT = _to_nhwc(input)
+    colT = _im2col_nhwc(xT, offset, mask, B, C, H, W, geom)
+    torch.bmm(_w_tap_major(weight).unsqueeze(0).expand(B, -1, -1), colT.view(B, -1, colT.size(1)).transpose(1, 2),
+              out=out.view(B, Cout, -1))
+    if bias is not None:
+        out += bias.to(out.dtype).view(1, -1, 1, 1)
+
+
+def _nhwc_backward(input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight, grad_bias,
+                   geom, scale=1.0):
+    """any of grad_input+grad_offset(+grad_mask) / grad_weight(+grad_bias) may be None (the v1 entry points ask for
+    them in two separate calls); accumulate / overwrite semantics of the reference functions"""
+    B, C, H, W = input.shape
+    Cout = weight.size(0) if weight is not None else grad_weight.size(0)
+    xT = _to_nhwc(input)
+    gT = _to_nhwc(grad_output)                                   # [B, Ho*Wo, Cout]
+    g2 = gT.view(-1, Cout)
+    if grad_input is not None:
+        W2 = _w_tap_major(weight)                                # [Cout, K*C]
+        colsG = torch.mm(g2, W2)                                 # column gradient, channel-fastest: [B*Ho*Wo, K*C]
+        _coord_nhwc(colsG, xT, offset, mask, grad_offset, grad_mask, B, C, H, W, geom)
+        del colsG
+        S_T = _transposed_sample(gT, offset, mask, B, C, H, W, Cout, geom)     # [B*H*W, K*Cout]
+        W2T = weight.permute(1, 2, 3, 0).reshape(C, -1)          # [C, K*Cout]
+        grad_input.view(B, C, -1).baddbmm_(W2T.unsqueeze(0).expand(B, -1, -1), S_T.view(B, H * W, -1).transpose(1, 2))
+    if grad_weight is not None:
+        colT = _im2col_nhwc(xT, offset, mask, B, C, H, W, geom)  # [B*Ho*Wo, K*C]
+        gw2 = torch.mm(g2.t(), colT)                             # [Cout, K*C]
+        kH, kW = geom[0], geom[1]
+        grad_weight.add_(gw2.view(Cout, kH, kW, C).permute(0, 3, 1, 2), alpha=float(scale))
+        if grad_bias is not None:
+            grad_bias += g2.sum(0)
 
 
 def _grouped_weight_times_cols(weight, col, group, out):
@@ -738,6 +863,9 @@ def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW
     if out.is_contiguous() and _fused_dcn_forward(input, weight, offset, None, None, out, kH, kW, padH, padW, dH, dW,
                                                   dilationH, dilationW, group, deformable_group):
         return 1
+    if out.is_contiguous() and _nhwc_ok(input, weight, group, deformable_group):
+        _nhwc_forward(input, weight, offset, None, None, out, (kH, kW, padH, padW, dH, dW, dilationH, dilationW, deformable_group))
+        return 1
     for b0 in range(0, B, im2col_step):
         sl = slice(b0, b0 + im2col_step)
         col = deformable_im2col(input[sl], offset[sl], None, kH, kW, padH, padW, dH, dW, dilationH,
@@ -760,6 +888,10 @@ def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset,
                           dilationW, group, deformable_group)
     B, C = input.shape[:2]
     Cout = weight.size(0)
+    if gradInput.is_contiguous() and gradOffset.is_contiguous() and _nhwc_ok(input, weight, group, deformable_group):
+        _nhwc_backward(input, weight, offset, None, gradOutput, gradInput, gradOffset, None, None, None,
+                       (kH, kW, padH, padW, dH, dW, dilationH, dilationW, deformable_group))
+        return 1
     Mg, Kg = Cout // group, (C // group) * kH * kW
     w2 = weight.reshape(group, Mg, Kg)
     for b0 in range(0, B, im2col_step):
@@ -786,6 +918,10 @@ def deform_conv_backward_parameters(input, offset, gradOutput, gradWeight, colum
                           dilationH, dilationW, group, deformable_group)
     B, C = input.shape[:2]
     Cout = gradWeight.size(0)
+    if gradWeight.is_contiguous() and _nhwc_ok(input, gradWeight, group, deformable_group):
+        _nhwc_backward(input, None, offset, None, gradOutput, None, None, None, gradWeight, None,
+                       (kH, kW, padH, padW, dH, dW, dilationH, dilationW, deformable_group), scale=scale)
+        return 1
     Mg, Kg = Cout // group, (C // group) * kH * kW
     gw = gradWeight.view(group, Mg, Kg)
     for b0 in range(0, B, im2col_step):
@@ -820,9 +956,13 @@ def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, outpu
     Ho, Wo = _out_hw(H, W, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w)
     offset, mask = offset.contiguous(), mask.contiguous()
     out = output.view(B, Cout, Ho, Wo)
-    if out.is_contiguous() and _fused_dcn_forward(input, weight, offset, mask, bias.contiguous() if with_bias else None,
+    if out.is_contiguous() and _fused_dcn_forward(input, weight, offset, mask, bias.to(input.dtype).contiguous() if with_bias else None,
                                                   out, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w,
                                                   dilation_h, dilation_w, group, deformable_group):
+        return
+    if out.is_contiguous() and _nhwc_ok(input, weight, group, deformable_group):
+        _nhwc_forward(input, weight, offset, mask, bias if with_bias else None, out,
+                      (kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w, deformable_group))
         return
     col = deformable_im2col(input, offset, mask, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w,
                             dilation_h, dilation_w, deformable_group)
@@ -858,6 +998,11 @@ def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, colu
     offset, mask, grad_output = offset.contiguous(), mask.contiguous(), grad_output.contiguous()
     geom = (kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w,
             deformable_group)
+    if (grad_input.is_contiguous() and grad_weight.is_contiguous() and grad_offset.is_contiguous() and grad_mask.is_contiguous()
+            and _nhwc_ok(input, weight, group, deformable_group)):
+        _nhwc_backward(input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight,
+                       grad_bias if with_bias else None, geom)
+        return
     Mg, Kg = Cout // group, Cker * kernel_h * kernel_w
     w2 = weight.reshape(group, Mg, Kg)
     go = grad_output.transpose(0, 1).reshape(Cout, B * Ho * Wo)

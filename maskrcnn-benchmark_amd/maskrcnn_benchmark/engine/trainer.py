@@ -22,8 +22,8 @@ def do_train(cfg, model, data_loader, optimizer, scheduler, checkpointer, device
     logger = logging.getLogger("maskrcnn_benchmark.trainer")
     logger.info("Start training")
     meters = MetricLogger(delimiter="  ")
-    max_iter = len(data_loader)
     start_iter = arguments["iteration"]
+    max_iter = start_iter + len(data_loader)      # the loader holds the REMAINING iterations (reference: IterationBasedBatchSampler)
     model.train()
     step = TrainStep(model, optimizer, scheduler, dtype=cfg.DTYPE, device_type=torch.device(device).type)
     start_training_time = time.time()

@@ -66,6 +66,12 @@ SIGNATURES = {
     "detops_deformable_col2im_ws": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P, ctypes.c_size_t, _P]),
     "detops_deform_conv_forward_fused_workspace_bytes": (ctypes.c_size_t, [c_int] * 15),
     "detops_deform_conv_forward_fused": (c_int, [_P] * 6 + [c_int] * 15 + [_P, ctypes.c_size_t, _P]),
+    "detops_nchw_to_nhwc": (c_int, [_P, _P] + [c_int] * 4 + [_P]),
+    "detops_deformable_nhwc_supported": (c_int, [c_int] * 4),
+    "detops_deformable_im2col_nhwc": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),
+    "detops_deformable_coord_nhwc": (c_int, [_P] * 6 + [c_int] * 14 + [_P]),
+    "detops_deformable_transposed_sample_workspace_bytes": (ctypes.c_size_t, [c_int] * 13),
+    "detops_deformable_transposed_sample": (c_int, [_P, _P, _P, _P] + [c_int] * 15 + [_P, ctypes.c_size_t, _P]),
     "detops_deformable_col2im_coord": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 14 + [_P]),
 }
 
@@ -82,7 +88,7 @@ def lib():
 
 
 TUNING_KEYS = ("roi_bwd_impl", "roi_bwd_seg", "roi_bwd_ring", "roi_bwd_groups", "roi_bwd_scan_ct", "roi_bwd_debug", "roi_fwd_impl",
-               "roi_fwd_order", "roi_fwd_order_mink", "dcn_col2im", "dcn_fused", "dcn_gather_xcd")
+               "roi_fwd_order", "roi_fwd_order_mink", "dcn_col2im", "dcn_fused", "dcn_gather_xcd", "dcn_nhwc")
 
 
 def tuning_set(key, value):
@@ -295,6 +301,58 @@ def deformable_col2im(col, offset, mask, B, C, H, W, kh, kw, pad, stride, dil, d
         rc = lib().detops_deformable_col2im(_p(col), _p(offset), mp, _p(gim), _DT[dt], *g, None)
     assert rc == 0, rc
     return gim
+
+
+def nchw_to_nhwc(x):
+    x = np.ascontiguousarray(x)
+    B, C, H, W = x.shape
+    out = np.full((B, H * W, C), np.nan, x.dtype)
+    rc = lib().detops_nchw_to_nhwc(_p(x), _p(out), _DT[x.dtype], B, C, H * W, None)
+    assert rc == 0, rc
+    return out
+
+
+def deformable_nhwc(im, offset, mask, weight, grad_out, kh, kw, pad, stride, dil):
+    """The channels-last pipeline with numpy standing in for the library GEMMs (what _C.py does with torch.mm):
+    -> (out, grad_input, grad_offset, grad_mask, grad_weight), everything in the reference's layouts."""
+    im = np.ascontiguousarray(im)
+    dt = im.dtype
+    offset = np.ascontiguousarray(offset, dtype=dt)
+    mask = None if mask is None else np.ascontiguousarray(mask, dtype=dt)
+    weight, grad_out = np.ascontiguousarray(weight, dtype=dt), np.ascontiguousarray(grad_out, dtype=dt)
+    B, C, H, W = im.shape
+    Cout = weight.shape[0]
+    K = kh * kw
+    Ho, Wo = _out_hw(H, W, kh, kw, pad, stride, dil)
+    g = _geom(B, C, H, W, kh, kw, pad, stride, dil, 1)
+    assert lib().detops_deformable_nhwc_supported(_DT[dt], C, Cout, 1) == 1
+    mp = None if mask is None else _p(mask)
+    xT = nchw_to_nhwc(im)
+    colT = np.full((B * Ho * Wo, K * C), np.nan, dt)
+    rc = lib().detops_deformable_im2col_nhwc(_p(xT), _p(offset), mp, _p(colT), _DT[dt], *g, None)
+    assert rc == 0, rc
+    f = np.float32
+    W2 = weight.transpose(0, 2, 3, 1).reshape(Cout, K * C).astype(f)
+    out = np.einsum("ok,bpk->bop", W2, colT.astype(f).reshape(B, Ho * Wo, K * C)).reshape(B, Cout, Ho, Wo)
+    gT = nchw_to_nhwc(grad_out)                                              # [B, Ho*Wo, Cout]
+    g2 = gT.reshape(-1, Cout).astype(f)
+    colsG = np.ascontiguousarray((g2 @ W2).astype(dt))
+    goff = np.full(offset.shape, np.nan, dt)
+    gmask = None if mask is None else np.full(mask.shape, np.nan, dt)
+    rc = lib().detops_deformable_coord_nhwc(_p(colsG), _p(xT), _p(offset), mp, _p(goff), None if gmask is None else _p(gmask),
+                                            _DT[dt], *g, None)
+    assert rc == 0, rc
+    nbytes = lib().detops_deformable_transposed_sample_workspace_bytes(*g)
+    assert nbytes > 0
+    ws = np.full((nbytes,), 0xAB, np.uint8)
+    S_T = np.full((B * H * W, K * Cout), np.nan, dt)
+    rc = lib().detops_deformable_transposed_sample(_p(gT), _p(offset), mp, _p(S_T), _DT[dt], B, C, H, W, Cout, *g[4:],
+                                                   _p(ws), nbytes, None)
+    assert rc == 0, rc
+    W2T = weight.transpose(1, 2, 3, 0).reshape(C, K * Cout).astype(f)
+    gin = np.einsum("ck,bpk->bcp", W2T, S_T.astype(f).reshape(B, H * W, K * Cout)).reshape(B, C, H, W)
+    gw = (g2.T @ colT.astype(f)).reshape(Cout, kh, kw, C).transpose(0, 3, 1, 2)
+    return out, gin, goff, gmask, gw
 
 
 def deformable_col2im_coord(col, im, offset, mask, kh, kw, pad, stride, dil, dg):

@@ -481,6 +481,65 @@ def test_emu_deformable_col2im_ell_overflow():
         np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()), err_msg=mode)
 
 
+# ================================================================================ deformable conv, channels-last pipeline
+@pytest.mark.parametrize("geom", [dict(B=2, C=64, H=9, W=11, Cout=128, k=3, pad=1, stride=1, dil=1),
+                                  dict(B=1, C=128, H=12, W=10, Cout=64, k=3, pad=2, stride=2, dil=2),
+                                  dict(B=1, C=512, H=5, W=6, Cout=64, k=3, pad=1, stride=1, dil=1),      # two vectors per lane
+                                  dict(B=2, C=64, H=7, W=8, Cout=256, k=1, pad=0, stride=1, dil=1)])
+@pytest.mark.parametrize("modulated", [False, True])
+def test_emu_deformable_channels_last_pipeline_vs_oracle(geom, modulated):
+    """NHWC im2col, coordinate / mask gradients with the in-wave channel reduction, and the input gradient through the
+    TRANSPOSED sampling operator (fixed-width inverted index) + GEMM — against the oracle's reference-order forward and
+    backward (fp32)."""
+    g = geom
+    rng = np.random.RandomState(17)
+    x, off, mask, wgt = synth.dcn_inputs(g["B"], g["C"], g["H"], g["W"], g["Cout"], g["k"], 1, modulated, seed=3)
+    pad, stride, dil = (g["pad"],) * 2, (g["stride"],) * 2, (g["dil"],) * 2
+    Ho = (g["H"] + 2 * g["pad"] - (g["dil"] * (g["k"] - 1) + 1)) // g["stride"] + 1
+    Wo = (g["W"] + 2 * g["pad"] - (g["dil"] * (g["k"] - 1) + 1)) // g["stride"] + 1
+    off = np.ascontiguousarray(off[:, :, :Ho, :Wo])
+    mask = None if mask is None else np.ascontiguousarray(mask[:, :, :Ho, :Wo])
+    go = rng.randn(g["B"], g["Cout"], Ho, Wo).astype(np.float32)
+    out, gin, goff, gmask, gw = emu.deformable_nhwc(x, off, mask, wgt, go, g["k"], g["k"], pad, stride, dil)
+    ref_out = oracle.deform_conv_forward(x, off, mask, wgt, None, pad, stride, dil, 1, 1)
+    np.testing.assert_allclose(out, ref_out, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref_out).max()))
+    rin, roff, rmask, rw, _ = oracle.deform_conv_backward(x, off, mask, wgt, go, False, pad, stride, dil, 1, 1)
+    tol = lambda r: dict(rtol=1e-4, atol=2e-4 * max(1.0, np.abs(r).max()))  # noqa: E731
+    np.testing.assert_allclose(gin, rin, **tol(rin))
+    np.testing.assert_allclose(goff, roff, **tol(roff))
+    np.testing.assert_allclose(gw, rw, **tol(rw))
+    if modulated:
+        np.testing.assert_allclose(gmask, rmask, **tol(rmask))
+
+
+def test_emu_deformable_transposed_sample_overflow_and_fp16():
+    """offsets that pile every sampling point of a tap onto one pixel (more than 8 entries per (pixel, tap): the
+    overflow list + atomic kernel), and fp16 storage of every intermediate."""
+    B, C, H, W, Cout, k = 1, 128, 9, 11, 128, 3
+    rng = np.random.RandomState(3)
+    off = np.zeros((B, 2 * k * k, H, W), np.float32)
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    for t in range(k * k):
+        i, j = t // k, t % k
+        off[0, 2 * t] = 4.3 - (ys - 1 + i)      # every sample of tap t lands at (4.3, 5.6)
+        off[0, 2 * t + 1] = 5.6 - (xs - 1 + j)
+    off += rng.randn(*off.shape).astype(np.float32) * 0.05
+    x = rng.randn(B, C, H, W).astype(np.float32)
+    wgt = (rng.randn(Cout, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    go = rng.randn(B, Cout, H, W).astype(np.float32)
+    rin, roff, _, rw, _ = oracle.deform_conv_backward(x, off, None, wgt, go, False, (1, 1), (1, 1), (1, 1), 1, 1)
+    for dt, rt in ((np.float32, 1e-4), (np.float16, 2e-2)):
+        out, gin, goff, _, gw = emu.deformable_nhwc(x.astype(dt), off.astype(dt), None, wgt.astype(dt), go.astype(dt), k, k,
+                                                    (1, 1), (1, 1), (1, 1))
+        if dt == np.float16:      # the oracle on the fp16-rounded operands
+            rin, roff, _, rw, _ = oracle.deform_conv_backward(x.astype(dt).astype(np.float32), off.astype(dt).astype(np.float32), None,
+                                                              wgt.astype(dt).astype(np.float32), go.astype(dt).astype(np.float32),
+                                                              False, (1, 1), (1, 1), (1, 1), 1, 1)
+        np.testing.assert_allclose(gin, rin, rtol=rt, atol=rt * max(1.0, np.abs(rin).max()))
+        np.testing.assert_allclose(goff.astype(np.float32), roff, rtol=rt, atol=2 * rt * max(1.0, np.abs(roff).max()))
+        np.testing.assert_allclose(gw, rw, rtol=rt, atol=rt * max(1.0, np.abs(rw).max()))
+
+
 # ================================================================================ fused deformable conv (MFMA)
 @pytest.mark.parametrize("geom", [dict(B=2, C=32, H=9, W=11, Cout=40, k=3, pad=1, stride=1, dil=1, dg=1),
                                   dict(B=1, C=64, H=12, W=10, Cout=130, k=3, pad=2, stride=2, dil=2, dg=2),

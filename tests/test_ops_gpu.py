@@ -572,6 +572,25 @@ def test_focal_full_size_properties_and_module():
     torch.testing.assert_close(xg.grad, explicit, rtol=1e-5, atol=1e-9)
 
 
+def test_focal_model_entry_points_vs_oracle_full_size():
+    """The two entry points the RetinaNet loss actually calls — the fused two-stage sum-forward
+    (detops_sigmoid_focal_loss_forward_sum_ws_f32) and the scalar-gradient backward (..._backward_scalar_f32) — against
+    the ORACLE (C restatement of SigmoidFocalLoss_cuda.cu:29-56, 71-99) at the full RetinaNet size R = 403,200 x 80."""
+    C = _C()
+    R = 403200
+    logits, targets = synth.focal_inputs(R, 80)
+    tl, tt = _t(logits), _t(targets)
+    ref = oracle.sigmoid_focal_loss_forward(logits, targets, 2.0, 0.25).astype(np.float64)
+    total = float(C.sigmoid_focalloss_forward_sum(tl, tt, 80, 2.0, 0.25))
+    assert abs(total - ref.sum()) <= 1e-4 * abs(ref.sum()), (total, ref.sum())
+    # bit-reproducible (fixed-order two-stage reduction)
+    assert float(C.sigmoid_focalloss_forward_sum(tl, tt, 80, 2.0, 0.25)) == total
+    scale = 1.0 / 1234.0                                   # what `.sum() / normaliser` back-propagates
+    dref = oracle.sigmoid_focal_loss_backward(logits, targets, np.full_like(logits, scale), 2.0, 0.25)
+    d = C.sigmoid_focalloss_backward_scalar(tl, tt, torch.full((), scale, device=DEV), 80, 2.0, 0.25).cpu().numpy()
+    np.testing.assert_allclose(d, dref, rtol=1e-4, atol=1e-4 * np.abs(dref).max())
+
+
 # ============================================================================ deformable conv
 GEOMS = [dict(B=2, C=8, H=13, W=17, Cout=6, k=3, stride=1, pad=1, dil=1, dg=1, group=1),
          dict(B=2, C=8, H=14, W=15, Cout=8, k=3, stride=2, pad=2, dil=2, dg=2, group=2),

@@ -110,7 +110,10 @@ def test_mask_targets_bit_equal_to_the_torch_cpu_path_at_model_size():
                        (xx - rng.uniform(100, 1200)) ** 2 / rng.uniform(900, 90000)) < 1 for _ in range(G)]).astype(np.uint8)
     rois = synth.fpn_rois(seed=11, per_image=P, n_images=1)[:, 1:]
     which = rng.randint(0, G, P).astype(np.int64)
-    for m in (torch.from_numpy(masks), torch.from_numpy(masks).float(), torch.from_numpy(masks).bool()):
+    # uint8 / float / bool, and other integer dtypes (int64, int16): the CPU composite's `.type_as(masks)` truncates for
+    # every non-floating mask, so they must yield 0 / 1 targets too
+    for m in (torch.from_numpy(masks), torch.from_numpy(masks).float(), torch.from_numpy(masks).bool(),
+              torch.from_numpy(masks).long(), torch.from_numpy(masks).short()):
         ref = project_masks_on_boxes(m, torch.from_numpy(which), torch.from_numpy(rois), M)
         out = _C.mask_targets(m.to(DEV), torch.from_numpy(which).to(DEV), torch.from_numpy(rois).to(DEV), M).cpu()
         assert torch.equal(out, ref), m.dtype

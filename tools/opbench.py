@@ -302,6 +302,75 @@ def bench_dcn(C, iters, experimental=False):
     return out
 
 
+def bench_dcn_block(C, iters):
+    """One modulated deformable 3x3 block of cfg-5 (R-101 + DCN, fp16) at its three layer shapes, forward and backward
+    through the `_C` entry points the layers call: channels-last pipeline (default) vs the reference-layout kernels
+    (tuning dcn_nhwc = 2), fused MFMA forward where it applies; plus the pipeline's own kernels one by one."""
+    out = []
+    for (Cc, H, W) in [(128, 100, 168), (256, 50, 84), (512, 25, 42)]:
+        for dt in (torch.float16, torch.float32):
+            e = 2 if dt == torch.float16 else 4
+            x = torch.randn(2, Cc, H, W, device="cuda").to(dt)
+            off = (torch.randn(2, 18, H, W, device="cuda") * 2).to(dt)
+            msk = torch.rand(2, 9, H, W, device="cuda").to(dt)
+            w = (torch.randn(Cc, Cc, 3, 3, device="cuda") / (3 * Cc ** 0.5)).to(dt)
+            bias = torch.zeros(Cc, device="cuda", dtype=dt)
+            y = torch.empty(2, Cc, H, W, device="cuda", dtype=dt)
+            go = torch.randn(2, Cc, H, W, device="cuda").to(dt)
+            empty = torch.empty(0, device="cuda", dtype=dt)
+            geo = (3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
+            flops = 2.0 * Cc * Cc * 9 * 2 * H * W
+            io_bytes = e * (x.numel() + off.numel() + msk.numel() + y.numel())
+            tag = f"C={Cc} {H}x{W} {str(dt)[6:]}"
+
+            def fwd():
+                C.modulated_deform_conv_forward(x, w, bias, empty, off, msk, y, empty, *geo, True)
+
+            gi, gw, gb = torch.zeros_like(x), torch.zeros_like(w), torch.zeros_like(bias)
+            goff, gm = torch.zeros_like(off), torch.zeros_like(msk)
+
+            def bwd():
+                C.modulated_deform_conv_backward(x, w, bias, empty, off, msk, empty, gi, gw, gb, goff, gm, go, *geo, True)
+
+            res = {}
+            for name, key, val in (("channels-last pipeline", "dcn_nhwc", 0), ("reference-layout kernels", "dcn_nhwc", 2)):
+                tune("dcn_fused", 2)
+                tune(key, val)
+                us = dev_time_us(fwd, iters)
+                out.append(_entry(f"dcn_block fwd [{name}] {tag}", us, io_bytes, {"TFLOPs": round(flops / us / 1e6, 1)}))
+                res["fwd " + name] = y.float().clone()
+                us = dev_time_us(bwd, max(3, iters // 2))
+                out.append(_entry(f"dcn_block bwd [{name}] {tag}", us, 2 * io_bytes, {"TFLOPs": round(2 * flops / us / 1e6, 1)}))
+                gi.zero_(); gw.zero_(); gb.zero_()
+                bwd()
+                res["bwd " + name] = (gi.float().clone(), gw.float().clone(), goff.float().clone(), gm.float().clone())
+                gi.zero_(); gw.zero_(); gb.zero_()
+                tune(key, 0)
+                tune("dcn_fused", 0)
+            if dt == torch.float16:
+                tune("dcn_fused", 1)
+                us = dev_time_us(fwd, iters)
+                tune("dcn_fused", 0)
+                out.append(_entry(f"dcn_block fwd [fused MFMA] {tag}", us, io_bytes, {"TFLOPs": round(flops / us / 1e6, 1)}))
+            a, b = res["bwd channels-last pipeline"], res["bwd reference-layout kernels"]
+            out[-1 if dt != torch.float16 else -2]["max_rel_diff_vs_reference_layout"] = [
+                round(float((p - q).abs().max() / q.abs().max().clamp_min(1e-6)), 5) for p, q in zip(a, b)]
+            # the pipeline's kernels, one by one
+            xT = C._to_nhwc(x)
+            us = dev_time_us(lambda: C._to_nhwc(x), iters)
+            out.append(_entry(f"dcn nchw->nhwc {tag}", us, 2 * e * x.numel()))
+            g9 = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+            colT = C._im2col_nhwc(xT, off, msk, 2, Cc, H, W, g9)
+            us = dev_time_us(lambda: C._im2col_nhwc(xT, off, msk, 2, Cc, H, W, g9), iters)
+            out.append(_entry(f"dcn im2col_nhwc {tag}", us, e * (x.numel() + off.numel() + msk.numel() + colT.numel())))
+            us = dev_time_us(lambda: C._coord_nhwc(colT, xT, off, msk, goff, gm, 2, Cc, H, W, g9), iters)
+            out.append(_entry(f"dcn coord_nhwc {tag}", us, e * (x.numel() + 2 * off.numel() + 2 * msk.numel() + colT.numel())))
+            gT = C._to_nhwc(go)
+            us = dev_time_us(lambda: C._transposed_sample(gT, off, msk, 2, Cc, H, W, Cc, g9), iters)
+            out.append(_entry(f"dcn transposed_sample (index build + gather) {tag}", us, e * (go.numel() + off.numel() + msk.numel() + colT.numel())))
+    return out
+
+
 def copy_ceiling(iters):
     a = torch.empty(256 * 1024 * 1024 // 4, device="cuda")
     b = torch.empty_like(a)
@@ -347,6 +416,8 @@ def main():
         res += bench_dcn(C, args.iters, experimental=args.experimental)
     if not only or "dcn_fused" in only:
         res += bench_dcn_fused(C, args.iters)
+    if not only or "dcn_block" in only:
+        res += bench_dcn_block(C, args.iters)
     for r in res:
         print("%-70s %10.2f us  %9.1f GB/s  (%.1f%% of 8 TB/s) %s" % (
             r["op"], r["us"], r["gbs"], 100 * r["frac_of_8TBs"],

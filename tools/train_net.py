@@ -47,12 +47,19 @@ def main():
     logger.info("Running with config:\n%s", cfg.dump())
     model, optimizer, scheduler, _ = build_training(cfg, device, distributed, local_rank)
     out_dir = cfg.OUTPUT_DIR if cfg.OUTPUT_DIR != "." else ""
+    if out_dir and get_rank() == 0:
+        os.makedirs(out_dir, exist_ok=True)      # reference tools/train_net.py:166-168
     checkpointer = DetectronCheckpointer(cfg, model, optimizer, scheduler, out_dir)
     arguments = {"iteration": 0}
     arguments.update(checkpointer.load(cfg.MODEL.WEIGHT or None))
-    loader = make_data_loader(cfg, is_train=True, is_distributed=distributed, start_iter=arguments["iteration"],
-                              length=cfg.SOLVER.MAX_ITER * max(cfg.SOLVER.IMS_PER_BATCH // world, 1))
-    do_train(cfg, model, loader, optimizer, scheduler, checkpointer, device, cfg.SOLVER.CHECKPOINT_PERIOD, arguments)
+    # the reference's IterationBasedBatchSampler yields MAX_ITER - start_iter batches (data/samplers/iteration_based_batch_sampler.py)
+    remaining = cfg.SOLVER.MAX_ITER - arguments["iteration"]
+    if remaining <= 0:
+        logger.info("iteration %d of %d: nothing left to train", arguments["iteration"], cfg.SOLVER.MAX_ITER)
+    else:
+        loader = make_data_loader(cfg, is_train=True, is_distributed=distributed, start_iter=arguments["iteration"],
+                                  length=remaining * max(cfg.SOLVER.IMS_PER_BATCH // world, 1))
+        do_train(cfg, model, loader, optimizer, scheduler, checkpointer, device, cfg.SOLVER.CHECKPOINT_PERIOD, arguments)
     if distributed:
         torch.distributed.destroy_process_group()
 
