@@ -1,6 +1,8 @@
 """Box-head post-processing for inference (reference roi_heads/box_head/inference.py:13-172):
 softmax scores, decode per-class boxes, clip, score threshold, per-class NMS, top detections."""
 import torch
+
+from maskrcnn_benchmark.modeling.utils import device_constant
 import torch.nn.functional as F
 from torch import nn
 
@@ -47,7 +49,7 @@ class PostProcessor(nn.Module):
             out.add_field("labels", torch.zeros((0,), dtype=torch.int64, device=scores.device))
             return out
         boxes = boxes.view(n, C, 4)
-        hi = boxes.new_tensor([W - 1, H - 1, W - 1, H - 1])
+        hi = device_constant([W - 1, H - 1, W - 1, H - 1], boxes.dtype, boxes.device)
         boxes = torch.minimum(boxes.clamp(min=0), hi)
         cand = scores > self.score_thresh
         cand[:, 0] = False
@@ -55,7 +57,7 @@ class PostProcessor(nn.Module):
         cb = boxes.permute(1, 0, 2).reshape(-1, 4)
         cs = scores.t().reshape(-1)
         cm = cand.t().reshape(-1)
-        far = cb.new_tensor([-1e6, -1e6, -1e6 + 1, -1e6 + 1])
+        far = device_constant([-1e6, -1e6, -1e6 + 1, -1e6 + 1], cb.dtype, cb.device)
         cb_n = torch.where(cm[:, None], cb, far)
         cs_n = torch.where(cm, cs, cs.new_full((), -1.0))
         seg = torch.arange(0, (C + 1) * n, n, dtype=torch.int32, device=cb.device)

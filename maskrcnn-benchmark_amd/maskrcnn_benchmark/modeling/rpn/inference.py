@@ -15,6 +15,8 @@ see exactly the reference's variable-length BoxLists.
 """
 import torch
 
+from maskrcnn_benchmark.modeling.utils import device_constant
+
 from maskrcnn_benchmark import _C
 from maskrcnn_benchmark.modeling.box_coder import BoxCoder
 from maskrcnn_benchmark.structures.bounding_box import BoxList
@@ -47,8 +49,7 @@ class RPNPostProcessor(torch.nn.Module):
         anchors = level_anchors[idx.reshape(-1)]
         boxes = self.box_coder.decode(deltas.reshape(-1, 4), anchors).view(N, k, 4)
         # clip_to_image(remove_empty=False): per image (w-1, h-1) upper bounds
-        hi = torch.tensor([[w - 1, h - 1, w - 1, h - 1] for (h, w) in image_sizes],
-                          dtype=boxes.dtype).to(boxes.device, non_blocking=True)[:, None, :]
+        hi = device_constant([[w - 1, h - 1, w - 1, h - 1] for (h, w) in image_sizes], boxes.dtype, boxes.device)[:, None, :]
         boxes = torch.minimum(boxes.clamp(min=0), hi)
         ws = boxes[..., 2] - boxes[..., 0] + 1
         hs = boxes[..., 3] - boxes[..., 1] + 1
@@ -89,7 +90,7 @@ class RPNPostProcessor(torch.nn.Module):
         flat_ok = torch.cat([k.reshape(-1) for k in oks], dim=0)
         if self.min_size > 0:
             # removed boxes must not take part in NMS: move them far away with the lowest score
-            far = flat_boxes.new_tensor([-1e6, -1e6, -1e6 + 1, -1e6 + 1])
+            far = device_constant([-1e6, -1e6, -1e6 + 1, -1e6 + 1], flat_boxes.dtype, flat_boxes.device)
             flat_boxes = torch.where(flat_ok[:, None], flat_boxes, far)
             flat_scores = torch.where(flat_ok, flat_scores, flat_scores.new_full((), -1.0))
         keep, _ = _C.nms_batched_mask(flat_boxes, flat_scores, self._segments(ks, N, dev), max(ks),

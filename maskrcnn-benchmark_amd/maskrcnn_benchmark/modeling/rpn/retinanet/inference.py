@@ -4,6 +4,8 @@ clip; over all levels run per-class NMS (NMS_TH) and keep the DETECTIONS_PER_IMG
 NMS problems run as one segmented launch of the HIP kernel; eval-only code, host syncs allowed."""
 import torch
 
+from maskrcnn_benchmark.modeling.utils import device_constant
+
 from maskrcnn_benchmark import _C
 from maskrcnn_benchmark.modeling.box_coder import BoxCoder
 from maskrcnn_benchmark.structures.bounding_box import BoxList
@@ -34,8 +36,7 @@ class RetinaNetPostProcessor(torch.nn.Module):
         loc, cls = idx // C, idx % C + 1
         boxes = self.box_coder.decode(torch.gather(deltas, 1, loc[:, :, None].expand(N, k, 4)).reshape(-1, 4).float(),
                                       level_anchors[loc.reshape(-1)]).view(N, k, 4)
-        hi = torch.tensor([[w - 1, h - 1, w - 1, h - 1] for (h, w) in image_sizes], dtype=boxes.dtype,
-                          device=boxes.device)[:, None, :]
+        hi = device_constant([[w - 1, h - 1, w - 1, h - 1] for (h, w) in image_sizes], boxes.dtype, boxes.device)[:, None, :]
         boxes = torch.minimum(boxes.clamp(min=0), hi)
         ok = (top > self.pre_nms_thresh)
         ok &= (boxes[..., 2] - boxes[..., 0] + 1 >= self.min_size) & (boxes[..., 3] - boxes[..., 1] + 1 >= self.min_size)
