@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--force-ddp", action="store_true",
                     help="N = 1 only: wrap the model in DDP over a 1-rank RCCL group so the overlapped-SGD hook "
                          "(bucket all-reduce -> update in the completion callback on a side stream) is what runs")
+    ap.add_argument("--bucket-mb", type=int, default=None, help="DDP gradient bucket size (default: engine/ddp_step.py)")
     ap.add_argument("--allow-ddp-fallback", action="store_true",
                     help="if the overlapped hook raises in the first distributed step, retry with stock DDP "
                          "(reported in \"ddp\"); default: fail loudly")
@@ -364,7 +365,8 @@ def main():
             print("[bench %6.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     model, optimizer, scheduler, step = build_training(cfg, device, distributed, local_rank,
-                                                       force_ddp=args.force_ddp and not distributed)
+                                                       force_ddp=args.force_ddp and not distributed,
+                                                       bucket_cap_mb=args.bucket_mb)
     if args.channels_last:
         model.to(memory_format=torch.channels_last)
     batches = make_device_batches(cfg, device, images_per_gpu=args.images_per_gpu, num_batches=2, seed=rank)

@@ -25,7 +25,7 @@ def load_cfg(config_file, opts=()):
     return cfg
 
 
-def build_training(cfg, device, distributed=False, local_rank=0, overlap_optimizer=True, force_ddp=False):
+def build_training(cfg, device, distributed=False, local_rank=0, overlap_optimizer=True, force_ddp=False, bucket_cap_mb=None):
     """-> (model (DDP-wrapped when distributed), optimizer, scheduler, TrainStep).  `force_ddp` wraps
     even at world size 1 (the process group must exist)."""
     model = build_detection_model(cfg).to(device)
@@ -35,8 +35,9 @@ def build_training(cfg, device, distributed=False, local_rank=0, overlap_optimiz
     fp16 = cfg.DTYPE == "float16"
     if distributed or force_ddp:
         ids = [local_rank] if torch.device(device).type == "cuda" else None
-        model = wrap_data_parallel(model, optimizer, device_ids=ids, overlap_optimizer=overlap_optimizer and not fp16,
-                                   force=force_ddp)
+        kw = {} if bucket_cap_mb is None else {"bucket_cap_mb": bucket_cap_mb}
+        model = wrap_data_parallel(model, optimizer, device_ids=ids, overlap_optimizer=overlap_optimizer,
+                                   force=force_ddp, **kw)
     step = TrainStep(model, optimizer, scheduler, dtype=cfg.DTYPE, device_type=torch.device(device).type)
     return model, optimizer, scheduler, step
 

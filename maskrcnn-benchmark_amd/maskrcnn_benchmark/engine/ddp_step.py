@@ -2,13 +2,19 @@
 DistributedDataParallel wrap, `losses.backward()`, `optimizer.step()`).
 
 MI355X design.  One process per GPU; gradients are all-reduced by RCCL over xGMI in ~25 MB fp32
-buckets while the backward pass is still running (torch DDP, `gradient_as_bucket_view=True`, no
-buffer broadcast — every BatchNorm is frozen).  Instead of running the optimizer after the whole
-backward, each bucket's SGD update is chained to that bucket's all-reduce as a future callback:
-it executes on the communication side stream as soon as the bucket's averaged gradient exists,
-overlapping the remaining backward compute; the main stream joins the side stream only when DDP
-finalises the backward.  With one process there is no communication and the same multi-tensor
-update runs on the main stream after backward.
+buckets while the backward pass is still running, and each bucket's SGD update is chained to that
+bucket's all-reduce as a future callback: it executes on the communication side stream as soon as the
+bucket's averaged gradient exists, overlapping the remaining backward compute; the main stream joins
+the side stream when the backward pass ends.  With one process there is no communication and the same
+multi-tensor update runs on the main stream after backward.
+
+The wrapper is `BucketedDataParallel` below, not torch's DistributedDataParallel: this model needs none
+of DDP's generality (every parameter receives a gradient in every step, no buffer is trained — every
+BatchNorm is frozen —, one backward per step), and DDP's per-step host work (the reducer's bucket
+bookkeeping, the forward-time graph walk, gradients accumulated INTO pre-assigned bucket views: one
+add kernel per parameter) costs 2.0-2.5 ms of a 39 ms step at ANY bucket size (profiles/r03m_*).
+Here a step costs one Python hook per parameter (a counter), one multi-tensor copy + one collective +
+one fused update per bucket.
 
 The update is SGD with momentum exactly as torch.optim.SGD computes it (dampening 0, no Nesterov):
     g <- g + wd * p ;  buf <- momentum * buf + g (buf <- g on the first step) ;  p <- p - lr * buf
@@ -33,38 +39,17 @@ class OverlappedSGD(torch.optim.Optimizer):
         for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
                 self._group_of[p] = gi
-        self.deferred = False  # True while a DDP hook applies the updates during backward
-        self.bucket_buffers = {}  # bucket index -> flat gradient buffer (the hook records them; see zero_buckets)
-        self.buckets_complete = False
-        self._buckets_seen = set()
-        self._pass_dirty = False
-        self._alias_checked = None
-
-    @torch.no_grad()
-    def zero_buckets(self):
-        """With `gradient_as_bucket_view` every p.grad is a view into one of DDP's flat bucket buffers: zero the
-        handful of buffers with one multi-tensor launch instead of one fill per parameter (~80 launches for
-        R-50-FPN).  False until the hook has seen every bucket once (the caller then zeroes per parameter)."""
-        if not self.bucket_buffers or not self.buckets_complete:
-            return False
-        if self._alias_checked is not self.bucket_buffers:
-            # once per bucket table: every gradient must live inside one of the recorded buffers
-            spans = [(b.data_ptr(), b.data_ptr() + b.numel() * b.element_size()) for b in self.bucket_buffers.values()]
-            for g in self.param_groups:
-                for p in g["params"]:
-                    if p.grad is None:
-                        continue
-                    a, e = p.grad.data_ptr(), p.grad.data_ptr() + p.grad.numel() * p.grad.element_size()
-                    if not p.grad.is_contiguous() or not any(lo <= a and e <= hi for lo, hi in spans):
-                        return False
-            self._alias_checked = self.bucket_buffers
-        torch._foreach_zero_(list(self.bucket_buffers.values()))
-        return True
+        self.deferred = False  # True while BucketedDataParallel applies the updates during backward
+        # torch.amp.GradScaler.step() then hands `grad_scale` / `found_inf` over as attributes and does NOT read
+        # found_inf back to the host: the fused kernel unscales and skips on the device (no sync in the fp16 step)
+        self._step_supports_amp_scaling = _FUSED_SGD and all(
+            p.is_cuda and p.dtype == torch.float32 for g in self.param_groups for p in g["params"])
 
     @torch.no_grad()
     def step_params(self, params, grads=None):
-        """Update `params`; `grads` (same order) overrides `p.grad` — the DDP hook passes the
+        """Update `params`; `grads` (same order) overrides `p.grad` — the bucket callback passes the
         bucket's gradient views, which hold the averaged values whatever `p.grad` points at."""
+        grad_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
         by_group = {}
         for i, p in enumerate(params):
             gr = p.grad if grads is None else grads[i]
@@ -77,7 +62,10 @@ class OverlappedSGD(torch.optim.Optimizer):
             g = self.param_groups[gi]
             lr, mom, wd = g["lr"], g["momentum"], g["weight_decay"]
             grads = list(grads_g)
-            if mom != 0 and _FUSED_SGD and all(p.is_cuda and p.dtype == torch.float32 for p in ps):
+            fused = mom != 0 and _FUSED_SGD and all(p.is_cuda and p.dtype == torch.float32 for p in ps)
+            if (grad_scale is not None or found_inf is not None) and not fused:
+                raise RuntimeError("loss scaling is only wired into the fused device update (fp32 parameters on the GPU)")
+            if fused:
                 # one multi-tensor pass (read g, p, buf; write buf, p) instead of four (weight decay, momentum
                 # scale, momentum add, parameter add): 0.46 -> 0.2 ms for the 176 MB of R-50-FPN parameters
                 fresh = [i for i, p in enumerate(ps) if "momentum_buffer" not in self.state[p]]
@@ -91,7 +79,7 @@ class OverlappedSGD(torch.optim.Optimizer):
                     torch._fused_sgd_([ps[i] for i in sel], [grads[i] for i in sel],
                                       [self.state[ps[i]]["momentum_buffer"] for i in sel], weight_decay=wd,
                                       momentum=mom, lr=lr, dampening=0.0, nesterov=False, maximize=False,
-                                      is_first_step=first)
+                                      is_first_step=first, grad_scale=grad_scale, found_inf=found_inf)
                 continue
             if wd != 0:
                 grads = torch._foreach_add(grads, ps, alpha=wd)
@@ -135,67 +123,153 @@ def make_overlapped_sgd(cfg, model):
     return OverlappedSGD(groups, S.BASE_LR, momentum=S.MOMENTUM)
 
 
-def _allreduce_then_step(optimizer, process_group):
-    """DDP communication hook: average the bucket over the ranks, then update the bucket's
-    parameters in the all-reduce's completion callback (side stream)."""
-    def hook(state, bucket):
-        group = process_group if process_group is not None else dist.group.WORLD
-        world = dist.get_world_size(group)
-        buf = bucket.buffer()
-        # remember the flat buffers for zero_buckets(); DDP rebuilds its buckets once after the first iteration,
-        # so the table is only trusted after a full pass that did not change it
-        idx = bucket.index()
-        known = optimizer.bucket_buffers.get(idx)
-        if known is None or known.data_ptr() != buf.data_ptr() or known.numel() != buf.numel():
-            table = dict(optimizer.bucket_buffers)   # a new object: zero_buckets re-validates the aliasing
-            table[idx] = buf
-            optimizer.bucket_buffers = table
-            optimizer.buckets_complete = False
-            optimizer._pass_dirty = True
-        optimizer._buckets_seen.add(idx)
-        if bucket.is_last():
-            if len(optimizer._buckets_seen) != len(optimizer.bucket_buffers):   # fewer buckets than before: start over
-                optimizer.bucket_buffers = {}
-                optimizer._pass_dirty = True
-            optimizer.buckets_complete = not optimizer._pass_dirty
-            optimizer._pass_dirty = False
-            optimizer._buckets_seen = set()
-        if world > 1:
-            buf.div_(world)
-        fut = dist.all_reduce(buf, group=group, async_op=True).get_future()
+class _Bucket(object):
+    __slots__ = ("params", "flat", "views", "pending")
 
-        def apply(f):
-            if optimizer.deferred:
-                if buf.is_cuda:  # which stream the update kernels are enqueued on (read by the tests)
-                    optimizer.last_update_stream = torch.cuda.current_stream(buf.device).cuda_stream
-                optimizer.step_params(bucket.parameters(), bucket.gradients())
-            return bucket.buffer()
+    def __init__(self, params):
+        self.params = params
+        self.flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
+        self.views, at = [], 0
+        for p in params:
+            self.views.append(self.flat[at:at + p.numel()].view(p.shape))
+            at += p.numel()
+        self.pending = len(params)
 
-        return fut.then(apply)
 
-    return hook
+class BucketedDataParallel(torch.nn.Module):
+    """Data parallelism for a model whose every parameter gets a gradient in every step.
+
+    Parameters are dealt into flat buckets of `bucket_cap_mb` in REVERSE registration order (about the order the
+    backward pass finishes them).  A post-accumulate hook per parameter counts its bucket down; a finished bucket
+    (buckets go out strictly in index order, so every rank issues the same collective sequence) is packed with one
+    multi-tensor copy, averaged over the ranks by one asynchronous all-reduce, and — `optimizer.deferred` — updated
+    in the all-reduce's completion callback on the communication stream.  `p.grad` is re-pointed at the bucket view,
+    i.e. after the step it holds the AVERAGED gradient like under torch DDP.  When the backward pass ends, buckets
+    that did not fill (a parameter without gradient on this rank: its slice is sent as zeros) are flushed and the
+    main stream joins the callbacks.  `module` is the wrapped model (checkpoints strip the prefix as for DDP).
+
+    Not supported, on purpose: gradient accumulation over several backward passes, trained buffers, parameters
+    of a rank that change `requires_grad` after wrapping."""
+
+    def __init__(self, module, optimizer=None, bucket_cap_mb=25, process_group=None, overlap_optimizer=True):
+        super(BucketedDataParallel, self).__init__()
+        self.module = module
+        self.process_group = process_group if process_group is not None else dist.group.WORLD
+        self.world = dist.get_world_size(self.process_group)
+        self.optimizer = optimizer if isinstance(optimizer, OverlappedSGD) else None
+        self.overlap_optimizer = bool(overlap_optimizer) and self.optimizer is not None
+        if self.optimizer is not None:
+            self.optimizer.deferred = self.overlap_optimizer
+        # RCCL averages inside the collective; gloo (CPU tests) has no AVG: pre-divide there
+        self._avg = dist.ReduceOp.AVG if dist.get_backend(self.process_group) == "nccl" else None
+        self._sync_module_states()
+        cap = max(int(bucket_cap_mb * 1024 * 1024), 1)
+        self.buckets, cur, cur_bytes = [], [], 0
+        for p in reversed([p for p in module.parameters() if p.requires_grad]):
+            if cur and (cur_bytes + p.numel() * p.element_size() > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                self.buckets.append(_Bucket(cur))
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+        if cur:
+            self.buckets.append(_Bucket(cur))
+        self._next, self._armed, self._futures = 0, False, []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(b))
+                       for b in self.buckets for p in b.params]
+
+    def forward(self, *args, **kwargs):
+        if self._armed:             # a backward pass that raised never reached _finish_backward: start clean
+            self._reset()
+        return self.module(*args, **kwargs)
+
+    def _reset(self):
+        del self._futures[:]
+        for b in self.buckets:
+            b.pending = len(b.params)
+        self._next, self._armed = 0, False
+
+    def _sync_module_states(self):
+        """rank 0's parameters and buffers everywhere (what DDP's constructor does), one broadcast per dtype"""
+        tensors = [t.detach() for t in list(self.module.parameters()) + list(self.module.buffers())]
+        by_kind = {}
+        for t in tensors:
+            by_kind.setdefault((t.dtype, t.device), []).append(t)
+        for group in by_kind.values():
+            flat = torch.cat([t.reshape(-1) for t in group])
+            dist.broadcast(flat, 0, group=self.process_group)   # group-local rank 0 == global rank 0 for WORLD
+            at = 0
+            with torch.no_grad():
+                for t in group:
+                    t.copy_(flat[at:at + t.numel()].view(t.shape))
+                    at += t.numel()
+
+    def _make_hook(self, bucket):
+        def hook(param):
+            if not self._armed:
+                self._armed = True
+                torch.autograd.Variable._execution_engine.queue_callback(self._finish_backward)
+            bucket.pending -= 1
+            if bucket.pending == 0:
+                self._advance()
+        return hook
+
+    def _advance(self):
+        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
+
+    @torch.no_grad()
+    def _launch(self, b):
+        grads = [p.grad for p in b.params]
+        if any(g is None for g in grads):       # only on the flush path
+            for v, g in zip(b.views, grads):
+                v.copy_(g) if g is not None else v.zero_()
+        else:
+            torch._foreach_copy_(b.views, grads)
+        for p, v in zip(b.params, b.views):
+            p.grad = v
+        if self._avg is None:
+            if self.world > 1:
+                b.flat.div_(self.world)
+            work = dist.all_reduce(b.flat, group=self.process_group, async_op=True)
+        else:
+            work = dist.all_reduce(b.flat, op=self._avg, group=self.process_group, async_op=True)
+        fut = work.get_future()
+        if self.overlap_optimizer and self.optimizer.deferred:
+            opt = self.optimizer
+
+            def apply(f, b=b):
+                if b.flat.is_cuda:  # which stream the update kernels are enqueued on (read by the tests)
+                    opt.last_update_stream = torch.cuda.current_stream(b.flat.device).cuda_stream
+                opt.step_params(b.params, b.views)
+                return b.flat       # a tensor: the child future records this stream's event for wait()
+
+            fut = fut.then(apply)
+        self._futures.append(fut)
+
+    def _finish_backward(self):
+        for b in self.buckets[self._next:]:
+            self._launch(b)
+        for f in self._futures:
+            f.wait()                # device: the current stream waits for the callbacks' stream; host does not block
+        self._reset()
 
 
 def wrap_data_parallel(model, optimizer=None, device_ids=None, bucket_cap_mb=25, process_group=None,
                        overlap_optimizer=True, force=False):
-    """DistributedDataParallel over RCCL (or gloo in tests) with the optimizer overlapped into the
+    """BucketedDataParallel over RCCL (or gloo in tests) with the optimizer overlapped into the
     gradient all-reduce.  Returns the wrapped model (the bare model for a single process, unless
     `force`: then a 1-rank process group runs the very same bucket -> all-reduce -> update-in-the-
-    callback path, which is how the hook is exercised on a single MI355X)."""
+    callback path, which is how the hook is exercised on a single MI355X).  `device_ids` is accepted
+    for the reference's call shape (tools/train_net.py:48-53); the module already lives on its device."""
     if not (dist.is_available() and dist.is_initialized()):
         if force:
             raise RuntimeError("force=True needs an initialised process group (world size 1 is fine)")
         return model
     if dist.get_world_size() == 1 and not force:
         return model
-    ddp = torch.nn.parallel.DistributedDataParallel(
-        model, device_ids=device_ids, output_device=None if device_ids is None else device_ids[0],
-        broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
-        process_group=process_group)
-    if optimizer is not None and overlap_optimizer and isinstance(optimizer, OverlappedSGD):
-        optimizer.deferred = True
-        ddp.register_comm_hook(None, _allreduce_then_step(optimizer, process_group))
-    return ddp
+    return BucketedDataParallel(model, optimizer, bucket_cap_mb=bucket_cap_mb, process_group=process_group,
+                                overlap_optimizer=overlap_optimizer)
 
 
 class TrainStep(object):
@@ -211,8 +285,10 @@ class TrainStep(object):
         self.device_type = device_type
         self.scaler = None
         if self.amp_dtype is torch.float16:
+            # the gradient all-reduce still overlaps the backward pass; the update waits for the whole step's
+            # found_inf (a skipped step must skip EVERY parameter), then runs fused on the device, no host sync
             if getattr(optimizer, "deferred", False):
-                raise ValueError("fp16 loss scaling needs the classic optimizer step (overlap_optimizer=False)")
+                optimizer.deferred = False
             self.scaler = torch.amp.GradScaler(device_type)
 
     def __call__(self, images, targets):
@@ -222,11 +298,7 @@ class TrainStep(object):
             with torch.autocast(device_type=self.device_type, dtype=self.amp_dtype):
                 loss_dict = self.model(images, targets)
         losses = sum(loss for loss in loss_dict.values())
-        if getattr(self.optimizer, "deferred", False):
-            if not self.optimizer.zero_buckets():
-                self.optimizer.zero_grad(set_to_none=False)
-        else:
-            self.optimizer.zero_grad(set_to_none=True)
+        self.optimizer.zero_grad(set_to_none=True)   # gradients are stolen, not accumulated: no fill, no add kernels
         if self.scaler is not None:
             self.scaler.scale(losses).backward()
             self.scaler.step(self.optimizer)

@@ -44,26 +44,35 @@ def _worker(rank, world, port, steps, out_dir, bucket_mb):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from maskrcnn_benchmark.engine.ddp_step import make_overlapped_sgd, wrap_data_parallel
+    from maskrcnn_benchmark.engine.ddp_step import BucketedDataParallel, make_overlapped_sgd, wrap_data_parallel
     from maskrcnn_benchmark.utils.comm import reduce_dict
     model = _toy()
+    if rank:
+        with torch.no_grad():           # the wrapper must hand every rank rank 0's weights
+            for p in model.parameters():
+                p.add_(1.0)
     opt = make_overlapped_sgd(_cfg(), model)
     ddp = wrap_data_parallel(model, opt, device_ids=None, bucket_cap_mb=bucket_mb)
-    assert opt.deferred and isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    assert opt.deferred and isinstance(ddp, BucketedDataParallel)
+    n_params = len(list(model.parameters()))
+    assert (len(ddp.buckets) == 1) if bucket_mb > 1 else (2 < len(ddp.buckets) <= n_params)
     reduced = None
-    used_bucket_zeroing = 0
     for it in range(steps):
         x, y = _data(rank, it)
+        # one rank leaves a parameter without gradient once: its bucket is flushed at the end of backward with a
+        # zero slice (torch DDP would raise); the reference run gives that rank a zero gradient too
+        frozen = it == 2 and rank == 1
+        model[0].weight.requires_grad_(not frozen)
         loss = ((ddp(x) - y) ** 2).mean()
-        if opt.zero_buckets():          # what TrainStep does: one multi-tensor zero of DDP's flat bucket buffers
-            used_bucket_zeroing += 1
-            assert all(float(p.grad.abs().sum()) == 0.0 for p in model.parameters())
-        else:
-            opt.zero_grad(set_to_none=False)
+        model[0].weight.requires_grad_(True)
+        opt.zero_grad(set_to_none=True)     # what TrainStep does: gradients are stolen, then packed per bucket
         loss.backward()   # all-reduce + SGD update happen inside, bucket by bucket
+        # after the step p.grad is the AVERAGED gradient (a view into the bucket), as under torch DDP
+        assert all(p.grad is not None and p.grad.data_ptr() >= b.flat.data_ptr()
+                   for b in ddp.buckets for p in b.params)
         opt.step()        # no-op in deferred mode
         reduced = reduce_dict({"loss": loss.detach(), "twice": 2 * loss.detach()})
-    assert used_bucket_zeroing >= steps - 3, used_bucket_zeroing   # active once the (rebuilt) buckets have been seen
+    assert ddp._next == 0 and not ddp._armed and not ddp._futures
     torch.save({"params": [p.detach().clone() for p in model.parameters()],
                 "reduced": {k: float(v) for k, v in reduced.items()}, "loss": float(loss)},
                os.path.join(out_dir, "rank%d.pt" % rank))
@@ -86,13 +95,18 @@ def test_overlapped_sgd_ddp_matches_single_process_sgd(tmp_path, bucket_mb):
     biases = [p for n, p in model.named_parameters() if "bias" in n]
     opt = torch.optim.SGD([{"params": weights, "lr": 0.05, "weight_decay": 0.01},
                            {"params": biases, "lr": 0.05 * 2, "weight_decay": 0.0}], lr=0.05, momentum=0.9)
+    params = list(model.parameters())
     for it in range(steps):
-        opt.zero_grad()
-        total = 0
+        mean = [torch.zeros_like(p) for p in params]
         for rank in range(world):
             x, y = _data(rank, it)
-            total = total + ((model(x) - y) ** 2).mean() / world
-        total.backward()
+            grads = list(torch.autograd.grad(((model(x) - y) ** 2).mean(), params))
+            if it == 2 and rank == 1:
+                grads[0] = torch.zeros_like(grads[0])     # the gradient that rank did not produce (see _worker)
+            for m, g in zip(mean, grads):
+                m += g / world
+        for p, m in zip(params, mean):
+            p.grad = m
         opt.step()
     for a, b in zip(r0["params"], model.parameters()):
         torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
@@ -123,8 +137,8 @@ def test_overlapped_sgd_single_process_equals_torch_sgd():
 # ------------------------------------------------------------------ the detector itself under the DDP hook
 def _detector_worker(rank, world, port, config, out_dir):
     """What bench.py / train_net.py do at N > 1, on the CPU shim: build_training(distributed=True) wraps
-    the detector in DDP with the overlapped-SGD hook; three iterations must run (a parameter that gets
-    no gradient would make DDP raise on the second one) and leave both ranks with identical weights."""
+    the detector in BucketedDataParallel with the overlapped SGD; three iterations must run and leave both ranks
+    with identical weights."""
     sys.path.insert(0, PKG)
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
@@ -141,9 +155,10 @@ def _detector_worker(rank, world, port, config, out_dir):
                             "MODEL.RESNETS.WIDTH_PER_GROUP", 4, "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 16,
                             "MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM", 32, "MODEL.ROI_MASK_HEAD.CONV_LAYERS", (16, 16),
                             "SOLVER.BASE_LR", 0.002])
-    torch.manual_seed(7 + rank)  # different initial weights per rank: DDP must broadcast rank 0's
+    torch.manual_seed(7 + rank)  # different initial weights per rank: the wrapper must broadcast rank 0's
     model, opt, sched, step = build_training(cfg, torch.device("cpu"), distributed=True, local_rank=rank)
-    assert isinstance(model, torch.nn.parallel.DistributedDataParallel) and opt.deferred
+    from maskrcnn_benchmark.engine.ddp_step import BucketedDataParallel
+    assert isinstance(model, BucketedDataParallel) and opt.deferred
     ds = SyntheticCOCODataset(length=2, height=96, width=128, with_masks=cfg.MODEL.MASK_ON, min_objects=2,
                               max_objects=4, seed=rank)
     images, targets, _ = BatchCollator(32)([ds[0], ds[1]])

@@ -153,7 +153,8 @@ def test_forced_ddp_hook_world1_nccl_matches_plain_step():
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1)
     try:
         ddp_p, opt, model = run(True)
-        assert isinstance(model, torch.nn.parallel.DistributedDataParallel) and opt.deferred
+        from maskrcnn_benchmark.engine.ddp_step import BucketedDataParallel
+        assert isinstance(model, BucketedDataParallel) and opt.deferred and len(model.buckets) > 1
         side = getattr(opt, "last_update_stream", None)
         assert side is not None, "the hook's update callback never ran"
         assert side != torch.cuda.default_stream(_dev()).cuda_stream, "update kernels must run on a side stream"
