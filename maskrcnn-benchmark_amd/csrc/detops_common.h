@@ -152,6 +152,70 @@ __device__ __forceinline__ void store_f4_wt(float* p, float4 v) {
 #define DETOPS_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #endif
 
+// ---- flags between workgroups of ONE launch (producer has a LOWER blockIdx than every consumer: workgroups are
+// dispatched in index order, so a waiting workgroup only ever waits for resident or finished ones).  Producer:
+// data stores -> detops_release_agent() by every storing wave -> (barrier) -> flag_store / flag_add by one lane.
+// Consumer: spin on flag_load (acquire, agent scope: other XCDs' L2 lines are invalidated) -> plain loads.
+// Spins are bounded (a wedged producer must not hang the device); the emulation runs workgroups one after another,
+// so there a flag that is not already set is a design error and aborts.
+typedef unsigned long long detops_u64;
+#ifdef DETOPS_CPU_EMU
+__device__ __forceinline__ void detops_release_agent() {}
+__device__ __forceinline__ void flag_store(detops_u64* p, detops_u64 v) { *p = v; }
+__device__ __forceinline__ detops_u64 flag_load(const detops_u64* p) { return *p; }
+__device__ __forceinline__ int flag_load(const int* p) { return *p; }
+__device__ __forceinline__ void flag_add(int* p, int v) { *p += v; }
+__device__ __forceinline__ detops_u64 flag_peek(const detops_u64* p) { return *p; }
+__device__ __forceinline__ int flag_peek(const int* p) { return *p; }
+__device__ __forceinline__ void store_u64_wt(detops_u64* p, detops_u64 v) { *p = v; }
+__device__ __forceinline__ void store_u32_wt(void* p, unsigned v) { *static_cast<unsigned*>(p) = v; }
+__device__ __forceinline__ float load_f32_coherent(const float* p) { return *p; }
+__device__ __forceinline__ bool spin_again(int& budget) {
+  (void)budget;
+  fprintf(stderr, "emu: a workgroup waits for a flag no earlier workgroup has set\n");
+  abort();
+}
+#else
+__device__ __forceinline__ void detops_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ __forceinline__ void flag_store(detops_u64* p, detops_u64 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ detops_u64 flag_load(const detops_u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int flag_load(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flag_add(int* p, int v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// polling form: relaxed (an sc1 load, no cache invalidate per poll); DETOPS_ACQUIRE_AGENT() once after the wait
+__device__ __forceinline__ detops_u64 flag_peek(const detops_u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int flag_peek(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// write-through 8-byte store (see store_f4_wt): followed by DETOPS_VMCNT_WAIT(0) and flag_add it publishes a result
+// WITHOUT the L2 write-back a release fence costs — the form for thousands of small producers
+__device__ __forceinline__ void store_u64_wt(detops_u64* p, detops_u64 v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_u32_wt(void* p, unsigned v) {
+  asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+// load that observes another workgroup's write-through stores WITHOUT an acquire fence (buffer_inv sc1 drops the
+// whole XCD's non-coherent cache lines: ruinous when thousands of consumer waves each execute one)
+__device__ __forceinline__ float load_f32_coherent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool spin_again(int& budget) {   // false: give up (seconds of polling)
+  __builtin_amdgcn_s_sleep(64);
+  return --budget > 0;
+}
+#endif
+constexpr int kSpinBudget = 1 << 22;
+
 // ---- tuning / test switches (read once at library load from DETOPS_TUNING="key=value,...", or set through
 // detops_tuning_set(); never read from the environment on the launch path)
 struct DetopsTuning {
@@ -161,6 +225,7 @@ struct DetopsTuning {
   int roi_bwd_groups;      // scan: ROI-list split over blockIdx.y (0 = auto)
   int roi_bwd_scan_ct;     // scan: channels per workgroup, 4 | 16 (0 = auto)
   int roi_bwd_debug;       // ablation bits (diagnosis only)
+  int nms_fused;           // 0 / 1 single launch for n <= 4096 | 2 three launches (sort, mask, scan) | 3 single launch, scans dispatched last
   int roi_fwd_impl;        // 0 auto | 1 generic gather kernel
   int roi_fwd_order;       // 0 auto | 1 never rank | 2 rank even for tiny maps
   int roi_fwd_order_mink;  // smallest K that gets the ranking pre-pass (0 = default)

@@ -21,11 +21,19 @@
 //                the later column blocks; finally kept sorted positions are scattered to a bitset
 //                in ORIGINAL index space and compacted with a workgroup prefix sum -> ascending
 //                original indices, exactly at::nonzero(suppressed == 0) (nms_cpu.cpp:64).
+//
+// n <= 4096 per segment (every RPN / box-head call of the detector): the three stages are ONE launch,
+// nms_fused_kernel — workgroups [0,S) sort, the next S*nb*ceil(nb/8) compute mask tiles (a wave per tile; they wait for
+// their segment's "sorted" token), the last S run the scan chain as the tiles of each row block are counted in.
+// Larger problems keep the three launches.
 #ifndef DETOPS_CPU_EMU
 #include <hipcub/hipcub.hpp>
 #else
 #include <algorithm>
 #endif
+
+#include <atomic>
+#include <random>
 
 #include "detops_common.h"
 
@@ -61,18 +69,18 @@ struct Work {
   float4* boxes;  // [S * stride] sorted boxes
   float* areas;   // [S * stride]
   int32_t* order; // [S * stride] sorted position -> local original index
-  u64* mask;      // [S * stride * nbmax]
-  int stride, nbmax;
+  u64* mask;      // [S * mrows * nbmax]; mrows = stride rounded up to whole 64-row blocks (the scan prefetches whole blocks)
+  int stride, nbmax, mrows;
 };
 
 // ---------------------------------------------------------------------------- 1. sort + gather
-__global__ void __launch_bounds__(1024)
-nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                const int32_t* __restrict__ seg_offsets, int n_single, int npad, Work w) {
-  DETOPS_DYNAMIC_LDS(unsigned char, smem_raw);
-  u64* keys = reinterpret_cast<u64*>(smem_raw);
-  const int s = blockIdx.x;
-  const SegView sv = seg_view(seg_offsets, n_single, s);
+// Bitonic sort of one segment's keys in LDS + gather of the boxes in sorted order.  The compare-exchange pairs of a
+// stage with j <= 64 stay inside the 128-key chunk the SAME wave handled in the previous stage (pair t covers keys
+// 2*(t - t%j) + t%j and + j; 64 consecutive t's = keys [2*t0, 2*t0 + 128)), so those stages need no workgroup
+// barrier: 56 of the 66 stages at n = 2048.
+template <bool WT>   // WT: the sorted rows are consumed by other workgroups of the same launch (write-through stores)
+__device__ __forceinline__ void sort_and_gather(u64* keys, const float* __restrict__ boxes,
+                                                const float* __restrict__ scores, SegView sv, int npad, const Work& w, int s) {
   const int n = sv.n;
   // smallest power of two >= n (uniform), bounded by npad (the host-side capacity)
   int np = 2;
@@ -91,9 +99,12 @@ nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ score
         const bool up = (i & k) == 0;
         if ((a > b) == up) { keys[i] = b; keys[p] = a; }
       }
-      __syncthreads();
+      const int jn = j > 1 ? (j >> 1) : k;   // the next stage's distance (k: first stage of the next merge)
+      if (j > kWave || jn > kWave) __syncthreads();
+      else DETOPS_WAVE_SYNC();
     }
   }
+  __syncthreads();
   float4* ob = w.boxes + static_cast<size_t>(s) * w.stride;
   float* oa = w.areas + static_cast<size_t>(s) * w.stride;
   int32_t* oo = w.order + static_cast<size_t>(s) * w.stride;
@@ -102,10 +113,25 @@ nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ score
 #pragma clang fp contract(off)
     const int src = static_cast<int>(keys[i] & 0xffffffffu);
     const float4 b = ib[src];
-    ob[i] = b;
-    oa[i] = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);  // nms_cpu.cpp:22
-    oo[i] = src;
+    const float area = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);  // nms_cpu.cpp:22
+    if (WT) {
+      store_f4_wt(reinterpret_cast<float*>(ob + i), b);
+      store_u32_wt(oa + i, __float_as_uint(area));
+      store_u32_wt(oo + i, static_cast<unsigned>(src));
+    } else {
+      ob[i] = b;
+      oa[i] = area;
+      oo[i] = src;
+    }
   }
+}
+
+__global__ void __launch_bounds__(1024)
+nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                const int32_t* __restrict__ seg_offsets, int n_single, int npad, Work w) {
+  DETOPS_DYNAMIC_LDS(unsigned char, smem_raw);
+  const int s = blockIdx.x;
+  sort_and_gather<false>(reinterpret_cast<u64*>(smem_raw), boxes, scores, seg_view(seg_offsets, n_single, s), npad, w, s);
 }
 
 // large-n path (n > 8192, any number of segments): per-segment key rows padded to `stride` with
@@ -137,53 +163,77 @@ __global__ void nms_gather_kernel(const float* __restrict__ boxes, const u64* __
 }
 
 // ---------------------------------------------------------------------------- 2. IoU bitmask
+// One wave = one 64x64 tile: lane r holds row box r, the 64 column boxes are broadcast lane by lane (v_readlane ->
+// scalar operands; no LDS, no barrier).  Every lane runs the whole loop (rows / columns past n carry zeros and are
+// masked off), so the broadcasts stay wave-wide.
+__device__ __forceinline__ float lane_bcast(float v, int c) {
+  return __int_as_float(static_cast<int>(__builtin_amdgcn_readlane(static_cast<unsigned>(__float_as_int(v)), c)));
+}
+
+template <bool WT>   // WT: the word is published to another workgroup of the same launch (write-through store)
+__device__ __forceinline__ void mask_tile(const float4* __restrict__ sb, const float* __restrict__ sa, u64* __restrict__ mask,
+                                          int n, int nb, int rb, int cb, float thr) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int ncol = min(kWave, n - cb * kWave);
+  const int col = cb * kWave + lane, row = rb * kWave + lane;
+  float4 cbx = make_float4(0.f, 0.f, 0.f, 0.f);
+  float car = 0.f;
+  float4 a;
+  float iarea;
+  const int rrow = min(row, n - 1);
+  if (WT) {   // the sorted rows were published by the sort workgroup of this launch
+    const float* fb = reinterpret_cast<const float*>(sb);
+    if (lane < ncol) {
+      cbx = make_float4(load_f32_coherent(fb + 4 * col), load_f32_coherent(fb + 4 * col + 1),
+                        load_f32_coherent(fb + 4 * col + 2), load_f32_coherent(fb + 4 * col + 3));
+      car = load_f32_coherent(sa + col);
+    }
+    a = make_float4(load_f32_coherent(fb + 4 * rrow), load_f32_coherent(fb + 4 * rrow + 1),
+                    load_f32_coherent(fb + 4 * rrow + 2), load_f32_coherent(fb + 4 * rrow + 3));
+    iarea = load_f32_coherent(sa + rrow);
+  } else {
+    if (lane < ncol) { cbx = sb[col]; car = sa[col]; }
+    a = sb[rrow];
+    iarea = sa[rrow];
+  }
+  u64 bits = 0;
+  // Diagonal tile: the FULL symmetric relation of the row (every c != lane).  The comparison is symmetric bit for
+  // bit (max / min / fp add commute, `iarea + carea - inter` sees the same two addends), so the bits below the
+  // diagonal are "rows j < lane that suppress lane" — the transposed view the scan's fixed-point resolve needs.
+#pragma unroll 8
+  for (int c = 0; c < kWave; ++c) {
+#pragma clang fp contract(off)
+    const float bx = lane_bcast(cbx.x, c), by = lane_bcast(cbx.y, c), bz = lane_bcast(cbx.z, c), bw = lane_bcast(cbx.w, c);
+    const float ca = lane_bcast(car, c);
+    const float xx1 = fmaxf(a.x, bx), yy1 = fmaxf(a.y, by);
+    const float xx2 = fminf(a.z, bz), yy2 = fminf(a.w, bw);
+    const float ww = fmaxf(0.f, xx2 - xx1 + 1.f);
+    const float hh = fmaxf(0.f, yy2 - yy1 + 1.f);
+    const float inter = ww * hh;
+    bool sup;
+    if (inter > 0.f || thr <= 0.f) {
+      const float ovr = inter / (iarea + ca - inter);  // IEEE fp32 division
+      sup = ovr >= thr;                                // nms_cpu.cpp:60
+    } else {
+      sup = false;  // inter == 0 -> ovr is +-0 (or NaN for a zero union): never >= a positive thr
+    }
+    if (sup && !(rb == cb && c == lane)) bits |= 1ull << c;
+  }
+  if (ncol < kWave) bits &= (1ull << ncol) - 1;
+  if (row < n) {
+    if (WT) store_u64_wt(mask + static_cast<size_t>(row) * nb + cb, bits);
+    else mask[static_cast<size_t>(row) * nb + cb] = bits;
+  }
+}
+
 __global__ void __launch_bounds__(kWave)
 nms_mask_kernel(const int32_t* __restrict__ seg_offsets, int n_single, float thr, Work w) {
   const int cb = blockIdx.x, rb = blockIdx.y, s = blockIdx.z;
   if (cb < rb) return;  // upper triangle only
   const int n = seg_view(seg_offsets, n_single, s).n;
   if (rb * kWave >= n || cb * kWave >= n) return;
-  const int nb = (n + kWave - 1) / kWave;  // words per row for THIS segment
-  const float4* sb = w.boxes + static_cast<size_t>(s) * w.stride;
-  const float* sa = w.areas + static_cast<size_t>(s) * w.stride;
-  u64* mask = w.mask + static_cast<size_t>(s) * w.stride * w.nbmax;
-
-  __shared__ float4 cbox[kWave];
-  __shared__ float carea[kWave];
-  const int lane = threadIdx.x;
-  const int ncol = min(kWave, n - cb * kWave);
-  if (lane < ncol) {
-    cbox[lane] = sb[cb * kWave + lane];
-    carea[lane] = sa[cb * kWave + lane];
-  }
-  __syncthreads();
-  const int row = rb * kWave + lane;
-  if (row >= n) return;
-  const float4 a = sb[row];
-  const float iarea = sa[row];
-  u64 bits = 0;
-  // Diagonal tile: the FULL symmetric relation of the row (every c != lane).  The comparison is symmetric bit for
-  // bit (max / min / fp add commute, `iarea + carea - inter` sees the same two addends), so the bits below the
-  // diagonal are "rows j < lane that suppress lane" — the transposed view the scan's fixed-point resolve needs.
-  for (int c = 0; c < ncol; ++c) {
-#pragma clang fp contract(off)
-    if (rb == cb && c == lane) continue;
-    const float4 b = cbox[c];
-    const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y);
-    const float xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
-    const float ww = fmaxf(0.f, xx2 - xx1 + 1.f);
-    const float hh = fmaxf(0.f, yy2 - yy1 + 1.f);
-    const float inter = ww * hh;
-    bool sup;
-    if (inter > 0.f || thr <= 0.f) {
-      const float ovr = inter / (iarea + carea[c] - inter);  // IEEE fp32 division
-      sup = ovr >= thr;                                      // nms_cpu.cpp:60
-    } else {
-      sup = false;  // inter == 0 -> ovr is +-0 (or NaN for a zero union): never >= a positive thr
-    }
-    if (sup) bits |= 1ull << c;
-  }
-  mask[static_cast<size_t>(row) * nb + cb] = bits;
+  mask_tile<false>(w.boxes + static_cast<size_t>(s) * w.stride, w.areas + static_cast<size_t>(s) * w.stride,
+                   w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, (n + kWave - 1) / kWave, rb, cb, thr);
 }
 
 // ---------------------------------------------------------------------------- 3. scan + compaction
@@ -197,6 +247,136 @@ __device__ __forceinline__ u64 uniform64(u64 v) {  // value known to be wave-uni
   const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
   const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
   return (static_cast<u64>(hi) << 32) | lo;
+}
+
+// The greedy chain of one segment with n <= 4096, walked by ONE wave with the pending "removed" words in registers.
+// A row of the mask has nb <= 64 words; with nb <= 32 (16) a wave-wide load covers RPI = 2 (4) rows at once: lane =
+// (sub, col) holds column word `col` of row t*RPI + sub in iteration t, and accumulates the removed bits of the rows
+// = sub (mod RPI) — the RPI partial words of a column are OR-ed when the chain reaches that column block.  Per row
+// block: resolve the diagonal tile (ballot fixed point over the kept rows), then 64/RPI iterations of
+// `removed |= row & -(kept bit)` with the same registers refilled from the NEXT block (rows / columns outside the
+// segment pick up words nobody consumes: no per-load predication; the mask region is padded to whole blocks).
+// `done` (fused launch): tile counters per row block; a block's rows are only requested once its nb - rb tiles are in.
+template <int RPI>
+__device__ __forceinline__ void scan_chain(const u64* __restrict__ mask, int n, int nb, const int* done, u64* keptw) {
+  constexpr int CW = kWave / RPI, NIT = kWave / RPI;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int sub = lane / CW, col = lane % CW;
+  const int ccol = min(col, nb - 1);
+  u64 ready = done ? 0ull : ~0ull;
+  int budget = kSpinBudget;
+  auto ensure = [&](int rbx) {                       // uniform: the tiles of row block rbx are in memory
+    if ((ready >> rbx) & 1ull) return;
+    for (;;) {
+      const bool ok = lane < nb ? flag_peek(done + lane) >= nb - lane : true;
+      ready = __ballot(ok);
+      if (((ready >> rbx) & 1ull) || !spin_again(budget)) break;
+    }
+    DETOPS_ACQUIRE_AGENT();                          // the rows of every block counted complete are now loadable
+  };
+  u64 removed = 0;                                   // lane (sub, c): pending removed bits of column block c, rows = sub
+  u64 sym_next = 0;                                  // lane i: symmetric diagonal-tile word of row rb*64 + i
+  ensure(0);
+  if (lane < n) sym_next = mask[static_cast<size_t>(lane) * nb];
+  const u64 below_me = (1ull << lane) - 1;
+  u64 v[NIT];
+  {
+    const u64* p = mask + static_cast<size_t>(sub) * nb + ccol;
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) v[t] = p[static_cast<size_t>(t * RPI) * nb];
+  }
+  for (int rb = 0; rb < nb; ++rb) {
+    const int nrow = min(kWave, n - rb * kWave);
+    const u64 below = sym_next & below_me;           // rows j < lane of this block that suppress row lane
+    sym_next = 0;
+    const int rbn = min(rb + 1, nb - 1);             // last block: re-reads itself, result unused
+    ensure(rbn);
+    if (rb + 1 < nb && (rb + 1) * kWave + lane < n)
+      sym_next = mask[static_cast<size_t>((rb + 1) * kWave + lane) * nb + rb + 1];
+    u64 dead = 0;
+#pragma unroll
+    for (int q = 0; q < RPI; ++q) dead |= readlane64(removed, rb + q * CW);   // rb < nb <= CW
+    if (nrow < kWave) dead |= ~0ull << nrow;
+    // greedy choice inside the block = the unique fixed point of K = alive & {i : no kept j < i suppresses i};
+    // the iteration settles rows of dependency depth <= t after t rounds (a handful for real boxes, 64 at worst)
+    const u64 alive = ~dead;
+    u64 kept = alive;
+    for (int round = 0; round <= kWave; ++round) {
+      const u64 next = __ballot((below & kept) == 0) & alive;
+      if (next == kept) break;
+      kept = next;
+    }
+    if (lane == 0) keptw[rb] = kept;
+    const u64 mine = kept >> sub;                    // bit t*RPI: is row t*RPI + sub kept
+    const u64* pn = mask + (static_cast<size_t>(rbn) * kWave + sub) * nb + ccol;
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) {
+      removed |= v[t] & (0ull - ((mine >> (t * RPI)) & 1ull));
+      v[t] = pn[static_cast<size_t>(t * RPI) * nb];
+    }
+  }
+}
+
+// WIDE = false: the caller guarantees nb <= 32 (the one-row-per-load form and its 128 prefetch registers are left out)
+template <bool WIDE>
+__device__ __forceinline__ void scan_chain_any(const u64* __restrict__ mask, int n, int nb, const int* done, u64* keptw) {
+  if (nb <= 16) scan_chain<4>(mask, n, nb, done, keptw);
+  else if (nb <= 32 || !WIDE) scan_chain<2>(mask, n, nb, done, keptw);
+  else scan_chain<1>(mask, n, nb, done, keptw);
+}
+
+// kept sorted positions -> ascending ORIGINAL indices (at::nonzero(suppressed == 0), nms_cpu.cpp:64), the dense 0/1
+// mask and the count.  Whole workgroup (kScanThreads); `flags` zeroed by the caller, `keptw` complete, barrier passed.
+__device__ __forceinline__ void compact_keep(const u64* keptw, u64* flags, int* wsum, const int32_t* __restrict__ order,
+                                             SegView sv, int s, int64_t* __restrict__ keep,
+                                             int32_t* __restrict__ num_keep, uint8_t* __restrict__ keep_mask) {
+  const int n = sv.n, nb = (n + kWave - 1) / kWave;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  constexpr int kWaves = kScanThreads / kWave;
+  // kept sorted positions -> bitset over original (segment-local) indices
+  for (int p = tid; p < n; p += kScanThreads) {
+    if ((keptw[p >> 6] >> (p & 63)) & 1ull) {
+      const int o = order[p];
+      atomicOr(&flags[o >> 6], 1ull << (o & 63));
+    }
+  }
+  __syncthreads();
+  if (keep_mask) {  // dense 0/1 form (original index space) for fixed-shape, sync-free callers
+    uint8_t* km = keep_mask + sv.begin;
+    for (int p = tid; p < n; p += kScanThreads) km[p] = static_cast<uint8_t>((flags[p >> 6] >> (p & 63)) & 1ull);
+  }
+  // workgroup exclusive prefix sum over popcounts of the flag words
+  const int wpt = (nb + kScanThreads - 1) / kScanThreads;  // words per thread (<= 2)
+  const int w0 = tid * wpt;
+  int local = 0;
+  for (int j = 0; j < wpt; ++j)
+    if (w0 + j < nb) local += __popcll(flags[w0 + j]);
+  int incl = local;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == kWave - 1) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int j = 0; j < kWaves; ++j) {
+    const int v = wsum[j];
+    if (j < wave) base += v;
+    total += v;
+  }
+  int pos = base + incl - local;
+  int64_t* kout = keep + sv.begin;
+  for (int j = 0; keep && j < wpt; ++j) {
+    if (w0 + j >= nb) break;
+    u64 f = flags[w0 + j];
+    while (f) {
+      const int b = __builtin_ctzll(f);
+      f &= f - 1;
+      kout[pos++] = static_cast<int64_t>((w0 + j) * 64 + b);
+    }
+  }
+  if (tid == 0) num_keep[s] = total;
 }
 
 __global__ void __launch_bounds__(kScanThreads)
@@ -213,7 +393,7 @@ nms_scan_kernel(const int32_t* __restrict__ seg_offsets, int n_single, Work w,
   const SegView sv = seg_view(seg_offsets, n_single, s);
   const int n = sv.n;
   const int nb = (n + kWave - 1) / kWave;
-  const u64* mask = w.mask + static_cast<size_t>(s) * w.stride * w.nbmax;
+  const u64* mask = w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax;
   const int32_t* order = w.order + static_cast<size_t>(s) * w.stride;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   constexpr int kWaves = kScanThreads / kWave;
@@ -221,58 +401,11 @@ nms_scan_kernel(const int32_t* __restrict__ seg_offsets, int n_single, Work w,
   for (int i = tid; i < nb; i += kScanThreads) { remv[i] = 0; flags[i] = 0; }
   __syncthreads();
 
-  // n <= 4096 (nb <= 64 column words): ONE wave walks the whole chain with the pending-removed words in registers,
-  // lane c = column block c.  Per row block: resolve the diagonal tile (SALU chain over the kept rows), then OR the
-  // kept rows' mask rows into the lanes — one coalesced load per kept row, all of a block's loads in flight
-  // together, no LDS, no barrier.  The shared-memory form below costs two workgroup barriers and a dependent
-  // global round trip per row block (32 blocks at n = 2000: 189 us for the 10 RPN segments of a training step).
+  // n <= 4096 (nb <= 64 column words): ONE wave walks the whole chain (scan_chain above), no LDS, no barrier.  The
+  // shared-memory form below costs two workgroup barriers and a dependent global round trip per row block.
   const bool one_wave = nb <= kWave;
   if (one_wave) {
-    if (wave == 0) {
-      u64 removed = 0;                                   // lane c: pending removed bits of column block c
-      u64 sym_next = 0;                                  // lane i: symmetric diagonal-tile word of row rb*64 + i
-      if (lane < n) sym_next = mask[static_cast<size_t>(lane) * nb];
-      const u64 below_me = (1ull << lane) - 1;
-      // A block's 64 mask rows, lane = column word.  Loads are unconditional (row / column clamped into the
-      // segment): lanes <= rb or >= nb pick up words nobody reads again (their `removed` is never consulted), rows
-      // >= nrow are never kept — no per-load predication.  Row u of the NEXT block is requested right after row u of
-      // this block has been consumed, into the same registers: the loads fly during the OR pass and the next
-      // resolve instead of stalling the chain once per block.
-      const int ccol = min(lane, nb - 1);
-      u64 v[kWave];
-      {
-        const int nrow0 = min(kWave, n);
-#pragma unroll
-        for (int u = 0; u < kWave; ++u) v[u] = mask[static_cast<size_t>(min(u, nrow0 - 1)) * nb + ccol];
-      }
-      for (int rb = 0; rb < nb; ++rb) {
-        const int nrow = min(kWave, n - rb * kWave);
-        const u64 below = sym_next & below_me;           // rows j < lane of this block that suppress row lane
-        sym_next = 0;
-        if (rb + 1 < nb && (rb + 1) * kWave + lane < n)
-          sym_next = mask[static_cast<size_t>((rb + 1) * kWave + lane) * nb + rb + 1];
-        u64 dead = readlane64(removed, rb);
-        if (nrow < kWave) dead |= ~0ull << nrow;
-        // greedy choice inside the block = the unique fixed point of K = alive & {i : no kept j < i suppresses i};
-        // the iteration settles rows of dependency depth <= t after t rounds (a handful for real boxes, 64 at worst)
-        const u64 alive = ~dead;
-        u64 kept = alive;
-        for (int round = 0; round <= kWave; ++round) {
-          const u64 next = __ballot((below & kept) == 0) & alive;
-          if (next == kept) break;
-          kept = next;
-        }
-        if (lane == 0) keptw[rb] = kept;
-        const int rbn = min(rb + 1, nb - 1);             // last block: re-reads itself, result unused
-        const int nrown = min(kWave, n - rbn * kWave);
-        const u64* blkn = mask + static_cast<size_t>(rbn) * kWave * nb;   // uniform
-#pragma unroll
-        for (int u = 0; u < kWave; ++u) {
-          if ((kept >> u) & 1ull) removed |= v[u];       // uniform condition
-          v[u] = blkn[static_cast<size_t>(min(u, nrown - 1)) * nb + ccol];
-        }
-      }
-    }
+    if (wave == 0 && nb > 0) scan_chain_any<true>(mask, n, nb, nullptr, keptw);
     __syncthreads();
   }
 
@@ -332,57 +465,89 @@ nms_scan_kernel(const int32_t* __restrict__ seg_offsets, int n_single, Work w,
     __syncthreads();
   }
 
-  // kept sorted positions -> bitset over original (segment-local) indices
-  for (int p = tid; p < n; p += kScanThreads) {
-    if ((keptw[p >> 6] >> (p & 63)) & 1ull) {
-      const int o = order[p];
-      atomicOr(&flags[o >> 6], 1ull << (o & 63));
+  compact_keep(keptw, flags, wsum, order, sv, s, keep, num_keep, keep_mask);
+}
+
+// ---------------------------------------------------------------------------- fused single launch (n <= 4096)
+constexpr int kFusedMaxN = 4096;
+constexpr int kFusedWaves = kScanThreads / kWave;   // tiles per tile workgroup
+
+struct FusedCtrl {        // one per segment, in the caller's workspace (arbitrary previous content)
+  u64 token;              // == this launch's token once the segment's sorted boxes / areas / order are in memory
+  int32_t done[kWave];    // finished mask tiles per row block; zeroed by the sort workgroup BEFORE the token
+};
+
+// blockIdx.x:  [0, S)                 sort + gather of segment s, then publish the token
+//              S * nbmax * G          mask tiles: ((rb * S) + s) * G + g -> column blocks rb + 8g + wave (row block 0 of
+//                                     every segment first: the scans start while later rows are still computed)
+//              S                      scan chain + compaction of segment s
+// scan_first = 0: tiles, then scans — every wait is for a workgroup with a LOWER index (detops_common.h, "flags between
+// workgroups"); the scans are dispatched last, i.e. once most tile workgroups have retired.  scan_first = 1 (the host
+// passes it when 2S workgroups are a small part of what the device holds at once): the scan workgroups sit right
+// behind the sorts and consume row blocks while the tiles are still being produced; they wait for later-indexed
+// workgroups, which is safe because those only need the S sort workgroups (earlier, never waiting) and one free slot.
+// The token is unique per launch (64 bits: random per process + call counter), so a stale or never-written control
+// block cannot match.
+template <bool WIDE>   // false: max_n <= 2048 (every call the detector makes): ~half the registers, two workgroups per CU
+__global__ void __launch_bounds__(kScanThreads)
+nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                 const int32_t* __restrict__ seg_offsets, int n_single, int npad, float thr, Work w,
+                 FusedCtrl* __restrict__ ctrl, u64 token, int S, int G, int scan_first, int64_t* __restrict__ keep,
+                 int32_t* __restrict__ num_keep, uint8_t* __restrict__ keep_mask) {
+  DETOPS_DYNAMIC_LDS(unsigned char, smem_raw);
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int T = w.nbmax * S * G;
+  int bid = blockIdx.x;                                           // role index: sorts, tiles, scans
+  if (scan_first && bid >= S) bid = bid < 2 * S ? bid + T : bid - S;
+  if (bid < S) {                                                  // ---- sort
+    const int s = bid;
+    if (tid < kWave) store_u32_wt(&ctrl[s].done[tid], 0u);
+    sort_and_gather<true>(reinterpret_cast<u64*>(smem_raw), boxes, scores, seg_view(seg_offsets, n_single, s), npad, w, s);
+    DETOPS_VMCNT_WAIT(0);            // this wave's write-through stores (sorted rows, the zeroed counters) are in memory
+    __syncthreads();
+    if (tid == 0) flag_store(&ctrl[s].token, token);
+    return;
+  }
+  if (bid < S + T) {                                              // ---- mask tiles, one per wave
+    const int idx = bid - S;
+    const int g = idx % G, s = (idx / G) % S, rb = idx / (G * S);
+    const int cb = rb + g * kFusedWaves + wave;
+    const int n = seg_view(seg_offsets, n_single, s).n;
+    if (rb * kWave >= n || cb * kWave >= n) return;
+    if (wave == 0) {                 // the workgroup's first wave always has a tile (cb = rb + 8g <= its siblings')
+      int budget = kSpinBudget;
+      while (flag_peek(&ctrl[s].token) != token && spin_again(budget)) {}
     }
+    __syncthreads();                 // waves without a tile have left; the barrier counts the remaining ones
+    mask_tile<true>(w.boxes + static_cast<size_t>(s) * w.stride, w.areas + static_cast<size_t>(s) * w.stride,
+                    w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, (n + kWave - 1) / kWave, rb, cb, thr);
+    DETOPS_VMCNT_WAIT(0);            // the 64 write-through stores of this wave have reached memory
+    if (lane == 0) flag_add(&ctrl[s].done[rb], 1);
+    return;
+  }
+  const int s = bid - S - T;                                      // ---- scan
+  const SegView sv = seg_view(seg_offsets, n_single, s);
+  const int n = sv.n, nb = (n + kWave - 1) / kWave;
+  u64* keptw = reinterpret_cast<u64*>(smem_raw);
+  u64* flags = keptw + kWave;
+  int* wsum = reinterpret_cast<int*>(flags + kWave);
+  if (tid < kWave) flags[tid] = 0;
+  if (wave == 0) {
+    int budget = kSpinBudget;
+    while (flag_peek(&ctrl[s].token) != token && spin_again(budget)) {}   // the counters below are valid from here on
+    DETOPS_ACQUIRE_AGENT();
+    if (nb > 0)
+      scan_chain_any<WIDE>(w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, nb, ctrl[s].done, keptw);
   }
   __syncthreads();
-  if (keep_mask) {  // dense 0/1 form (original index space) for fixed-shape, sync-free callers
-    uint8_t* km = keep_mask + sv.begin;
-    for (int p = tid; p < n; p += kScanThreads) km[p] = static_cast<uint8_t>((flags[p >> 6] >> (p & 63)) & 1ull);
-  }
-  // workgroup exclusive prefix sum over popcounts of the flag words
-  const int wpt = (nb + kScanThreads - 1) / kScanThreads;  // words per thread (<= 2)
-  const int w0 = tid * wpt;
-  int local = 0;
-  for (int j = 0; j < wpt; ++j)
-    if (w0 + j < nb) local += __popcll(flags[w0 + j]);
-  int incl = local;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const int t = __shfl_up(incl, off);
-    if (lane >= off) incl += t;
-  }
-  if (lane == kWave - 1) wsum[wave] = incl;
-  __syncthreads();
-  int base = 0, total = 0;
-  for (int j = 0; j < kWaves; ++j) {
-    const int v = wsum[j];
-    if (j < wave) base += v;
-    total += v;
-  }
-  int pos = base + incl - local;
-  int64_t* kout = keep + sv.begin;
-  for (int j = 0; keep && j < wpt; ++j) {
-    if (w0 + j >= nb) break;
-    u64 f = flags[w0 + j];
-    while (f) {
-      const int b = __builtin_ctzll(f);
-      f &= f - 1;
-      kout[pos++] = static_cast<int64_t>((w0 + j) * 64 + b);
-    }
-  }
-  if (tid == 0) num_keep[s] = total;
+  compact_keep(keptw, flags, wsum, w.order + static_cast<size_t>(s) * w.stride, sv, s, keep, num_keep, keep_mask);
 }
 
 // ---------------------------------------------------------------------------- host side
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Layout {
-  size_t off_boxes, off_areas, off_order, off_mask, off_keys, off_keys2, off_cub, total;
+  size_t off_boxes, off_areas, off_order, off_mask, off_ctrl, off_keys, off_keys2, off_cub, total;
   size_t cub_bytes;
 };
 
@@ -394,7 +559,8 @@ Layout make_layout(int S, int max_n, bool big) {
   l.off_boxes = o; o = align_up(o + rows * sizeof(float4), 256);
   l.off_areas = o; o = align_up(o + rows * sizeof(float), 256);
   l.off_order = o; o = align_up(o + rows * sizeof(int32_t), 256);
-  l.off_mask = o;  o = align_up(o + rows * nbmax * sizeof(u64), 256);
+  l.off_mask = o;  o = align_up(o + static_cast<size_t>(S) * nbmax * kWave * nbmax * sizeof(u64), 256);
+  l.off_ctrl = o;  o = align_up(o + static_cast<size_t>(S) * sizeof(FusedCtrl), 256);
   if (big) {
     l.off_keys = o;  o = align_up(o + rows * sizeof(u64), 256);
     l.off_keys2 = o; o = align_up(o + rows * sizeof(u64), 256);
@@ -420,7 +586,8 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
   const bool big = max_n > kSortLdsMax;
   const Layout l = make_layout(S, max_n, big);
   if (ws_bytes < l.total || !ws) return DETOPS_EWORKSPACE;
-  unsigned char* base = static_cast<unsigned char*>(ws);
+  unsigned char* base_ptr = static_cast<unsigned char*>(ws);
+  unsigned char* base = base_ptr;
   Work w;
   w.boxes = reinterpret_cast<float4*>(base + l.off_boxes);
   w.areas = reinterpret_cast<float*>(base + l.off_areas);
@@ -428,6 +595,38 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
   w.mask = reinterpret_cast<u64*>(base + l.off_mask);
   w.stride = max_n;
   w.nbmax = (max_n + kWave - 1) / kWave;
+  w.mrows = w.nbmax * kWave;
+
+  if (max_n <= kFusedMaxN && detops_tuning().nms_fused != 2) {
+    int npad = 2;
+    while (npad < max_n) npad <<= 1;
+    static const u64 base = (static_cast<u64>(std::random_device{}()) << 32) ^ 0x9e3779b97f4a7c15ull;
+    static std::atomic<u64> calls{0};
+    const u64 token = base + calls.fetch_add(1) + 1;
+    const int G = (w.nbmax + kFusedWaves - 1) / kFusedWaves;
+    const size_t lds = std::max<size_t>(npad * sizeof(u64), 2 * kWave * sizeof(u64) + 64);
+    auto kernel = w.nbmax <= 32 ? nms_fused_kernel<false> : nms_fused_kernel<true>;
+    int scan_first = 0;
+#ifndef DETOPS_CPU_EMU   // (the emulation runs workgroups one after another: producers first)
+    static int resident[2] = {0, 0};   // workgroups the device holds at once, per kernel variant (first device seen)
+    int& cap = resident[w.nbmax <= 32 ? 0 : 1];
+    if (cap == 0) {
+      int dev = 0, cus = 0, per_cu = 1;
+      if (hipGetDevice(&dev) == hipSuccess &&
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+        DETOPS_OCCUPANCY(per_cu, kernel, kScanThreads, 32 * 1024);
+        cap = cus * per_cu;
+      } else {
+        cap = -1;
+      }
+    }
+    scan_first = (cap > 0 && 8 * S <= cap && detops_tuning().nms_fused != 3) ? 1 : 0;
+#endif
+    hipLaunchKernelGGL(kernel, dim3(2 * S + w.nbmax * S * G), dim3(kScanThreads), lds, st, boxes, scores,
+                       seg_offsets, max_n, npad, thr, w, reinterpret_cast<FusedCtrl*>(base_ptr + l.off_ctrl), token, S, G,
+                       scan_first, keep, num_keep, keep_mask);
+    return launch_status();
+  }
 
   if (!big) {
     int npad = 2;
@@ -521,3 +720,4 @@ DETOPS_API int detops_nms_batched_mask_f32(const float* boxes, const float* scor
   return run_nms(boxes, scores, seg_offsets, num_segments, max_n, threshold, nullptr, num_keep,
                  keep_mask, workspace, workspace_bytes, st);
 }
+

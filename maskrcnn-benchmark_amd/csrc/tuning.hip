@@ -16,6 +16,7 @@ const Key kKeys[] = {
     {"roi_fwd_order", &DetopsTuning::roi_fwd_order},     {"roi_fwd_order_mink", &DetopsTuning::roi_fwd_order_mink},
     {"dcn_col2im", &DetopsTuning::dcn_col2im},           {"dcn_fused", &DetopsTuning::dcn_fused},
     {"dcn_gather_xcd", &DetopsTuning::dcn_gather_xcd},   {"dcn_nhwc", &DetopsTuning::dcn_nhwc},
+    {"nms_fused", &DetopsTuning::nms_fused},
 };
 
 bool set_key(DetopsTuning& t, const char* key, size_t len, int value) {

@@ -88,7 +88,7 @@ def lib():
 
 
 TUNING_KEYS = ("roi_bwd_impl", "roi_bwd_seg", "roi_bwd_ring", "roi_bwd_groups", "roi_bwd_scan_ct", "roi_bwd_debug", "roi_fwd_impl",
-               "roi_fwd_order", "roi_fwd_order_mink", "dcn_col2im", "dcn_fused", "dcn_gather_xcd", "dcn_nhwc")
+               "roi_fwd_order", "roi_fwd_order_mink", "dcn_col2im", "dcn_fused", "dcn_gather_xcd", "dcn_nhwc", "nms_fused")
 
 
 def tuning_set(key, value):
@@ -389,7 +389,7 @@ def nms_batched(boxes, scores, offsets, max_n, thr, mask=False):
     S = offsets.shape[0] - 1
     num = np.full((S,), -1, np.int32)
     nbytes = lib().detops_nms_batched_workspace_bytes(S, max_n)
-    ws = np.empty((nbytes,), np.uint8)
+    ws = np.full((nbytes,), 0xA5, np.uint8)       # the library must not rely on any workspace content
     if mask:
         km = np.full((boxes.shape[0],), 7, np.uint8)
         rc = lib().detops_nms_batched_mask_f32(_p(boxes), _p(scores), _p(offsets), S, max_n, thr, _p(km), _p(num),

@@ -243,6 +243,36 @@ def test_emu_nms_ties_large_n_and_batched():
         assert np.array_equal(km[offs[i]:offs[i + 1]], want)
 
 
+@pytest.mark.parametrize("fused", [0, 2])
+def test_emu_nms_single_launch_and_three_launch_paths(fused):
+    """n <= 4096: sort, mask tiles and scan are ONE launch (workgroup roles + flags between them); `nms_fused=2` keeps the
+    three launches.  Segment lengths hit the three scan widths (<= 16 / <= 32 / <= 64 column words: 4 / 2 / 1 mask rows
+    per wave-wide load), block boundaries, an empty segment and dependency chains; called twice on the same (dirty)
+    workspace contents, since the control block of the fused launch is never cleared by the host."""
+    emu.tuning_set("nms_fused", fused)
+    sizes = (1000, 0, 1025, 64, 2000, 1, 2049, 4096, 65, 3000)
+    segs = [synth.nms_boxes(n, seed=40 + i) if n else (np.zeros((0, 4), np.float32), np.zeros(0, np.float32))
+            for i, n in enumerate(sizes)]
+    segs[4] = _nms_chain(2000, 25)            # depth-64 chains inside the 2-rows-per-load width
+    boxes = np.concatenate([x for x, _ in segs])
+    scores = np.concatenate([y for _, y in segs])
+    offs = np.cumsum([0] + [len(y) for _, y in segs]).astype(np.int32)
+    for thr in (0.7, 0.55):
+        keep, num = emu.nms_batched(boxes, scores, offs, 4096, thr)
+        km, num2 = emu.nms_batched(boxes, scores, offs, 4096, thr, mask=True)
+        assert np.array_equal(num, num2)
+        for i, (x, y) in enumerate(segs):
+            ref = oracle.nms(x, y, thr) if len(y) else np.zeros(0, np.int64)
+            assert num[i] == len(ref), (i, sizes[i])
+            assert np.array_equal(keep[offs[i]:offs[i] + num[i]], ref), (i, sizes[i])
+            want = np.zeros(len(y), np.uint8)
+            want[ref] = 1
+            assert np.array_equal(km[offs[i]:offs[i + 1]], want)
+    for n in (17 * 64, 33 * 64 - 1):
+        b, sc = synth.nms_boxes(n, seed=n)
+        assert np.array_equal(emu.nms(b, sc, 0.6), oracle.nms(b, sc, 0.6))
+
+
 def test_emu_nms_batched_segments_beyond_the_lds_sort():
     """segments with more than 8192 candidates (the reference's non-FPN PRE_NMS_TOP_N_TRAIN = 12000): per-
     segment radix sort instead of the in-LDS bitonic network; ragged segment lengths."""

@@ -499,6 +499,53 @@ def test_nms_batched_rpn_segments():
         np.testing.assert_array_equal(keep[offs[i]:offs[i] + num[i]], ref)
 
 
+@pytest.mark.parametrize("fused", [0, 3, 2])
+def test_nms_single_launch_and_three_launch_paths(fused):
+    """n <= 4096: sort, mask tiles and scan are ONE launch (workgroup roles, flags between workgroups, no host-cleared
+    state); `nms_fused=2` keeps the three launches.  Ragged segments over the three scan widths, an empty one, dependency
+    chains; repeated calls reuse the allocator's (dirty) workspace."""
+    from maskrcnn_benchmark import _lib
+    _lib.tuning_set("nms_fused", fused)
+    try:
+        sizes = (1000, 0, 1025, 64, 2000, 1, 2049, 4096, 65, 3000)
+        segs = [synth.nms_boxes(n, seed=40 + i) if n else (np.zeros((0, 4), np.float32), np.zeros(0, np.float32))
+                for i, n in enumerate(sizes)]
+        x0 = np.arange(2000, dtype=np.float32) * 25
+        segs[4] = (np.stack([x0, np.zeros(2000, np.float32), x0 + 99, np.full(2000, 49, np.float32)], 1),
+                   np.linspace(1.0, 0.1, 2000).astype(np.float32))
+        boxes = np.concatenate([b for b, _ in segs])
+        scores = np.concatenate([s for _, s in segs])
+        offs = np.cumsum([0] + [len(s) for _, s in segs]).astype(np.int32)
+        tb, ts, to = _t(boxes), _t(scores), _t(offs)
+        for rep in range(3):
+            for thr in (0.7, 0.55):
+                keep, num = _C().nms_batched(tb, ts, to, 4096, thr)
+                km, num2 = _C().nms_batched_mask(tb, ts, to, 4096, thr)
+                keep, num, km = keep.cpu().numpy(), num.cpu().numpy(), km.cpu().numpy()
+                np.testing.assert_array_equal(num, num2.cpu().numpy())
+                for i, (b, s) in enumerate(segs):
+                    ref = oracle.nms(b, s, thr) if len(s) else np.zeros(0, np.int64)
+                    assert num[i] == len(ref), (rep, thr, i)
+                    np.testing.assert_array_equal(keep[offs[i]:offs[i] + num[i]], ref)
+                    want = np.zeros(len(s), np.uint8)
+                    want[ref] = 1
+                    np.testing.assert_array_equal(km[offs[i]:offs[i + 1]], want)
+        # the detector's shape: 10 segments of <= 2000 (two workgroups per CU variant)
+        segs = synth.rpn_nms_segments()
+        boxes = np.concatenate([b for b, _ in segs])
+        scores = np.concatenate([s for _, s in segs])
+        offs = np.cumsum([0] + [len(s) for _, s in segs]).astype(np.int32)
+        for rep in range(20):
+            keep, num = _C().nms_batched(_t(boxes), _t(scores), _t(offs), 2000, 0.7)
+        keep, num = keep.cpu().numpy(), num.cpu().numpy()
+        for i, (b, s) in enumerate(segs):
+            ref = oracle.nms(b, s, 0.7)
+            assert num[i] == len(ref)
+            np.testing.assert_array_equal(keep[offs[i]:offs[i] + num[i]], ref)
+    finally:
+        _lib.tuning_set("nms_fused", 0)
+
+
 def test_nms_layer_amp_hint():
     from maskrcnn_benchmark.layers import nms
 

@@ -174,11 +174,14 @@ def bench_nms(C, iters):
     boxes = _t(np.concatenate([b for b, _ in segs]))
     scores = _t(np.concatenate([s for _, s in segs]))
     offs = _t(np.cumsum([0] + [len(s) for _, s in segs]).astype(np.int32))
-    us = dev_time_us(lambda: C.nms_batched(boxes, scores, offs, 2000, 0.7), iters)
     tot = int(boxes.size(0))
     pairs = sum(len(s) * (len(s) - 1) // 2 for _, s in segs)
-    out.append(_entry("nms batched 10 RPN segments (no sync)", us, 20 * tot,
-                      {"pairs_per_us": round(pairs / us, 1)}))
+    for fused, label in ((0, "one launch"), (3, "one launch, scans last"), (2, "three launches")):
+        tune("nms_fused", fused)
+        us = dev_time_us(lambda: C.nms_batched(boxes, scores, offs, 2000, 0.7), iters)
+        out.append(_entry("nms batched 10 RPN segments, %s (no sync)" % label, us, 20 * tot,
+                          {"pairs_per_us": round(pairs / us, 1)}))
+    tune("nms_fused", 0)
     return out
 
 
