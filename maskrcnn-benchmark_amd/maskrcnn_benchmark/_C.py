@@ -41,22 +41,13 @@ def _f32c(name, t):
     return t.contiguous()
 
 
-class _on_device:
-    """Make `t`'s device current for the launch (no-op in the single-device case)."""
-
-    def __init__(self, t):
-        self.idx = t.device.index
-        self.prev = None
-
-    def __enter__(self):
-        cur = torch.cuda.current_device()
-        if self.idx is not None and self.idx != cur:
-            self.prev = cur
-            torch.cuda.set_device(self.idx)
-
-    def __exit__(self, *a):
-        if self.prev is not None:
-            torch.cuda.set_device(self.prev)
+def _on_device(t):
+    """Context: `t`'s device is current for the launch (a shared no-op object in the usual case — the tensor lives
+    on the current device — so the launch path allocates nothing)."""
+    idx = t.device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NOSPAN
+    return torch.cuda.device(idx)
 
 
 class KernelTimer(object):
@@ -110,7 +101,13 @@ KERNEL_TIMER = None  # set to a KernelTimer to collect timings
 
 
 def _timed(name, t, every=1):
-    return _NOSPAN if KERNEL_TIMER is None else KERNEL_TIMER.span(name, t, every)
+    """`name`: a string, or (format, args) — formatted only when a timer is installed (the launch path of an
+    untimed run does no string work)"""
+    if KERNEL_TIMER is None:
+        return _NOSPAN
+    if type(name) is tuple:
+        name = name[0] % name[1]
+    return KERNEL_TIMER.span(name, t, every)
 
 
 _ESIZE = {torch.float32: 4, torch.float16: 2, torch.bfloat16: 2}
@@ -183,7 +180,7 @@ def nms_batched_mask(boxes, scores, seg_offsets, max_n, threshold):
     seg_offsets = seg_offsets.contiguous()
     ws_bytes = lib.detops_nms_batched_workspace_bytes(S, int(max_n))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=boxes.device)
-    with _on_device(boxes), _timed("nms_batched[S=%d,max_n=%d]" % (S, int(max_n)), boxes):
+    with _on_device(boxes), _timed(("nms_batched[S=%d,max_n=%d]", (S, int(max_n))), boxes):
         check(lib.detops_nms_batched_mask_f32(ptr(boxes), ptr(scores), ptr(seg_offsets), S, int(max_n),
                                               float(threshold), ptr(mask), ptr(num), ptr(ws), ws_bytes,
                                               stream_of(boxes)), "nms_batched_mask")
@@ -209,7 +206,7 @@ class _RpnLoss(torch.autograd.Function):
         Ws = (ctypes.c_int * L)(*[t.size(3) for t in obj])
         arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])
         w4 = (ctypes.c_float * 4)(*[float(w) for w in weights])
-        with _on_device(anchors), _timed("rpn_loss[N=%d,T=%d]" % (N, T), anchors):
+        with _on_device(anchors), _timed(("rpn_loss[N=%d,T=%d]", (N, T)), anchors):
             check(lib.detops_rpn_loss_f32(arr(obj), arr(box), Hs, Ws, L, int(A), ptr(anchors), ptr(matched), ptr(pos),
                                           ptr(neg), ptr(gt), N, M, T, float(beta), w4, arr(gobj), arr(gbox), ptr(out3),
                                           ptr(ws), nbytes, stream_of(anchors)), "rpn_loss")
@@ -262,7 +259,7 @@ def match_boxes(gt_boxes, gt_valid, boxes, high_threshold, low_threshold, allow_
         return out
     nbytes = int(lib.detops_match_boxes_workspace_bytes(N, M))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=boxes.device)
-    with _on_device(boxes), _timed("match_boxes[N=%d,M=%d,K=%d]" % (N, M, K), boxes):
+    with _on_device(boxes), _timed(("match_boxes[N=%d,M=%d,K=%d]", (N, M, K)), boxes):
         check(lib.detops_match_boxes_f32(ptr(gt_boxes), ptr(valid), ptr(boxes), int(batched), N, M, K,
                                          float(high_threshold), float(low_threshold), int(bool(allow_low_quality_matches)),
                                          ptr(out), ptr(ws), nbytes, stream_of(boxes)), "match_boxes")
@@ -307,7 +304,7 @@ def sample_labels(labels, batch_size_per_image, max_positives, with_list=False, 
     if N and n:
         nbytes = int(lib.detops_sample_labels_workspace_bytes(N, B))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=labels.device)
-        with _on_device(labels), _timed("sample_labels[N=%d,n=%d,B=%d]" % (N, n, B), labels):
+        with _on_device(labels), _timed(("sample_labels[N=%d,n=%d,B=%d]", (N, n, B)), labels):
             check(lib.detops_sample_labels(ptr(labels), 0 if labels.dtype == torch.float32 else 1, N, n, B,
                                            int(max_positives), ctypes.c_uint64(seed), ptr(pos), ptr(neg), ptr(idx),
                                            ptr(val), ptr(ws), nbytes, stream_of(labels)), "sample_labels")
@@ -339,7 +336,7 @@ def mask_targets(masks, mask_index, boxes, discretization_size):
     P, M = boxes.size(0), int(discretization_size)
     out = torch.empty((P, M, M), dtype=torch.float32, device=boxes.device)
     if P:
-        with _on_device(boxes), _timed("mask_targets[P=%d,M=%d]" % (P, M), boxes):
+        with _on_device(boxes), _timed(("mask_targets[P=%d,M=%d]", (P, M)), boxes):
             check(lib.detops_mask_targets(ptr(m), code, ptr(mask_index), ptr(boxes), G, H, W, P, M, ptr(out),
                                           stream_of(boxes)), "mask_targets")
     return out
@@ -442,7 +439,7 @@ def roi_align_fpn_forward(inputs, rois, scales, pooled_height, pooled_width, sam
     if K == 0:
         return out, levels
     ptrs, Hs, Ws, sc = _host_arrays(inputs, scales)
-    with _on_device(rois), _timed("roi_align_fpn_fwd[K=%d,C=%d,%dx%d]" % (K, C, pooled_height, pooled_width), rois):
+    with _on_device(rois), _timed(("roi_align_fpn_fwd[K=%d,C=%d,%dx%d]", (K, C, pooled_height, pooled_width)), rois):
         ws, nbytes = _fwd_workspace(rois.device, K)
         check(lib.detops_roi_align_fpn_forward_ws_f32(
             ptrs, Hs, Ws, sc, len(inputs), ptr(rois), ptr(out), ptr(levels), N, C, K, pooled_height,
@@ -462,7 +459,7 @@ def roi_align_fpn_backward(grad, rois, levels, shapes, scales, pooled_height, po
     ptrs, Hs, Ws, sc = _host_arrays(gins, scales)
     with _on_device(grad):
         ws, nbytes = _bwd_workspace(grad.device, Hs, Ws, len(gins), N, C, K, pooled_height, pooled_width)
-        with _timed("roi_align_fpn_bwd[K=%d,C=%d,%dx%d]" % (K, C, pooled_height, pooled_width), grad):
+        with _timed(("roi_align_fpn_bwd[K=%d,C=%d,%dx%d]", (K, C, pooled_height, pooled_width)), grad):
             check(lib.detops_roi_align_fpn_backward_ws_f32(
                 ptr(grad), ptr(rois), ptr(levels), ptrs, Hs, Ws, sc, len(gins), N, C, K, pooled_height,
                 pooled_width, int(sampling_ratio), 1, ptr(ws), nbytes, stream_of(grad)), "roi_align_fpn_backward")
@@ -555,7 +552,7 @@ def sigmoid_focalloss_forward_sum(logits, targets, num_classes, gamma, alpha):
     nbytes = int(lib.detops_sigmoid_focal_loss_sum_workspace_bytes())
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=logits.device)
     total = torch.empty((), dtype=torch.float32, device=logits.device)
-    with _on_device(logits), _timed("focal_fwd_sum[R=%d,C=%d]" % (logits.size(0), num_classes), logits):
+    with _on_device(logits), _timed(("focal_fwd_sum[R=%d,C=%d]", (logits.size(0), num_classes)), logits):
         check(lib.detops_sigmoid_focal_loss_forward_sum_ws_f32(
             ptr(logits), ptr(targets), None, ptr(total), logits.size(0), num_classes, float(gamma), float(alpha),
             ptr(ws), nbytes, stream_of(logits)), "sigmoid_focalloss_forward_sum")
@@ -568,7 +565,7 @@ def sigmoid_focalloss_backward_scalar(logits, targets, d_loss, num_classes, gamm
     _need_cuda("sigmoid_focalloss_backward_scalar", d_loss)
     d_loss = d_loss.reshape(1).to(torch.float32).contiguous()
     d_logits = torch.empty_like(logits)
-    with _on_device(logits), _timed("focal_bwd_scalar[R=%d,C=%d]" % (logits.size(0), num_classes), logits):
+    with _on_device(logits), _timed(("focal_bwd_scalar[R=%d,C=%d]", (logits.size(0), num_classes)), logits):
         check(lib.detops_sigmoid_focal_loss_backward_scalar_f32(
             ptr(logits), ptr(targets), ptr(d_loss), ptr(d_logits), logits.size(0), num_classes,
             float(gamma), float(alpha), stream_of(logits)), "sigmoid_focalloss_backward_scalar")
@@ -588,7 +585,7 @@ def frozen_bn_act_forward(x, scale, bias, residual, relu):
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // max(N * C, 1)
     y = torch.empty_like(x)
-    with _on_device(x), _timed("frozen_bn_fwd[n=%d,e=%d,res=%d]" % (x.numel(), _ESIZE[x.dtype], residual is not None), x, every=16):
+    with _on_device(x), _timed(("frozen_bn_fwd[n=%d,e=%d,res=%d]", (x.numel(), _ESIZE[x.dtype], residual is not None)), x, every=16):
         check(lib.detops_frozen_bn_act_forward(ptr(x), ptr(scale), ptr(bias), ptr(residual), ptr(y), code, N, C, HW,
                                                int(bool(relu)), stream_of(x)), "frozen_bn_act_forward")
     return y
@@ -603,7 +600,7 @@ def frozen_bn_act_backward(grad_y, y, scale, relu, need_residual):
     HW = grad_y.numel() // max(N * C, 1)
     gx = torch.empty_like(grad_y)
     gres = torch.empty_like(grad_y) if need_residual else None
-    with _on_device(grad_y), _timed("frozen_bn_bwd[n=%d,e=%d,res=%d,relu=%d]" % (grad_y.numel(), _ESIZE[grad_y.dtype], bool(need_residual), bool(relu)),
+    with _on_device(grad_y), _timed(("frozen_bn_bwd[n=%d,e=%d,res=%d,relu=%d]", (grad_y.numel(), _ESIZE[grad_y.dtype], bool(need_residual), bool(relu))),
                                      grad_y, every=16):
         check(lib.detops_frozen_bn_act_backward(ptr(grad_y), ptr(y) if relu else None, ptr(scale), ptr(gx), ptr(gres),
                                                 code, N, C, HW, int(bool(relu)), stream_of(grad_y)),
@@ -683,7 +680,7 @@ def deformable_im2col(im, offset, mask, kH, kW, padH, padW, dH, dW, dilH, dilW, 
     B, C, H, W = im.shape
     Ho, Wo = _out_hw(H, W, kH, kW, padH, padW, dH, dW, dilH, dilW)
     col = torch.empty((C * kH * kW, B * Ho * Wo), dtype=im.dtype, device=im.device)
-    with _on_device(im), _timed("dcn_im2col[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]" % (B, C, H, W, kH, _ESIZE[im.dtype], mask is not None), im):
+    with _on_device(im), _timed(("dcn_im2col[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[im.dtype], mask is not None)), im):
         check(lib.detops_deformable_im2col(ptr(im), ptr(offset), ptr(mask), ptr(col), code,
                                            *_geom_args(B, C, H, W, kH, kW, padH, padW, dH, dW, dilH,
                                                        dilW, dg), stream_of(im)), "deformable_im2col")
@@ -700,7 +697,7 @@ def deformable_col2im(col, offset, mask, grad_im, kH, kW, padH, padW, dH, dW, di
         # stream-ordered reuse, no hipMalloc per call); 0 bytes = shape outside the index plan
         nbytes = int(lib.detops_deformable_col2im_workspace_bytes(*geom))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=col.device) if nbytes > 0 else None
-        with _timed("dcn_col2im[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]" % (B, C, H, W, kH, _ESIZE[col.dtype], mask is not None), col):
+        with _timed(("dcn_col2im[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[col.dtype], mask is not None)), col):
             check(lib.detops_deformable_col2im_ws(ptr(col), ptr(offset), ptr(mask), ptr(grad_im), code, *geom,
                                                   ptr(ws), nbytes, stream_of(col)), "deformable_col2im")
 
@@ -710,7 +707,7 @@ def deformable_col2im_coord(col, im, offset, mask, grad_offset, grad_mask, kH, k
     """overwrites grad_offset (and grad_mask) (deform_conv_kernel_cuda.cu:380-443 / :702-774)."""
     code = _dcn_check("deformable_col2im_coord", col, im, offset, mask, grad_offset, grad_mask)
     B, C, H, W = im.shape
-    with _on_device(col), _timed("dcn_col2im_coord[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]" % (B, C, H, W, kH, _ESIZE[col.dtype], mask is not None), col):
+    with _on_device(col), _timed(("dcn_col2im_coord[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[col.dtype], mask is not None)), col):
         check(lib.detops_deformable_col2im_coord(ptr(col), ptr(im), ptr(offset), ptr(mask),
                                                  ptr(grad_offset), ptr(grad_mask), code,
                                                  *_geom_args(B, C, H, W, kH, kW, padH, padW, dH, dW,
@@ -733,7 +730,7 @@ def _fused_dcn_forward(input, weight, offset, mask, bias, out, kH, kW, padH, pad
         return False
     with _on_device(input):
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=input.device)
-        with _timed("dcn_fused_fwd[B=%d,C=%d,%dx%d,Cout=%d,k=%d,e=2,m=%d]" % (B, C, H, W, Cout, kH, mask is not None), input):
+        with _timed(("dcn_fused_fwd[B=%d,C=%d,%dx%d,Cout=%d,k=%d,e=2,m=%d]", (B, C, H, W, Cout, kH, mask is not None)), input):
             check(lib.detops_deform_conv_forward_fused(ptr(input), ptr(weight), ptr(offset), ptr(mask), ptr(bias),
                                                        ptr(out), *geo, ptr(ws), nbytes, stream_of(input)),
                   "deform_conv_forward_fused")
@@ -756,7 +753,7 @@ def _to_nhwc(x):
     x = x.contiguous()
     out = torch.empty((B, H * W, C), dtype=x.dtype, device=x.device)
     if out.numel():
-        with _on_device(x), _timed("dcn_to_nhwc[n=%d,e=%d]" % (x.numel(), _ESIZE[x.dtype]), x, every=4):
+        with _on_device(x), _timed(("dcn_to_nhwc[n=%d,e=%d]", (x.numel(), _ESIZE[x.dtype])), x, every=4):
             check(lib.detops_nchw_to_nhwc(ptr(x), ptr(out), _lib.DTYPE_CODE[x.dtype], B, C, H * W, stream_of(x)), "nchw_to_nhwc")
     return out
 
@@ -766,14 +763,14 @@ def _im2col_nhwc(xT, offset, mask, B, C, H, W, geom):
     Ho, Wo = _out_hw(H, W, *geom[:8])
     colT = torch.empty((B * Ho * Wo, kH * kW * C), dtype=xT.dtype, device=xT.device)
     if colT.numel():
-        with _on_device(xT), _timed("dcn_im2col_nhwc[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]" % (B, C, H, W, kH, _ESIZE[xT.dtype], mask is not None), xT):
+        with _on_device(xT), _timed(("dcn_im2col_nhwc[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[xT.dtype], mask is not None)), xT):
             check(lib.detops_deformable_im2col_nhwc(ptr(xT), ptr(offset), ptr(mask), ptr(colT), _lib.DTYPE_CODE[xT.dtype],
                                                     B, C, H, W, *geom, stream_of(xT)), "deformable_im2col_nhwc")
     return colT
 
 
 def _coord_nhwc(colsG, xT, offset, mask, grad_offset, grad_mask, B, C, H, W, geom):
-    with _on_device(xT), _timed("dcn_coord_nhwc[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]" % (B, C, H, W, geom[0], _ESIZE[xT.dtype], mask is not None), xT):
+    with _on_device(xT), _timed(("dcn_coord_nhwc[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, geom[0], _ESIZE[xT.dtype], mask is not None)), xT):
         check(lib.detops_deformable_coord_nhwc(ptr(colsG), ptr(xT), ptr(offset), ptr(mask), ptr(grad_offset), ptr(grad_mask),
                                                _lib.DTYPE_CODE[xT.dtype], B, C, H, W, *geom, stream_of(xT)), "deformable_coord_nhwc")
 
@@ -787,7 +784,7 @@ def _transposed_sample(gT, offset, mask, B, C, H, W, Cout, geom):
     if nbytes == 0:
         raise RuntimeError("deformable_transposed_sample: shape outside the index plan")
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=gT.device)
-    with _on_device(gT), _timed("dcn_transposed_sample[B=%d,Cout=%d,%dx%d,k=%d,e=%d,m=%d]" % (B, Cout, H, W, kH, _ESIZE[gT.dtype], mask is not None), gT):
+    with _on_device(gT), _timed(("dcn_transposed_sample[B=%d,Cout=%d,%dx%d,k=%d,e=%d,m=%d]", (B, Cout, H, W, kH, _ESIZE[gT.dtype], mask is not None)), gT):
         check(lib.detops_deformable_transposed_sample(ptr(gT), ptr(offset), ptr(mask), ptr(S_T), _lib.DTYPE_CODE[gT.dtype],
                                                       B, C, H, W, Cout, *geom, ptr(ws), nbytes, stream_of(gT)),
               "deformable_transposed_sample")
@@ -835,6 +832,47 @@ def _nhwc_backward(input, weight, offset, mask, grad_output, grad_input, grad_of
         grad_weight.add_(gw2.view(Cout, kH, kW, C).permute(0, 3, 1, 2), alpha=float(scale))
         if grad_bias is not None:
             grad_bias += g2.sum(0)
+
+
+def deform_conv_backward_all(input, offset, mask, weight, grad_output, kH, kW, padH, padW, dH, dW, dilH, dilW, group,
+                             deformable_group, need_input=True, need_weight=True, need_bias=False):
+    """Extension (not a name of the reference's `_C`): every gradient of one deformable convolution (v1: mask None;
+    v2: modulated) from ONE pass over the channels-last pipeline.  The reference API (deform_conv_backward_input +
+    deform_conv_backward_parameters, kept above) asks for them in two calls, each of which must rebuild the
+    channel-fastest copies of the input and of the output gradient and accumulates into caller-zeroed tensors:
+    per layer that is two extra transposes, three fills and an accumulate — about a third of the launches of a
+    host-bound step (R-101 + DCN under fp16).
+
+    -> (grad_input, grad_offset, grad_mask, grad_weight, grad_bias), None where not asked for / not applicable;
+    returns None when the shape is outside the channels-last plan (the caller then uses the reference entry points)."""
+    _dcn_check("deform_conv_backward_all", input, offset, weight, grad_output)
+    if not _nhwc_ok(input, weight, group, deformable_group):
+        return None
+    input, offset, weight, grad_output = input.contiguous(), offset.contiguous(), weight.contiguous(), grad_output.contiguous()
+    if mask is not None:
+        mask = mask.contiguous()
+    geom = (kH, kW, padH, padW, dH, dW, dilH, dilW, deformable_group)
+    B, C, H, W = input.shape
+    Cout = weight.size(0)
+    xT = _to_nhwc(input)
+    gT = _to_nhwc(grad_output)                                   # [B, Ho*Wo, Cout]
+    g2 = gT.view(-1, Cout)
+    grad_input = grad_offset = grad_mask = grad_weight = grad_bias = None
+    if need_input:
+        colsG = torch.mm(g2, _w_tap_major(weight))               # column gradient, channel-fastest: [B*Ho*Wo, K*C]
+        grad_offset = torch.empty_like(offset)                   # written in full by the coordinate kernel
+        grad_mask = torch.empty_like(mask) if mask is not None else None
+        _coord_nhwc(colsG, xT, offset, mask, grad_offset, grad_mask, B, C, H, W, geom)
+        del colsG
+        S_T = _transposed_sample(gT, offset, mask, B, C, H, W, Cout, geom)     # [B*H*W, K*Cout]
+        W2T = weight.permute(1, 2, 3, 0).reshape(C, -1)          # [C, K*Cout]
+        grad_input = torch.bmm(W2T.unsqueeze(0).expand(B, -1, -1), S_T.view(B, H * W, -1).transpose(1, 2)).view(B, C, H, W)
+    if need_weight:
+        colT = _im2col_nhwc(xT, offset, mask, B, C, H, W, geom)  # [B*Ho*Wo, K*C]
+        grad_weight = torch.mm(g2.t(), colT).view(Cout, kH, kW, C).permute(0, 3, 1, 2).contiguous()
+    if need_bias:
+        grad_bias = g2.sum(0)
+    return grad_input, grad_offset, grad_mask, grad_weight, grad_bias
 
 
 def _grouped_weight_times_cols(weight, col, group, out):
@@ -1048,7 +1086,7 @@ def deform_psroi_pooling_forward(input, bbox, trans, out, top_count, no_trans, s
     if not (out.is_contiguous() and top_count.is_contiguous() and out.dtype == torch.float32
             and top_count.dtype == torch.float32):
         raise RuntimeError("%s: out/top_count must be contiguous float32" % name)
-    with _on_device(input), _timed("psroi_fwd[K=%d,D=%d,P=%d]" % (K, output_dim, pooled_size), input):
+    with _on_device(input), _timed(("psroi_fwd[K=%d,D=%d,P=%d]", (K, output_dim, pooled_size)), input):
         check(lib.detops_deform_psroi_pool_forward_f32(
             ptr(input), ptr(bbox), ptr(trans), ptr(out), ptr(top_count), N, C, H, W, K, ct,
             int(bool(no_trans)), float(spatial_scale), output_dim, group_size, pooled_size, part_size,
@@ -1076,7 +1114,7 @@ def deform_psroi_pooling_backward(out_grad, input, bbox, trans, top_count, input
     if not no_trans and not (trans_grad.is_cuda and trans_grad.is_contiguous()
                              and trans_grad.dtype == torch.float32 and trans_grad.shape == trans.shape):
         raise RuntimeError("%s: trans_grad must be a contiguous float32 CUDA tensor shaped like trans" % name)
-    with _on_device(input), _timed("psroi_bwd[K=%d,D=%d,P=%d]" % (K, output_dim, pooled_size), input):
+    with _on_device(input), _timed(("psroi_bwd[K=%d,D=%d,P=%d]", (K, output_dim, pooled_size)), input):
         check(lib.detops_deform_psroi_pool_backward_f32(
             ptr(out_grad), ptr(input), ptr(bbox), ptr(trans), ptr(top_count), ptr(input_grad),
             None if no_trans else ptr(trans_grad), N, C, H, W, K, ct, int(bool(no_trans)),

@@ -120,8 +120,14 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_of(t):
-    """The current HIP stream of the tensor's device, as an integer handle."""
+    """The current HIP stream of the tensor's device, as an integer handle (the raw-handle query: building a
+    torch.cuda.Stream object per launch costs ~5 us of host time, ~200 launches per training step)."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

@@ -52,7 +52,16 @@ class DeformConvFunction(Function):
         assert (input.shape[0] % step) == 0, "im2col step must divide batchsize"
         geom = (weight.size(3), weight.size(2), ctx.stride[1], ctx.stride[0], ctx.padding[1],
                 ctx.padding[0], ctx.dilation[1], ctx.dilation[0], ctx.groups, ctx.deformable_groups)
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        # one pass for all gradients where the channels-last pipeline serves the shape (_C.deform_conv_backward_all);
+        # otherwise the reference's two calls (deform_conv_func.py:87-127)
+        fused = _C.deform_conv_backward_all(input, offset, None, weight, grad_output, weight.size(2), weight.size(3),
+                                            ctx.padding[0], ctx.padding[1], ctx.stride[0], ctx.stride[1],
+                                            ctx.dilation[0], ctx.dilation[1], ctx.groups, ctx.deformable_groups,
+                                            need_input=need_in, need_weight=ctx.needs_input_grad[2])
+        if fused is not None:
+            return (fused[0], fused[1], fused[3], None, None, None, None, None, None)
+        if need_in:
             grad_input = torch.zeros_like(input)
             grad_offset = torch.zeros_like(offset)
             _C.deform_conv_backward_input(input, offset, grad_output, grad_input, grad_offset, weight,
@@ -107,6 +116,11 @@ class ModulatedDeformConvFunction(Function):
             raise NotImplementedError
         input, offset, mask, weight, bias = ctx.saved_tensors
         (grad_output,) = _same_dtype(input, grad_output)
+        fused = _C.deform_conv_backward_all(input, offset, mask, weight, grad_output, weight.shape[2], weight.shape[3],
+                                            ctx.padding, ctx.padding, ctx.stride, ctx.stride, ctx.dilation, ctx.dilation,
+                                            ctx.groups, ctx.deformable_groups, need_bias=ctx.with_bias)
+        if fused is not None:
+            return fused + (None, None, None, None, None)
         grad_input = torch.zeros_like(input)
         grad_offset = torch.zeros_like(offset)
         grad_mask = torch.zeros_like(mask)
