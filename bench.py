@@ -103,11 +103,11 @@ def algorithmic_bytes(name, feat_bytes):
     if m:
         R, C = int(m.group(2)), int(m.group(3))
         return (4 * R * C + 4 * R) if m.group(1) == "fwd_sum" else (8 * R * C + 4 * R)
-    m = re.match(r"frozen_bn_fwd\[n=(\d+),e=(\d+),res=(\d)\]", name)
+    m = re.match(r"frozen_bn_fwd\[n=(\d+),nc=\d+,e=(\d+),res=(\d)\]", name)
     if m:
         n, e, res = (int(g) for g in m.groups())
         return e * n * (2 + res)
-    m = re.match(r"frozen_bn_bwd\[n=(\d+),e=(\d+),res=(\d),relu=(\d)\]", name)
+    m = re.match(r"frozen_bn_bwd\[n=(\d+),nc=\d+,e=(\d+),res=(\d),relu=(\d)\]", name)
     if m:
         n, e, res, relu = (int(g) for g in m.groups())
         return e * n * (2 + res + relu)
@@ -137,8 +137,14 @@ def rocprof_kernel_us(entry_name):
     if key is None:
         return None
     bins = re.search(r",(\d+)x(\d+)\]", entry_name)
+    bn = re.match(r"frozen_bn_(fwd|bwd)\[n=\d+,nc=(\d+),e=\d+,res=(\d)", entry_name)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*kernel_times*.txt")), reverse=True):
         for line in open(path):
+            if bn:   # frozen_bn_{fwd,bwd}_kernel<T, V, relu, residual> launched on (N*C) x chunks workgroups of 256 threads
+                want = "frozen_bn_%s_kernel<" % bn.group(1)
+                flag = ", %s>" % ("true" if bn.group(3) == "1" else "false")
+                if want not in line or flag not in line or ("grid=%d " % (int(bn.group(2)) * 256)) not in line:
+                    continue
             if key in line and "mean=" in line and (not bins or "roi_align" not in key or ("<%s, %s" % bins.groups()) in line):
                 m = re.search(r"mean=\s*([0-9.]+) us", line)
                 if m:

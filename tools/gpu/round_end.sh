@@ -1,0 +1,58 @@
+# Reproduces the committed round profiles on one MI355X box:  gpurun -- 'bash tools/gpu/round_end.sh [parts]'
+# parts (default all): tests bench trace opbench pmc extra
+T0=$(date +%s); el() { echo "[t+$(( $(date +%s) - T0 ))s] $*"; }
+PARTS="${*:-tests bench trace opbench pmc extra}"
+has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
+O=gpurun_out/round; mkdir -p $O; export MIOPEN_LOG_LEVEL=1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+jline() { grep -E "^\{" "$1" | tail -1; }
+brief() { jline "$1" | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}
+print('$2', d['value'], 'img/s', d['ms_per_step'], 'ms host', d.get('host_enqueue_ms_per_step'), d.get('ddp'), '| roofline', r.get('kernel'), r.get('frac'), 'rocprof', r.get('rocprof_us'), 'traffic', r.get('traffic'))
+print('  families', d.get('kernel_families_ms_per_step'))" 2>/dev/null || tail -3 "$1"; }
+if has tests; then
+  timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider < /dev/null > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+  grep -E "passed|failed|rc=|Error" $O/pytest_gpu.log | tail -4 | cut -c1-200; el pytest
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" < /dev/null > $O/smoke.log 2>&1; tail -1 $O/smoke.log; el smoke
+fi
+if has bench; then
+  timeout 600 python bench.py < /dev/null > $O/bench_f32.log 2>&1; jline $O/bench_f32.log > $O/bench_f32.json; brief $O/bench_f32.log f32; el bench
+fi
+if has trace; then
+  P=/tmp/prof_bench; rm -rf $P
+  timeout 500 rocprofv3 --kernel-trace --output-format csv -d $P -o bench -- python bench.py --steps 6 --warmup 6 --no-cpu-baseline < /dev/null > $O/prof_bench.log 2>&1
+  T=$(find $P -name "*kernel_trace.csv" | head -1)
+  if [ -n "$T" ]; then
+    python tools/trace_steps.py "$T" 4 60 > $O/bench_f32_step_breakdown.txt 2>&1
+    python tools/kernel_times.py $P "" 2>/dev/null | grep -E "roi_align|nms_|frozen_bn|focal|match_|sampler|mask_targets|rpn_loss|dcn|col2im|im2col" > $O/bench_kernel_times.txt
+    head -3 $O/bench_f32_step_breakdown.txt; head -12 $O/bench_kernel_times.txt | cut -c1-150
+  fi; el trace
+fi
+if has opbench; then
+  timeout 600 python tools/opbench.py --iters 50 --json $O/opbench.json < /dev/null > $O/opbench.log 2>&1; grep -E "roi_align_(fwd|bwd) fpn|nms batched|frozen_bn|focal|match|dcn block" $O/opbench.log | cut -c1-150 | head -40; el opbench
+fi
+if has pmc; then
+  PM="python tools/opbench.py --only roi_sets --heads box --dir bwd --iters 5 --sets model-random-init"
+  for pass in "sq:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+              "sq2:SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+              "tcc:TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "fw:FETCH_SIZE" "ww:WRITE_SIZE"; do
+    n=${pass%%:*}; c=${pass#*:}; rm -rf /tmp/pmc_$n
+    timeout 150 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$n -o x -- $PM < /dev/null > $O/pmc_$n.log 2>&1
+  done
+  python tools/pmc_diag.py /tmp/pmc_sq /tmp/pmc_sq2 /tmp/pmc_tcc /tmp/pmc_fw /tmp/pmc_ww > $O/roi_align_bwd_ring_pmc.txt 2>&1; grep -v "roi_order" $O/roi_align_bwd_ring_pmc.txt | head -40; el pmc-ring
+  TR="python tools/opbench.py --only roi_align_fpn,frozen_bn,nms --iters 5"
+  rm -rf /tmp/tr_f /tmp/tr_w
+  timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/tr_f -o x -- $TR < /dev/null > $O/traffic_fetch.log 2>&1
+  timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/tr_w -o x -- $TR < /dev/null > $O/traffic_write.log 2>&1
+  python tools/pmc_traffic.py /tmp/tr_f /tmp/tr_w $O/traffic.json 2>&1 | cut -c1-150 | head -30; el pmc-traffic
+fi
+if has extra; then
+  B="python bench.py --steps 40 --warmup 12 --no-cpu-baseline"
+  timeout 300 $B --dtype bfloat16 < /dev/null > $O/bench_bf16.log 2>&1; jline $O/bench_bf16.log > $O/bench_bf16.json; brief $O/bench_bf16.log bf16; el bf16
+  timeout 400 $B --config e2e_mask_rcnn_R_101_FPN_1x.yaml --dtype float16 MODEL.RESNETS.STAGE_WITH_DCN "(False, True, True, True)" < /dev/null > $O/bench_cfg5.log 2>&1; jline $O/bench_cfg5.log > $O/bench_cfg5.json; brief $O/bench_cfg5.log cfg5; el cfg5
+  timeout 300 $B --force-ddp < /dev/null > $O/bench_forceddp.log 2>&1; jline $O/bench_forceddp.log > $O/bench_forceddp.json; brief $O/bench_forceddp.log force-ddp; el force-ddp
+  timeout 300 $B --config e2e_faster_rcnn_R_50_FPN_1x.yaml < /dev/null > $O/bench_faster.log 2>&1; jline $O/bench_faster.log > $O/bench_faster.json; brief $O/bench_faster.log faster; el faster
+  timeout 300 $B --config retinanet/retinanet_R-50-FPN_1x.yaml < /dev/null > $O/bench_retinanet.log 2>&1; jline $O/bench_retinanet.log > $O/bench_retinanet.json; brief $O/bench_retinanet.log retinanet; el retinanet
+fi
+du -sh gpurun_out | tail -1

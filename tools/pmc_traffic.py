@@ -52,6 +52,14 @@ def tag_fused_launches(res):
     for (d, ph, _), (_, k) in best.items():
         K = 1024 if ph == "7" else 256
         res[k]["tag"] = "roi_align_fpn_%s[K=%d,C=256,%sx%s]" % (d, K, ph, ph)
+    # opbench --only frozen_bn runs the res2-sized activation [2, 256, 200, 336] fp32 (n = 34,406,400; N*C = 512): the
+    # residual forward is the largest FrozenBN member of a training step (bench.py names it the same way)
+    for k in res:
+        m = re.match(r"frozen_bn_(fwd|bwd)_kernel<float, 4, (true|false), (true|false)>\|grid=", k)
+        if m:
+            s_, r_ = int(m.group(2) == "true"), int(m.group(3) == "true")    # <T, V, kRelu, kRes>
+            res[k]["tag"] = ("frozen_bn_fwd[n=34406400,nc=512,e=4,res=%d]" % r_ if m.group(1) == "fwd"
+                             else "frozen_bn_bwd[n=34406400,nc=512,e=4,res=%d,relu=%d]" % (r_, s_))
 
 
 def main(fetch_dir, write_dir, out):
