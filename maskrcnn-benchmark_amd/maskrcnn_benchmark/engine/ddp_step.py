@@ -68,18 +68,18 @@ class OverlappedSGD(torch.optim.Optimizer):
             if fused:
                 # one multi-tensor pass (read g, p, buf; write buf, p) instead of four (weight decay, momentum
                 # scale, momentum add, parameter add): 0.46 -> 0.2 ms for the 176 MB of R-50-FPN parameters
-                fresh = [i for i, p in enumerate(ps) if "momentum_buffer" not in self.state[p]]
-                seen = [i for i, p in enumerate(ps) if "momentum_buffer" in self.state[p]]
-                for first, sel in ((True, fresh), (False, seen)):
-                    if not sel:
-                        continue
-                    if first:
-                        for i in sel:
-                            self.state[ps[i]]["momentum_buffer"] = torch.empty_like(grads[i])
-                    torch._fused_sgd_([ps[i] for i in sel], [grads[i] for i in sel],
-                                      [self.state[ps[i]]["momentum_buffer"] for i in sel], weight_decay=wd,
-                                      momentum=mom, lr=lr, dampening=0.0, nesterov=False, maximize=False,
-                                      is_first_step=first, grad_scale=grad_scale, found_inf=found_inf)
+                # Momentum buffers start as ZEROS and every call is a "later" step: momentum * 0 + g = g is bit for bit
+                # the first step of torch.optim.SGD (buf = g), and a step the loss scaler skips (found_inf: the kernel
+                # returns without touching anything) leaves a valid buffer behind — an uninitialised buffer marked as
+                # existing would feed garbage into the first step that is NOT skipped.
+                bufs = []
+                for p, gr in zip(ps, grads):
+                    st = self.state[p]
+                    if "momentum_buffer" not in st:
+                        st["momentum_buffer"] = torch.zeros_like(gr, dtype=p.dtype)
+                    bufs.append(st["momentum_buffer"])
+                torch._fused_sgd_(ps, grads, bufs, weight_decay=wd, momentum=mom, lr=lr, dampening=0.0, nesterov=False,
+                                  maximize=False, is_first_step=False, grad_scale=grad_scale, found_inf=found_inf)
                 continue
             if wd != 0:
                 grads = torch._foreach_add(grads, ps, alpha=wd)

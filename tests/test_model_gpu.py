@@ -200,6 +200,55 @@ def test_overlapped_sgd_fused_kernel_equals_torch_sgd_on_device():
         torch.testing.assert_close(a, c, rtol=1e-6, atol=1e-7)
 
 
+def test_overlapped_sgd_under_grad_scaler_skips_and_unscales_on_device():
+    """fp16 path: torch.amp.GradScaler hands `grad_scale` / `found_inf` to the optimizer (`_step_supports_amp_scaling`)
+    and never reads them back.  A step with non-finite gradients must leave parameters AND momentum state untouched —
+    in particular the FIRST step (loss scale 65536: the first iterations of a real run overflow) — and the next finite
+    step must equal torch.optim.SGD's step on the unscaled gradients."""
+    from maskrcnn_benchmark.engine import ddp_step
+
+    class Cfg:
+        class SOLVER:
+            BASE_LR, MOMENTUM, WEIGHT_DECAY, BIAS_LR_FACTOR, WEIGHT_DECAY_BIAS = 0.05, 0.9, 0.01, 2, 0.0
+
+    def toy():
+        torch.manual_seed(5)
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1)).to(DEV)
+
+    m1, m2 = toy(), toy()
+    o1 = ddp_step.make_overlapped_sgd(Cfg, m1)
+    assert o1._step_supports_amp_scaling
+    w = [p for n, p in m2.named_parameters() if "bias" not in n]
+    b = [p for n, p in m2.named_parameters() if "bias" in n]
+    o2 = torch.optim.SGD([{"params": w, "lr": 0.05, "weight_decay": 0.01}, {"params": b, "lr": 0.1, "weight_decay": 0.0}],
+                         lr=0.05, momentum=0.9)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    before = [p.detach().clone() for p in m1.parameters()]
+    for it in range(6):
+        x = torch.randn(2, 3, 9, 11, generator=g).to(DEV)
+        poison = it in (0, 1, 3)                     # overflowing iterations, the first two included
+        o1.zero_grad()
+        loss = (m1(x) ** 2).mean()
+        if poison:
+            loss = loss * float("inf")
+        scaler.scale(loss).backward()
+        scaler.step(o1)
+        scaler.update()
+        if poison:
+            if it < 2:
+                for a, c in zip(m1.parameters(), before):
+                    assert torch.equal(a, c), "a skipped step changed a parameter"
+            continue
+        o2.zero_grad()
+        (m2(x) ** 2).mean().backward()
+        o2.step()
+    assert all(torch.isfinite(p).all() for p in m1.parameters())
+    assert scaler.get_scale() < 1024.0
+    for a, c in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(a, c, rtol=2e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("launcher", ["plain", "torchrun"])
 def test_train_net_entry_script_runs_and_checkpoints(launcher, tmp_path):
     """tools/train_net.py — the reference's entry point (tools/train_net.py:133-197), same command line — executed as a
