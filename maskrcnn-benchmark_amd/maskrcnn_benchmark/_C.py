@@ -62,6 +62,7 @@ class KernelTimer(object):
         self.calls = {}
 
     def span(self, name, t, every=1):
+        """`name`: a string or (format, args) — kept as the key and formatted in results() (no string work per launch)"""
         n = self.calls.get(name, 0)
         self.calls[name] = n + 1
         return _Span(self, name, t) if n % every == 0 else _NOSPAN
@@ -70,7 +71,8 @@ class KernelTimer(object):
         """name -> (calls, timed launches, total_ms of the timed launches)"""
         out = {}
         for name, pairs in self.pairs.items():
-            out[name] = (self.calls.get(name, len(pairs)), len(pairs), sum(a.elapsed_time(b) for a, b in pairs))
+            text = name[0] % name[1] if type(name) is tuple else name
+            out[text] = (self.calls.get(name, len(pairs)), len(pairs), sum(a.elapsed_time(b) for a, b in pairs))
         return out
 
 
@@ -105,8 +107,6 @@ def _timed(name, t, every=1):
     untimed run does no string work)"""
     if KERNEL_TIMER is None:
         return _NOSPAN
-    if type(name) is tuple:
-        name = name[0] % name[1]
     return KERNEL_TIMER.span(name, t, every)
 
 
@@ -680,7 +680,7 @@ def deformable_im2col(im, offset, mask, kH, kW, padH, padW, dH, dW, dilH, dilW, 
     B, C, H, W = im.shape
     Ho, Wo = _out_hw(H, W, kH, kW, padH, padW, dH, dW, dilH, dilW)
     col = torch.empty((C * kH * kW, B * Ho * Wo), dtype=im.dtype, device=im.device)
-    with _on_device(im), _timed(("dcn_im2col[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[im.dtype], mask is not None)), im):
+    with _on_device(im), _timed(("dcn_im2col[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[im.dtype], mask is not None)), im, every=8):
         check(lib.detops_deformable_im2col(ptr(im), ptr(offset), ptr(mask), ptr(col), code,
                                            *_geom_args(B, C, H, W, kH, kW, padH, padW, dH, dW, dilH,
                                                        dilW, dg), stream_of(im)), "deformable_im2col")
@@ -697,7 +697,7 @@ def deformable_col2im(col, offset, mask, grad_im, kH, kW, padH, padW, dH, dW, di
         # stream-ordered reuse, no hipMalloc per call); 0 bytes = shape outside the index plan
         nbytes = int(lib.detops_deformable_col2im_workspace_bytes(*geom))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=col.device) if nbytes > 0 else None
-        with _timed(("dcn_col2im[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[col.dtype], mask is not None)), col):
+        with _timed(("dcn_col2im[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[col.dtype], mask is not None)), col, every=8):
             check(lib.detops_deformable_col2im_ws(ptr(col), ptr(offset), ptr(mask), ptr(grad_im), code, *geom,
                                                   ptr(ws), nbytes, stream_of(col)), "deformable_col2im")
 
@@ -707,7 +707,7 @@ def deformable_col2im_coord(col, im, offset, mask, grad_offset, grad_mask, kH, k
     """overwrites grad_offset (and grad_mask) (deform_conv_kernel_cuda.cu:380-443 / :702-774)."""
     code = _dcn_check("deformable_col2im_coord", col, im, offset, mask, grad_offset, grad_mask)
     B, C, H, W = im.shape
-    with _on_device(col), _timed(("dcn_col2im_coord[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[col.dtype], mask is not None)), col):
+    with _on_device(col), _timed(("dcn_col2im_coord[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[col.dtype], mask is not None)), col, every=8):
         check(lib.detops_deformable_col2im_coord(ptr(col), ptr(im), ptr(offset), ptr(mask),
                                                  ptr(grad_offset), ptr(grad_mask), code,
                                                  *_geom_args(B, C, H, W, kH, kW, padH, padW, dH, dW,
@@ -730,7 +730,7 @@ def _fused_dcn_forward(input, weight, offset, mask, bias, out, kH, kW, padH, pad
         return False
     with _on_device(input):
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=input.device)
-        with _timed(("dcn_fused_fwd[B=%d,C=%d,%dx%d,Cout=%d,k=%d,e=2,m=%d]", (B, C, H, W, Cout, kH, mask is not None)), input):
+        with _timed(("dcn_fused_fwd[B=%d,C=%d,%dx%d,Cout=%d,k=%d,e=2,m=%d]", (B, C, H, W, Cout, kH, mask is not None)), input, every=8):
             check(lib.detops_deform_conv_forward_fused(ptr(input), ptr(weight), ptr(offset), ptr(mask), ptr(bias),
                                                        ptr(out), *geo, ptr(ws), nbytes, stream_of(input)),
                   "deform_conv_forward_fused")
@@ -753,7 +753,7 @@ def _to_nhwc(x):
     x = x.contiguous()
     out = torch.empty((B, H * W, C), dtype=x.dtype, device=x.device)
     if out.numel():
-        with _on_device(x), _timed(("dcn_to_nhwc[n=%d,e=%d]", (x.numel(), _ESIZE[x.dtype])), x, every=4):
+        with _on_device(x), _timed(("dcn_to_nhwc[n=%d,e=%d]", (x.numel(), _ESIZE[x.dtype])), x, every=8):
             check(lib.detops_nchw_to_nhwc(ptr(x), ptr(out), _lib.DTYPE_CODE[x.dtype], B, C, H * W, stream_of(x)), "nchw_to_nhwc")
     return out
 
@@ -763,14 +763,14 @@ def _im2col_nhwc(xT, offset, mask, B, C, H, W, geom):
     Ho, Wo = _out_hw(H, W, *geom[:8])
     colT = torch.empty((B * Ho * Wo, kH * kW * C), dtype=xT.dtype, device=xT.device)
     if colT.numel():
-        with _on_device(xT), _timed(("dcn_im2col_nhwc[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[xT.dtype], mask is not None)), xT):
+        with _on_device(xT), _timed(("dcn_im2col_nhwc[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[xT.dtype], mask is not None)), xT, every=8):
             check(lib.detops_deformable_im2col_nhwc(ptr(xT), ptr(offset), ptr(mask), ptr(colT), _lib.DTYPE_CODE[xT.dtype],
                                                     B, C, H, W, *geom, stream_of(xT)), "deformable_im2col_nhwc")
     return colT
 
 
 def _coord_nhwc(colsG, xT, offset, mask, grad_offset, grad_mask, B, C, H, W, geom):
-    with _on_device(xT), _timed(("dcn_coord_nhwc[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, geom[0], _ESIZE[xT.dtype], mask is not None)), xT):
+    with _on_device(xT), _timed(("dcn_coord_nhwc[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, geom[0], _ESIZE[xT.dtype], mask is not None)), xT, every=8):
         check(lib.detops_deformable_coord_nhwc(ptr(colsG), ptr(xT), ptr(offset), ptr(mask), ptr(grad_offset), ptr(grad_mask),
                                                _lib.DTYPE_CODE[xT.dtype], B, C, H, W, *geom, stream_of(xT)), "deformable_coord_nhwc")
 
@@ -784,7 +784,7 @@ def _transposed_sample(gT, offset, mask, B, C, H, W, Cout, geom):
     if nbytes == 0:
         raise RuntimeError("deformable_transposed_sample: shape outside the index plan")
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=gT.device)
-    with _on_device(gT), _timed(("dcn_transposed_sample[B=%d,Cout=%d,%dx%d,k=%d,e=%d,m=%d]", (B, Cout, H, W, kH, _ESIZE[gT.dtype], mask is not None)), gT):
+    with _on_device(gT), _timed(("dcn_transposed_sample[B=%d,Cout=%d,%dx%d,k=%d,e=%d,m=%d]", (B, Cout, H, W, kH, _ESIZE[gT.dtype], mask is not None)), gT, every=8):
         check(lib.detops_deformable_transposed_sample(ptr(gT), ptr(offset), ptr(mask), ptr(S_T), _lib.DTYPE_CODE[gT.dtype],
                                                       B, C, H, W, Cout, *geom, ptr(ws), nbytes, stream_of(gT)),
               "deformable_transposed_sample")
