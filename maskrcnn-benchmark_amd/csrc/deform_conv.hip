@@ -10,14 +10,9 @@
 // mask) once, computes the 4 tap indices + weights once, and then walks a chunk of channels.
 // Lanes run along wo, so offset loads, column stores/loads and gradient stores are coalesced and
 // the 4 gathers of neighbouring lanes fall into neighbouring addresses.
-#ifndef DETOPS_CPU_EMU
-#include <hip/hip_bf16.h>
-#include <hip/hip_fp16.h>
-#include <hipcub/hipcub.hpp>
-#endif
 #include <cstdlib>
 
-#include "detops_common.h"
+#include "detops_devlib.h"
 
 namespace {
 
@@ -812,11 +807,7 @@ inline bool gather_plan(const Geom& g, GatherPlan& P) {
   P.max_entries = 4 * P.npoints_per_dg * g.dg;
   if (P.nslots + 1 > 0x7fffffff || P.max_entries > 0x7fffffff || K * g.B * HWo > 0x7fffffff) return false;
   P.scan_bytes = 0;
-#ifndef DETOPS_CPU_EMU
-  if (hipcub::DeviceScan::ExclusiveSum(nullptr, P.scan_bytes, static_cast<int32_t*>(nullptr),
-                                       static_cast<int32_t*>(nullptr), static_cast<int>(P.nslots + 1)) != hipSuccess)
-    return false;
-#endif
+  if (!detops_exclusive_sum_i32_bytes(static_cast<int>(P.nslots + 1), &P.scan_bytes)) return false;
   size_t o = 0;
   P.off_count = o;   o = align256(o + sizeof(int32_t) * (P.nslots + 1));
   P.off_cursor = o;  o = align256(o + sizeof(int32_t) * P.nslots);
@@ -842,16 +833,10 @@ int col2im_gather_t(const void* col, const void* offset, const void* mask, void*
   hipLaunchKernelGGL((col2im_index_kernel<T, false>), pgrid, dim3(kBlock), 0, st_, static_cast<const T*>(offset),
                      static_cast<const T*>(mask), g, P.npoints_per_dg, count, static_cast<const int32_t*>(nullptr),
                      static_cast<ColEntry*>(nullptr));
-#ifdef DETOPS_CPU_EMU
   {
-    int32_t run = 0;
-    for (int64_t i = 0; i <= P.nslots; ++i) { start[i] = run; run += count[i]; }
+    const int rc = detops_exclusive_sum_i32(w + P.off_scan, P.scan_bytes, count, start, static_cast<int>(P.nslots + 1), st_);
+    if (rc) return rc;
   }
-#else
-  size_t scan_bytes = P.scan_bytes;
-  DETOPS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w + P.off_scan, scan_bytes, count, start,
-                                                  static_cast<int>(P.nslots + 1), st_));
-#endif
   hipLaunchKernelGGL((col2im_index_kernel<T, true>), pgrid, dim3(kBlock), 0, st_, static_cast<const T*>(offset),
                      static_cast<const T*>(mask), g, P.npoints_per_dg, cursor, static_cast<const int32_t*>(start),
                      entries);
@@ -919,13 +904,8 @@ typedef unsigned short dcn_u16;
 constexpr int kFM = 128, kFN = 64;   // workgroup tile: Cout x pixels
 constexpr int kFK = 32;              // channel granularity of the fused plan ((C / dg) % 32 == 0)
 
-#ifdef DETOPS_CPU_EMU
-#define DCN_MFMA_F16(a, b, c) emu_mfma_f32_32x32x16<dcn_h8, _Float16>(a, b, c)
-#define DCN_MFMA_BF16(a, b, c) emu_mfma_f32_32x32x16<dcn_b8, __bf16>(a, b, c)
-#else
-#define DCN_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-#define DCN_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-#endif
+#define DCN_MFMA_F16(a, b, c) DETOPS_MFMA_32x32x16_F16(a, b, c)
+#define DCN_MFMA_BF16(a, b, c) DETOPS_MFMA_32x32x16_BF16(a, b, c)
 
 // pre-pass: blocks [0, nb_im): input NCHW -> NHWC (32 channels x 64 pixels per block through LDS);
 //           the rest: weights [Cout, C, T] -> [T, Cout, C]

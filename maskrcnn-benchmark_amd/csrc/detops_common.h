@@ -4,6 +4,8 @@
 #include "hip_cpu_emu.h"
 #else
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 #endif
 #include <stdint.h>
 
@@ -215,6 +217,36 @@ __device__ __forceinline__ bool spin_again(int& budget) {   // false: give up (s
 }
 #endif
 constexpr int kSpinBudget = 1 << 22;
+
+// ---- hardware transcendental / matrix instructions and their host-emulation stand-ins
+#ifdef DETOPS_CPU_EMU
+__device__ __forceinline__ float detops_exp(float x) { return expf(x); }
+__device__ __forceinline__ float detops_log(float x) { return logf(x); }
+#define DETOPS_MFMA_32x32x16_F16(a, b, c) emu_mfma_f32_32x32x16<decltype(a), _Float16>(a, b, c)
+#define DETOPS_MFMA_32x32x16_BF16(a, b, c) emu_mfma_f32_32x32x16<decltype(a), __bf16>(a, b, c)
+#else
+__device__ __forceinline__ float detops_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float detops_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }   // v_log_f32 is log2
+#define DETOPS_MFMA_32x32x16_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define DETOPS_MFMA_32x32x16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+
+// Workgroups of `kernel` (block size, dynamic LDS) the current device holds at once; -1 when unknown and in the host
+// emulation (which runs workgroups one after another).
+template <typename K>
+static inline int detops_resident_workgroups(K kernel, int block, size_t lds) {
+#ifdef DETOPS_CPU_EMU
+  (void)kernel; (void)block; (void)lds;
+  return -1;
+#else
+  int dev = 0, cus = 0, per_cu = 1;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return -1;
+  DETOPS_OCCUPANCY(per_cu, kernel, block, lds);
+  return cus * per_cu;
+#endif
+}
 
 // ---- tuning / test switches (read once at library load from DETOPS_TUNING="key=value,...", or set through
 // detops_tuning_set(); never read from the environment on the launch path)

@@ -39,18 +39,10 @@ struct Terms {
 // below 2e-7 — the kernels are VALU-bound on this math, not HBM-bound, when they do not also write [R, C]
 // (rocprofv3: the sum-forward read 129 MB in 51 us with the libm-accurate expf / logf, ~75 instructions / element).
 __device__ __forceinline__ float fast_exp(float x) {
-#ifdef DETOPS_CPU_EMU
-  return expf(x);
-#else
-  return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
-#endif
+  return detops_exp(x);
 }
 __device__ __forceinline__ float fast_log(float x) {   // x in [1, 2]
-#ifdef DETOPS_CPU_EMU
-  return logf(x);
-#else
-  return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
-#endif
+  return detops_log(x);
 }
 
 __device__ __forceinline__ Terms terms(float x) {

@@ -8,11 +8,6 @@
 // backward's ReLU-mask + scale becomes one pass as well.  Pure HBM streaming: one workgroup row
 // per (n, c) plane so scale/bias are wave-uniform scalars, 16-byte vector accesses when the plane
 // size allows it.
-#ifndef DETOPS_CPU_EMU
-#include <hip/hip_bf16.h>
-#include <hip/hip_fp16.h>
-#endif
-
 #include "detops_common.h"
 
 namespace {

@@ -26,16 +26,10 @@
 // nms_fused_kernel — workgroups [0,S) sort, the next S*nb*ceil(nb/8) compute mask tiles (a wave per tile; they wait for
 // their segment's "sorted" token), the last S run the scan chain as the tiles of each row block are counted in.
 // Larger problems keep the three launches.
-#ifndef DETOPS_CPU_EMU
-#include <hipcub/hipcub.hpp>
-#else
-#include <algorithm>
-#endif
-
 #include <atomic>
 #include <random>
 
-#include "detops_common.h"
+#include "detops_devlib.h"
 
 namespace {
 
@@ -564,15 +558,8 @@ Layout make_layout(int S, int max_n, bool big) {
   if (big) {
     l.off_keys = o;  o = align_up(o + rows * sizeof(u64), 256);
     l.off_keys2 = o; o = align_up(o + rows * sizeof(u64), 256);
-    size_t cub = 0;
-#ifndef DETOPS_CPU_EMU
-    const hipError_t qe = hipcub::DeviceRadixSort::SortKeys(
-        nullptr, cub, static_cast<u64*>(nullptr), static_cast<u64*>(nullptr), max_n);
-    // size query failed (e.g. no device visible): use a safe upper bound
-    if (qe != hipSuccess || cub == 0) cub = rows * sizeof(u64) * 2 + (1u << 20);
-#else
-    cub = 256;
-#endif
+    size_t cub = detops_sort_u64_bytes(max_n);
+    if (cub == 0) cub = rows * sizeof(u64) * 2 + (1u << 20);   // size query failed (e.g. no device visible): a safe upper bound
     l.cub_bytes = cub;
     l.off_cub = o; o = align_up(o + cub, 256);
   }
@@ -607,21 +594,10 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
     const size_t lds = std::max<size_t>(npad * sizeof(u64), 2 * kWave * sizeof(u64) + 64);
     auto kernel = w.nbmax <= 32 ? nms_fused_kernel<false> : nms_fused_kernel<true>;
     int scan_first = 0;
-#ifndef DETOPS_CPU_EMU   // (the emulation runs workgroups one after another: producers first)
     static int resident[2] = {0, 0};   // workgroups the device holds at once, per kernel variant (first device seen)
     int& cap = resident[w.nbmax <= 32 ? 0 : 1];
-    if (cap == 0) {
-      int dev = 0, cus = 0, per_cu = 1;
-      if (hipGetDevice(&dev) == hipSuccess &&
-          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
-        DETOPS_OCCUPANCY(per_cu, kernel, kScanThreads, 32 * 1024);
-        cap = cus * per_cu;
-      } else {
-        cap = -1;
-      }
-    }
+    if (cap == 0) cap = detops_resident_workgroups(kernel, kScanThreads, 32 * 1024);   // -1: unknown / host emulation
     scan_first = (cap > 0 && 8 * S <= cap && detops_tuning().nms_fused != 3) ? 1 : 0;
-#endif
     hipLaunchKernelGGL(kernel, dim3(2 * S + w.nbmax * S * G), dim3(kScanThreads), lds, st, boxes, scores,
                        seg_offsets, max_n, npad, thr, w, reinterpret_cast<FusedCtrl*>(base_ptr + l.off_ctrl), token, S, G,
                        scan_first, keep, num_keep, keep_mask);
@@ -642,13 +618,10 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
     for (int sg = 0; sg < S; ++sg) {
       u64* k1 = keys + static_cast<size_t>(sg) * max_n;
       u64* k2 = keys2 + static_cast<size_t>(sg) * max_n;
-#ifndef DETOPS_CPU_EMU
-      size_t cub = l.cub_bytes;
-      DETOPS_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(base + l.off_cub, cub, k1, k2, max_n, 0, 64, st));
-#else
-      std::copy(k1, k1 + max_n, k2);
-      std::sort(k2, k2 + max_n);
-#endif
+      {
+        const int rc = detops_sort_u64(base + l.off_cub, l.cub_bytes, k1, k2, max_n, st);
+        if (rc) return rc;
+      }
     }
     hipLaunchKernelGGL(nms_gather_kernel, dim3((max_n + 255) / 256, S), dim3(256), 0, st, boxes, keys2,
                        seg_offsets, max_n, w);
