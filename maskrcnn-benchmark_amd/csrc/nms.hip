@@ -480,8 +480,9 @@ struct FusedCtrl {        // one per segment, in the caller's workspace (arbitra
 // passes it when 2S workgroups are a small part of what the device holds at once): the scan workgroups sit right
 // behind the sorts and consume row blocks while the tiles are still being produced; they wait for later-indexed
 // workgroups, which is safe because those only need the S sort workgroups (earlier, never waiting) and one free slot.
-// The token is unique per launch (64 bits: random per process + call counter), so a stale or never-written control
-// block cannot match.
+// The token is unique per launch (64 bits: random per process + call counter, never 0), so a stale or never-written
+// control block cannot match; the scan workgroup clears it at the end, so a replay of the same launch (captured
+// graph: same kernel arguments) starts from a word that does not match either.
 template <bool WIDE>   // false: max_n <= 2048 (every call the detector makes): ~half the registers, two workgroups per CU
 __global__ void __launch_bounds__(kScanThreads)
 nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
@@ -532,6 +533,10 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
     DETOPS_ACQUIRE_AGENT();
     if (nb > 0)
       scan_chain_any<WIDE>(w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, nb, ctrl[s].done, keptw);
+    // every tile of the segment is counted in, so nobody reads the token any more: clear it.  A captured graph
+    // replays this launch with the SAME token value — the cleared word is what makes the replay wait again.
+    DETOPS_WAVE_SYNC();          // every lane of this wave has read the token
+    if (lane == 0) flag_store(&ctrl[s].token, 0ull);
   }
   __syncthreads();
   compact_keep(keptw, flags, wsum, w.order + static_cast<size_t>(s) * w.stride, sv, s, keep, num_keep, keep_mask);
@@ -589,7 +594,7 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
     while (npad < max_n) npad <<= 1;
     static const u64 base = (static_cast<u64>(std::random_device{}()) << 32) ^ 0x9e3779b97f4a7c15ull;
     static std::atomic<u64> calls{0};
-    const u64 token = base + calls.fetch_add(1) + 1;
+    const u64 token = (base + calls.fetch_add(1)) | 1ull;   // never 0: the scan workgroups clear the word when done
     const int G = (w.nbmax + kFusedWaves - 1) / kFusedWaves;
     const size_t lds = std::max<size_t>(npad * sizeof(u64), 2 * kWave * sizeof(u64) + 64);
     auto kernel = w.nbmax <= 32 ? nms_fused_kernel<false> : nms_fused_kernel<true>;
