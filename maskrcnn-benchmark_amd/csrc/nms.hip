@@ -23,7 +23,7 @@
 //                original indices, exactly at::nonzero(suppressed == 0) (nms_cpu.cpp:64).
 //
 // n <= 4096 per segment (every RPN / box-head call of the detector): the three stages are ONE launch,
-// nms_fused_kernel — workgroups [0,S) sort, the next S*nb*ceil(nb/8) compute mask tiles (a wave per tile; they wait for
+// nms_fused_kernel — workgroups [0,S) sort, the next S*ceil(nb(nb+1)/16) compute mask tiles (a wave per tile; they wait for
 // their segment's "sorted" token), the last S run the scan chain as the tiles of each row block are counted in.
 // Larger problems keep the three launches.
 #include <atomic>
@@ -472,8 +472,9 @@ struct FusedCtrl {        // one per segment, in the caller's workspace (arbitra
 };
 
 // blockIdx.x:  [0, S)                 sort + gather of segment s, then publish the token
-//              S * nbmax * G          mask tiles: ((rb * S) + s) * G + g -> column blocks rb + 8g + wave (row block 0 of
-//                                     every segment first: the scans start while later rows are still computed)
+//              S * G                  mask tiles: chunk * S + s -> 8 consecutive tiles of segment s's upper triangle, row
+//                                     major (row block 0 of every segment first: the scans start while later rows
+//                                     are still computed); G = ceil(nbmax (nbmax + 1) / 16)
 //              S                      scan chain + compaction of segment s
 // scan_first = 0: tiles, then scans — every wait is for a workgroup with a LOWER index (detops_common.h, "flags between
 // workgroups"); the scans are dispatched last, i.e. once most tile workgroups have retired.  scan_first = 1 (the host
@@ -491,7 +492,7 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
                  int32_t* __restrict__ num_keep, uint8_t* __restrict__ keep_mask) {
   DETOPS_DYNAMIC_LDS(unsigned char, smem_raw);
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int T = w.nbmax * S * G;
+  const int T = S * G;                                            // G tile workgroups per segment
   int bid = blockIdx.x;                                           // role index: sorts, tiles, scans
   if (scan_first && bid >= S) bid = bid < 2 * S ? bid + T : bid - S;
   if (bid < S) {                                                  // ---- sort
@@ -504,18 +505,25 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
     return;
   }
   if (bid < S + T) {                                              // ---- mask tiles, one per wave
+    // G workgroups per segment, each 8 consecutive tiles of the segment's upper triangle in row-major order (row block
+    // 0 first); workgroup index = chunk * S + segment, so all segments advance together
     const int idx = bid - S;
-    const int g = idx % G, s = (idx / G) % S, rb = idx / (G * S);
-    const int cb = rb + g * kFusedWaves + wave;
+    const int s = idx % S, chunk = idx / S;
     const int n = seg_view(seg_offsets, n_single, s).n;
-    if (rb * kWave >= n || cb * kWave >= n) return;
-    if (wave == 0) {                 // the workgroup's first wave always has a tile (cb = rb + 8g <= its siblings')
+    const int nb = (n + kWave - 1) / kWave;
+    const int ntiles = nb * (nb + 1) / 2;
+    int t = chunk * kFusedWaves + wave;                           // wave-uniform
+    if (t >= ntiles) return;                                      // (wave 0 holds the smallest t: it leaves last)
+    int rb = 0;
+    while (t >= nb - rb) { t -= nb - rb; ++rb; }                  // row lengths nb, nb - 1, ..., 1
+    const int cb = rb + t;
+    if (wave == 0) {
       int budget = kSpinBudget;
       while (flag_peek(&ctrl[s].token) != token && spin_again(budget)) {}
     }
     __syncthreads();                 // waves without a tile have left; the barrier counts the remaining ones
     mask_tile<true>(w.boxes + static_cast<size_t>(s) * w.stride, w.areas + static_cast<size_t>(s) * w.stride,
-                    w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, (n + kWave - 1) / kWave, rb, cb, thr);
+                    w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, nb, rb, cb, thr);
     DETOPS_VMCNT_WAIT(0);            // the 64 write-through stores of this wave have reached memory
     if (lane == 0) flag_add(&ctrl[s].done[rb], 1);
     return;
@@ -595,7 +603,7 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
     static const u64 base = (static_cast<u64>(std::random_device{}()) << 32) ^ 0x9e3779b97f4a7c15ull;
     static std::atomic<u64> calls{0};
     const u64 token = (base + calls.fetch_add(1)) | 1ull;   // never 0: the scan workgroups clear the word when done
-    const int G = (w.nbmax + kFusedWaves - 1) / kFusedWaves;
+    const int G = (w.nbmax * (w.nbmax + 1) / 2 + kFusedWaves - 1) / kFusedWaves;   // tile workgroups per segment
     const size_t lds = std::max<size_t>(npad * sizeof(u64), 2 * kWave * sizeof(u64) + 64);
     auto kernel = w.nbmax <= 32 ? nms_fused_kernel<false> : nms_fused_kernel<true>;
     int scan_first = 0;
@@ -603,7 +611,7 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
     int& cap = resident[w.nbmax <= 32 ? 0 : 1];
     if (cap == 0) cap = detops_resident_workgroups(kernel, kScanThreads, 32 * 1024);   // -1: unknown / host emulation
     scan_first = (cap > 0 && 8 * S <= cap && detops_tuning().nms_fused != 3) ? 1 : 0;
-    hipLaunchKernelGGL(kernel, dim3(2 * S + w.nbmax * S * G), dim3(kScanThreads), lds, st, boxes, scores,
+    hipLaunchKernelGGL(kernel, dim3(2 * S + S * G), dim3(kScanThreads), lds, st, boxes, scores,
                        seg_offsets, max_n, npad, thr, w, reinterpret_cast<FusedCtrl*>(base_ptr + l.off_ctrl), token, S, G,
                        scan_first, keep, num_keep, keep_mask);
     return launch_status();
