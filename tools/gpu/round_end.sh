@@ -41,11 +41,14 @@ if has pmc; then
     timeout 150 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$n -o x -- $PM < /dev/null > $O/pmc_$n.log 2>&1
   done
   python tools/pmc_diag.py /tmp/pmc_sq /tmp/pmc_sq2 /tmp/pmc_tcc /tmp/pmc_fw /tmp/pmc_ww > $O/roi_align_bwd_ring_pmc.txt 2>&1; grep -v "roi_order" $O/roi_align_bwd_ring_pmc.txt | head -40; el pmc-ring
-  TR="python tools/opbench.py --only roi_align_fpn,frozen_bn,nms --iters 5"
+  TR="python tools/opbench.py --only roi_align_fpn,frozen_bn,nms,dcn_block --iters 5"
   rm -rf /tmp/tr_f /tmp/tr_w
   timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/tr_f -o x -- $TR < /dev/null > $O/traffic_fetch.log 2>&1
   timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/tr_w -o x -- $TR < /dev/null > $O/traffic_write.log 2>&1
-  python tools/pmc_traffic.py /tmp/tr_f /tmp/tr_w $O/traffic.json 2>&1 | cut -c1-150 | head -30; el pmc-traffic
+  python tools/pmc_traffic.py /tmp/tr_f /tmp/tr_w $O/traffic.json 2>&1 | cut -c1-150 > $O/traffic.txt; grep -v "nms_sort\|nms_scan\|nms_mask" $O/traffic.txt | head -40; el pmc-traffic
+  rm -rf /tmp/kt_dcn
+  timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_dcn -o x -- python tools/opbench.py --only dcn_block --iters 10 < /dev/null > $O/dcn_block_trace.log 2>&1
+  python tools/kernel_times.py /tmp/kt_dcn "" 2>/dev/null | grep -v "Cijk\|at::\|rocclr\|elementwise" > $O/dcn_block_kernel_times.txt; head -24 $O/dcn_block_kernel_times.txt | cut -c1-150; el dcn-trace
 fi
 if has extra; then
   B="python bench.py --steps 40 --warmup 12 --no-cpu-baseline"

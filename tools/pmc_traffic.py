@@ -16,7 +16,8 @@ import json
 import os
 import sys
 
-OURS = ("roi_align_fwd", "roi_align_bwd", "nms_", "focal_kernel", "im2col_kernel", "col2im", "frozen_bn", "roi_pool")
+OURS = ("roi_align_fwd", "roi_align_bwd", "nms_", "focal_kernel", "im2col_kernel", "col2im", "frozen_bn", "roi_pool",
+        "nchw_to_nhwc", "im2col_nhwc", "coord_nhwc", "sampleT", "dcn_fused_fwd")
 
 
 def load(dirname, counter):
