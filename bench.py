@@ -111,11 +111,24 @@ def algorithmic_bytes(name, feat_bytes):
     if m:
         n, e, res, relu = (int(g) for g in m.groups())
         return e * n * (2 + res + relu)
-    m = re.match(r"dcn_(im2col|col2im|col2im_coord)\[B=(\d+),C=(\d+),(\d+)x(\d+),k=(\d+),e=(\d+),m=(\d)\]", name)
+    m = re.match(r"dcn_(im2col|col2im|col2im_coord|im2col_nhwc)\[B=(\d+),C=(\d+),(\d+)x(\d+),k=(\d+),e=(\d+),m=(\d)\]", name)
     if m:
         B, C, H, W, k, e, msk = (int(g) for g in m.groups()[1:])
         pix = B * H * W        # 3x3 / stride 1 / pad 1 in every model config: Ho x Wo = H x W
         return e * (B * C * H * W + 2 * k * k * pix + msk * k * k * pix + C * k * k * pix)
+    m = re.match(r"dcn_to_nhwc\[n=(\d+),e=(\d+)\]", name)
+    if m:      # one read + one write of the tensor
+        return 2 * int(m.group(1)) * int(m.group(2))
+    m = re.match(r"dcn_coord_nhwc\[B=(\d+),C=(\d+),(\d+)x(\d+),k=(\d+),e=(\d+),m=(\d)\]", name)
+    if m:      # column gradient + input + offsets (+ mask) read, offset (+ mask) gradients written
+        B, C, H, W, k, e, msk = (int(g) for g in m.groups())
+        pix = B * H * W
+        return e * (C * k * k * pix + B * C * H * W + 2 * (2 * k * k * pix) + 2 * msk * k * k * pix)
+    m = re.match(r"dcn_transposed_sample\[B=(\d+),Cout=(\d+),(\d+)x(\d+),k=(\d+),e=(\d+),m=(\d)\]", name)
+    if m:      # output gradient + offsets (+ mask) read, S_T [B HW, k k Cout] written
+        B, Co, H, W, k, e, msk = (int(g) for g in m.groups())
+        pix = B * H * W
+        return e * (B * Co * H * W + 2 * k * k * pix + msk * k * k * pix + Co * k * k * pix)
     m = re.match(r"dcn_fused_fwd\[B=(\d+),C=(\d+),(\d+)x(\d+),Cout=(\d+),k=(\d+),e=(\d+),m=(\d)\]", name)
     if m:
         B, C, H, W, Co, k, e, msk = (int(g) for g in m.groups())
@@ -133,7 +146,9 @@ def rocprof_kernel_us(entry_name):
     key = {"roi_align_fpn_bwd": "roi_align_bwd_ring_kernel", "roi_align_fpn_fwd": "roi_align_fwd_dma_kernel",
            "focal_fwd_sum": "focal_kernel", "focal_bwd_scalar": "focal_kernel", "frozen_bn_fwd": "frozen_bn",
            "frozen_bn_bwd": "frozen_bn", "dcn_col2im": "col2im", "dcn_im2col": "im2col_kernel",
-           "dcn_col2im_coord": "col2im_coord", "dcn_fused_fwd": "dcn_fused_fwd"}.get(entry_name.split("[")[0])
+           "dcn_col2im_coord": "col2im_coord", "dcn_fused_fwd": "dcn_fused_fwd", "dcn_to_nhwc": "nchw_to_nhwc",
+           "dcn_im2col_nhwc": "im2col_nhwc_kernel", "dcn_coord_nhwc": "coord_nhwc_kernel",
+           "dcn_transposed_sample": "sampleT_gather_kernel"}.get(entry_name.split("[")[0])
     if key is None:
         return None
     bins = re.search(r",(\d+)x(\d+)\]", entry_name)
