@@ -164,6 +164,7 @@ typedef unsigned long long detops_u64;
 #ifdef DETOPS_CPU_EMU
 __device__ __forceinline__ void detops_release_agent() {}
 __device__ __forceinline__ void flag_store(detops_u64* p, detops_u64 v) { *p = v; }
+__device__ __forceinline__ void flag_store_relaxed(detops_u64* p, detops_u64 v) { *p = v; }
 __device__ __forceinline__ detops_u64 flag_load(const detops_u64* p) { return *p; }
 __device__ __forceinline__ int flag_load(const int* p) { return *p; }
 __device__ __forceinline__ void flag_add(int* p, int v) { *p += v; }
@@ -181,6 +182,11 @@ __device__ __forceinline__ bool spin_again(int& budget) {
 __device__ __forceinline__ void detops_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
 __device__ __forceinline__ void flag_store(detops_u64* p, detops_u64 v) {
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// for data already in memory (write-through stores + DETOPS_VMCNT_WAIT(0) + barrier): no release fence, i.e. no
+// write-back of the XCD's whole L2 (buffer_wbl2) in front of the flag
+__device__ __forceinline__ void flag_store_relaxed(detops_u64* p, detops_u64 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ detops_u64 flag_load(const detops_u64* p) {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);

@@ -120,6 +120,88 @@ __device__ __forceinline__ void sort_and_gather(u64* keys, const float* __restri
   }
 }
 
+// The same network for n <= 4 * blockDim keys with the keys in REGISTERS: thread t holds keys 4t .. 4t+3.  Partner
+// distance j = 1, 2: inside the thread (21 of the 66 stages of a 2048-key sort); j = 4 .. 128: the same slot of lane
+// (t ^ j/4) of the same wave, fetched with a lane shuffle (39 stages, no LDS memory, no barrier); j >= 256: another
+// wave — the four keys go through LDS once (6 stages).  Element e, partner e ^ j: it keeps the smaller key iff
+// ((e & j) == 0) == ((e & k) == 0).  `xch` is LDS for 4 * blockDim keys.
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src_lane) {
+  const unsigned lo = __shfl(static_cast<unsigned>(v), src_lane);
+  const unsigned hi = __shfl(static_cast<unsigned>(v >> 32), src_lane);
+  return (static_cast<u64>(hi) << 32) | lo;
+}
+
+template <bool WT>
+__device__ __forceinline__ void sort_and_gather_reg(u64* xch, const float* __restrict__ boxes,
+                                                    const float* __restrict__ scores, SegView sv, const Work& w, int s) {
+  const int n = sv.n, tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int np = 4 * static_cast<int>(blockDim.x);
+  u64 key[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = 4 * tid + r;
+    key[r] = e < n ? make_key(scores[sv.begin + e], static_cast<unsigned>(e)) : ~0ull;
+  }
+  for (int k = 2; k <= np; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j < 4) {                                  // partner in this thread: slots (0,1),(2,3) for j = 1, (0,2),(1,3) for j = 2
+        auto cx = [&](u64& a, u64& b, int r) {      // compare-exchange of slots r < r ^ j (constant register indices)
+          const bool up = ((4 * tid + r) & k) == 0;
+          const bool sw = (a > b) == up;
+          const u64 lo = sw ? b : a, hi = sw ? a : b;
+          a = lo; b = hi;
+        };
+        if (j == 1) { cx(key[0], key[1], 0); cx(key[2], key[3], 2); }
+        else        { cx(key[0], key[2], 0); cx(key[1], key[3], 1); }
+        continue;
+      }
+      u64 other[4];
+      const int dt = j >> 2;                        // partner thread = tid ^ dt, same slot
+      if (dt < kWave) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) other[r] = shfl_u64(key[r], lane ^ dt);
+      } else {
+        __syncthreads();                            // previous readers of xch are done
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xch[4 * tid + r] = key[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) other[r] = xch[4 * (tid ^ dt) + r];
+      }
+      const bool lower = (tid & dt) == 0;           // (e & j) == 0 for all four slots
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool up = ((4 * tid + r) & k) == 0;
+        const u64 a = key[r], b = other[r];
+        const u64 mn = a < b ? a : b, mx = a < b ? b : a;
+        key[r] = (lower == up) ? mn : mx;
+      }
+    }
+  }
+  float4* ob = w.boxes + static_cast<size_t>(s) * w.stride;
+  float* oa = w.areas + static_cast<size_t>(s) * w.stride;
+  int32_t* oo = w.order + static_cast<size_t>(s) * w.stride;
+  const float4* ib = reinterpret_cast<const float4*>(boxes) + sv.begin;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma clang fp contract(off)
+    const int i = 4 * tid + r;
+    if (i >= n) continue;
+    const int src = static_cast<int>(key[r] & 0xffffffffu);
+    const float4 b = ib[src];
+    const float area = (b.z - b.x + 1.f) * (b.w - b.y + 1.f);  // nms_cpu.cpp:22
+    if (WT) {
+      store_f4_wt(reinterpret_cast<float*>(ob + i), b);
+      store_u32_wt(oa + i, __float_as_uint(area));
+      store_u32_wt(oo + i, static_cast<unsigned>(src));
+    } else {
+      ob[i] = b;
+      oa[i] = area;
+      oo[i] = src;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(1024)
 nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                 const int32_t* __restrict__ seg_offsets, int n_single, int npad, Work w) {
@@ -498,10 +580,14 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
   if (bid < S) {                                                  // ---- sort
     const int s = bid;
     if (tid < kWave) store_u32_wt(&ctrl[s].done[tid], 0u);
-    sort_and_gather<true>(reinterpret_cast<u64*>(smem_raw), boxes, scores, seg_view(seg_offsets, n_single, s), npad, w, s);
+    const SegView sv = seg_view(seg_offsets, n_single, s);
+    if (sv.n <= 4 * kScanThreads)     // every call of the detector (n <= 2048): keys in registers
+      sort_and_gather_reg<true>(reinterpret_cast<u64*>(smem_raw), boxes, scores, sv, w, s);
+    else
+      sort_and_gather<true>(reinterpret_cast<u64*>(smem_raw), boxes, scores, sv, npad, w, s);
     DETOPS_VMCNT_WAIT(0);            // this wave's write-through stores (sorted rows, the zeroed counters) are in memory
     __syncthreads();
-    if (tid == 0) flag_store(&ctrl[s].token, token);
+    if (tid == 0) flag_store_relaxed(&ctrl[s].token, token);   // everything it guards is already in memory
     return;
   }
   if (bid < S + T) {                                              // ---- mask tiles, one per wave
@@ -544,7 +630,7 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
     // every tile of the segment is counted in, so nobody reads the token any more: clear it.  A captured graph
     // replays this launch with the SAME token value — the cleared word is what makes the replay wait again.
     DETOPS_WAVE_SYNC();          // every lane of this wave has read the token
-    if (lane == 0) flag_store(&ctrl[s].token, 0ull);
+    if (lane == 0) flag_store_relaxed(&ctrl[s].token, 0ull);
   }
   __syncthreads();
   compact_keep(keptw, flags, wsum, w.order + static_cast<size_t>(s) * w.stride, sv, s, keep, num_keep, keep_mask);
@@ -604,7 +690,7 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
     static std::atomic<u64> calls{0};
     const u64 token = (base + calls.fetch_add(1)) | 1ull;   // never 0: the scan workgroups clear the word when done
     const int G = (w.nbmax * (w.nbmax + 1) / 2 + kFusedWaves - 1) / kFusedWaves;   // tile workgroups per segment
-    const size_t lds = std::max<size_t>(npad * sizeof(u64), 2 * kWave * sizeof(u64) + 64);
+    const size_t lds = std::max<size_t>(npad * sizeof(u64), 4 * kScanThreads * sizeof(u64));   // LDS sort keys / the register sort's exchange buffer
     auto kernel = w.nbmax <= 32 ? nms_fused_kernel<false> : nms_fused_kernel<true>;
     int scan_first = 0;
     static int resident[2] = {0, 0};   // workgroups the device holds at once, per kernel variant (first device seen)
