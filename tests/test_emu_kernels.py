@@ -273,6 +273,45 @@ def test_emu_nms_single_launch_and_three_launch_paths(fused):
         assert np.array_equal(emu.nms(b, sc, 0.6), oracle.nms(b, sc, 0.6))
 
 
+def test_emu_nms_threshold_boundary_is_exact():
+    """Pairs whose IoU is EXACTLY the threshold, one ulp above and one ulp below it, and degenerate unions (negative
+    "areas", huge coordinates) must come out as the reference's `inter / union >= thr` (nms_cpu.cpp:59-60) does: the
+    decision needs the correctly rounded IEEE quotient."""
+    rng = np.random.RandomState(11)
+    f = np.float32
+    cases = 0
+    for trial in range(120):
+        w0, h0 = rng.uniform(5, 400, 2).astype(f)
+        a = np.array([10.25, 20.5, f(10.25) + w0, f(20.5) + h0], f)
+        dx, dy = (rng.uniform(-0.6, 0.6, 2) * np.array([w0, h0])).astype(f)
+        sc = f(rng.uniform(0.6, 1.6))
+        b = np.array([a[0] + dx, a[1] + dy, a[0] + dx + w0 * sc, a[1] + dy + h0 / sc], f)
+        ia = f(f(a[2] - a[0] + f(1)) * f(a[3] - a[1] + f(1)))
+        ib = f(f(b[2] - b[0] + f(1)) * f(b[3] - b[1] + f(1)))
+        ww = max(f(0), f(f(min(a[2], b[2]) - max(a[0], b[0])) + f(1)))
+        hh = max(f(0), f(f(min(a[3], b[3]) - max(a[1], b[1])) + f(1)))
+        inter = f(ww * hh)
+        if inter <= 0:
+            continue
+        ovr = f(inter / f(f(ia + ib) - inter))
+        boxes = np.stack([a, b])
+        scores = np.array([0.9, 0.8], f)
+        for thr in (ovr, np.nextafter(ovr, f(2)), np.nextafter(ovr, f(-1)), f(ovr * f(1.0000005)), f(ovr * f(0.9999995))):
+            if not (0 < thr < 1):
+                continue
+            want = oracle.nms(boxes, scores, float(thr))
+            assert np.array_equal(emu.nms(boxes, scores, float(thr)), want), (trial, float(ovr), float(thr))
+            assert len(want) == (1 if ovr >= thr else 2)
+            cases += 1
+    assert cases > 300
+    # degenerate unions: zero-area / inverted boxes (negative "areas"), identical boxes, huge coordinates
+    odd = np.array([[0, 0, -1, -1], [0, 0, -1, -1], [5, 5, 4, 9], [5, 5, 4, 9], [0, 0, 10, 10], [0, 0, 10, 10],
+                    [-3e18, -3e18, 3e18, 3e18], [-3e18, -3e18, 3e18, 3e18], [1, 1, 0.5, 0.5], [0, 0, 1e-20, 1e-20]], f)
+    sc = np.linspace(1.0, 0.1, len(odd)).astype(f)
+    for thr in (0.0, 1e-6, 0.5, 1.0):
+        assert np.array_equal(emu.nms(odd, sc, thr), oracle.nms(odd, sc, thr)), thr
+
+
 def test_emu_nms_batched_segments_beyond_the_lds_sort():
     """segments with more than 8192 candidates (the reference's non-FPN PRE_NMS_TOP_N_TRAIN = 12000): per-
     segment radix sort instead of the in-LDS bitonic network; ragged segment lengths."""
