@@ -268,7 +268,7 @@ def test_emu_nms_single_launch_and_three_launch_paths(fused):
             want = np.zeros(len(y), np.uint8)
             want[ref] = 1
             assert np.array_equal(km[offs[i]:offs[i + 1]], want)
-    for n in (17 * 64, 33 * 64 - 1):
+    for n in (17 * 64, 33 * 64 - 1, 2048, 1024, 3):     # register sort: full, half-full and nearly empty key sets
         b, sc = synth.nms_boxes(n, seed=n)
         assert np.array_equal(emu.nms(b, sc, 0.6), oracle.nms(b, sc, 0.6))
 
