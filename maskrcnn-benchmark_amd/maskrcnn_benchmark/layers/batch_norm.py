@@ -39,15 +39,27 @@ class FrozenBatchNorm2d(nn.Module):
         self._folded = None
 
     def folded(self):
-        """(scale, bias) fp32 [C]: scale = weight * rsqrt(var), bias = bias - mean * scale."""
-        bufs = (self.weight, self.bias, self.running_mean, self.running_var)
-        key = tuple((b._version, b.data_ptr()) for b in bufs)
-        if self._folded is None or self._folded[0] != key:
+        """(scale, bias) fp32 [C]: scale = weight * rsqrt(var), bias = bias - mean * scale.  Cached; the check on the hot
+        path is the sum of the four buffers' version counters (in-place writes, `load_state_dict`) — a replaced buffer
+        object (`.to()`, `.cuda()`, assignment) drops the cache through `_apply` / `__setattr__`."""
+        b = self._buffers      # (nn.Module.__getattr__ costs ~0.5 us per buffer access)
+        version = b["weight"]._version + b["bias"]._version + b["running_mean"]._version + b["running_var"]._version
+        f = self._folded
+        if f is None or f[0] != version:
             with torch.no_grad():
                 scale = self.weight.float() * self.running_var.float().rsqrt()
                 bias = self.bias.float() - self.running_mean.float() * scale
-            self._folded = (key, scale.contiguous(), bias.contiguous())
-        return self._folded[1], self._folded[2]
+            f = self._folded = (version, scale.contiguous(), bias.contiguous())
+        return f[1], f[2]
+
+    def _apply(self, fn, *args, **kwargs):
+        self._folded = None
+        return super(FrozenBatchNorm2d, self)._apply(fn, *args, **kwargs)
+
+    def __setattr__(self, name, value):
+        if name in ("weight", "bias", "running_mean", "running_var"):
+            object.__setattr__(self, "_folded", None)
+        super(FrozenBatchNorm2d, self).__setattr__(name, value)
 
     def forward(self, x):
         # the folded scale/bias follow the activation dtype (reference casts the buffers to half)
