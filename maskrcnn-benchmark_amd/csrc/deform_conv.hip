@@ -582,6 +582,11 @@ inline size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255);
 // spills to an overflow list that a small atomic kernel adds afterwards.
 constexpr int kEllCap = 8;
 
+struct __attribute__((aligned(8))) EllEntry {   // one 8-byte record per slot: a scattered fill writes ONE line per entry
+  int32_t idx;      // column index: tap * B * Ho * Wo + b * Ho * Wo + output pixel
+  float w;          // bilinear weight (x mask)
+};
+
 struct EllOverflow {
   int32_t li;       // (b*dg + dgi) * H*W + pixel
   int32_t colidx;
@@ -591,7 +596,7 @@ struct EllOverflow {
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 col2im_ell_fill_kernel(const T* __restrict__ offset, const T* __restrict__ mask, Geom g, int64_t npoints,
-                       int32_t* __restrict__ counter, int32_t* __restrict__ ent_idx, float* __restrict__ ent_w,
+                       int32_t* __restrict__ counter, EllEntry* __restrict__ ent,
                        int32_t* __restrict__ ovf_count, EllOverflow* __restrict__ ovf, int ovf_cap) {
   const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (p >= npoints) return;
@@ -614,8 +619,7 @@ col2im_ell_fill_kernel(const T* __restrict__ offset, const T* __restrict__ mask,
     const int pos = atomicAdd(counter + cslot, 1);
     if (pos < kEllCap) {
       const size_t e = ((img * K + q.tap) * kEllCap + pos) * HW + tgt[t];   // [img][tap][slot][pixel]
-      ent_idx[e] = colidx;
-      ent_w[e] = wgt[t] * m;
+      ent[e] = EllEntry{colidx, wgt[t] * m};
     } else {
       const int o = atomicAdd(ovf_count, 1);
       if (o < ovf_cap) ovf[o] = EllOverflow{static_cast<int32_t>(img * HW + tgt[t]), colidx, wgt[t] * m};
@@ -625,22 +629,21 @@ col2im_ell_fill_kernel(const T* __restrict__ offset, const T* __restrict__ mask,
 
 // sort the (<= kEllCap) entries of each (pixel, tap) by column index: coalesced loads / stores, in registers
 __global__ void __launch_bounds__(kBlock)
-col2im_ell_sort_kernel(const int32_t* __restrict__ counter, int64_t ncols, int HW, int32_t* __restrict__ ent_idx,
-                       float* __restrict__ ent_w) {
+col2im_ell_sort_kernel(const int32_t* __restrict__ counter, int64_t ncols, int HW, EllEntry* __restrict__ ent) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;   // (img, tap, pixel) linear
   if (i >= ncols) return;
   const int n = min(counter[i], kEllCap);
   if (n < 2) return;
   const int64_t it = i / HW;             // img * K + tap
   const int pix = static_cast<int>(i - it * HW);
-  int32_t* ei = ent_idx + static_cast<size_t>(it) * kEllCap * HW + pix;
-  float* ew = ent_w + static_cast<size_t>(it) * kEllCap * HW + pix;
+  EllEntry* ee = ent + static_cast<size_t>(it) * kEllCap * HW + pix;
   int32_t k[kEllCap];
   float w[kEllCap];
 #pragma unroll
   for (int j = 0; j < kEllCap; ++j) {
-    k[j] = j < n ? ei[static_cast<size_t>(j) * HW] : 0x7fffffff;
-    w[j] = j < n ? ew[static_cast<size_t>(j) * HW] : 0.f;
+    const EllEntry r = j < n ? ee[static_cast<size_t>(j) * HW] : EllEntry{0x7fffffff, 0.f};
+    k[j] = r.idx;
+    w[j] = r.w;
   }
   // odd-even transposition sort on 8 registers (static indices)
 #pragma unroll
@@ -655,14 +658,13 @@ col2im_ell_sort_kernel(const int32_t* __restrict__ counter, int64_t ncols, int H
   }
 #pragma unroll
   for (int j = 0; j < kEllCap; ++j)
-    if (j < n) { ei[static_cast<size_t>(j) * HW] = k[j]; ew[static_cast<size_t>(j) * HW] = w[j]; }
+    if (j < n) ee[static_cast<size_t>(j) * HW] = EllEntry{k[j], w[j]};
 }
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 col2im_ell_gather_kernel(const T* __restrict__ col, const int32_t* __restrict__ counter,
-                         const int32_t* __restrict__ ent_idx, const float* __restrict__ ent_w,
-                         T* __restrict__ grad_im, Geom g, int cchunk, int xcd_remap) {
+                         const EllEntry* __restrict__ ent, T* __restrict__ grad_im, Geom g, int cchunk, int xcd_remap) {
   const int HW = g.H * g.W;
   int64_t lin = (static_cast<int64_t>(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   if (xcd_remap) lin = xcd_contiguous(lin, static_cast<int64_t>(gridDim.x) * gridDim.y * gridDim.z);
@@ -687,13 +689,13 @@ col2im_ell_gather_kernel(const T* __restrict__ col, const int32_t* __restrict__ 
     const T* cbase = col + static_cast<size_t>(cs) * chan_stride;
     for (int tap = 0; tap < K; ++tap) {
       const int n = live ? min(counter[(img * K + tap) * HW + p], kEllCap) : 0;
-      const int32_t* ei = ent_idx + (img * K + tap) * kEllCap * HW + p;
-      const float* ew = ent_w + (img * K + tap) * kEllCap * HW + p;
+      const EllEntry* ee = ent + (img * K + tap) * kEllCap * HW + p;
       for (int j = 0; j < kEllCap; ++j) {
         if (__ballot(j < n) == 0ull) break;        // wave-uniform trip count
         if (j < n) {
-          const int32_t ci = ei[static_cast<size_t>(j) * HW];
-          const float w = ew[static_cast<size_t>(j) * HW];
+          const EllEntry r = ee[static_cast<size_t>(j) * HW];
+          const int32_t ci = r.idx;
+          const float w = r.w;
           const T* cp = cbase + ci;
 #pragma unroll
           for (int c = 0; c < kGatherCC; ++c)
@@ -735,7 +737,7 @@ col2im_ell_overflow_kernel(const T* __restrict__ col, const int32_t* __restrict_
 struct EllPlan {
   int64_t ncols, npoints_per_dg;     // ncols = B*dg*K*H*W  (pixel, tap) columns
   int ovf_cap;
-  size_t off_count, off_ovf_count, off_idx, off_w, off_ovf, total;
+  size_t off_count, off_ovf_count, off_ent, off_ovf, total;
 };
 
 inline bool ell_plan(const Geom& g, EllPlan& P) {
@@ -751,8 +753,7 @@ inline bool ell_plan(const Geom& g, EllPlan& P) {
   size_t o = 0;
   P.off_count = o;     o = align256(o + sizeof(int32_t) * P.ncols);
   P.off_ovf_count = o; o = align256(o + sizeof(int32_t));
-  P.off_idx = o;       o = align256(o + sizeof(int32_t) * P.ncols * kEllCap);
-  P.off_w = o;         o = align256(o + sizeof(float) * P.ncols * kEllCap);
+  P.off_ent = o;       o = align256(o + sizeof(EllEntry) * P.ncols * kEllCap);
   P.off_ovf = o;       o = align256(o + sizeof(EllOverflow) * static_cast<size_t>(P.ovf_cap));
   P.total = o;
   return true;
@@ -765,16 +766,15 @@ int col2im_ell_t(const void* col, const void* offset, const void* mask, void* gr
   char* w = static_cast<char*>(ws);
   int32_t* count = reinterpret_cast<int32_t*>(w + P.off_count);
   int32_t* ovf_count = reinterpret_cast<int32_t*>(w + P.off_ovf_count);
-  int32_t* ent_idx = reinterpret_cast<int32_t*>(w + P.off_idx);
-  float* ent_w = reinterpret_cast<float*>(w + P.off_w);
+  EllEntry* ent = reinterpret_cast<EllEntry*>(w + P.off_ent);
   EllOverflow* ovf = reinterpret_cast<EllOverflow*>(w + P.off_ovf);
-  DETOPS_HIP_TRY(hipMemsetAsync(count, 0, P.off_idx - P.off_count, st_));   // counters + overflow counter
+  DETOPS_HIP_TRY(hipMemsetAsync(count, 0, P.off_ent - P.off_count, st_));   // counters + overflow counter
   const dim3 pgrid(static_cast<unsigned>(ceil_div64(P.npoints_per_dg, kBlock)), static_cast<unsigned>(g.dg));
   hipLaunchKernelGGL(col2im_ell_fill_kernel<T>, pgrid, dim3(kBlock), 0, st_, static_cast<const T*>(offset),
-                     static_cast<const T*>(mask), g, P.npoints_per_dg, count, ent_idx, ent_w, ovf_count, ovf,
+                     static_cast<const T*>(mask), g, P.npoints_per_dg, count, ent, ovf_count, ovf,
                      P.ovf_cap);
   hipLaunchKernelGGL(col2im_ell_sort_kernel, dim3(static_cast<unsigned>(ceil_div64(P.ncols, kBlock))), dim3(kBlock),
-                     0, st_, static_cast<const int32_t*>(count), P.ncols, g.H * g.W, ent_idx, ent_w);
+                     0, st_, static_cast<const int32_t*>(count), P.ncols, g.H * g.W, ent);
   const int cpg = g.C / g.dg;
   const int64_t pix_blocks = ceil_div64(static_cast<int64_t>(g.H) * g.W, kBlock) * g.B;
   int cc = cpg;
@@ -784,8 +784,8 @@ int col2im_ell_t(const void* col, const void* offset, const void* mask, void* gr
   const dim3 ggrid(static_cast<unsigned>(ceil_div64(static_cast<int64_t>(g.H) * g.W, kBlock)),
                    static_cast<unsigned>(g.dg * ceil_div64(cpg, cc)), static_cast<unsigned>(g.B));
   hipLaunchKernelGGL(col2im_ell_gather_kernel<T>, ggrid, dim3(kBlock), 0, st_, static_cast<const T*>(col),
-                     static_cast<const int32_t*>(count), static_cast<const int32_t*>(ent_idx),
-                     static_cast<const float*>(ent_w), static_cast<T*>(grad_im), g, cc, xcd_remap);
+                     static_cast<const int32_t*>(count), static_cast<const EllEntry*>(ent), static_cast<T*>(grad_im), g, cc,
+                     xcd_remap);
   hipLaunchKernelGGL(col2im_ell_overflow_kernel<T>, dim3(kNumCU), dim3(kBlock), 0, st_, static_cast<const T*>(col),
                      static_cast<const int32_t*>(ovf_count), static_cast<const EllOverflow*>(ovf), P.ovf_cap,
                      static_cast<T*>(grad_im), g);
@@ -1395,8 +1395,8 @@ coord_nhwc_kernel(const T* __restrict__ colsG, const T* __restrict__ xT, const T
 // weight * gT[q, co]  (weight = bilinear corner weight x modulation mask, from the fixed-width inverted index)
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-sampleT_gather_kernel(const T* __restrict__ gT, const int32_t* __restrict__ counter, const int32_t* __restrict__ ent_idx,
-                      const float* __restrict__ ent_w, T* __restrict__ S_T, Geom g, int Cout, int sub, int nv, int64_t npix) {
+sampleT_gather_kernel(const T* __restrict__ gT, const int32_t* __restrict__ counter, const EllEntry* __restrict__ ent,
+                      T* __restrict__ S_T, Geom g, int Cout, int sub, int nv, int64_t npix) {
   constexpr int V = VecT<T>::N;
   const int ls = threadIdx.x % sub;
   const int64_t gp = static_cast<int64_t>(blockIdx.x) * (kBlock / sub) + threadIdx.x / sub;   // b * H * W + pixel
@@ -1406,14 +1406,14 @@ sampleT_gather_kernel(const T* __restrict__ gT, const int32_t* __restrict__ coun
   for (int tap = 0; tap < K; ++tap) {
     const size_t col = (static_cast<size_t>(b) * K + tap) * HW + p;             // counter: [img][tap][pixel]
     const int n = min(counter[col], kEllCap);
-    const int32_t* ei = ent_idx + (static_cast<size_t>(b) * K + tap) * kEllCap * HW + p;
-    const float* ew = ent_w + (static_cast<size_t>(b) * K + tap) * kEllCap * HW + p;
+    const EllEntry* ee = ent + (static_cast<size_t>(b) * K + tap) * kEllCap * HW + p;
     int32_t qi[kEllCap];
     float wi[kEllCap];
 #pragma unroll
     for (int j = 0; j < kEllCap; ++j) {            // the (<= 8) entries: same addresses across the pixel group
-      qi[j] = j < n ? ei[static_cast<size_t>(j) * HW] - tap * (g.B * HWo) : 0;   // column index -> b * Ho * Wo + pix
-      wi[j] = j < n ? ew[static_cast<size_t>(j) * HW] : 0.f;
+      const EllEntry r = j < n ? ee[static_cast<size_t>(j) * HW] : EllEntry{tap * (g.B * HWo), 0.f};
+      qi[j] = r.idx - tap * (g.B * HWo);           // column index -> b * Ho * Wo + pix
+      wi[j] = r.w;
     }
     T* dst = S_T + (static_cast<size_t>(gp) * K + tap) * Cout;
     for (int k = 0; k < nv; ++k) {
@@ -1500,18 +1500,17 @@ int sampleT_t(const void* gT, const void* offset, const void* mask, void* S_T, c
   char* w = static_cast<char*>(ws);
   int32_t* count = reinterpret_cast<int32_t*>(w + P.off_count);
   int32_t* ovf_count = reinterpret_cast<int32_t*>(w + P.off_ovf_count);
-  int32_t* ent_idx = reinterpret_cast<int32_t*>(w + P.off_idx);
-  float* ent_w = reinterpret_cast<float*>(w + P.off_w);
+  EllEntry* ent = reinterpret_cast<EllEntry*>(w + P.off_ent);
   EllOverflow* ovf = reinterpret_cast<EllOverflow*>(w + P.off_ovf);
-  DETOPS_HIP_TRY(hipMemsetAsync(count, 0, P.off_idx - P.off_count, st_));   // counters + overflow counter
+  DETOPS_HIP_TRY(hipMemsetAsync(count, 0, P.off_ent - P.off_count, st_));   // counters + overflow counter
   hipLaunchKernelGGL(col2im_ell_fill_kernel<T>, dim3(static_cast<unsigned>(ceil_div64(P.npoints_per_dg, kBlock)), 1u), dim3(kBlock),
-                     0, st_, static_cast<const T*>(offset), static_cast<const T*>(mask), g, P.npoints_per_dg, count, ent_idx,
-                     ent_w, ovf_count, ovf, P.ovf_cap);
+                     0, st_, static_cast<const T*>(offset), static_cast<const T*>(mask), g, P.npoints_per_dg, count, ent,
+                     ovf_count, ovf, P.ovf_cap);
   hipLaunchKernelGGL(col2im_ell_sort_kernel, dim3(static_cast<unsigned>(ceil_div64(P.ncols, kBlock))), dim3(kBlock), 0, st_,
-                     static_cast<const int32_t*>(count), P.ncols, g.H * g.W, ent_idx, ent_w);
+                     static_cast<const int32_t*>(count), P.ncols, g.H * g.W, ent);
   hipLaunchKernelGGL(sampleT_gather_kernel<T>, dim3(static_cast<unsigned>(ceil_div64(npix, m.ppb))), dim3(kBlock), 0, st_,
-                     static_cast<const T*>(gT), static_cast<const int32_t*>(count), static_cast<const int32_t*>(ent_idx),
-                     static_cast<const float*>(ent_w), static_cast<T*>(S_T), g, Cout, m.sub, m.nv, npix);
+                     static_cast<const T*>(gT), static_cast<const int32_t*>(count), static_cast<const EllEntry*>(ent),
+                     static_cast<T*>(S_T), g, Cout, m.sub, m.nv, npix);
   hipLaunchKernelGGL(sampleT_overflow_kernel<T>, dim3(kNumCU), dim3(kBlock), 0, st_, static_cast<const T*>(gT),
                      static_cast<const int32_t*>(ovf_count), static_cast<const EllOverflow*>(ovf), P.ovf_cap,
                      static_cast<T*>(S_T), g, Cout);
