@@ -410,13 +410,14 @@ def main():
             losses = step(*batches[i % len(batches)])
             torch.cuda.synchronize(device)
         except Exception as e:  # noqa: BLE001
-            # Opt-in (--allow-ddp-fallback) safety net for the N > 1 path: a Python-level failure of the
-            # overlapped hook in the first step falls back to stock DDP (all-reduce, then the optimizer
-            # after backward).  Off by default: a scaling run must measure the design DESIGN.md describes.
+            # Opt-in (--allow-ddp-fallback) safety net for the N > 1 path: a Python-level failure of the update-in-the-
+            # all-reduce-callback in the first step falls back to the same wrapper without it (bucketed all-reduce
+            # overlapped with backward, then the optimizer).  Off by default: a scaling run must measure the design
+            # DESIGN.md describes.
             if not args.allow_ddp_fallback or not distributed or i > 0 or ddp_mode != "overlapped-sgd-hook":
                 raise
-            progress("overlapped DDP hook failed (%r): falling back to plain DDP" % (e,))
-            ddp_mode = "plain-ddp (fallback: %s)" % type(e).__name__
+            progress("overlapped update failed (%r): falling back to all-reduce, then optimizer" % (e,))
+            ddp_mode = "allreduce-then-sgd (fallback: %s)" % type(e).__name__
             del model, optimizer, scheduler, step
             torch.manual_seed(1234 + rank)
             model, optimizer, scheduler, step = build_training(cfg, device, distributed, local_rank,

@@ -134,6 +134,60 @@ def test_overlapped_sgd_single_process_equals_torch_sgd():
         torch.testing.assert_close(a, c, rtol=1e-6, atol=1e-7)
 
 
+def _recovery_worker(rank, world, port, out_dir):
+    sys.path.insert(0, PKG)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from maskrcnn_benchmark.engine.ddp_step import make_overlapped_sgd, wrap_data_parallel
+    model = _toy()
+    opt = make_overlapped_sgd(_cfg(), model)
+    ddp = wrap_data_parallel(model, opt, bucket_cap_mb=0.001)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    for it in range(4):
+        x, y = _data(rank, it)
+        out = ddp(x)
+        opt.zero_grad(set_to_none=True)
+        if it == 1:
+            # a backward pass that dies half-way: the last layer's buckets have been launched (their collectives match
+            # on both ranks), the rest never arrive and the end-of-backward callback does not run
+            h = model[2](torch.relu(model[0](x)))
+            bad = model[4](torch.relu(Boom.apply(h)))
+            with pytest.raises(RuntimeError, match="boom"):
+                ((bad - y) ** 2).mean().backward()
+            assert ddp._armed
+            continue
+        ((out - y) ** 2).mean().backward()
+        assert not ddp._armed and ddp._next == 0 and not ddp._futures
+    # eval-mode forward and the state dict go through the wrapper untouched
+    ddp.eval()
+    with torch.no_grad():
+        assert ddp(_data(rank, 0)[0]).shape == (8, 3)
+    assert all(k.startswith("module.") for k in ddp.state_dict())
+    torch.save([p.detach().clone() for p in model.parameters()], os.path.join(out_dir, "rec_rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_data_parallel_recovers_from_a_failed_backward(tmp_path):
+    """A backward pass that raises leaves buckets half-launched; the next forward starts clean, training continues and
+    both ranks still hold identical parameters."""
+    mp.spawn(_recovery_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "rec_rank0.pt"), torch.load(tmp_path / "rec_rank1.pt")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+        assert torch.isfinite(x).all()
+
+
 # ------------------------------------------------------------------ the detector itself under the DDP hook
 def _detector_worker(rank, world, port, config, out_dir):
     """What bench.py / train_net.py do at N > 1, on the CPU shim: build_training(distributed=True) wraps
