@@ -11,8 +11,8 @@ import torch
 class SmoothedValue(object):
     def __init__(self, window_size=20):
         self.deque = deque(maxlen=window_size)
-        self.total = 0.0
-        self.count = 0
+        self._total = 0.0
+        self._count = 0
         self._pending = []
 
     def update(self, value):
@@ -24,9 +24,19 @@ class SmoothedValue(object):
         for v in self._pending:
             v = float(v.item()) if isinstance(v, torch.Tensor) else float(v)
             self.deque.append(v)
-            self.count += 1
-            self.total += v
+            self._count += 1
+            self._total += v
         self._pending = []
+
+    @property
+    def count(self):      # the reference's public counters (utils/metric_logger.py:16-17), exact after every update
+        self._drain()
+        return self._count
+
+    @property
+    def total(self):
+        self._drain()
+        return self._total
 
     @property
     def median(self):
@@ -41,7 +51,7 @@ class SmoothedValue(object):
     @property
     def global_avg(self):
         self._drain()
-        return self.total / max(self.count, 1)
+        return self._total / max(self._count, 1)
 
 
 class MetricLogger(object):

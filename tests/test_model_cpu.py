@@ -424,6 +424,37 @@ def test_tiny_model_trains_on_cpu_shim(config, monkeypatch):
         assert len(det) == 2 and det[0].has_field("scores") and det[0].has_field("labels")
 
 
+def test_box_coder_reference_known_answers(golden_dir):
+    """the reference's own tests/test_box_coder.py:11-105 vectors (captured by tests/golden/make_golden.py) + an encode
+    fixture from the reference's BoxCoder: decode within the reference test's atol, encode exact"""
+    from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+    g = np.load(os.path.join(golden_dir, "box_coder_reference_tests.npz"))
+    coder = BoxCoder(tuple(float(x) for x in g["weights"]))
+    out = coder.decode(torch.from_numpy(g["rel_codes"]), torch.from_numpy(g["boxes"])).numpy()
+    np.testing.assert_allclose(out, g["expected"], atol=float(g["atol"]))
+    np.testing.assert_allclose(out, g["decoded"], rtol=1e-6, atol=1e-5)
+    enc = BoxCoder(tuple(float(x) for x in g["enc_weights"]))
+    codes = enc.encode(torch.from_numpy(g["enc_reference_boxes"]), torch.from_numpy(g["enc_proposals"])).numpy()
+    np.testing.assert_allclose(codes, g["enc_codes"], rtol=1e-6, atol=1e-6)
+    back = enc.decode(torch.from_numpy(codes), torch.from_numpy(g["enc_proposals"])).numpy()
+    np.testing.assert_allclose(back[:, :2], g["enc_reference_boxes"][:, :2], atol=2e-3)
+
+
+def test_metric_logger_reference_known_answers():
+    """the reference's tests/test_metric_logger.py:9-28"""
+    from maskrcnn_benchmark.utils.metric_logger import MetricLogger
+    meter = MetricLogger()
+    for i in range(10):
+        meter.update(metric=float(i))
+    m = meter.meters["metric"]
+    assert m.count == 10 and m.total == 45 and m.median == 4 and m.avg == 4.5
+    meter.update(loss=torch.tensor(2.0))          # device tensors are accepted and read back lazily
+    assert meter.loss.global_avg == 2.0 and "loss: 2.0000 (2.0000)" in str(meter)
+    assert meter.delimiter == "\t"
+    with pytest.raises(AttributeError):
+        meter.not_existent
+
+
 def test_do_train_loop_checkpoints_and_resumes(tmp_path, caplog):
     """engine.trainer.do_train over the synthetic loader (reference engine/trainer.py:43-150): logs,
     saves model_final + last_checkpoint, and a second run resumes from the saved iteration."""
