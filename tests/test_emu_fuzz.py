@@ -100,3 +100,107 @@ def test_emu_fuzz_deformable(seed):
     np.testing.assert_allclose(goff, roff, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(roff).max()))
     if mask is not None:
         np.testing.assert_allclose(gmask, rmask, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(rmask).max()))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_emu_fuzz_nms_batched_single_launch(seed):
+    """ragged segment sets through the ONE-launch path (sort, mask tiles and scan as workgroup roles of one kernel) and
+    through the three launches: random segment counts and lengths over every scan width, integer boxes (exact IoU ties),
+    score ties, empty segments"""
+    rng = np.random.RandomState(5000 + seed)
+    S = int(rng.randint(1, 9))
+    sizes = [int(rng.choice([0, 1, 2, 63, 64, 65, 130, 700, 1025, 1500, 2049])) for _ in range(S)]
+    segs = []
+    for n in sizes:
+        cx, cy = rng.uniform(0, 300, n), rng.uniform(0, 300, n)
+        w, h = rng.uniform(1, 90, n), rng.uniform(1, 90, n)
+        b = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32)
+        if seed % 2:
+            b = np.round(b)
+        s = rng.rand(n).astype(np.float32)
+        if seed % 3 == 1:
+            s = np.round(s, 1)
+        segs.append((b.reshape(n, 4), s))
+    boxes = np.concatenate([b for b, _ in segs]) if sum(sizes) else np.zeros((0, 4), np.float32)
+    scores = np.concatenate([s for _, s in segs]) if sum(sizes) else np.zeros((0,), np.float32)
+    offs = np.cumsum([0] + sizes).astype(np.int32)
+    thr = float(rng.choice([0.3, 0.5, 0.7]))
+    max_n = max(max(sizes), 1)
+    for fused in (0, 2):
+        emu.tuning_set("nms_fused", fused)
+        keep, num = emu.nms_batched(boxes, scores, offs, max_n, thr)
+        km, num2 = emu.nms_batched(boxes, scores, offs, max_n, thr, mask=True)
+        assert np.array_equal(num, num2)
+        for i, (b, s) in enumerate(segs):
+            ref = oracle.nms(b, s, thr) if len(s) else np.zeros(0, np.int64)
+            assert num[i] == len(ref), (fused, i, sizes[i])
+            assert np.array_equal(keep[offs[i]:offs[i] + num[i]], ref), (fused, i, sizes[i])
+            want = np.zeros(len(s), np.uint8)
+            want[ref] = 1
+            assert np.array_equal(km[offs[i]:offs[i + 1]], want)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_emu_fuzz_roi_align_fpn_fused(seed):
+    """the multi-level launches the pooler uses (level mapping on the device, LDS-DMA forward, ring backward with split
+    hit lists) on random pyramids: odd map sizes, 2-4 levels, ROIs of every scale incl. degenerate ones"""
+    rng = np.random.RandomState(6000 + seed)
+    N = int(rng.randint(1, 3))
+    C = int(rng.choice([4, 16, 17, 32]))
+    L = int(rng.randint(2, 5))
+    H0, W0 = int(rng.randint(24, 64)), int(rng.randint(24, 80))
+    shapes = [(N, C, -(-H0 // (1 << l)), -(-W0 // (1 << l))) for l in range(L)]
+    scales = [1.0 / (4 << l) for l in range(L)]
+    feats = [rng.randn(*s).astype(np.float32) for s in shapes]
+    K = int(rng.choice([3, 40, 150]))
+    rois = _rois(rng, K, N, shapes[0][2], shapes[0][3], scales[0])
+    ph = [7, 14][seed % 2]
+    out, lv = emu.roi_align_fpn_forward(feats, rois, scales, ph, ph, 2, 2, 2 + L - 1)
+    ref_lv = oracle.fpn_level(rois, 2, 2 + L - 1, 224.0, 4.0, 1e-6)
+    assert np.array_equal(lv, ref_lv)
+    for l in range(L):
+        sel = np.nonzero(lv == l)[0]
+        if sel.size:
+            assert np.array_equal(out[sel], oracle.roi_align_forward(feats[l], rois[sel], scales[l], ph, ph, 2)), l
+    g = rng.randn(K, C, ph, ph).astype(np.float32)
+    emu.tuning_set("roi_bwd_seg", 4 + seed % 5)
+    gins = emu.roi_align_fpn_backward(g, rois, lv, shapes, scales, ph, ph, 2)
+    again = emu.roi_align_fpn_backward(g, rois, lv, shapes, scales, ph, ph, 2)
+    for l in range(L):
+        sel = np.nonzero(lv == l)[0]
+        ref = oracle.roi_align_backward(g[sel], rois[sel], scales[l], ph, ph, *shapes[l], 2, acc64=True) if sel.size \
+            else np.zeros(shapes[l], np.float32)
+        assert np.abs(gins[l] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), l
+        assert np.array_equal(gins[l], again[l]), "bit-reproducible"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_emu_fuzz_deformable_channels_last(seed):
+    """the channels-last pipeline (NHWC im2col, in-wave coordinate-gradient reduction, transposed sampling + GEMMs) on
+    random geometries against the oracle's reference-layout arithmetic"""
+    rng = np.random.RandomState(7000 + seed)
+    B = int(rng.randint(1, 3))
+    C, Cout = int(rng.choice([64, 128])), int(rng.choice([64, 128, 256]))   # fp32: channel counts / 4 a power of two >= 16
+    H, W = int(rng.randint(4, 10)), int(rng.randint(4, 12))
+    k = 3
+    stride, pad, dil = int(rng.choice([1, 2])), int(rng.choice([0, 1, 2])), int(rng.choice([1, 2]))
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    if Ho < 1 or Wo < 1:
+        pytest.skip("empty output")
+    x = rng.randn(B, C, H, W).astype(np.float32)
+    off = (rng.randn(B, 2 * k * k, Ho, Wo) * rng.choice([0.0, 0.7, 3.0])).astype(np.float32)
+    mask = rng.rand(B, k * k, Ho, Wo).astype(np.float32) if seed % 2 else None
+    wgt = (rng.randn(Cout, C, k, k) / np.sqrt(C * k * k)).astype(np.float32)
+    go = rng.randn(B, Cout, Ho, Wo).astype(np.float32)
+    geo = ((pad, pad), (stride, stride), (dil, dil))
+    out, gin, goff, gmask, gw = emu.deformable_nhwc(x, off, mask, wgt, go, k, k, *geo)
+    ref_out = oracle.deform_conv_forward(x, off, mask, wgt, None, *geo, 1, 1)
+    np.testing.assert_allclose(out, ref_out, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref_out).max()))
+    rin, roff, rmask, rw, _ = oracle.deform_conv_backward(x, off, mask, wgt, go, False, *geo, 1, 1)
+    tol = lambda r: dict(rtol=1e-4, atol=2e-4 * max(1.0, np.abs(r).max()))  # noqa: E731
+    np.testing.assert_allclose(gin, rin, **tol(rin))
+    np.testing.assert_allclose(goff, roff, **tol(roff))
+    np.testing.assert_allclose(gw, rw, **tol(rw))
+    if mask is not None:
+        np.testing.assert_allclose(gmask, rmask, **tol(rmask))
