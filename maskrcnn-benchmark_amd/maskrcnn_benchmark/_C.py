@@ -19,7 +19,6 @@ There is no CPU path: CPU tensors raise "Not implemented on the CPU" (the refere
 for its CUDA-only operators, e.g. csrc/ROIAlign.h:44).
 """
 import ctypes
-import os
 
 import torch
 
