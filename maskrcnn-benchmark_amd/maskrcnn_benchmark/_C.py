@@ -584,7 +584,7 @@ def frozen_bn_act_forward(x, scale, bias, residual, relu):
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // max(N * C, 1)
     y = torch.empty_like(x)
-    with _on_device(x), _timed(("frozen_bn_fwd[n=%d,nc=%d,e=%d,res=%d]", (x.numel(), N * C, _ESIZE[x.dtype], residual is not None)), x, every=16):
+    with _on_device(x), _timed(("frozen_bn_fwd[n=%d,nc=%d,e=%d,res=%d]", (x.numel(), N * C, _ESIZE[x.dtype], residual is not None)), x, every=8):
         check(lib.detops_frozen_bn_act_forward(ptr(x), ptr(scale), ptr(bias), ptr(residual), ptr(y), code, N, C, HW,
                                                int(bool(relu)), stream_of(x)), "frozen_bn_act_forward")
     return y
@@ -600,7 +600,7 @@ def frozen_bn_act_backward(grad_y, y, scale, relu, need_residual):
     gx = torch.empty_like(grad_y)
     gres = torch.empty_like(grad_y) if need_residual else None
     with _on_device(grad_y), _timed(("frozen_bn_bwd[n=%d,nc=%d,e=%d,res=%d,relu=%d]", (grad_y.numel(), N * C, _ESIZE[grad_y.dtype], bool(need_residual), bool(relu))),
-                                     grad_y, every=16):
+                                     grad_y, every=8):
         check(lib.detops_frozen_bn_act_backward(ptr(grad_y), ptr(y) if relu else None, ptr(scale), ptr(gx), ptr(gres),
                                                 code, N, C, HW, int(bool(relu)), stream_of(grad_y)),
               "frozen_bn_act_backward")
