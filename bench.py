@@ -6,8 +6,12 @@
 A "step" is one training iteration (forward + backward + gradient all-reduce + SGD update) of
 `e2e_mask_rcnn_R_50_FPN_1x` (BASELINE.json's metric config) on one batch of 2 synthetic
 1333x800 COCO-shaped images per GPU (padded to 800x1344), random-init weights, batches resident in
-HBM before the timed region.  N > 1 is launched by the driver with torch.distributed.run, one rank
-per GPU over RCCL; per-GPU work is fixed (weak scaling), value = total images / max-over-ranks time.
+HBM before the timed region.  N > 1: one rank per GPU over RCCL, launched by the driver with torch.distributed.run —
+or by this script itself: `python bench.py --gpus N` without WORLD_SIZE in the environment re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (the reference's
+`python -m torch.distributed.launch --nproc_per_node=$NGPUS tools/train_net.py`, README.md:147-163) and refuses to print
+a line whose RCCL world size differs from --gpus.  Per-GPU work is fixed (weak scaling), value = total images /
+max-over-ranks time.
 
 Besides the contract line, rank 0 reports
   * "roofline": the dominant hand-written kernel of the step (largest total time among the HIP
@@ -58,6 +62,9 @@ def parse():
     ap.add_argument("--no-miopen-search", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--export-miopen-db", default=None, metavar="DIR",
                     help="write MIOpen's find-db + kernel cache of this run to DIR (see setup_miopen_db)")
+    ap.add_argument("--stub-step", action="store_true",
+                    help="test hook: CPU tensors, gloo, a stub step — exercises the launch / world-size / timed-region / "
+                         "JSON logic without a GPU; the line is marked as a stub, not a measurement")
     ap.add_argument("opts", nargs=argparse.REMAINDER, default=[])
     return ap.parse_args()
 
@@ -145,6 +152,7 @@ def rocprof_kernel_us(entry_name):
     import re
     key = {"roi_align_fpn_bwd": "roi_align_bwd_ring_kernel", "roi_align_fpn_fwd": "roi_align_fwd_dma_kernel",
            "focal_fwd_sum": "focal_kernel", "focal_bwd_scalar": "focal_kernel", "frozen_bn_fwd": "frozen_bn",
+           "nms_batched": "nms_fused_kernel",
            "frozen_bn_bwd": "frozen_bn", "dcn_col2im": "col2im", "dcn_im2col": "im2col_kernel",
            "dcn_col2im_coord": "col2im_coord", "dcn_fused_fwd": "dcn_fused_fwd", "dcn_to_nhwc": "nchw_to_nhwc",
            "dcn_im2col_nhwc": "im2col_nhwc_kernel", "dcn_coord_nhwc": "coord_nhwc_kernel",
@@ -338,8 +346,119 @@ def cpu_baseline_extras(ref, budget_s=6.0):
     return out
 
 
+HW_QUEUES_DEFAULT = "2"
+
+
+def pin_hip_queues():
+    """GPU_MAX_HW_QUEUES: HIP maps streams onto this many hardware queues.  The data-parallel step has exactly two busy
+    streams (compute, RCCL); measured at one rank through the full wrapper (profiles/r03n_data_parallel_overhead.txt):
+    8 / runtime default / 2 / 1 queues -> 70.6 / 41.5-42.8 / 41.0 / 40.0 ms per step.  2 keeps the all-reduce on its own
+    queue (overlap with backward) without the many-queue penalty; an explicit setting in the environment wins.  Read by
+    the HIP runtime at initialisation: must run before the first torch.cuda call."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", HW_QUEUES_DEFAULT)
+    return os.environ["GPU_MAX_HW_QUEUES"]
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch_command(argv, gpus, port=None):
+    """The command `bench.py --gpus N` re-executes itself as when nothing launched it as a rank (no WORLD_SIZE)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def check_world(gpus, world, backend_world=None):
+    """--gpus is a promise about the number of RCCL ranks: never print a line measured on a different world."""
+    if world != gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, "
+                         "or without WORLD_SIZE so that bench.py launches the ranks itself)" % (gpus, world, gpus))
+    if backend_world is not None and backend_world != gpus:
+        raise SystemExit("bench.py: --gpus %d but the process group has %d ranks" % (gpus, backend_world))
+
+
+def timed_steps(step, batches, steps, sync, distributed, device, before=None):
+    """The contract's timed region: barrier + device sync, EXACTLY `steps` steps, barrier + device sync; the clock is
+    the MAX over ranks.  Returns (elapsed seconds, this rank's host-enqueue seconds, the last step's result)."""
+    import torch
+    import torch.distributed as dist
+    sync()
+    if before is not None:
+        before()
+    host_pad = float(os.environ.get("BENCH_HOST_PAD_MS", "0")) / 1000.0   # diagnosis: is the host or the device the limiter?
+    out = None
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(*batches[i % len(batches)])
+        if host_pad:
+            time.sleep(host_pad)
+    host_elapsed = time.perf_counter() - t0      # everything enqueued; the device may still be running
+    sync()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, host_elapsed, out
+
+
+def stub_main(args):
+    """Test hook (`--stub-step`, tests/test_bench_launch.py): the launch / rendezvous / world check / timed region /
+    max-over-ranks / one-JSON-line logic of this script on CPU tensors over gloo with a stub step — no model, no HIP
+    library, NOT a measurement (the line says so).  What it proves: `bench.py --gpus N` really runs N ranks."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    check_world(args.gpus, world)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", init_method="env://")
+        check_world(args.gpus, world, dist.get_world_size())
+    device = torch.device("cpu")
+    w = torch.ones(64, 64)
+
+    def step(x):
+        y = (x @ w).sum().reshape(1)
+        if distributed:
+            dist.all_reduce(y)            # every rank contributes: the sum counts the ranks
+        return {"ranks_seen": y / (x @ w).sum()}
+
+    def sync():
+        if distributed:
+            dist.barrier()
+
+    batches = [(torch.full((8, 64), float(i + 1)),) for i in range(2)]
+    for i in range(args.warmup):
+        step(*batches[i % 2])
+    elapsed, host_elapsed, out = timed_steps(step, batches, args.steps, sync, distributed, device)
+    if rank == 0:
+        images = args.images_per_gpu * world * args.steps
+        print(json.dumps({"metric": "STUB (bench.py --stub-step: launch-logic test, not a measurement)",
+                          "value": round(images / elapsed, 3), "unit": "images/sec", "n_gpus": world,
+                          "rccl_ranks": dist.get_world_size() if distributed else 1, "backend": "gloo",
+                          "ranks_seen_by_allreduce": round(float(out["ranks_seen"]), 3),
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "scaling": "weak", "data": "stub", "stub": True}), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    hw_queues = pin_hip_queues()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        cmd = self_launch_command(sys.argv[1:], args.gpus)
+        print("[bench] launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.call(cmd))
+    if args.stub_step:
+        return stub_main(args)
     miopen_db = setup_miopen_db(args.export_miopen_db)
     import torch
     import torch.distributed as dist
@@ -347,15 +466,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    check_world(args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the detection-head operators are HIP-only)"
+    if torch.cuda.device_count() < max(1, world if int(os.environ.get("LOCAL_WORLD_SIZE", world)) == world else 1):
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", init_method="env://")
+        check_world(args.gpus, world, dist.get_world_size())
     elif args.force_ddp:
         dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % (29500 + os.getpid() % 400),
                                 rank=0, world_size=1)
@@ -425,26 +546,18 @@ def main():
             losses = step(*batches[i % len(batches)])
             torch.cuda.synchronize(device)
         progress("warm-up step %d done" % (i + 1))
-    sync()
-    timer = None
-    if rank == 0 and not args.no_kernel_timing:
-        timer = _C.KernelTimer()
+    # The kernel timers cost host time (two event records per timed launch).  They run on EVERY rank so that no rank is a
+    # taxed straggler under the max-over-ranks clock (rank 0's figures are the ones reported); sampled entry points are
+    # sampled densely enough for >= 10 event pairs per name over the timed steps.
+    timer = None if args.no_kernel_timing else _C.KernelTimer(every_cap=max(1, args.steps // 10))
+
+    def install_timer():
         _C.KERNEL_TIMER = timer
-    t0 = time.perf_counter()
-    host_pad = float(os.environ.get("BENCH_HOST_PAD_MS", "0")) / 1000.0   # diagnosis: is the host or the device the limiter?
-    for i in range(args.steps):
-        losses = step(*batches[i % len(batches)])
-        if host_pad:
-            time.sleep(host_pad)
-    host_elapsed = time.perf_counter() - t0      # everything enqueued; the device may still be running
-    sync()
-    elapsed = time.perf_counter() - t0
+
+    elapsed, host_elapsed, losses = timed_steps(step, batches, args.steps, sync, distributed, device,
+                                                before=install_timer)
     _C.KERNEL_TIMER = None
     progress("%d timed steps done" % args.steps)
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     loss_vals = {k: float(v) for k, v in losses.items()} if losses else {}
 
     if rank == 0:
@@ -454,6 +567,7 @@ def main():
             "value": round(images / elapsed, 3),
             "unit": "images/sec",
             "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if (distributed or args.force_ddp) else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -472,6 +586,8 @@ def main():
             "losses": {k: round(v, 4) for k, v in loss_vals.items()},
             "max_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
             "miopen": {"search": bool(torch.backends.cudnn.benchmark), "db": miopen_db},
+            "hip": {"GPU_MAX_HW_QUEUES": hw_queues},
+            "kernel_timers": ("all ranks" if distributed else "rank 0") if timer is not None else "off",
             "ddp": ddp_mode,
             # host time to ENQUEUE the timed steps (rank 0): close to ms_per_step = the host is the limiter
             "host_enqueue_ms_per_step": round(1000.0 * host_elapsed / args.steps, 3),
@@ -511,6 +627,24 @@ def main():
                                     "alg_bytes_per_launch": e["alg_bytes"], "mean_us": e["mean_us"],
                                     "family_ms_per_step": round(sum(m[0] for m in fam[name.split("[")[0]]), 4),
                                     "rocprof_us": rocprof_kernel_us(name)}
+            # the SURVEY §8(a) flagship entry points of the path BASELINE.json's metric names ("ROIAlign HBM GB/s", NMS,
+            # focal loss), whatever kernel family dominates the step: live HIP-event figure, the committed rocprofv3
+            # average of the same kernel and the committed PMC traffic beside it
+            path = []
+            for name, e in kernels.items():
+                fam_name = name.split("[")[0]
+                if fam_name in ("roi_align_fpn_fwd", "roi_align_fpn_bwd", "focal_fwd_sum", "focal_bwd_scalar"):
+                    traffic, source = measured_traffic(name)
+                    path.append({"kernel": name, "bound": "hbm", "mean_us": e["mean_us"], "timed": e["timed"],
+                                 "alg_bytes_per_launch": e["alg_bytes"], "achieved": e["achieved_GBs"], "unit": "GB/s",
+                                 "peak": HBM_PEAK_GBS, "frac": round(e["achieved_GBs"] / HBM_PEAK_GBS, 4),
+                                 "rocprof_us": rocprof_kernel_us(name), "traffic": traffic, "traffic_source": source})
+                elif fam_name == "nms_batched":
+                    # neither HBM nor MFMA bound (O(n^2) VALU + a serial chain): reported as us per launch
+                    path.append({"kernel": name, "bound": "valu+latency (no roofline claimed)", "mean_us": e["mean_us"],
+                                 "timed": e["timed"], "rocprof_us": rocprof_kernel_us(name)})
+            if path:
+                line["roofline_path"] = path
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()

@@ -56,14 +56,17 @@ class KernelTimer(object):
     High-frequency entry points (FrozenBN: ~100 launches per step) are SAMPLED — every `every`-th call of a name
     gets an event pair, all calls are counted — so that the timer's own host cost stays out of the step."""
 
-    def __init__(self):
+    def __init__(self, every_cap=None):
         self.pairs = {}
         self.calls = {}
+        self.every_cap = every_cap   # upper bound on the sampling stride (short runs: enough samples per name)
 
     def span(self, name, t, every=1):
         """`name`: a string or (format, args) — kept as the key and formatted in results() (no string work per launch)"""
         n = self.calls.get(name, 0)
         self.calls[name] = n + 1
+        if self.every_cap is not None and every > self.every_cap:
+            every = self.every_cap
         return _Span(self, name, t) if n % every == 0 else _NOSPAN
 
     def results(self):

@@ -1,0 +1,84 @@
+"""bench.py's launch logic without a GPU: `--gpus N` must produce N ranks by itself (the reference is started with
+`python -m torch.distributed.launch --nproc_per_node=$NGPUS tools/train_net.py`, README.md:147-163, process-group init at
+tools/train_net.py:158-166), must refuse a world size that differs from --gpus, and the timed region / max-over-ranks /
+one-JSON-line plumbing must work over a real 2-rank process group (gloo here; RCCL on the GPU node)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env.update(extra)
+    return env
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0: %r" % (stdout,)
+    return json.loads(lines[0])
+
+
+def test_gpus_2_launches_two_ranks_by_itself():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "1", "--stub-step"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    assert line["ranks_seen_by_allreduce"] == 2.0      # the collective really spanned two processes
+    assert line["steps"] == 4 and line["warmup"] == 1 and line["stub"] is True
+    assert "launching 2 ranks" in r.stderr
+
+
+def test_driver_style_launch_is_not_relaunched():
+    """Under torch.distributed.run (WORLD_SIZE set) bench.py is a rank: it must not spawn again."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.self_launch_command(["--gpus", "2", "--steps", "3", "--warmup", "0", "--stub-step"], 2)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and "127.0.0.1" in cmd
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _json_line(r.stdout)["rccl_ranks"] == 2
+    assert "launching" not in r.stderr
+
+
+def test_world_size_mismatch_fails_loudly():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--stub-step"], env=_env(WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--stub-step"],
+                       env=_env(WORLD_SIZE="2", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_hw_queue_pin_and_sampling_cap():
+    sys.path.insert(0, ROOT)
+    import bench
+    old = os.environ.pop("GPU_MAX_HW_QUEUES", None)
+    try:
+        assert bench.pin_hip_queues() == bench.HW_QUEUES_DEFAULT == os.environ["GPU_MAX_HW_QUEUES"]
+        os.environ["GPU_MAX_HW_QUEUES"] = "4"
+        assert bench.pin_hip_queues() == "4"      # an explicit setting wins
+    finally:
+        os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        if old is not None:
+            os.environ["GPU_MAX_HW_QUEUES"] = old
+    pytest.importorskip("torch")
+    sys.path.insert(0, os.path.join(ROOT, "maskrcnn-benchmark_amd"))
+    from maskrcnn_benchmark._C import KernelTimer, _NOSPAN
+    t = KernelTimer(every_cap=2)
+    import torch
+    x = torch.zeros(1)
+    # a name sampled every 8th call is sampled every 2nd under the cap: 20 calls -> 10 spans (>= 10 event pairs at
+    # the driver's --steps 20)
+    spans = [t.span("frozen_bn_fwd", x, every=8) for _ in range(20)]
+    assert sum(s is not _NOSPAN for s in spans) == 10
