@@ -78,12 +78,14 @@ int detops_roi_align_backward_f32(const float* grad_out, const float* rois, floa
                                   float spatial_scale, int sampling_ratio, int zero_grad_in,
                                   detops_stream_t stream);
 
-/* Forward with a caller-provided workspace (`detops_roi_align_forward_workspace_bytes(K)` bytes; 0 = not used for
- * this K): a pre-pass launch ranks the ROIs by (level, image, position) and the main launch visits them in that
- * order, so that overlapping footprints are fetched while they are still in the XCD's L2.  The output is identical,
- * bit for bit, to the workspace-free call (what detops_roi_align_forward_f32 / detops_roi_align_fpn_forward_f32
- * do); workspace == NULL or too small selects that path. */
-size_t detops_roi_align_forward_workspace_bytes(int K);
+/* Forward with a caller-provided workspace (`detops_roi_align_forward_workspace_bytes(K, PH, PW, sampling_ratio)`
+ * bytes; 0 = not used for this shape): ONE pre-pass launch (a) builds per-ROI sample records — footprint bounds and,
+ * per output bin, the patch offsets and bilinear weights of its samples by the reference arithmetic — which every
+ * channel-chunk workgroup of the main launch loads instead of re-deriving, and (b) for K >= 384 ranks the ROIs by
+ * (level, image, position) so that the main launch visits overlapping footprints while they are still in the XCD's
+ * L2.  The output is identical, bit for bit, to the workspace-free call (what detops_roi_align_forward_f32 /
+ * detops_roi_align_fpn_forward_f32 do); workspace == NULL or too small selects that path. */
+size_t detops_roi_align_forward_workspace_bytes(int K, int PH, int PW, int sampling_ratio);
 
 int detops_roi_align_forward_ws_f32(const float* input, const float* rois, float* output,
                                     int N, int C, int H, int W, int K, int PH, int PW,

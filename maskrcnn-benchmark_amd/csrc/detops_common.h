@@ -257,8 +257,9 @@ static inline int detops_resident_workgroups(K kernel, int block, size_t lds) {
 // ---- tuning / test switches (read once at library load from DETOPS_TUNING="key=value,...", or set through
 // detops_tuning_set(); never read from the environment on the launch path)
 struct DetopsTuning {
-  int roi_bwd_impl;        // 0 auto | 1 ring (needs a workspace) | 2 scan | 3 atomic scatter
+  int roi_bwd_impl;        // 0 auto | 1 ring (needs a workspace) | 2 scan | 3 atomic scatter | 4 acc (small single map, needs a workspace)
   int roi_bwd_seg;         // ring: hits per segment before a tile's hit list is split over workgroups (0 = default)
+  int roi_bwd_ct;          // ring: channels per unit of the 7x7 kernel, 16 | 32 (0 = default = 32)
   int roi_bwd_ring;        // ring: LDS slots (hits in flight) of the 7x7 kernel, 2 | 3 | 4 (0 = default)
   int roi_bwd_groups;      // scan: ROI-list split over blockIdx.y (0 = auto)
   int roi_bwd_scan_ct;     // scan: channels per workgroup, 4 | 16 (0 = auto)
@@ -267,6 +268,8 @@ struct DetopsTuning {
   int roi_fwd_impl;        // 0 auto | 1 generic gather kernel
   int roi_fwd_order;       // 0 auto | 1 never rank | 2 rank even for tiny maps
   int roi_fwd_order_mink;  // smallest K that gets the ranking pre-pass (0 = default)
+  int roi_fwd_records;     // 0 auto (per-ROI sample records from the pre-pass when a workspace is given, static staging offsets) | 1 off | 2 records only
+  int roi_fwd_ct;          // channels per workgroup of the fast forward (0 = default)
   int dcn_col2im;          // 0 auto | 1 gather | 2 scatter | 3 ell
   int dcn_fused;           // 0 auto | 1 force | 2 off
   int dcn_gather_xcd;      // 0 auto (XCD-contiguous block order) | 1 plain block order

@@ -105,6 +105,71 @@ __device__ __forceinline__ TileGeom tile_geom(const Levels& L, const RingPlan& P
   return g;
 }
 
+// One wave builds one ROI's compact adjoint rows (a lane per (axis, footprint pixel)): the pixel's row of the adjoint
+// matrix as {first contributing bin | other axis' longest range << 8 | count << 16, w[0], w[1], ...} (zero beyond),
+// candidate samples from the inverse of the sample-coordinate map, decided by the exact reference arithmetic.  Rows
+// are footprint-relative (row 0 = the ROI's first reachable pixel): y rows at slot[i * PPH], x rows at
+// slot[ax_off + i * PPW].  `slot` may be global memory (the ring's pre-pass) or LDS (the acc kernel).
+__device__ __forceinline__ void build_adjoint_rows(const float* __restrict__ roi, float scale, int H, int W, int PH, int PW,
+                                                   int sr, float* slot, size_t ax_off, int PPH, int PPW, int lane) {
+  const RoiGeom g = roi_geometry(roi, scale, PH, PW, sr);
+  const RoiExtent e = roi_extent(roi, scale, H, W);
+  const int ny = max(e.ny, 0), nx = max(e.nx, 0);
+  int cmax_y = 0, cmax_x = 0;   // longest bin range among this lane's rows, per axis
+  for (int p = lane; p < ny + nx; p += kWave) {
+    const bool isy = p < ny;
+    const int pi = isy ? p : p - ny;
+    const int pix = (isy ? e.fy0 : e.fx0) + pi;
+    const int PB = isy ? PH : PW, PP = isy ? PPH : PPW;
+    const int grid = isy ? g.gh : g.gw, size = isy ? H : W;
+    const float start = isy ? g.start_h : g.start_w, bin = isy ? g.bin_h : g.bin_w;
+    float* row = slot + (isy ? 0 : ax_off) + static_cast<size_t>(pi) * PP;
+    const float inv = 1.f / static_cast<float>(grid);
+    for (int q = 0; q < PP; ++q) row[q] = 0.f;
+    // only samples whose coordinate lies within one pixel of `pix` can have a tap on it (border pixels also
+    // collect the clamped samples: c in [-1, 0] -> pixel 0, c in [size-1, size] -> pixel size-1).  Candidate
+    // sample range from the inverse of c(s) = start + (s + .5) * bin / grid, widened by one sample on each
+    // side; the exact reference arithmetic then decides.
+    const float step = bin * inv;
+    const float clo = (pix == 0) ? -1.f : static_cast<float>(pix - 1);
+    const float chi = (pix == size - 1) ? static_cast<float>(size) : static_cast<float>(pix + 1);
+    const int ns = PB * grid;
+    int s0 = static_cast<int>(fminf(fmaxf(floorf((clo - start) / step - 0.5f) - 1.f, 0.f), static_cast<float>(ns)));
+    int s1 = static_cast<int>(fminf(fmaxf(ceilf((chi - start) / step - 0.5f) + 1.f, -1.f), static_cast<float>(ns - 1)));
+    if (!(step > 0.f)) { s0 = 0; s1 = ns - 1; }   // degenerate geometry (NaN / inf): look at everything
+    int lo = -1, hi = -1;
+    int q = s0 / grid, i = s0 - q * grid;
+    float w = 0.f;
+    for (int sidx = s0; sidx <= s1; ++sidx) {   // per bin: samples in ascending order, like the scan kernel
+      const Tap tp = axis_entry(start, bin, q, i, grid, size, 1);
+      if (tp.lo == pix) w += tp.h * inv;
+      if (tp.hi == pix) w += tp.l * inv;
+      if (++i == grid || sidx == s1) {
+        if (w != 0.f) {
+          if (lo < 0) lo = q;
+          hi = q;
+          row[1 + q - lo] = w;
+        }
+        w = 0.f; i = 0; ++q;
+      }
+    }
+    row[0] = __int_as_float((lo >= 0) ? (lo | ((hi - lo + 1) << 16)) : 0);
+    if (lo >= 0) { if (isy) cmax_y = max(cmax_y, hi - lo + 1); else cmax_x = max(cmax_x, hi - lo + 1); }
+  }
+  // bits 8..15 of every row head: the ROI's longest bin range on the OTHER axis — the ring walk learns both of its
+  // trip counts from the two AY heads of a wave's rows (two readlanes) instead of wave-wide ballots over the pixels
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    cmax_y = max(cmax_y, __shfl(cmax_y, lane ^ off));
+    cmax_x = max(cmax_x, __shfl(cmax_x, lane ^ off));
+  }
+  for (int p = lane; p < ny + nx; p += kWave) {
+    const bool isy = p < ny;
+    float* row = slot + (isy ? static_cast<size_t>(p) * PPH : ax_off + static_cast<size_t>(p - ny) * PPW);
+    row[0] = __int_as_float(__float_as_int(row[0]) | ((isy ? cmax_x : cmax_y) << 8));
+  }
+}
+
 constexpr int kPrepTiles = 4;      // tiles per role-B workgroup (1 per wave)
 constexpr int kPrepRois = 1024;    // ROI footprints parked in LDS per pass
 
@@ -140,63 +205,8 @@ roi_bwd_prep_kernel(Levels L, RingPlan P, RingWs ws, const float* __restrict__ r
     for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
       if (i == lvl) { H = L.lv[i].H; W = L.lv[i].W; scale = L.lv[i].scale; }
     if (lvl < 0 || lvl >= L.num) return;
-    const RoiGeom g = roi_geometry(roi, scale, PH, PW, sr);
-    const RoiExtent e = roi_extent(roi, scale, H, W);
     float* slot = ws.tabs + static_cast<size_t>(r) * (static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(P.Wmax) * P.PPW);
-    const int ny = max(e.ny, 0), nx = max(e.nx, 0);
-    int cmax_y = 0, cmax_x = 0;   // longest bin range among this lane's rows, per axis
-    for (int p = lane; p < ny + nx; p += kWave) {
-      const bool isy = p < ny;
-      const int pi = isy ? p : p - ny;
-      const int pix = (isy ? e.fy0 : e.fx0) + pi;
-      const int PB = isy ? PH : PW, PP = isy ? P.PPH : P.PPW;
-      const int grid = isy ? g.gh : g.gw, size = isy ? H : W;
-      const float start = isy ? g.start_h : g.start_w, bin = isy ? g.bin_h : g.bin_w;
-      float* row = slot + (isy ? 0 : static_cast<size_t>(P.Hmax) * P.PPH) + static_cast<size_t>(pi) * PP;
-      const float inv = 1.f / static_cast<float>(grid);
-      for (int q = 0; q < PP; ++q) row[q] = 0.f;
-      // only samples whose coordinate lies within one pixel of `pix` can have a tap on it (border pixels also
-      // collect the clamped samples: c in [-1, 0] -> pixel 0, c in [size-1, size] -> pixel size-1).  Candidate
-      // sample range from the inverse of c(s) = start + (s + .5) * bin / grid, widened by one sample on each
-      // side; the exact reference arithmetic then decides.
-      const float step = bin * inv;
-      const float clo = (pix == 0) ? -1.f : static_cast<float>(pix - 1);
-      const float chi = (pix == size - 1) ? static_cast<float>(size) : static_cast<float>(pix + 1);
-      const int ns = PB * grid;
-      int s0 = static_cast<int>(fminf(fmaxf(floorf((clo - start) / step - 0.5f) - 1.f, 0.f), static_cast<float>(ns)));
-      int s1 = static_cast<int>(fminf(fmaxf(ceilf((chi - start) / step - 0.5f) + 1.f, -1.f), static_cast<float>(ns - 1)));
-      if (!(step > 0.f)) { s0 = 0; s1 = ns - 1; }   // degenerate geometry (NaN / inf): look at everything
-      int lo = -1, hi = -1;
-      int q = s0 / grid, i = s0 - q * grid;
-      float w = 0.f;
-      for (int sidx = s0; sidx <= s1; ++sidx) {   // per bin: samples in ascending order, like the scan kernel
-        const Tap tp = axis_entry(start, bin, q, i, grid, size, 1);
-        if (tp.lo == pix) w += tp.h * inv;
-        if (tp.hi == pix) w += tp.l * inv;
-        if (++i == grid || sidx == s1) {
-          if (w != 0.f) {
-            if (lo < 0) lo = q;
-            hi = q;
-            row[1 + q - lo] = w;
-          }
-          w = 0.f; i = 0; ++q;
-        }
-      }
-      row[0] = __int_as_float((lo >= 0) ? (lo | ((hi - lo + 1) << 16)) : 0);
-      if (lo >= 0) { if (isy) cmax_y = max(cmax_y, hi - lo + 1); else cmax_x = max(cmax_x, hi - lo + 1); }
-    }
-    // bits 8..15 of every row head: the ROI's longest bin range on the OTHER axis — the walk learns both of its trip
-    // counts from the two AY heads of a wave's rows (two readlanes) instead of wave-wide ballots over the pixels
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      cmax_y = max(cmax_y, __shfl(cmax_y, lane ^ off));
-      cmax_x = max(cmax_x, __shfl(cmax_x, lane ^ off));
-    }
-    for (int p = lane; p < ny + nx; p += kWave) {
-      const bool isy = p < ny;
-      float* row = slot + (isy ? static_cast<size_t>(p) * P.PPH : static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(p - ny) * P.PPW);
-      row[0] = __int_as_float(__float_as_int(row[0]) | ((isy ? cmax_x : cmax_y) << 8));
-    }
+    build_adjoint_rows(roi, scale, H, W, PH, PW, sr, slot, static_cast<size_t>(P.Hmax) * P.PPH, P.PPH, P.PPW, lane);
     return;
   }
   // ---- role B: hit lists.  Per pass of <= 1024 ROIs: (1) all threads park the ROIs' footprints {roi | level |
@@ -335,6 +345,9 @@ struct RingGeom {
   }
 };
 
+// gradient piece p of a staged ROI -> its LDS piece index when every wave's share (GPW pieces) is padded to GPWp
+__host__ __device__ constexpr int wave_region(int p, int GPW, int GPWp) { return (p / GPW) * GPWp + (p % GPW); }
+
 typedef float f2v __attribute__((ext_vector_type(2)));   // packed fp32 pairs: v_pk_fma_f32 (one instruction, two FMAs per lane)
 __device__ __forceinline__ f2v pk_fma(float w, float a, float b, f2v acc) {
   return __builtin_elementwise_fma(f2v{w, w}, f2v{a, b}, acc);
@@ -358,7 +371,7 @@ __device__ __forceinline__ f2v pk_fma(float w, float a, float b, f2v acc) {
 //          stores, counted wait, barrier, relaxed agent-scope ticket); the unit that draws the last ticket re-reads
 //          ALL segments' partials in segment order and stores the tile — same sum order every run.
 template <int PH, int PW, int CT, int NR>
-__global__ void __launch_bounds__(kBlock, (CT <= 16 ? 6 : 3))
+__global__ void __launch_bounds__(kBlock, (CT <= 16 ? 6 : 4))
 roi_align_bwd_ring_kernel(Levels L, RingPlan P, RingWs ws, const float* __restrict__ gout, int C) {
   using G = RingGeom<PH, PW, CT>;
   static_assert(NR >= 2 && NR <= 4 && CT % 4 == 0, "");
@@ -886,6 +899,332 @@ roi_align_bwd_scan_kernel(Levels L, GPlan P, const float* __restrict__ rois,
   }
 }
 // ------------------------------------------------------------------------------------------
+// acc backward (small maps with a workspace — BASELINE configs[0]: 512 ROIs on ONE 14 x 14 map).  The ring kernel's
+// pixel-owner tiles leave such a launch with two tiles; the scan kernel splits the ROI list and pays with data atomics
+// (119 us, 4.6x its own forward).  Here the gradient map of one image x a CT-channel chunk LIVES IN LDS (14 x 14 x 16
+// floats = 12.5 KB): a workgroup walks its share of the ROI list in index order and adds every ROI's footprint into
+// the LDS map — lanes enumerate the ROI's OWN pixels (no idle lanes over a fixed tile), the adds are LDS adds to
+// addresses no other lane touches in the same pass, passes are separated by barriers: no global atomics, the same
+// sum order every run.  Per round of <= 8 ROIs: four waves build the ROIs' compact adjoint rows straight into LDS
+// (build_adjoint_rows: no pre-pass launch) while the first pooled-gradient blocks are already in flight; per ROI
+// (one LDS-only barrier each):
+//   staging  pooled gradients [c][bin] by LDS-DMA into a ring of slots, ahead of the walk, completion counted with
+//            s_waitcnt vmcnt(N);
+//   pass 1   task = (footprint row, channel, bin-row piece): T[row][bin column][channel] = sum_a AY[row][a] g[c][a][.];
+//   pass 2   task = (footprint row, footprint column, 4-channel group): sum_b AX[col][b] T[row][b][cg] -> ds_add into
+//            the LDS map at the pixel.
+// The ROI list is split over `groups` workgroups per (image, chunk); each stores its LDS map as a partial and a second
+// launch (roi_align_bwd_acc_combine_kernel) adds the partials in GROUP ORDER into the gradient map: no counters to
+// clear, no tickets, two launches in all (the ticket form's last arriver summed 32 partials with one memory round
+// trip per partial: 33 us of an 87 us call).
+// ------------------------------------------------------------------------------------------
+constexpr int kAccMaxDim = 32;      // map height / width served
+constexpr int kAccRound = 8;        // candidate ROIs per round (= adjoint-row slots in LDS)
+
+struct AccPlan {
+  int H, W, HWp;                    // HWp: H * W rounded up to 4
+  int chunks, groups, accumulate;
+  int debug;                        // ablation bits (tuning roi_bwd_debug): 1 skip the passes, 2 skip the staging
+};
+
+template <int PH, int PW, int CT>
+struct AccGeom {
+  using G = RingGeom<PH, PW, CT>;
+  static constexpr int GPWp = ((G::GPW + 63) / 64) * 64;    // per-wave gradient region padded to whole instructions
+  static constexpr int SLOTF = 4 * GPWp * 4;                // floats per ring slot
+  __host__ __device__ static constexpr int rows_floats(int H, int W) { return H * G::PPH + W * G::PPW; }
+  __host__ __device__ static constexpr size_t lds_bytes(int nring, int H, int W, int HWp) {
+    return sizeof(float) * (static_cast<size_t>(nring) * SLOTF + 2 * static_cast<size_t>(H) * G::PWP * G::TS +
+                            static_cast<size_t>(CT) * HWp + static_cast<size_t>(kAccRound) * rows_floats(H, W)) +
+           sizeof(int4) * (kAccRound + 1);
+  }
+};
+
+template <int PH, int PW, int CT, int NR>
+__global__ void __launch_bounds__(kBlock)
+roi_align_bwd_acc_kernel(AccPlan P, const float* __restrict__ rois, const float* __restrict__ gout,
+                         float* __restrict__ gin, float* __restrict__ partials, float scale, int C, int K, int sr) {
+  using G = RingGeom<PH, PW, CT>;
+  using A = AccGeom<PH, PW, CT>;
+  static_assert(NR >= 3 && NR <= 4 && CT % 4 == 0, "");
+  constexpr int CG = CT / 4;
+  constexpr int ROWT = CT * G::NP;                                   // pass-1 tasks per footprint row
+  constexpr int SLOTF = A::SLOTF;
+  DETOPS_DYNAMIC_LDS(float, lds);
+  const int ROWF = A::rows_floats(P.H, P.W);
+  float* ring = lds;                                                 // [NR][SLOTF]
+  float* tbuf = ring + NR * SLOTF;                                   // [2][H][PWP][TS]
+  float* acc = tbuf + 2 * P.H * G::PWP * G::TS;                      // [CT][HWp]
+  float* rtab = acc + CT * P.HWp;                                    // [kAccRound][H * PPH + W * PPW] compact adjoint rows
+  int4* s_ent = reinterpret_cast<int4*>(rtab + kAccRound * ROWF);    // [kAccRound] {roi, fy0 | ny << 16, fx0 | nx << 16, candidate}
+  int* s_cnt = reinterpret_cast<int*>(s_ent + kAccRound);
+
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+  const int chunk = static_cast<int>(blockIdx.x);
+  const int b = static_cast<int>(blockIdx.y) / P.groups, grp = static_cast<int>(blockIdx.y) % P.groups;
+  const int c0 = chunk * CT;
+
+  // ---- this lane's gradient pieces of a staged ROI (fixed for the launch)
+  bool gact[G::NIG];
+  unsigned goff_u[G::NIG];
+#pragma unroll
+  for (int i = 0; i < G::NIG; ++i) {
+    const int pw_ = 64 * i + lane;
+    gact[i] = pw_ < G::GPW;
+    const int p = wave * G::GPW + min(pw_, G::GPW - 1);
+    const int c = p / (PH * G::NP), rem = p - c * (PH * G::NP);
+    const int r = rem / G::NP, q = rem - r * G::NP;
+    goff_u[i] = static_cast<unsigned>(min(c, C - 1 - c0) * (G::BINS * 4)) + static_cast<unsigned>((r * PW + G::off(q)) * 4);
+  }
+  for (int e = tid; e < CT * P.HWp; e += kBlock) acc[e] = 0.f;
+
+  auto issue = [&](int j, int slot) {
+    if (P.debug & 2) return;
+    const unsigned r = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(s_ent[j].x));
+    const float* gb = gout + (static_cast<size_t>(r) * C + c0) * G::BINS;
+    float* dst = ring + slot * SLOTF;
+#pragma unroll
+    for (int i = 0; i < G::NIG; ++i)
+      glds16_async_so(gact[i], gb, goff_u[i], dst + (wave * A::GPWp + 64 * i) * 4);
+  };
+  constexpr int NI = G::NIG;                                         // LDS-DMA instructions per ROI and wave
+
+  const int r_begin = static_cast<int>(static_cast<int64_t>(K) * grp / P.groups);
+  const int r_end = static_cast<int>(static_cast<int64_t>(K) * (grp + 1) / P.groups);
+  int tpar = 0;                                                      // T buffer parity, continued across rounds
+  for (int r0 = r_begin; r0 < r_end; r0 += kAccRound) {
+    // ---- the round's ROIs that belong to this image and reach the map, in index order (wave 0: ballot compaction)
+    __syncthreads();                                                 // the previous round's walks are over (s_ent, rtab, ring, T)
+    if (tid < kWave) {
+      const int r = r0 + tid;
+      bool ok = false;
+      int4 ent = make_int4(0, 0, 0, 0);
+      if (tid < kAccRound && r < r_end) {
+        const RoiExtent e = roi_extent(rois + static_cast<size_t>(r) * 5, scale, P.H, P.W);
+        ok = e.b == b && e.ny > 0 && e.nx > 0;
+        ent = make_int4(r, e.fy0 | (e.ny << 16), e.fx0 | (e.nx << 16), 0);
+      }
+      const unsigned long long m = __ballot(ok);
+      if (ok) s_ent[__popcll(m & ((1ull << lane) - 1ull))] = ent;
+      if (lane == 0) s_cnt[0] = __popcll(m);
+    }
+    __syncthreads();
+    const int nr = __builtin_amdgcn_readfirstlane(s_cnt[0]);
+    if (nr == 0) continue;
+    if (tid == 0) { DETOPS_STAT("bwda.rounds", 1); DETOPS_STAT("bwda.rois", nr); }
+#pragma unroll
+    for (int j = 0; j < NR - 1; ++j)
+      if (j < nr) issue(j, j);
+    // ---- the round's adjoint rows while the first gradient blocks are in flight.  DENSE rows {head, w[bin 0 .. PB-1]},
+    //      built SAMPLE-major: a lane per (ROI, axis, bin) runs the bin's samples in order through the reference tap
+    //      arithmetic and adds each tap's weight into the (pixel, bin) cell — a cell is only ever touched by its bin's
+    //      lane, so the sums are ordered and race-free; then a lane per (ROI, pixel) finds the row's non-zero range.
+    //      (The pixel-major search of the ring's pre-pass — build_adjoint_rows — cost 4 us per ROI and wave here.)
+    if (!(P.debug & 32)) {
+      for (int e = tid; e < nr * ROWF; e += kBlock) rtab[e] = 0.f;
+      DETOPS_LDS_BARRIER();
+      for (int t = tid; t < nr * (PH + PW); t += kBlock) {
+        const int i = t / (PH + PW), qa = t - i * (PH + PW);
+        const bool isy = qa < PH;
+        const int q = isy ? qa : qa - PH;
+        const int4 en = s_ent[i];
+        const RoiGeom g = roi_geometry(rois + static_cast<size_t>(en.x) * 5, scale, PH, PW, sr);
+        const int f0 = (isy ? en.y : en.z) & 0xffff, n = (isy ? en.y : en.z) >> 16;
+        const int grid = isy ? g.gh : g.gw, size = isy ? P.H : P.W, PP = isy ? G::PPH : G::PPW;
+        const float start = isy ? g.start_h : g.start_w, bin = isy ? g.bin_h : g.bin_w;
+        const float inv = 1.f / static_cast<float>(grid);
+        float* rows = rtab + i * ROWF + (isy ? 0 : P.H * G::PPH) + 1 + q;
+        for (int sidx = 0; sidx < grid; ++sidx) {
+          const Tap tp = axis_entry(start, bin, q, sidx, grid, size, 1);
+          const int a0 = tp.lo - f0, a1 = tp.hi - f0;
+          if (tp.h != 0.f && static_cast<unsigned>(a0) < static_cast<unsigned>(n)) rows[a0 * PP] += tp.h * inv;
+          if (tp.l != 0.f && static_cast<unsigned>(a1) < static_cast<unsigned>(n)) rows[a1 * PP] += tp.l * inv;
+        }
+      }
+      DETOPS_LDS_BARRIER();
+      for (int t = tid; t < nr * 2 * kAccMaxDim; t += kBlock) {
+        const int i = t / (2 * kAccMaxDim), p = t - i * (2 * kAccMaxDim);
+        const int4 en = s_ent[i];
+        const int ny = en.y >> 16, nx = en.z >> 16;
+        if (p < ny + nx) {
+          const bool isy = p < ny;
+          float* row = rtab + i * ROWF + (isy ? p * G::PPH : P.H * G::PPH + (p - ny) * G::PPW);
+          const int PB = isy ? PH : PW;
+          int lo = -1, hi = -1;
+          for (int q = 0; q < PB; ++q)
+            if (row[1 + q] != 0.f) { if (lo < 0) lo = q; hi = q; }
+          row[0] = __int_as_float((lo >= 0) ? (lo | ((hi - lo + 1) << 16)) : 0);
+        }
+      }
+    }
+    {
+      const int later = min(NR - 2, nr - 1);                         // ROIs issued after ROI 0
+      if (later >= 2) DETOPS_VMCNT_WAIT(2 * NI); else if (later == 1) DETOPS_VMCNT_WAIT(NI); else DETOPS_VMCNT_WAIT(0);
+    }
+    DETOPS_LDS_BARRIER();                                            // ROI 0 has landed everywhere, every row table is written
+    int slot = 0, islot = NR - 1;
+    for (int j = 0; j < nr; ++j) {
+      const float* sb = ring + slot * SLOTF;
+      const int4 en = s_ent[j];
+      const int yp = __builtin_amdgcn_readfirstlane(en.y), xp = __builtin_amdgcn_readfirstlane(en.z);
+      const int fy0 = yp & 0xffff, ny = yp >> 16, fx0 = xp & 0xffff, nx = xp >> 16;
+      float* T = tbuf + tpar * (P.H * G::PWP * G::TS);
+      // ---- pass 1: T[row][bin column][channel]
+      const float* ayr = rtab + j * ROWF;
+      for (int tb = 0; tb < ((P.debug & 1) ? 0 : ny * ROWT); tb += kBlock) {   // wave-uniform trips (the ballots below)
+        const bool act = tb + tid < ny * ROWT;
+        const int t = min(tb + tid, ny * ROWT - 1);
+        const int iy = t / ROWT, l5 = t - iy * ROWT;
+        const int q = l5 % G::NP, cl = l5 / G::NP;
+        const float* ay = ayr + iy * G::PPH;
+        const float4 hy = *reinterpret_cast<const float4*>(ay);
+        const int hb = __float_as_int(hy.x);
+        const int ylo = hb & 0xff, na = hb >> 16;
+        // every load of the task is independent of the others (weights beyond the row's range are stored as zeros,
+        // bin rows are clamped into the staged block): all issued back to back, ONE LDS round trip per task — small
+        // maps mean ROIs smaller than their bin grid, i.e. long ranges (a dependent loop cost ~130 cycles per step)
+        f2v t0 = f2v{0.f, 0.f}, t1 = f2v{0.f, 0.f};
+        const int pbase = cl * PH * G::NP + q;
+        if (__ballot(act && na > 3) == 0ull) {
+          float4 g4[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+            g4[a] = *reinterpret_cast<const float4*>(sb + wave_region(pbase + min(ylo + a, PH - 1) * G::NP, G::GPW, A::GPWp) * 4);
+          float wv[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) wv[a] = ay[1 + min(ylo + a, PH - 1)];   // dense row; zero beyond the range
+#pragma unroll
+          for (int a = 0; a < 3; ++a) { t0 = pk_fma((a < na) ? wv[a] : 0.f, g4[a].x, g4[a].y, t0); t1 = pk_fma((a < na) ? wv[a] : 0.f, g4[a].z, g4[a].w, t1); }
+        } else {
+          constexpr int NW = (PH + 3) / 4;                             // float4 reads covering the row's PH weights
+          float wv[4 * NW + 4];
+#pragma unroll
+          for (int k4 = 0; k4 <= NW; ++k4) {
+            if (k4 * 4 < G::PPH) {
+              const float4 w4 = *reinterpret_cast<const float4*>(ay + 4 * k4);
+              wv[4 * k4] = w4.x; wv[4 * k4 + 1] = w4.y; wv[4 * k4 + 2] = w4.z; wv[4 * k4 + 3] = w4.w;
+            }
+          }
+          float4 g4[PH];                                               // dense row: bin a's weight is wv[1 + a], zero outside the range
+#pragma unroll
+          for (int a = 0; a < PH; ++a)
+            g4[a] = *reinterpret_cast<const float4*>(sb + wave_region(pbase + a * G::NP, G::GPW, A::GPWp) * 4);
+#pragma unroll
+          for (int a = 0; a < PH; ++a) { t0 = pk_fma(wv[1 + a], g4[a].x, g4[a].y, t0); t1 = pk_fma(wv[1 + a], g4[a].z, g4[a].w, t1); }
+        }
+        float* td = T + (iy * G::PWP + min(4 * q, PW - 4)) * G::TS + cl;
+        if (act) { td[0] = t0.x; td[G::TS] = t0.y; td[2 * G::TS] = t1.x; td[3 * G::TS] = t1.y; }
+      }
+      // ---- ROI j + 1 has landed (this wave's pieces), T of ROI j is complete, pass 2 of ROI j - 1 is over everywhere
+      {
+        const int later = min(NR - 3, nr - 2 - j);                   // ROIs issued after ROI j + 1 so far
+        if (later >= 1) DETOPS_VMCNT_WAIT(NI); else DETOPS_VMCNT_WAIT(0);
+      }
+      DETOPS_LDS_BARRIER();
+      if (j + NR - 1 < nr) issue(j + NR - 1, islot);                 // into the slot ROI j - 1 has just released
+      // ---- pass 2: the ROI's own pixels
+      const float* axr = ayr + P.H * G::PPH;
+      const float inv_nx = 1.f / static_cast<float>(nx);
+      for (int tb = 0; tb < ((P.debug & (1 | 8)) ? 0 : ny * nx * CG); tb += kBlock) {
+        const bool act = tb + tid < ny * nx * CG;
+        const int t = min(tb + tid, ny * nx * CG - 1);
+        const int rowcg = static_cast<int>((static_cast<float>(t) + 0.5f) * inv_nx);
+        const int xi = t - rowcg * nx;
+        const int iy = rowcg / CG, cg = rowcg - iy * CG;
+        const float* ax = axr + xi * G::PPW;
+        const float4 hx = *reinterpret_cast<const float4*>(ax);
+        const int hb = __float_as_int(hx.x);
+        const int xlo = hb & 0xff, nb = hb >> 16;
+        const float* tr = T + iy * G::PWP * G::TS + 4 * cg;
+        f2v v0 = f2v{0.f, 0.f}, v1 = f2v{0.f, 0.f};
+        if (__ballot(act && nb > 3) == 0ull) {
+          float4 t4[3];
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) t4[b2] = *reinterpret_cast<const float4*>(tr + min(xlo + b2, PW - 1) * G::TS);
+          float wv[3];
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) wv[b2] = ax[1 + min(xlo + b2, PW - 1)];
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) { v0 = pk_fma((b2 < nb) ? wv[b2] : 0.f, t4[b2].x, t4[b2].y, v0); v1 = pk_fma((b2 < nb) ? wv[b2] : 0.f, t4[b2].z, t4[b2].w, v1); }
+        } else {
+          constexpr int NW = (PW + 3) / 4;
+          float wv[4 * NW + 4];
+#pragma unroll
+          for (int k4 = 0; k4 <= NW; ++k4) {
+            if (k4 * 4 < G::PPW) {
+              const float4 w4 = *reinterpret_cast<const float4*>(ax + 4 * k4);
+              wv[4 * k4] = w4.x; wv[4 * k4 + 1] = w4.y; wv[4 * k4 + 2] = w4.z; wv[4 * k4 + 3] = w4.w;
+            }
+          }
+          float4 t4[PW];
+#pragma unroll
+          for (int b2 = 0; b2 < PW; ++b2) t4[b2] = *reinterpret_cast<const float4*>(tr + b2 * G::TS);
+#pragma unroll
+          for (int b2 = 0; b2 < PW; ++b2) { v0 = pk_fma(wv[1 + b2], t4[b2].x, t4[b2].y, v0); v1 = pk_fma(wv[1 + b2], t4[b2].z, t4[b2].w, v1); }
+        }
+        float* ap = acc + (4 * cg) * P.HWp + (fy0 + iy) * P.W + (fx0 + xi);
+        // plain read-add-write: no other lane touches these four cells in this pass, passes are barrier-separated
+        // (ds_add_f32 cost 18 us of a 63 us call: ~670 cycles per wave-wide LDS float atomic)
+        if (act && nb > 0 && !(P.debug & 16)) {
+          const float a0 = ap[0], a1 = ap[P.HWp], a2 = ap[2 * P.HWp], a3 = ap[3 * P.HWp];
+          ap[0] = a0 + v0.x; ap[P.HWp] = a1 + v0.y; ap[2 * P.HWp] = a2 + v1.x; ap[3 * P.HWp] = a3 + v1.y;
+        }
+      }
+      tpar ^= 1;
+      slot = (slot + 1 == NR) ? 0 : slot + 1;
+      islot = (islot + 1 == NR) ? 0 : islot + 1;
+    }
+  }
+  __syncthreads();                                                   // every pass-2 add has landed in the LDS map
+
+  // ---- epilogue: the gradient map itself (one group) or this group's partial map
+  if (tid == 0) DETOPS_STAT("bwda.units", 1);
+  const int HW = P.H * P.W;
+  if (P.groups > 1) {
+    float* mine = partials + ((static_cast<size_t>(b) * P.chunks + chunk) * P.groups + grp) * (static_cast<size_t>(CT) * P.HWp);
+    for (int e = tid * 4; e < CT * P.HWp; e += kBlock * 4)
+      *reinterpret_cast<float4*>(mine + e) = *reinterpret_cast<const float4*>(acc + e);
+    return;
+  }
+  float* gb = gin + (static_cast<size_t>(b) * C + c0) * HW;
+  const int cn = min(CT, C - c0);
+  for (int e = tid; e < cn * HW; e += kBlock) {
+    const int c = e / HW, pix = e - c * HW;
+    float v = acc[c * P.HWp + pix];
+    if (P.accumulate) v += gb[e];
+    gb[e] = v;
+  }
+}
+
+// grad_in[b, c, pix] (+)= sum over groups, in group order, of the groups' partial maps.  One thread per element, the
+// loads of a thread independent of each other (16 in flight per trip).
+template <int CT>
+__global__ void __launch_bounds__(kBlock)
+roi_align_bwd_acc_combine_kernel(AccPlan P, const float* __restrict__ partials, float* __restrict__ gin, int N, int C) {
+  const int HW = P.H * P.W;
+  const int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (idx >= static_cast<int64_t>(N) * C * HW) return;
+  const int pix = static_cast<int>(idx % HW);
+  const int c = static_cast<int>((idx / HW) % C), b = static_cast<int>(idx / (static_cast<int64_t>(HW) * C));
+  const int chunk = c / CT, cl = c - chunk * CT;
+  const size_t unit = static_cast<size_t>(CT) * P.HWp;
+  const float* p = partials + (static_cast<size_t>(b) * P.chunks + chunk) * P.groups * unit + static_cast<size_t>(cl) * P.HWp + pix;
+  float sum = P.accumulate ? gin[idx] : 0.f;
+  int g2 = 0;
+  for (; g2 + 16 <= P.groups; g2 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[static_cast<size_t>(g2 + u) * unit];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) sum += v[u];
+  }
+  for (; g2 < P.groups; ++g2) sum += p[static_cast<size_t>(g2) * unit];
+  gin[idx] = sum;
+  if (idx == 0) DETOPS_STAT("bwda.combines", 1);
+}
+
+// ------------------------------------------------------------------------------------------
 // atomic backward (universal fallback: any bin count, any map).  One thread per pooled-gradient element, the
 // reference's sample loop (ROIAlign_cuda.cu:224-252) over the axis taps, hardware fp32 atomics into the map
 // (zero-filled by the caller of this kernel unless accumulating).
@@ -926,8 +1265,16 @@ roi_align_bwd_atomic_kernel(Levels L, const float* __restrict__ rois, const int3
 // ------------------------------------------------------------------------------------------
 // host: plans, launches, dispatch
 // ------------------------------------------------------------------------------------------
-constexpr int kRingCT = 16;      // channels per unit
+constexpr int kRingCT = 16;      // channels per unit (tuning roi_bwd_ct = 32: twice the channels per unit, half the units)
 constexpr int kRingSlots = 3;    // LDS ring depth (hits in flight per workgroup)
+
+inline int ring_ct(int PH) {
+  // 7x7 bins: 32-channel units (half the units, half the per-hit scalar work: box head 93.9 -> 82.8 us on the log-uniform
+  // ROI set, 107 -> 105 us on the model's; tuning roi_bwd_ct = 16 restores the 16-channel units).  14x14 bins: two
+  // 32-channel slots would leave one workgroup per CU.
+  const int t = detops_tuning().roi_bwd_ct;
+  return (PH == 7 && t != 16) ? 32 : kRingCT;
+}
 
 inline bool ring_shape(int PH, int PW) { return (PH == 7 && PW == 7) || (PH == 14 && PW == 14); }
 
@@ -939,7 +1286,8 @@ bool ring_plan(const Levels& L, int N, int C, int K, int PH, int PW, RingPlan& P
   P.PPH = (PH + 4) & ~3;
   P.PPW = (PW + 4) & ~3;
   P.cap = K;
-  P.chunks = static_cast<int>(ceil_div64(C, kRingCT));
+  const int CT = ring_ct(PH);
+  P.chunks = static_cast<int>(ceil_div64(C, CT));
   int64_t tiles = 0;
   for (int i = L.num - 1; i >= 0; --i) {  // coarsest level first (its tiles see the most ROIs)
     if (L.lv[i].W > 32767 || L.lv[i].H > 32767) return false;
@@ -971,7 +1319,7 @@ bool ring_plan(const Levels& L, int N, int C, int K, int PH, int PW, RingPlan& P
   lay.off_lists = o;    o = up(o + sizeof(int4) * static_cast<size_t>(P.num_tiles) * P.cap);
   lay.off_tabs = o;     o = up(o + sizeof(float) * static_cast<size_t>(K) *
                                    (static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(P.Wmax) * P.PPW) + 16);   // + the zero piece
-  lay.off_partials = o; o = up(o + sizeof(float) * static_cast<size_t>(P.slot_cap) * P.chunks * (kGTH * kGTW) * kRingCT);
+  lay.off_partials = o; o = up(o + sizeof(float) * static_cast<size_t>(P.slot_cap) * P.chunks * (kGTH * kGTW) * CT);
   lay.total = o;
   return true;
 }
@@ -998,15 +1346,68 @@ int run_backward_ring(const Levels& L, const float* rois, const int32_t* levels_
                      L, P, ws, rois, levels_in, K, C, PH, PW, sr);
   const dim3 grid(static_cast<unsigned>(P.chunks), static_cast<unsigned>(P.extra_cap + P.num_tiles));
   if (PH == 7) {
-    using G = RingGeom<7, 7, kRingCT>;
     const int nr = detops_tuning().roi_bwd_ring ? detops_tuning().roi_bwd_ring : kRingSlots;
-#define RING_LAUNCH(NR_) hipLaunchKernelGGL((roi_align_bwd_ring_kernel<7, 7, kRingCT, NR_>), grid, dim3(kBlock), G::lds_bytes(NR_), st, L, P, ws, gout, C)
-    if (nr == 2) RING_LAUNCH(2); else if (nr == 4) RING_LAUNCH(4); else RING_LAUNCH(3);
+#define RING_LAUNCH(CT_, NR_) hipLaunchKernelGGL((roi_align_bwd_ring_kernel<7, 7, CT_, NR_>), grid, dim3(kBlock), (RingGeom<7, 7, CT_>::lds_bytes(NR_)), st, L, P, ws, gout, C)
+    if (ring_ct(PH) == 32) { if (nr == 2) RING_LAUNCH(32, 2); else RING_LAUNCH(32, 3); }
+    else if (nr == 2) RING_LAUNCH(16, 2); else if (nr == 4) RING_LAUNCH(16, 4); else RING_LAUNCH(16, 3);
 #undef RING_LAUNCH
   } else {
     using G = RingGeom<14, 14, kRingCT>;
     hipLaunchKernelGGL((roi_align_bwd_ring_kernel<14, 14, kRingCT, 2>), grid, dim3(kBlock), G::lds_bytes(2), st,
                        L, P, ws, gout, C);
+  }
+  return launch_status();
+}
+
+// ---- acc backward: plan, workspace (the groups' partial maps), launch
+constexpr int kAccMaxGroups = 64;
+
+inline bool acc_shape(int H, int W, int PH, int PW) {
+  return ring_shape(PH, PW) && H <= kAccMaxDim && W <= kAccMaxDim && H > 0 && W > 0;
+}
+
+bool acc_plan(int N, int C, int H, int W, int K, int PH, int PW, AccPlan& P, size_t& bytes) {
+  if (!acc_shape(H, W, PH, PW) || K <= 0 || K > 65535 || N <= 0 || N > 4096 || C <= 0) return false;
+  if (static_cast<int64_t>(K) * C * PH * PW > 0xfffffff0ll) return false;
+  P = AccPlan{};
+  P.H = H; P.W = W; P.HWp = (H * W + 3) & ~3;
+  P.chunks = static_cast<int>(ceil_div64(C, kRingCT));
+  // ROI-list split: ~2 workgroups per CU (measured on cfg-1: 16 / 32 / 64 groups -> 50 / 33 / 37 us), one round
+  // (8 ROIs) or more per workgroup
+  int64_t groups = ceil_div64(2 * kNumCU, static_cast<int64_t>(N) * P.chunks);
+  groups = std::min<int64_t>(groups, std::max<int64_t>(1, K / kAccRound));
+  groups = std::max<int64_t>(1, std::min<int64_t>(groups, kAccMaxGroups));
+  if (detops_tuning().roi_bwd_groups) groups = max(1, min(kAccMaxGroups, detops_tuning().roi_bwd_groups));
+  P.groups = static_cast<int>(groups);
+  bytes = sizeof(float) * static_cast<size_t>(N) * P.chunks * kAccMaxGroups * kRingCT * P.HWp;
+  return true;
+}
+
+// -1: not applicable (no / too small workspace, shape outside the plan) -> the other kernels
+int run_backward_acc(const Levels& L, const float* rois, const float* gout, int N, int C, int K, int PH, int PW, int sr,
+                     int accumulate, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (C == 0 || N == 0) return 0;
+  if (!workspace || K == 0 || L.num != 1) return -1;
+  AccPlan P; size_t need = 0;
+  const int H = L.lv[0].H, W = L.lv[0].W;
+  if (!acc_plan(N, C, H, W, K, PH, PW, P, need) || workspace_bytes < need) return -1;
+  P.accumulate = accumulate;
+  P.debug = detops_tuning().roi_bwd_debug;
+  float* partials = static_cast<float*>(workspace);
+  const dim3 grid(static_cast<unsigned>(P.chunks), static_cast<unsigned>(N * P.groups));
+  if (PH == 7) {
+    using A = AccGeom<7, 7, kRingCT>;
+    hipLaunchKernelGGL((roi_align_bwd_acc_kernel<7, 7, kRingCT, 4>), grid, dim3(kBlock), A::lds_bytes(4, H, W, P.HWp), st,
+                       P, rois, gout, L.lv[0].gin, partials, L.lv[0].scale, C, K, sr);
+  } else {
+    using A = AccGeom<14, 14, kRingCT>;
+    hipLaunchKernelGGL((roi_align_bwd_acc_kernel<14, 14, kRingCT, 3>), grid, dim3(kBlock), A::lds_bytes(3, H, W, P.HWp), st,
+                       P, rois, gout, L.lv[0].gin, partials, L.lv[0].scale, C, K, sr);
+  }
+  if (P.groups > 1) {
+    const int64_t total = static_cast<int64_t>(N) * C * H * W;
+    hipLaunchKernelGGL((roi_align_bwd_acc_combine_kernel<kRingCT>), dim3(static_cast<unsigned>(ceil_div64(total, kBlock))),
+                       dim3(kBlock), 0, st, P, partials, L.lv[0].gin, N, C);
   }
   return launch_status();
 }
@@ -1084,14 +1485,18 @@ int run_backward_atomic(const Levels& L, const float* rois, const int32_t* level
   return launch_status();
 }
 
-// Dispatch: the ring kernel when the caller supplies a workspace, the shape is in its plan and the launch fills the
-// chip; otherwise the scan kernel (small maps: ROI-list split); the atomic kernel for bin counts beyond both LDS
+// Dispatch: the acc kernel for one small map with a workspace (the map lives in LDS); the ring kernel when the caller
+// supplies a workspace, the shape is in its plan and the launch fills the chip; otherwise the scan kernel (small maps: ROI-list split); the atomic kernel for bin counts beyond both LDS
 // plans.  Tuning `roi_bwd_impl` = 1 (ring wherever its plan applies, under-filled launches included) | 2 | 3 forces
 // one (tests, A/B measurements).
 int run_backward(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
                  int N, int C, int K, int PH, int PW, int sr, int accumulate, hipStream_t st,
                  void* workspace = nullptr, size_t workspace_bytes = 0) {
   const int impl = detops_tuning().roi_bwd_impl;
+  if (impl == 0 || impl == 4) {             // small single maps with a workspace: the whole map accumulates in LDS
+    const int rc = run_backward_acc(L, rois, gout, N, C, K, PH, PW, sr, accumulate, workspace, workspace_bytes, st);
+    if (rc != -1) return rc;
+  }
   if (impl == 0 || impl == 1) {
     const bool forced = impl == 1 && K > 0;
     const int rc = run_backward_ring(L, rois, levels_in, gout, N, C, K, PH, PW, sr, accumulate, workspace,
@@ -1146,9 +1551,12 @@ DETOPS_API size_t detops_roi_align_backward_workspace_bytes(const int* H_host, c
     if (H_host[i] <= 0 || W_host[i] <= 0) return 0;
     L.lv[i] = Level{nullptr, nullptr, H_host[i], W_host[i], 1.f};
   }
+  size_t need = 0;
   RingPlan P; RingLayout lay;
-  if (!ring_plan(L, N, C, K, PH, PW, P, lay)) return 0;
-  return lay.total;
+  if (ring_plan(L, N, C, K, PH, PW, P, lay)) need = lay.total;
+  AccPlan AP; size_t abytes = 0;
+  if (num_levels == 1 && acc_plan(N, C, H_host[0], W_host[0], K, PH, PW, AP, abytes)) need = std::max(need, abytes);
+  return need;
 }
 
 DETOPS_API int detops_roi_align_fpn_backward_ws_f32(

@@ -13,7 +13,7 @@
 //     reference CPU kernel for finite inputs.
 //   * fast path (fixed 1x1 / 2x2 sampling, 7x7 / 14x14 bins): the ROI footprint is staged in LDS by LDS-DMA
 //     (global_load_lds_dwordx4, double-buffered), a thread keeps its bin's sample offsets + weights in registers
-//     across the channel loop; ROIs are visited in (level, image, position) rank order (roi_order_kernel) so that
+//     across the channel loop; ROIs are visited in (level, image, position) rank order (roi_fwd_prep_kernel) so that
 //     overlapping footprints are fetched while still in the XCD's L2.
 //   * everything else (adaptive sampling, other bin counts): roi_align_fwd_kernel, direct gathers.
 #include "roi_align_common.h"
@@ -132,16 +132,16 @@ __device__ __forceinline__ unsigned long long roi_order_key(const Levels& L, con
   return (static_cast<unsigned long long>(key) << 32) | static_cast<unsigned>(i);
 }
 
-__global__ void __launch_bounds__(kOrderBlock)
-roi_order_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in, int K,
-                 int32_t* __restrict__ order) {
-  __shared__ __attribute__((aligned(16))) unsigned long long keys[kOrderMaxK + 2 * kOrderLanes];
+// Ranking role of the pre-pass (one 1024-thread workgroup per 64 ROIs): see roi_fwd_prep_kernel.
+__device__ __forceinline__ void roi_order_role(const Levels& L, const float* __restrict__ rois,
+                                               const int32_t* __restrict__ levels_in, int K,
+                                               int32_t* __restrict__ order, unsigned long long* keys, int block) {
   const int tid = threadIdx.x;
   const int Kp = (K + 2 * kOrderLanes - 1) / (2 * kOrderLanes) * (2 * kOrderLanes);   // padded with +inf keys
   for (int i = tid; i < Kp; i += kOrderBlock)
     keys[i] = i < K ? roi_order_key(L, rois, levels_in, i) : ~0ull;
   __syncthreads();
-  const int r = (blockIdx.x * kOrderBlock + tid) / kOrderLanes;
+  const int r = (block * kOrderBlock + tid) / kOrderLanes;
   const int sub = tid & (kOrderLanes - 1);
   int cnt = 0;
   if (r < K) {
@@ -159,14 +159,126 @@ roi_order_kernel(Levels L, const float* __restrict__ rois, const int32_t* __rest
   if (r < K && sub == 0) { order[cnt] = r; DETOPS_STAT("fwd.ranked_rois", 1); }
 }
 
-template <int PH, int PW, int SR, int G, int WPS>
+// Per-ROI sample records of the fast path (workspace): what EVERY channel-chunk workgroup of a ROI used to re-derive
+// (geometry, 2 x PH*SR axis taps by the reference arithmetic, the footprint bounds, per bin 4 patch offsets + 16
+// bilinear weights: ~350 VALU instructions per wave, 8 chunk workgroups per ROI = 40 % of the launch's VALU work)
+// is computed ONCE per ROI by one wave of the pre-pass and loaded by the main kernel.
+//   hdr  [K][2] int4   {level, image, ymin, rows | valid << 16}, {xmin, w4, 0, 0}
+//   rec  [K][5][BINS] float4: j = 0 patch offsets of the bin's SR*SR samples (int), j = 1..4 the weights w1..w4
+struct FwdRecs {
+  int4* hdr;
+  float4* rec;
+};
+
+constexpr int kPrepWaves = kOrderBlock / kWave;   // ROIs per record-role workgroup (one wave each)
+
+template <int PH, int PW, int SR>
+__device__ __forceinline__ void roi_record_role(const Levels& L, const float* __restrict__ rois,
+                                                const int32_t* __restrict__ levels_in,
+                                                int32_t* __restrict__ levels_out, int K, FwdRecs R, Tap* tabs, int block) {
+  constexpr int BINS = PH * PW, NS = SR * SR;
+  static_assert(PH * SR <= 32 && PW * SR <= 32 && NS <= 4, "one wave builds both axis tables at once");
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int k = block * kPrepWaves + wave;
+  if (k >= K) return;
+  Tap* tabY = tabs + wave * 64;
+  Tap* tabX = tabY + 32;
+  const float* roi = rois + static_cast<size_t>(k) * 5;
+  int lvl = 0;
+  if (L.num > 1) lvl = levels_in ? levels_in[k] : fpn_level(roi, L);
+  if (levels_out && lane == 0) levels_out[k] = lvl;
+  int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
+#pragma unroll
+  for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+    if (i == lvl) { H = L.lv[i].H; W = L.lv[i].W; scale = L.lv[i].scale; }
+  const RoiGeom g = roi_geometry(roi, scale, PH, PW, SR);
+  // lanes 0..31: y taps, lanes 32..63: x taps
+  const bool isy = lane < 32;
+  const int u = lane & 31;
+  const int nent = isy ? PH * SR : PW * SR;
+  int lo_min = 0x7fffffff, lo_max = -1;
+  if (u < nent) {
+    const Tap e = isy ? axis_entry(g.start_h, g.bin_h, u / SR, u % SR, SR, H, 1)
+                      : axis_entry(g.start_w, g.bin_w, u / SR, u % SR, SR, W, 1);
+    (isy ? tabY : tabX)[u] = e;
+    if (e.l != 0.f || e.h != 0.f) { lo_min = e.lo; lo_max = e.lo; }
+  }
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) {   // min / max within each half of the wave
+    lo_min = min(lo_min, __shfl(lo_min, lane ^ off));
+    lo_max = max(lo_max, __shfl(lo_max, lane ^ off));
+  }
+  const int ymin = __shfl(lo_min, 0), ymax = __shfl(lo_max, 0);
+  const int xmin = __shfl(lo_min, 32), xmax = __shfl(lo_max, 32);
+  DETOPS_WAVE_SYNC();   // the tables are read by other lanes of this wave
+  const bool valid = ymax >= 0 && xmax >= 0;
+  const int rows = ymax - ymin + 2;
+  int w4 = (xmax - xmin + 2 + 3) >> 2;
+  w4 |= 1;
+  const int ps = 4 * w4;
+  if (lane == 0) {
+    R.hdr[2 * static_cast<size_t>(k)] = make_int4(lvl, g.b, ymin, (valid ? rows : 0) | ((valid ? 1 : 0) << 16));
+    R.hdr[2 * static_cast<size_t>(k) + 1] = make_int4(xmin, w4, 0, 0);
+    DETOPS_STAT("fwd.records", 1);
+  }
+  if (!valid) return;
+  float4* rec = R.rec + static_cast<size_t>(k) * 5 * BINS;
+  for (int bin = lane; bin < BINS; bin += kWave) {
+    const int ph = bin / PW, pw = bin - ph * PW;
+    int off[4] = {0, 0, 0, 0};
+    float w1[4] = {0.f, 0.f, 0.f, 0.f}, w2[4] = {0.f, 0.f, 0.f, 0.f}, w3[4] = {0.f, 0.f, 0.f, 0.f}, w4s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int iy = 0; iy < SR; ++iy) {
+      const Tap ty = tabY[ph * SR + iy];
+      const bool vy = (ty.l != 0.f || ty.h != 0.f);
+#pragma unroll
+      for (int ix = 0; ix < SR; ++ix) {
+#pragma clang fp contract(off)
+        const Tap tx = tabX[pw * SR + ix];
+        const bool vv = vy && (tx.l != 0.f || tx.h != 0.f);
+        const int s_ = iy * SR + ix;
+        off[s_] = vv ? (ty.lo - ymin) * ps + (tx.lo - xmin) : 0;
+        w1[s_] = vv ? ty.h * tx.h : 0.f;
+        w2[s_] = vv ? ty.h * tx.l : 0.f;
+        w3[s_] = vv ? ty.l * tx.h : 0.f;
+        w4s[s_] = vv ? ty.l * tx.l : 0.f;
+      }
+    }
+    rec[0 * BINS + bin] = make_float4(__int_as_float(off[0]), __int_as_float(off[1]), __int_as_float(off[2]), __int_as_float(off[3]));
+    rec[1 * BINS + bin] = make_float4(w1[0], w1[1], w1[2], w1[3]);
+    rec[2 * BINS + bin] = make_float4(w2[0], w2[1], w2[2], w2[3]);
+    rec[3 * BINS + bin] = make_float4(w3[0], w3[1], w3[2], w3[3]);
+    rec[4 * BINS + bin] = make_float4(w4s[0], w4s[1], w4s[2], w4s[3]);
+  }
+}
+
+// The forward's pre-pass, ONE launch, two roles by block index: blocks [0, order_blocks) rank the ROIs (visiting
+// order, L2 locality), the rest build the per-ROI sample records (one wave per ROI).
+template <int PH, int PW, int SR>
+__global__ void __launch_bounds__(kOrderBlock)
+roi_fwd_prep_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
+                    int32_t* __restrict__ levels_out, int K, int32_t* __restrict__ order, int order_blocks, FwdRecs R) {
+  constexpr size_t kKeyBytes = sizeof(unsigned long long) * (kOrderMaxK + 2 * kOrderLanes);
+  constexpr size_t kTabBytes = sizeof(Tap) * 64 * kPrepWaves;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kKeyBytes > kTabBytes ? kKeyBytes : kTabBytes];
+  if (static_cast<int>(blockIdx.x) < order_blocks)
+    roi_order_role(L, rois, levels_in, K, order, reinterpret_cast<unsigned long long*>(smem), static_cast<int>(blockIdx.x));
+  else
+    roi_record_role<PH, PW, SR>(L, rois, levels_in, levels_out, K, R, reinterpret_cast<Tap*>(smem),
+                                static_cast<int>(blockIdx.x) - order_blocks);
+}
+
+template <int PH, int PW, int SR, int G, int WPS, int MODE>
 __global__ void __launch_bounds__(((PH * PW * G + 63) / 64) * 64, WPS)
 roi_align_fwd_dma_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
                          int32_t* __restrict__ levels_out, float* __restrict__ out, int C, int K, int CT,
-                         int chunks, int buf_floats, const int32_t* __restrict__ order) {
+                         int chunks, int buf_floats, const int32_t* __restrict__ order, FwdRecs R) {
   constexpr int BINS = PH * PW;
   constexpr int NS = SR * SR;
   constexpr int NT = ((BINS * G + 63) / 64) * 64;
+  constexpr bool PRE = MODE >= 1;            // per-ROI sample records from the pre-pass
+  constexpr bool STATIC_ISSUE = MODE >= 2;   // staging offsets fixed per lane for the whole workgroup (see below)
+  constexpr int kMaxPass = 3;                // staging passes per batch the static form unrolls
   DETOPS_DYNAMIC_LDS(float, patch);          // two buffers of buf_floats (multiple of 256 floats = one wave-instruction)
   __shared__ Tap tabY[PH * SR];
   __shared__ Tap tabX[PW * SR];
@@ -177,50 +289,74 @@ roi_align_fwd_dma_kernel(Levels L, const float* __restrict__ rois, const int32_t
   const int kk = bid / chunks;
   const int chunk = bid - kk * chunks;
   const int k = order ? order[kk] : kk;
-  const float* roi = rois + static_cast<size_t>(k) * 5;
-  int lvl = 0;
-  if (L.num > 1) lvl = levels_in ? levels_in[k] : fpn_level(roi, L);
-  if (levels_out && chunk == 0 && tid == 0) levels_out[k] = lvl;
+  const int c0 = chunk * CT;
+  const int cend = min(C, c0 + CT);
+  float* obase = out + (static_cast<size_t>(k) * C + c0) * BINS;
+  int lvl = 0, roi_b = 0, ymin = 0, rows = 0, xmin = 0, w4 = 0;
+  bool any_inside = true;
+  if constexpr (PRE) {   // everything per ROI comes from the pre-pass (roi_record_role): wave-uniform scalar loads
+    const int4 h0 = R.hdr[2 * static_cast<size_t>(k)], h1 = R.hdr[2 * static_cast<size_t>(k) + 1];
+    lvl = __builtin_amdgcn_readfirstlane(h0.x); roi_b = __builtin_amdgcn_readfirstlane(h0.y);
+    ymin = __builtin_amdgcn_readfirstlane(h0.z);
+    const int rv = __builtin_amdgcn_readfirstlane(h0.w);
+    rows = rv & 0xffff; any_inside = (rv >> 16) != 0;
+    xmin = __builtin_amdgcn_readfirstlane(h1.x); w4 = __builtin_amdgcn_readfirstlane(h1.y);
+  } else {
+    const float* roi = rois + static_cast<size_t>(k) * 5;
+    if (L.num > 1) lvl = levels_in ? levels_in[k] : fpn_level(roi, L);
+    if (levels_out && chunk == 0 && tid == 0) levels_out[k] = lvl;
+  }
   const float* in = L.lv[0].in; int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
 #pragma unroll
   for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
     if (i == lvl) { in = L.lv[i].in; H = L.lv[i].H; W = L.lv[i].W; scale = L.lv[i].scale; }
 
-  const RoiGeom g = roi_geometry(roi, scale, PH, PW, SR);
-  if (tid == 0) { s_bounds[0] = 0x7fffffff; s_bounds[1] = -1; s_bounds[2] = 0x7fffffff; s_bounds[3] = -1; }
-  __syncthreads();
-  if (tid < PH * SR + PW * SR) {
-    if (tid < PH * SR) {
-      const Tap e = axis_entry(g.start_h, g.bin_h, tid / SR, tid % SR, SR, H, 1);
-      tabY[tid] = e;
-      if (e.l != 0.f || e.h != 0.f) { atomicMin(&s_bounds[0], e.lo); atomicMax(&s_bounds[1], e.lo); }
-    } else {
-      const int u = tid - PH * SR;
-      const Tap e = axis_entry(g.start_w, g.bin_w, u / SR, u % SR, SR, W, 1);
-      tabX[u] = e;
-      if (e.l != 0.f || e.h != 0.f) { atomicMin(&s_bounds[2], e.lo); atomicMax(&s_bounds[3], e.lo); }
+  if constexpr (!PRE) {
+    const float* roi = rois + static_cast<size_t>(k) * 5;
+    const RoiGeom g = roi_geometry(roi, scale, PH, PW, SR);
+    roi_b = g.b;
+    if (tid == 0) { s_bounds[0] = 0x7fffffff; s_bounds[1] = -1; s_bounds[2] = 0x7fffffff; s_bounds[3] = -1; }
+    __syncthreads();
+    if (tid < PH * SR + PW * SR) {
+      if (tid < PH * SR) {
+        const Tap e = axis_entry(g.start_h, g.bin_h, tid / SR, tid % SR, SR, H, 1);
+        tabY[tid] = e;
+        if (e.l != 0.f || e.h != 0.f) { atomicMin(&s_bounds[0], e.lo); atomicMax(&s_bounds[1], e.lo); }
+      } else {
+        const int u = tid - PH * SR;
+        const Tap e = axis_entry(g.start_w, g.bin_w, u / SR, u % SR, SR, W, 1);
+        tabX[u] = e;
+        if (e.l != 0.f || e.h != 0.f) { atomicMin(&s_bounds[2], e.lo); atomicMax(&s_bounds[3], e.lo); }
+      }
+    }
+    __syncthreads();
+    any_inside = !(s_bounds[1] < 0 || s_bounds[3] < 0);
+    if (any_inside) {
+      ymin = s_bounds[0];
+      rows = s_bounds[1] - ymin + 2;   // (lo range) + the lo+1 row
+      xmin = s_bounds[2];
+      w4 = (s_bounds[3] - xmin + 2 + 3) >> 2;   // float4 pieces per patch row incl. the lo+1 column
+      w4 |= 1;                                   // odd: rows spread over the LDS banks
     }
   }
-  __syncthreads();
-  const int c0 = chunk * CT;
-  const int cend = min(C, c0 + CT);
-  float* obase = out + (static_cast<size_t>(k) * C + c0) * BINS;
-  if (s_bounds[1] < 0 || s_bounds[3] < 0) {  // every sample falls outside the map: all-zero output
+  (void)scale;
+  if (!any_inside) {  // every sample falls outside the map: all-zero output
     for (int o = tid; o < (cend - c0) * BINS; o += NT) obase[o] = 0.f;
     return;
   }
-  const int ymin = s_bounds[0];
-  const int rows = s_bounds[1] - ymin + 2;   // (lo range) + the lo+1 row
   const size_t plane = static_cast<size_t>(H) * W;
-  const float* base = in + (static_cast<size_t>(g.b) * C + c0) * plane;
-  const int xmin = s_bounds[2];
-  int w4 = (s_bounds[3] - xmin + 2 + 3) >> 2;   // float4 pieces per patch row incl. the lo+1 column
-  w4 |= 1;                                       // odd: rows spread over the LDS banks
+  const float* base = in + (static_cast<size_t>(roi_b) * C + c0) * plane;
   const int ps = 4 * w4;
   const int a4 = rows * w4;                      // float4 pieces per channel
   const int area = 4 * a4;
 
   if (area > buf_floats) {  // footprint too large for LDS: gather straight from the map
+    if constexpr (PRE) {    // the records hold patch-relative offsets: rebuild the axis tables for the direct gathers
+      const RoiGeom g = roi_geometry(rois + static_cast<size_t>(k) * 5, scale, PH, PW, SR);
+      if (tid < PH * SR) tabY[tid] = axis_entry(g.start_h, g.bin_h, tid / SR, tid % SR, SR, H, 1);
+      else if (tid < PH * SR + PW * SR) { const int u = tid - PH * SR; tabX[u] = axis_entry(g.start_w, g.bin_w, u / SR, u % SR, SR, W, 1); }
+      __syncthreads();
+    }
     for (int o = tid; o < (cend - c0) * BINS; o += NT) {
 #pragma clang fp contract(off)
       const int cl = o / BINS;
@@ -238,7 +374,7 @@ roi_align_fwd_dma_kernel(Levels L, const float* __restrict__ rois, const int32_t
           acc += w1 * r0[tx.lo] + w2 * r0[tx.hi] + w3 * r1[tx.lo] + w4_ * r1[tx.hi];
         }
       }
-      obase[o] = acc / g.count;
+      obase[o] = acc / static_cast<float>(NS);
     }
     return;
   }
@@ -267,9 +403,52 @@ roi_align_fwd_dma_kernel(Levels L, const float* __restrict__ rois, const int32_t
   const int wrap_v = W - 4 * w4;                          // (y + 1, v - w4)
   const int wrap_y = static_cast<int>(plane) - rows * W;  // (c + 1, y - rows)
   const bool planes_fit = static_cast<size_t>(ctb + 1) * plane < 0x7fffffffu;
+  // Static form: every batch has the same channel count and footprint, so piece p = tid + i * NT of a batch maps to the
+  // same (channel, row, column piece) in EVERY batch: its source offset relative to the batch's first plane is computed
+  // once; per batch only the scalar base moves (global_load_lds with saddr + per-lane offset, no vector arithmetic
+  // per piece — the incremental form below costs ~12 VALU instructions per piece and pass).  Completion is counted
+  // by hand (DETOPS_VMCNT_WAIT(0) in front of the batch barrier).
+  unsigned so_off[kMaxPass];
+  int so_slow = 0;                           // bit i: piece tid + i * NT reaches beyond the map (register path)
+  const bool use_static = STATIC_ISSUE && ctb * a4 <= kMaxPass * NT && static_cast<size_t>(ctb + 1) * plane < 0x3fffffffu;
+  if (use_static) {
+#pragma unroll
+    for (int i = 0; i < kMaxPass; ++i) {
+      const int p = tid + i * NT;
+      const int c = static_cast<int>((static_cast<float>(p) + 0.5f) * inv_a4);
+      const int rem = p - c * a4;
+      const int y = static_cast<int>((static_cast<float>(rem) + 0.5f) * inv_w4);
+      const int v = rem - y * w4;
+      const int gx = xmin + 4 * v;
+      if (!(gx + 3 < W && ymin + y < H)) so_slow |= 1 << i;
+      so_off[i] = static_cast<unsigned>(c * static_cast<int>(plane) + (ymin + y) * W + gx) * 4u;
+    }
+  }
   auto issue = [&](int cs, int cn, float* buf) {
     const float* src = base + static_cast<size_t>(cs - c0) * plane;
     const int total = cn * a4;
+    if (use_static) {
+#pragma unroll
+      for (int i = 0; i < kMaxPass; ++i)
+        if (i * NT < total)                         // wave-uniform
+          glds16_async_so(tid + i * NT < total && !((so_slow >> i) & 1), src, so_off[i], buf + 4 * i * NT + wave_off);
+      if (so_slow) {                                // pieces reaching beyond the map: replicated border column / row
+#pragma unroll 1
+        for (int i = 0; i < kMaxPass; ++i) {
+          const int p = tid + i * NT;
+          if (((so_slow >> i) & 1) && p < total) {
+            const int c = static_cast<int>((static_cast<float>(p) + 0.5f) * inv_a4);
+            const int rem = p - c * a4;
+            const int y = static_cast<int>((static_cast<float>(rem) + 0.5f) * inv_w4);
+            const int gx = xmin + 4 * (rem - y * w4);
+            const float* rowp = src + static_cast<size_t>(c) * plane + static_cast<size_t>(min(ymin + y, H - 1)) * W;
+            *reinterpret_cast<float4*>(buf + 4 * p) =
+                make_float4(rowp[min(gx, W - 1)], rowp[min(gx + 1, W - 1)], rowp[min(gx + 2, W - 1)], rowp[min(gx + 3, W - 1)]);
+          }
+        }
+      }
+      return;
+    }
     int y = py0, v = pv0, go = go0;
     int c = pc0;
 #pragma unroll 1
@@ -296,6 +475,14 @@ roi_align_fwd_dma_kernel(Levels L, const float* __restrict__ rois, const int32_t
   const int ph = bin / PW, pw = bin - ph * PW;
   int off[NS];
   float w1[NS], w2[NS], w3[NS], w4s[NS];
+  if constexpr (PRE) {
+    const float4* rec = R.rec + static_cast<size_t>(k) * 5 * BINS + bin;
+    const float4 r0 = rec[0], r1 = rec[BINS], r2 = rec[2 * BINS], r3 = rec[3 * BINS], r4 = rec[4 * BINS];
+    const float ro[4] = {r0.x, r0.y, r0.z, r0.w}, ra[4] = {r1.x, r1.y, r1.z, r1.w}, rb[4] = {r2.x, r2.y, r2.z, r2.w};
+    const float rc[4] = {r3.x, r3.y, r3.z, r3.w}, rd[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) { off[s_] = __float_as_int(ro[s_]); w1[s_] = ra[s_]; w2[s_] = rb[s_]; w3[s_] = rc[s_]; w4s[s_] = rd[s_]; }
+  } else {
 #pragma unroll
   for (int iy = 0; iy < SR; ++iy) {
     const Tap ty = tabY[ph * SR + iy];
@@ -313,6 +500,8 @@ roi_align_fwd_dma_kernel(Levels L, const float* __restrict__ rois, const int32_t
       w4s[s] = vv ? ty.l * tx.l : 0.f;
     }
   }
+  }
+  (void)ph; (void)pw;
   const float inv_count = 1.f / static_cast<float>(NS);  // NS in {1,4}: exact reciprocal
 
   issue(c0, min(ctb, cend - c0), patch);
@@ -320,7 +509,11 @@ roi_align_fwd_dma_kernel(Levels L, const float* __restrict__ rois, const int32_t
   for (int cs = c0; cs < cend; cs += ctb, ++n) {
     const int cn = min(ctb, cend - cs);
     if (tid == 0) { DETOPS_STAT("fwd.stage_batches", 1); DETOPS_STAT("fwd.staged_floats", cn * area); }
-    __syncthreads();   // batch n has landed (vmcnt(0) + barrier); every wave is done reading the other buffer
+    // this wave's LDS-DMA pieces of batch n have landed BEFORE the barrier — explicitly: the asm-issued form is invisible
+    // to the compiler, and for the builtin form hipcc only waits in front of the issuing wave's own LDS reads (seen on
+    // the device: `s_waitcnt lgkmcnt(0); s_barrier` here, another wave's pieces still in flight behind the barrier)
+    DETOPS_VMCNT_WAIT(0);
+    __syncthreads();   // batch n has landed everywhere; every wave is done reading the other buffer
     const float* cur = patch + (n & 1) * buf_floats;
     if (cs + ctb < cend) issue(cs + ctb, min(ctb, cend - cs - ctb), patch + ((n + 1) & 1) * buf_floats);
     if (csub < G) {
@@ -367,9 +560,51 @@ inline void dispatch_shape(int PH, int PW, int sr, F&& f) {
   else f(IC<0>{}, IC<0>{}, IC<kTabBig>{});
 }
 
+// Workspace of the fast path: [order: K int32][hdr: 2 K int4][rec: 5 K BINS float4], each part 256-byte aligned.
+struct FwdWs {
+  int32_t* order;   // nullptr: no ranking for this K
+  FwdRecs recs;     // hdr == nullptr: no records (workspace absent / too small)
+};
+
+int order_min_k() {
+  const int v = detops_tuning().roi_fwd_order_mink;
+  return v > 0 ? max(2, v) : kOrderMinK;
+}
+
+inline bool fwd_dma_shape(int PH, int PW, int sr) {
+  return (PH == 7 && PW == 7 && (sr == 1 || sr == 2)) || (PH == 14 && PW == 14 && sr == 2);
+}
+
+inline size_t up256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+struct FwdWsLayout { size_t off_hdr, off_rec, total; bool order, recs; };
+
+inline FwdWsLayout fwd_ws_layout(int K, int PH, int PW, int sr) {
+  FwdWsLayout l{};
+  l.order = K >= order_min_k() && K <= kOrderMaxK;
+  l.recs = K > 0 && fwd_dma_shape(PH, PW, sr) && detops_tuning().roi_fwd_records != 1;
+  size_t o = l.order ? up256(sizeof(int32_t) * static_cast<size_t>(K)) : 0;
+  l.off_hdr = o;
+  if (l.recs) o = up256(o + sizeof(int4) * 2 * static_cast<size_t>(K));
+  l.off_rec = o;
+  if (l.recs) o = up256(o + sizeof(float4) * 5 * static_cast<size_t>(K) * PH * PW);
+  l.total = o;
+  return l;
+}
+
+inline FwdWs fwd_workspace(int K, int PH, int PW, int sr, void* workspace, size_t workspace_bytes) {
+  FwdWs w{};
+  const FwdWsLayout l = fwd_ws_layout(K, PH, PW, sr);
+  if (!workspace || l.total == 0 || workspace_bytes < l.total) return w;
+  unsigned char* base = static_cast<unsigned char*>(workspace);
+  if (l.order) w.order = reinterpret_cast<int32_t*>(base);
+  if (l.recs) { w.recs.hdr = reinterpret_cast<int4*>(base + l.off_hdr); w.recs.rec = reinterpret_cast<float4*>(base + l.off_rec); }
+  return w;
+}
+
 template <int PH, int PW, int SR, int G>
 void launch_fwd_dma(const Levels& L, const float* rois, const int32_t* levels_in, int32_t* levels_out,
-                    float* out, int C, int K, hipStream_t st, int32_t* order_ws) {
+                    float* out, int C, int K, hipStream_t st, const FwdWs& ws) {
   constexpr int NT = ((PH * PW * G + 63) / 64) * 64;
   // channels per workgroup.  32: with C = 256 the 8 chunks of a ROI land on the 8 XCDs (workgroup b runs on XCD
   // b % 8), so every L2 caches ONE 32-channel slice of the maps and sees all ROIs in ranked order; and 8 K short
@@ -378,6 +613,7 @@ void launch_fwd_dma(const Levels& L, const float* rois, const int32_t* levels_in
   for (int i = 0; i < L.num; ++i) map_pixels += static_cast<int64_t>(L.lv[i].H) * L.lv[i].W;
   // small maps = small footprints: the per-workgroup setup dominates, fewer and fatter workgroups win (cfg-1: 63 vs 86 us)
   int CT = (map_pixels < 16384) ? 64 : 32;
+  if (detops_tuning().roi_fwd_ct) CT = max(8, min(256, detops_tuning().roi_fwd_ct));   // A/B
   while (CT > 16 && static_cast<int64_t>(K) * ceil_div64(C, CT) < 4 * kNumCU) CT >>= 1;
   if (CT > C) CT = C;
   const int chunks = static_cast<int>(ceil_div64(C, CT));
@@ -389,29 +625,38 @@ void launch_fwd_dma(const Levels& L, const float* rois, const int32_t* levels_in
   const int buf_floats = max(4, (160 * 1024 / wgs - 768) / 2048) * 256;
   const size_t lds2 = 2 * static_cast<size_t>(buf_floats) * sizeof(float);
   const int32_t* order = nullptr;
-  // order_ws != nullptr implies K >= order_min_k(); maps that fit an L2 slice several times over need no ranking
+  // ws.order != nullptr implies K >= order_min_k(); maps that fit an L2 slice several times over need no ranking
   const int order_mode = detops_tuning().roi_fwd_order;   // 0 auto, 1 off, 2 force (tests: rank even for tiny maps)
-  if (order_ws && order_mode != 1 && K <= kOrderMaxK && (map_pixels * C * 4 > (2 << 20) || order_mode == 2)) {
-    const unsigned og = static_cast<unsigned>(ceil_div64(static_cast<int64_t>(K) * kOrderLanes, kOrderBlock));
-    hipLaunchKernelGGL(roi_order_kernel, dim3(og), dim3(kOrderBlock), 0, st, L, rois, levels_in, K, order_ws);
-    order = order_ws;
+  unsigned og = 0;
+  if (ws.order && order_mode != 1 && K <= kOrderMaxK && (map_pixels * C * 4 > (2 << 20) || order_mode == 2)) {
+    og = static_cast<unsigned>(ceil_div64(static_cast<int64_t>(K) * kOrderLanes, kOrderBlock));
+    order = ws.order;
   }
-  hipLaunchKernelGGL((roi_align_fwd_dma_kernel<PH, PW, SR, G, kFwdDmaWps>), grid, dim3(NT), lds2, st, L, rois, levels_in,
-                     levels_out, out, C, K, CT, chunks, buf_floats, order);
+  const bool pre = ws.recs.hdr != nullptr;
+  const unsigned rg = pre ? static_cast<unsigned>(ceil_div64(K, kPrepWaves)) : 0u;
+  if (og + rg > 0)
+    hipLaunchKernelGGL((roi_fwd_prep_kernel<PH, PW, SR>), dim3(og + rg), dim3(kOrderBlock), 0, st, L, rois, levels_in,
+                       levels_out, K, ws.order, static_cast<int>(og), ws.recs);
+#define FWD_LAUNCH(MODE_) hipLaunchKernelGGL((roi_align_fwd_dma_kernel<PH, PW, SR, G, kFwdDmaWps, MODE_>), grid, dim3(NT), lds2, st, L, rois, levels_in, \
+                                             levels_out, out, C, K, CT, chunks, buf_floats, order, ws.recs)
+  if (!pre) FWD_LAUNCH(0);
+  else if (detops_tuning().roi_fwd_records == 2) FWD_LAUNCH(1);   // records, incremental staging offsets (A/B)
+  else FWD_LAUNCH(2);
+#undef FWD_LAUNCH
 }
 
 int run_forward(const Levels& L, const float* rois, const int32_t* levels_in, int32_t* levels_out,
-                float* out, int C, int K, int PH, int PW, int sr, hipStream_t st, int32_t* order_ws = nullptr) {
+                float* out, int C, int K, int PH, int PW, int sr, hipStream_t st, const FwdWs& ws = FwdWs{}) {
   if (K == 0 || C == 0) return 0;
   if (detops_tuning().roi_fwd_impl == 1) {   // generic kernel forced (tests, A/B)
   } else if (PH == 7 && PW == 7 && sr == 2) {
-    launch_fwd_dma<7, 7, 2, 5>(L, rois, levels_in, levels_out, out, C, K, st, order_ws);
+    launch_fwd_dma<7, 7, 2, 5>(L, rois, levels_in, levels_out, out, C, K, st, ws);
     return launch_status();
   } else if (PH == 14 && PW == 14 && sr == 2) {
-    launch_fwd_dma<14, 14, 2, 2>(L, rois, levels_in, levels_out, out, C, K, st, order_ws);
+    launch_fwd_dma<14, 14, 2, 2>(L, rois, levels_in, levels_out, out, C, K, st, ws);
     return launch_status();
   } else if (PH == 7 && PW == 7 && sr == 1) {
-    launch_fwd_dma<7, 7, 1, 5>(L, rois, levels_in, levels_out, out, C, K, st, order_ws);
+    launch_fwd_dma<7, 7, 1, 5>(L, rois, levels_in, levels_out, out, C, K, st, ws);
     return launch_status();
   }
   const int CT = pick_chunk(C, K);
@@ -424,21 +669,11 @@ int run_forward(const Levels& L, const float* rois, const int32_t* levels_in, in
   return launch_status();
 }
 
-int order_min_k() {
-  const int v = detops_tuning().roi_fwd_order_mink;
-  return v > 0 ? max(2, v) : kOrderMinK;
-}
-
-int32_t* order_workspace(int K, void* workspace, size_t workspace_bytes) {
-  const size_t need = detops_roi_align_forward_workspace_bytes(K);
-  return (workspace && need && workspace_bytes >= need) ? static_cast<int32_t*>(workspace) : nullptr;
-}
-
 }  // namespace
 
-DETOPS_API size_t detops_roi_align_forward_workspace_bytes(int K) {
-  if (K < order_min_k() || K > kOrderMaxK) return 0;
-  return (sizeof(int32_t) * static_cast<size_t>(K) + 255) & ~static_cast<size_t>(255);
+DETOPS_API size_t detops_roi_align_forward_workspace_bytes(int K, int PH, int PW, int sampling_ratio) {
+  if (K <= 0 || PH <= 0 || PW <= 0) return 0;
+  return fwd_ws_layout(K, PH, PW, sampling_ratio).total;
 }
 
 DETOPS_API int detops_roi_align_forward_ws_f32(const float* input, const float* rois, float* output,
@@ -452,7 +687,7 @@ DETOPS_API int detops_roi_align_forward_ws_f32(const float* input, const float* 
   L.num = 1;
   L.lv[0] = Level{input, nullptr, H, W, spatial_scale};
   return run_forward(L, rois, nullptr, nullptr, output, C, K, PH, PW, sampling_ratio,
-                     as_stream(stream), order_workspace(K, workspace, workspace_bytes));
+                     as_stream(stream), fwd_workspace(K, PH, PW, sampling_ratio, workspace, workspace_bytes));
 }
 
 DETOPS_API int detops_roi_align_forward_f32(const float* input, const float* rois, float* output,
@@ -484,7 +719,7 @@ DETOPS_API int detops_roi_align_fpn_forward_ws_f32(
   hipStream_t st = as_stream(stream);
   if (num_levels == 1 && levels_out) DETOPS_HIP_TRY(hipMemsetAsync(levels_out, 0, sizeof(int32_t) * K, st));
   return run_forward(L, rois, nullptr, levels_out, output, C, K, PH, PW, sampling_ratio, st,
-                     order_workspace(K, workspace, workspace_bytes));
+                     fwd_workspace(K, PH, PW, sampling_ratio, workspace, workspace_bytes));
 }
 
 DETOPS_API int detops_roi_align_fpn_forward_f32(

@@ -10,13 +10,14 @@ namespace {
 struct Key { const char* name; int DetopsTuning::*field; };
 const Key kKeys[] = {
     {"roi_bwd_impl", &DetopsTuning::roi_bwd_impl},       {"roi_bwd_seg", &DetopsTuning::roi_bwd_seg},
-    {"roi_bwd_ring", &DetopsTuning::roi_bwd_ring},
+    {"roi_bwd_ring", &DetopsTuning::roi_bwd_ring},       {"roi_bwd_ct", &DetopsTuning::roi_bwd_ct},
     {"roi_bwd_groups", &DetopsTuning::roi_bwd_groups},   {"roi_bwd_scan_ct", &DetopsTuning::roi_bwd_scan_ct},
     {"roi_bwd_debug", &DetopsTuning::roi_bwd_debug},     {"roi_fwd_impl", &DetopsTuning::roi_fwd_impl},
     {"roi_fwd_order", &DetopsTuning::roi_fwd_order},     {"roi_fwd_order_mink", &DetopsTuning::roi_fwd_order_mink},
     {"dcn_col2im", &DetopsTuning::dcn_col2im},           {"dcn_fused", &DetopsTuning::dcn_fused},
     {"dcn_gather_xcd", &DetopsTuning::dcn_gather_xcd},   {"dcn_nhwc", &DetopsTuning::dcn_nhwc},
-    {"nms_fused", &DetopsTuning::nms_fused},
+    {"nms_fused", &DetopsTuning::nms_fused},             {"roi_fwd_records", &DetopsTuning::roi_fwd_records},
+    {"roi_fwd_ct", &DetopsTuning::roi_fwd_ct},
 };
 
 bool set_key(DetopsTuning& t, const char* key, size_t len, int value) {

@@ -358,7 +358,7 @@ def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, s
     if out.numel() == 0:
         return out
     with _on_device(input):
-        ws, nbytes = _fwd_workspace(input.device, K)
+        ws, nbytes = _fwd_workspace(input.device, K, pooled_height, pooled_width, sampling_ratio)
         check(lib.detops_roi_align_forward_ws_f32(ptr(input), ptr(rois), ptr(out), N, C, H, W, K,
                                                   pooled_height, pooled_width, float(spatial_scale),
                                                   int(sampling_ratio), ptr(ws), nbytes, stream_of(input)),
@@ -382,10 +382,10 @@ def _roi_align_forward_cpu(input, rois, spatial_scale, pooled_height, pooled_wid
     return out
 
 
-def _fwd_workspace(device, K):
-    """Scratch for the forward's ROI visiting order (one int32 per ROI), from torch's stream-ordered caching
-    allocator; (None, 0) when this ROI count is served without a pre-pass."""
-    nbytes = int(lib.detops_roi_align_forward_workspace_bytes(int(K)))
+def _fwd_workspace(device, K, ph, pw, sr):
+    """Scratch for the forward's pre-pass (per-ROI sample records; the ROI visiting order for K >= 384), from
+    torch's stream-ordered caching allocator; (None, 0) when this shape is served without a pre-pass."""
+    nbytes = int(lib.detops_roi_align_forward_workspace_bytes(int(K), int(ph), int(pw), int(sr)))
     if nbytes <= 0:
         return None, 0
     return torch.empty((nbytes,), dtype=torch.uint8, device=device), nbytes
@@ -442,7 +442,7 @@ def roi_align_fpn_forward(inputs, rois, scales, pooled_height, pooled_width, sam
         return out, levels
     ptrs, Hs, Ws, sc = _host_arrays(inputs, scales)
     with _on_device(rois), _timed(("roi_align_fpn_fwd[K=%d,C=%d,%dx%d]", (K, C, pooled_height, pooled_width)), rois):
-        ws, nbytes = _fwd_workspace(rois.device, K)
+        ws, nbytes = _fwd_workspace(rois.device, K, pooled_height, pooled_width, sampling_ratio)
         check(lib.detops_roi_align_fpn_forward_ws_f32(
             ptrs, Hs, Ws, sc, len(inputs), ptr(rois), ptr(out), ptr(levels), N, C, K, pooled_height,
             pooled_width, int(sampling_ratio), int(k_min), int(k_max), float(canonical_scale),

@@ -31,7 +31,7 @@ SIGNATURES = {
     "detops_roi_align_backward_ws_f32": (
         c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P, c_size_t, _P]),
     "detops_roi_align_backward_workspace_bytes": (c_size_t, [_P, _P] + [c_int] * 6),
-    "detops_roi_align_forward_workspace_bytes": (c_size_t, [c_int]),
+    "detops_roi_align_forward_workspace_bytes": (c_size_t, [c_int] * 4),
     "detops_nms_cpu_f32": (c_int, [_P, _P, c_int, c_float, _P, _P]),
     "detops_rpn_loss_workspace_bytes": (c_size_t, []),
     "detops_rpn_loss_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,

@@ -25,7 +25,7 @@ SIGNATURES = {
     "detops_roi_align_backward_ws_f32": (
         c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P, ctypes.c_size_t, _P]),
     "detops_roi_align_backward_workspace_bytes": (ctypes.c_size_t, [_P, _P] + [c_int] * 6),
-    "detops_roi_align_forward_workspace_bytes": (ctypes.c_size_t, [c_int]),
+    "detops_roi_align_forward_workspace_bytes": (ctypes.c_size_t, [c_int] * 4),
     "detops_roi_align_forward_ws_f32": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, _P, ctypes.c_size_t, _P]),
     "detops_roi_align_fpn_forward_ws_f32": (
         c_int, [_P, _P, _P, _P, c_int, _P, _P, _P] + [c_int] * 8 + [c_float, c_float, c_float, _P, ctypes.c_size_t, _P]),
@@ -87,7 +87,7 @@ def lib():
     return _LIB
 
 
-TUNING_KEYS = ("roi_bwd_impl", "roi_bwd_seg", "roi_bwd_ring", "roi_bwd_groups", "roi_bwd_scan_ct", "roi_bwd_debug", "roi_fwd_impl",
+TUNING_KEYS = ("roi_bwd_impl", "roi_bwd_seg", "roi_bwd_ring", "roi_bwd_ct", "roi_bwd_groups", "roi_bwd_scan_ct", "roi_bwd_debug", "roi_fwd_impl", "roi_fwd_records", "roi_fwd_ct",
                "roi_fwd_order", "roi_fwd_order_mink", "dcn_col2im", "dcn_fused", "dcn_gather_xcd", "dcn_nhwc", "nms_fused")
 
 
@@ -116,7 +116,7 @@ def roi_align_forward(inp, rois, scale, ph, pw, sr):
     N, C, H, W = inp.shape
     K = rois.shape[0]
     out = np.full((K, C, ph, pw), np.nan, np.float32)
-    nbytes = lib().detops_roi_align_forward_workspace_bytes(K)
+    nbytes = lib().detops_roi_align_forward_workspace_bytes(K, ph, pw, sr)
     ws = np.full((max(nbytes, 1),), 0xAB, np.uint8)   # poisoned: the order pre-pass must write every slot
     rc = lib().detops_roi_align_forward_ws_f32(_p(inp), _p(rois), _p(out), N, C, H, W, K, ph, pw, scale, sr,
                                                _p(ws) if nbytes else None, nbytes, None)
@@ -156,7 +156,7 @@ def roi_align_fpn_forward(feats, rois, scales, ph, pw, sr, k_min, k_max):
     out = np.full((K, C, ph, pw), np.nan, np.float32)
     levels = np.full((K,), -1, np.int32)
     ptrs, Hs, Ws, sc = _host_arrays(feats, scales)
-    nbytes = lib().detops_roi_align_forward_workspace_bytes(K)
+    nbytes = lib().detops_roi_align_forward_workspace_bytes(K, ph, pw, sr)
     ws = np.full((max(nbytes, 1),), 0xAB, np.uint8)
     rc = lib().detops_roi_align_fpn_forward_ws_f32(ptrs, Hs, Ws, sc, len(feats), _p(rois), _p(out), _p(levels), N, C, K,
                                                    ph, pw, sr, k_min, k_max, 224.0, 4.0, 1e-6,

@@ -108,7 +108,7 @@ def test_emu_roi_align_fpn_forward_visiting_order_and_staging_variants(impl):
     rois[:7, 3] = 335.0                      # touching the right / bottom border: replicated border pieces
     rois[7:14, 4] = 199.0
     rois[14] = rois[15]                      # identical ROIs: equal keys, ranks must stay distinct
-    assert emu.lib().detops_roi_align_forward_workspace_bytes(rois.shape[0]) > 0
+    assert emu.lib().detops_roi_align_forward_workspace_bytes(rois.shape[0], 7, 7, 2) > 0
     lv = synth.level_map(rois)
     emu.stats(reset=True)
     out, levels = emu.roi_align_fpn_forward(feats, rois, scales, 7, 7, 2, 2, 5)
@@ -432,13 +432,53 @@ def test_emu_roi_align_backward_lane_walk(ct):
         assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("seg", [None, 8, 9])
-def test_emu_roi_align_backward_ring(seg):
+@pytest.mark.parametrize("groups", [0, 1, 5])
+def test_emu_roi_align_backward_acc_small_maps(groups):
+    """acc backward (one small map with a workspace: the map of an (image, 16-channel chunk) accumulates in LDS, the ROI
+    list is split over `groups` workgroups whose partial maps a second launch adds in group order): two images, ROI
+    lists longer than one 8-entry round, slivers / outside / degenerate ROIs, a ragged last channel chunk, accumulate
+    mode, run-to-run identical."""
+    emu.tuning_set("roi_bwd_groups", groups)
+    rng = np.random.RandomState(61)
+    N, C, H, W = 2, 21, 14, 19
+    K = 150
+    x1 = rng.uniform(-10, 80, K)
+    y1 = rng.uniform(-10, 60, K)
+    rois = np.stack([rng.randint(0, N, K), x1, y1, x1 + rng.uniform(0.2, 70, K), y1 + rng.uniform(0.2, 50, K)], 1).astype(np.float32)
+    rois = np.concatenate([rois, _edge_rois()])
+    rois[:, 0] = np.minimum(rois[:, 0], N - 1)
+    for (ph, pw, sr) in ((7, 7, 2), (14, 14, 2), (7, 7, 0)):
+        g = rng.randn(rois.shape[0], C, ph, pw).astype(np.float32)
+        ref = oracle.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, acc64=True)
+        emu.stats(reset=True)
+        out = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr)
+        st = emu.stats()
+        assert st.get("bwda.units", 0) > 0, "the acc kernel did not run"
+        if groups != 1:
+            assert st.get("bwda.combines", 0) == 1, st          # the combine launch ran
+        tol = 1e-5 * max(1.0, np.abs(ref).max())
+        assert np.abs(out - ref).max() <= tol
+        assert np.array_equal(out, emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr))
+        base = rng.randn(N, C, H, W).astype(np.float32)
+        acc = emu.roi_align_backward(g, rois, 0.25, ph, pw, N, C, H, W, sr, into=base)
+        assert np.abs(acc - (base + ref)).max() <= 2 * tol
+    # a map beyond the plan (33 columns) keeps the other kernels
+    g = rng.randn(rois.shape[0], C, 7, 7).astype(np.float32)
+    emu.stats(reset=True)
+    out = emu.roi_align_backward(g, rois, 0.25, 7, 7, N, C, 14, 33, 2)
+    assert emu.stats().get("bwda.units", 0) == 0
+    ref = oracle.roi_align_backward(g, rois, 0.25, 7, 7, N, C, 14, 33, 2, acc64=True)
+    assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("seg,ct", [(None, 0), (8, 0), (9, 0), (None, 16), (8, 16)])
+def test_emu_roi_align_backward_ring(seg, ct):
     """ring pixel-owner backward (pre-pass adjoint rows + per-tile hit lists in a poisoned workspace, LDS-DMA ring
     with counted waits — the emulation lands a staged piece only at a covering wait): ragged ROIs, slivers (bin
     ranges longer than 3), channel tails, accumulate mode; `seg` = 8 / 9 splits the crowded tiles into segments
-    whose partial sums the last arriver combines."""
+    whose partial sums the last arriver combines; `ct` = 16: the 16-channel units of the 7x7 kernel (default: 32)."""
     emu.tuning_set("roi_bwd_impl", 1)
+    emu.tuning_set("roi_bwd_ct", ct)
     if seg:
         emu.tuning_set("roi_bwd_seg", seg)
     rng = np.random.RandomState(51)

@@ -97,7 +97,11 @@ def test_roi_align_forward_variants_bit_equal():
         base, lv = _C().roi_align_fpn_forward(feats, rois, scales, ph, ph, 2, 2, 5)
         assert torch.isfinite(base).all()
         from maskrcnn_benchmark import _lib
-        for env in ({"roi_fwd_order": 1}, {"roi_fwd_order": 2, "roi_fwd_order_mink": 64}, {"roi_fwd_impl": 1}):
+        # roi_fwd_records: 1 = no per-ROI sample records (every workgroup derives its ROI's geometry itself), 2 = records
+        # with the incremental staging offsets; default = records + per-lane static staging offsets
+        for env in ({"roi_fwd_order": 1}, {"roi_fwd_order": 2, "roi_fwd_order_mink": 64}, {"roi_fwd_impl": 1},
+                    {"roi_fwd_records": 1}, {"roi_fwd_records": 2}, {"roi_fwd_records": 1, "roi_fwd_order": 1},
+                    {"roi_fwd_ct": 64}):
             for k, v in env.items():
                 _lib.tuning_set(k, v)
             out, lv2 = _C().roi_align_fpn_forward(feats, rois, scales, ph, ph, 2, 2, 5)
@@ -146,13 +150,15 @@ def test_roi_align_forward_edge_cases():
 
 
 # ============================================================================ ROIAlign backward
-@pytest.fixture(params=["ring", "scan", "atomic"])
+@pytest.fixture(params=["ring", "ring-ct16", "scan", "atomic", "acc"])
 def bwd_impl(request):
     """The three backward kernels behind the same entry points: the ring pixel-owner kernel (default for filled
     launches of the model's bin shapes; forced here also for under-filled ones), the scan pixel-owner kernel (small
-    maps, other shapes) and the atomic scatter kernel (universal fallback).  tests/conftest.py resets the switch."""
+    maps, other shapes), the atomic scatter kernel (universal fallback) and the acc kernel (one small map: the map lives
+    in LDS; shapes outside its plan fall through to the scan kernel).  tests/conftest.py resets the switch."""
     from maskrcnn_benchmark import _lib
-    _lib.tuning_set("roi_bwd_impl", {"ring": 1, "scan": 2, "atomic": 3}[request.param])
+    _lib.tuning_set("roi_bwd_impl", {"ring": 1, "ring-ct16": 1, "scan": 2, "atomic": 3, "acc": 4}[request.param])
+    _lib.tuning_set("roi_bwd_ct", 16 if request.param == "ring-ct16" else 0)
     return request.param
 
 

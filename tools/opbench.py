@@ -130,11 +130,11 @@ def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False, experiment
     return out
 
 
-def bench_roi_sets(C, iters, model_npz=None, only_sets=None, only_heads=None, which=("fwd", "bwd")):
+def bench_roi_sets(C, iters, model_npz=None, only_sets=None, only_heads=None, which=("fwd", "bwd"), images=2, tag=""):
     """FPN-fused ROIAlign forward / backward on every ROI set of synth.roi_sets(): the SURVEY 8d log-uniform set, the
     trained-like set and the sets the detector itself produced (tools/dump_model_rois.py) - VERDICT r02 item 1a."""
     out = []
-    feats = [torch.randn(2, 256, h, w, device="cuda") for (h, w) in synth.fpn_shapes()[:4]]
+    feats = [torch.randn(images, 256, h, w, device="cuda") for (h, w) in synth.fpn_shapes()[:4]]
     scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
     shapes = [tuple(f.shape) for f in feats]
     feat_bytes = sum(f.numel() * 4 for f in feats)
@@ -145,6 +145,19 @@ def bench_roi_sets(C, iters, model_npz=None, only_sets=None, only_heads=None, wh
             if only_heads and head not in only_heads:
                 continue
             rois = sets[head]
+            label = name
+            if images != 2:
+                # the > L3 variant of SURVEY 8d (4 img/GPU: 365.6 MB of maps against the 256 MiB Infinity Cache): the
+                # 2-image ROI set repeated on image pairs (2, 3), ... — same per-image ROI statistics
+                reps = []
+                for r in range((images + 1) // 2):
+                    rr = rois.copy()
+                    rr[:, 0] = np.minimum(rr[:, 0] + 2 * r, images - 1)
+                    reps.append(rr)
+                rois = np.concatenate(reps)[: rois.shape[0] * images // 2]
+                label = label + " x%d images" % images
+            if tag:
+                label = label + " | " + tag
             K = rois.shape[0]
             tr = _t(rois)
             lv = synth.level_map(rois)
@@ -154,10 +167,10 @@ def bench_roi_sets(C, iters, model_npz=None, only_sets=None, only_heads=None, wh
             extra = {"rois_per_level": np.bincount(lv, minlength=4).tolist()}
             if "fwd" in which:
                 us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
-                out.append(_entry(f"roi_align_fwd fpn-fused {head}-head K={K} {ph}x{ph} [{name}]", us, alg, extra))
+                out.append(_entry(f"roi_align_fwd fpn-fused {head}-head K={K} {ph}x{ph} [{label}]", us, alg, extra))
             if "bwd" in which:
                 us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
-                out.append(_entry(f"roi_align_bwd fpn-fused {head}-head K={K} {ph}x{ph} [{name}]", us, alg, extra))
+                out.append(_entry(f"roi_align_bwd fpn-fused {head}-head K={K} {ph}x{ph} [{label}]", us, alg, extra))
     return out
 
 
@@ -390,6 +403,9 @@ def main():
     ap.add_argument("--heads", default="", help="roi_sets: box,mask (default both)")
     ap.add_argument("--dir", default="", help="roi_sets: fwd,bwd (default both)")
     ap.add_argument("--model-rois", default=None, help="npz of tools/dump_model_rois.py (default: tests/golden/model_rois.npz)")
+    ap.add_argument("--images", type=int, default=2, help="roi_sets: images per batch (4 = the > L3 variant: 365.6 MB of maps)")
+    ap.add_argument("--tune", default="", help="library tuning switches for the whole run, key=value,key=value")
+    ap.add_argument("--sweep", default="", help="roi_sets: cartesian sweep over tuning switches, 'key=v1|v2,key2=v1|v2'")
     ap.add_argument("--experimental", action="store_true",
                     help="also time the opt-in, not-yet-measured kernel variants (DESIGN.md section 7)")
     args = ap.parse_args()
@@ -398,6 +414,9 @@ def main():
     only = set(filter(None, args.only.split(",")))
     res = []
     t0 = time.time()
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        tune(k, int(v))
     if not only or "copy" in only:
         res.append(copy_ceiling(args.iters))
     if not only or "roi_align" in only:
@@ -405,8 +424,16 @@ def main():
     if "roi_align_fpn" in only:
         res += bench_roi_align(C, args.iters, fused_only=True)
     if not only or "roi_sets" in only:
-        res += bench_roi_sets(C, args.iters, args.model_rois, set(filter(None, args.sets.split(","))),
-                              set(filter(None, args.heads.split(","))), tuple(filter(None, args.dir.split(","))) or ("fwd", "bwd"))
+        import itertools
+        axes = [(kv.split("=")[0], [int(v) for v in kv.split("=")[1].split("|")]) for kv in filter(None, args.sweep.split(","))]
+        for combo in itertools.product(*[vals for _, vals in axes]):
+            for (k, _), v in zip(axes, combo):
+                tune(k, v)
+            res += bench_roi_sets(C, args.iters, args.model_rois, set(filter(None, args.sets.split(","))),
+                                  set(filter(None, args.heads.split(","))), tuple(filter(None, args.dir.split(","))) or ("fwd", "bwd"),
+                                  images=args.images, tag=" ".join("%s=%d" % (k, v) for (k, _), v in zip(axes, combo)))
+        for k, _ in axes:
+            tune(k, 0)
     if "roi_align_fwd" in only:
         res += bench_roi_align(C, args.iters, which=("fwd",))
     if not only or "nms" in only:

@@ -13,6 +13,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "maskrcnn-benchmark_amd"))
+# two busy streams per rank (compute, RCCL): two HIP hardware queues — see bench.py::pin_hip_queues for the measurement;
+# read by the HIP runtime at initialisation, an explicit setting in the environment wins
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 import torch  # noqa: E402
 
