@@ -259,6 +259,9 @@ static inline int detops_resident_workgroups(K kernel, int block, size_t lds) {
 struct DetopsTuning {
   int roi_bwd_impl;        // 0 auto | 1 ring (needs a workspace) | 2 scan | 3 atomic scatter | 4 acc (small single map, needs a workspace)
   int roi_bwd_seg;         // ring: hits per segment before a tile's hit list is split over workgroups (0 = default)
+  int roi_bwd_split;       // ring: 0 floor(c / seg) segments | 1 ceil(c / seg) segments of at most seg hits
+  int roi_bwd_maxseg;      // ring: segments per tile at most (0 = default 8)
+  int roi_bwd_extras;      // ring: capacity of the extra-segment table (0 = default 128)
   int roi_bwd_ct;          // ring: channels per unit of the 7x7 kernel, 16 | 32 (0 = default = 32)
   int roi_bwd_ring;        // ring: LDS slots (hits in flight) of the 7x7 kernel, 2 | 3 | 4 (0 = default)
   int roi_bwd_groups;      // scan: ROI-list split over blockIdx.y (0 = auto)

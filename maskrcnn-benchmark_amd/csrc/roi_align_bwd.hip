@@ -47,6 +47,7 @@ struct RingPlan {
   int Hmax, Wmax;                      // per-ROI table slot = Hmax * PPH + Wmax * PPW floats
   int tab_blocks;                      // pre-pass: blocks [0, tab_blocks) = role A, the rest role B
   int seg, extra_cap, slot_cap;        // split policy and the capacities of the extras table / partial-sum slots
+  int split_ceil, max_seg;
   int debug;                           // ablation bits (tuning roi_bwd_debug): 1 = skip the walk
 };
 
@@ -286,8 +287,11 @@ roi_bwd_prep_kernel(Levels L, RingPlan P, RingWs ws, const float* __restrict__ r
   }
   if (!have_tile || lane != 0) return;
   int nseg = 1, sbase = 0;
-  if (c >= 2 * P.seg) {
-    const int want = min(kMaxSeg, c / P.seg);
+  // split policy (plan): 0 = floor(c / seg) segments of seg .. 2 seg - 1 hits once c >= 2 seg; 1 = ceil(c / seg)
+  // segments of at most seg hits once c > seg + seg / 4
+  const bool split = P.split_ceil ? (c > P.seg + P.seg / 4) : (c >= 2 * P.seg);
+  if (split) {
+    const int want = min(P.max_seg, P.split_ceil ? (c + P.seg - 1) / P.seg : c / P.seg);
     const int base = atomicAdd(&ws.ctrl[1], want);
     if (base + want <= P.slot_cap) {
       const int e0 = atomicAdd(&ws.ctrl[0], want - 1);
@@ -1308,8 +1312,11 @@ bool ring_plan(const Levels& L, int N, int C, int K, int PH, int PW, RingPlan& P
   const int seg = detops_tuning().roi_bwd_seg;
   P.seg = seg > 0 ? max(8, seg) : kSegDefault;
   // extra segments / partial-sum slots: sized by the map set, not by the data (a refused split is only slower)
-  P.extra_cap = static_cast<int>(std::min<int64_t>(128, std::max<int64_t>(8, tiles / 4)));
+  const int ecap = detops_tuning().roi_bwd_extras > 0 ? detops_tuning().roi_bwd_extras : 128;
+  P.extra_cap = static_cast<int>(std::min<int64_t>(ecap, std::max<int64_t>(8, tiles / 4)));
   P.slot_cap = 2 * P.extra_cap;
+  P.split_ceil = detops_tuning().roi_bwd_split == 1;
+  P.max_seg = detops_tuning().roi_bwd_maxseg > 0 ? std::min(detops_tuning().roi_bwd_maxseg, 32) : kMaxSeg;
   auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
   size_t o = kCtrlBytes;
   lay.off_arrive = o;   o = up(o + sizeof(int) * static_cast<size_t>(P.num_tiles) * P.chunks);

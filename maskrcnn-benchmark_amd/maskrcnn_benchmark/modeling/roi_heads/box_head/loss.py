@@ -65,7 +65,10 @@ class FastRCNNLossComputation(object):
             bl.add_field("matched_idxs", matched[i][sel])
             bl.add_field("valid", slot_valid[i])
             if p.has_field("objectness"):
-                bl.add_field("objectness", p.get_field("objectness")[sel])
+                obj = p.get_field("objectness")
+                if obj.shape[0] < boxes.shape[1]:     # lists of different lengths were padded to the longest: so is the field
+                    obj = torch.cat([obj, obj.new_zeros(boxes.shape[1] - obj.shape[0])])
+                bl.add_field("objectness", obj[sel])
             out.append(bl)
         self._proposals = out
         return out
