@@ -172,7 +172,9 @@ int detops_roi_pool_backward_f32(const float* grad_out, const float* rois,
  *   boxes [n,4] xyxy fp32, scores [n] fp32.  Sort order: score descending, ties broken by
  *   ascending original index (stable).
  *   keep      [n]  int64, first *num_keep entries valid (ascending original indices)
- *   num_keep  [1]  int32 on device (the caller decides when/if to read it back)
+ *   num_keep  [1]  int32 on device (the caller decides when/if to read it back); -1 = FAILED: a workgroup of the
+ *                  single-launch kernel waited for another one of the same launch beyond its polling budget (seconds:
+ *                  the compute units were held by other work) — nothing is kept for that segment (all-zero keep mask)
  *   Entirely device-side: no host round trip (the reference's CUDA path copies the n x n/64
  *   bitmask to the host and scans it there, csrc/cuda/nms.cu:100-123).
  * ---------------------------------------------------------------------------------------- */

@@ -268,6 +268,8 @@ struct DetopsTuning {
   int roi_bwd_scan_ct;     // scan: channels per workgroup, 4 | 16 (0 = auto)
   int roi_bwd_debug;       // ablation bits (diagnosis only)
   int nms_fused;           // 0 / 1 single launch for n <= 4096 | 2 three launches (sort, mask, scan) | 3 single launch, scans dispatched last
+  int nms_fault;           // tests: 1 = the fused launch's sort workgroups publish a wrong token (every consumer wait times out)
+  int nms_spin_budget;     // polls before a wait of the fused launch gives up (0 = default: seconds)
   int roi_fwd_impl;        // 0 auto | 1 generic gather kernel
   int roi_fwd_order;       // 0 auto | 1 never rank | 2 rank even for tiny maps
   int roi_fwd_order_mink;  // smallest K that gets the ranking pre-pass (0 = default)

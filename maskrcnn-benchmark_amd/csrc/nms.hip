@@ -333,20 +333,24 @@ __device__ __forceinline__ u64 uniform64(u64 v) {  // value known to be wave-uni
 // `removed |= row & -(kept bit)` with the same registers refilled from the NEXT block (rows / columns outside the
 // segment pick up words nobody consumes: no per-load predication; the mask region is padded to whole blocks).
 // `done` (fused launch): tile counters per row block; a block's rows are only requested once its nb - rb tiles are in.
+// Returns false when a wait for the tile counters ran out of its polling budget (fused launch only): the caller then
+// reports the segment as failed instead of publishing a keep set built from unpublished rows.
 template <int RPI>
-__device__ __forceinline__ void scan_chain(const u64* __restrict__ mask, int n, int nb, const int* done, u64* keptw) {
+__device__ __forceinline__ bool scan_chain(const u64* __restrict__ mask, int n, int nb, const int* done, u64* keptw, int spin_budget = kSpinBudget) {
   constexpr int CW = kWave / RPI, NIT = kWave / RPI;
   const int lane = threadIdx.x & (kWave - 1);
   const int sub = lane / CW, col = lane % CW;
   const int ccol = min(col, nb - 1);
   u64 ready = done ? 0ull : ~0ull;
-  int budget = kSpinBudget;
+  int budget = spin_budget;
+  bool timed_out = false;
   auto ensure = [&](int rbx) {                       // uniform: the tiles of row block rbx are in memory
     if ((ready >> rbx) & 1ull) return;
     for (;;) {
       const bool ok = lane < nb ? flag_peek(done + lane) >= nb - lane : true;
       ready = __ballot(ok);
-      if (((ready >> rbx) & 1ull) || !spin_again(budget)) break;
+      if ((ready >> rbx) & 1ull) break;
+      if (!spin_again(budget)) { timed_out = true; break; }
     }
     DETOPS_ACQUIRE_AGENT();                          // the rows of every block counted complete are now loadable
   };
@@ -391,14 +395,16 @@ __device__ __forceinline__ void scan_chain(const u64* __restrict__ mask, int n, 
       v[t] = pn[static_cast<size_t>(t * RPI) * nb];
     }
   }
+  return !timed_out;
 }
 
 // WIDE = false: the caller guarantees nb <= 32 (the one-row-per-load form and its 128 prefetch registers are left out)
 template <bool WIDE>
-__device__ __forceinline__ void scan_chain_any(const u64* __restrict__ mask, int n, int nb, const int* done, u64* keptw) {
-  if (nb <= 16) scan_chain<4>(mask, n, nb, done, keptw);
-  else if (nb <= 32 || !WIDE) scan_chain<2>(mask, n, nb, done, keptw);
-  else scan_chain<1>(mask, n, nb, done, keptw);
+__device__ __forceinline__ bool scan_chain_any(const u64* __restrict__ mask, int n, int nb, const int* done, u64* keptw,
+                                               int spin_budget = kSpinBudget) {
+  if (nb <= 16) return scan_chain<4>(mask, n, nb, done, keptw, spin_budget);
+  if (nb <= 32 || !WIDE) return scan_chain<2>(mask, n, nb, done, keptw, spin_budget);
+  return scan_chain<1>(mask, n, nb, done, keptw, spin_budget);
 }
 
 // kept sorted positions -> ascending ORIGINAL indices (at::nonzero(suppressed == 0), nms_cpu.cpp:64), the dense 0/1
@@ -551,6 +557,9 @@ constexpr int kFusedWaves = kScanThreads / kWave;   // tiles per tile workgroup
 struct FusedCtrl {        // one per segment, in the caller's workspace (arbitrary previous content)
   u64 token;              // == this launch's token once the segment's sorted boxes / areas / order are in memory
   int32_t done[kWave];    // finished mask tiles per row block; zeroed by the sort workgroup BEFORE the token
+  int32_t error;          // != 0: a wait of this launch ran out of its polling budget (zeroed by the sort workgroup
+                          // BEFORE the token, raised by tile workgroups, read by the scan workgroup after its chain)
+  int32_t pad[15];
 };
 
 // blockIdx.x:  [0, S)                 sort + gather of segment s, then publish the token
@@ -570,7 +579,7 @@ template <bool WIDE>   // false: max_n <= 2048 (every call the detector makes): 
 __global__ void __launch_bounds__(kScanThreads)
 nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                  const int32_t* __restrict__ seg_offsets, int n_single, int npad, float thr, Work w,
-                 FusedCtrl* __restrict__ ctrl, u64 token, int S, int G, int scan_first, int64_t* __restrict__ keep,
+                 FusedCtrl* __restrict__ ctrl, u64 token, u64 publish_token, int spin_budget, int S, int G, int scan_first, int64_t* __restrict__ keep,
                  int32_t* __restrict__ num_keep, uint8_t* __restrict__ keep_mask) {
   DETOPS_DYNAMIC_LDS(unsigned char, smem_raw);
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -580,6 +589,7 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
   if (bid < S) {                                                  // ---- sort
     const int s = bid;
     if (tid < kWave) store_u32_wt(&ctrl[s].done[tid], 0u);
+    if (tid == kWave) store_u32_wt(&ctrl[s].error, 0u);
     const SegView sv = seg_view(seg_offsets, n_single, s);
     if (sv.n <= 4 * kScanThreads)     // every call of the detector (n <= 2048): keys in registers
       sort_and_gather_reg<true>(reinterpret_cast<u64*>(smem_raw), boxes, scores, sv, w, s);
@@ -587,7 +597,7 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
       sort_and_gather<true>(reinterpret_cast<u64*>(smem_raw), boxes, scores, sv, npad, w, s);
     DETOPS_VMCNT_WAIT(0);            // this wave's write-through stores (sorted rows, the zeroed counters) are in memory
     __syncthreads();
-    if (tid == 0) flag_store_relaxed(&ctrl[s].token, token);   // everything it guards is already in memory
+    if (tid == 0) flag_store_relaxed(&ctrl[s].token, publish_token);   // everything it guards is already in memory (== token, except under the fault-injection switch)
     return;
   }
   if (bid < S + T) {                                              // ---- mask tiles, one per wave
@@ -603,11 +613,22 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
     int rb = 0;
     while (t >= nb - rb) { t -= nb - rb; ++rb; }                  // row lengths nb, nb - 1, ..., 1
     const int cb = rb + t;
+    int* s_ok = reinterpret_cast<int*>(smem_raw);
     if (wave == 0) {
-      int budget = kSpinBudget;
-      while (flag_peek(&ctrl[s].token) != token && spin_again(budget)) {}
+      int budget = spin_budget;
+      bool seen = true;
+      while (flag_peek(&ctrl[s].token) != token) {
+        if (!spin_again(budget)) { seen = false; break; }
+      }
+      if (lane == 0) s_ok[0] = seen ? 1 : 0;
     }
     __syncthreads();                 // waves without a tile have left; the barrier counts the remaining ones
+    if (!s_ok[0]) {
+      // the segment's sorted rows never showed up within the polling budget: this tile is NOT computed and NOT counted,
+      // so the scan workgroup cannot complete its chain either and reports the segment as failed (num_keep = -1)
+      if (tid == 0) flag_add(&ctrl[s].error, 1);
+      return;
+    }
     mask_tile<true>(w.boxes + static_cast<size_t>(s) * w.stride, w.areas + static_cast<size_t>(s) * w.stride,
                     w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, nb, rb, cb, thr);
     DETOPS_VMCNT_WAIT(0);            // the 64 write-through stores of this wave have reached memory
@@ -620,13 +641,23 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
   u64* keptw = reinterpret_cast<u64*>(smem_raw);
   u64* flags = keptw + kWave;
   int* wsum = reinterpret_cast<int*>(flags + kWave);
+  int* s_fail = wsum + kScanThreads / kWave;
   if (tid < kWave) flags[tid] = 0;
   if (wave == 0) {
-    int budget = kSpinBudget;
-    while (flag_peek(&ctrl[s].token) != token && spin_again(budget)) {}   // the counters below are valid from here on
+    int budget = spin_budget;
+    bool ok = true;
+    while (flag_peek(&ctrl[s].token) != token) {   // the counters below are valid from here on
+      if (!spin_again(budget)) { ok = false; break; }
+    }
     DETOPS_ACQUIRE_AGENT();
-    if (nb > 0)
-      scan_chain_any<WIDE>(w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, nb, ctrl[s].done, keptw);
+    if (ok && nb > 0)
+      ok = scan_chain_any<WIDE>(w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, nb, ctrl[s].done, keptw, spin_budget);
+    if (ok && flag_peek(&ctrl[s].error) != 0) ok = false;
+    // a wait ran out of its budget (a producer workgroup was starved for seconds — another process or stream holding
+    // the CUs): publish NOTHING for this segment and say so (num_keep[s] = -1, all-zero keep mask) instead of a keep
+    // set built from rows that were never written
+    if (!ok) keptw[lane] = 0ull;
+    if (lane == 0) s_fail[0] = ok ? 0 : 1;
     // every tile of the segment is counted in, so nobody reads the token any more: clear it.  A captured graph
     // replays this launch with the SAME token value — the cleared word is what makes the replay wait again.
     DETOPS_WAVE_SYNC();          // every lane of this wave has read the token
@@ -634,6 +665,7 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
   }
   __syncthreads();
   compact_keep(keptw, flags, wsum, w.order + static_cast<size_t>(s) * w.stride, sv, s, keep, num_keep, keep_mask);
+  if (tid == 0 && s_fail[0]) num_keep[s] = -1;     // (same thread that wrote the count in compact_keep)
 }
 
 // ---------------------------------------------------------------------------- host side
@@ -698,7 +730,9 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
     if (cap == 0) cap = detops_resident_workgroups(kernel, kScanThreads, 32 * 1024);   // -1: unknown / host emulation
     scan_first = (cap > 0 && 8 * S <= cap && detops_tuning().nms_fused != 3) ? 1 : 0;
     hipLaunchKernelGGL(kernel, dim3(2 * S + S * G), dim3(kScanThreads), lds, st, boxes, scores,
-                       seg_offsets, max_n, npad, thr, w, reinterpret_cast<FusedCtrl*>(base_ptr + l.off_ctrl), token, S, G,
+                       seg_offsets, max_n, npad, thr, w, reinterpret_cast<FusedCtrl*>(base_ptr + l.off_ctrl), token,
+                       detops_tuning().nms_fault == 1 ? (token ^ 2ull) : token,   // fault injection (tests): the token never shows up
+                       detops_tuning().nms_spin_budget > 0 ? detops_tuning().nms_spin_budget : kSpinBudget, S, G,
                        scan_first, keep, num_keep, keep_mask);
     return launch_status();
   }

@@ -141,7 +141,11 @@ def nms(dets, scores, threshold):
     with _on_device(dets):
         check(lib.detops_nms_f32(ptr(dets), ptr(scores), n, float(threshold), ptr(keep), ptr(num),
                                  ptr(ws), ws_bytes, stream_of(dets)), "nms")
-    return keep[: int(num.item())]  # the variable-length return value forces one readback
+    k = int(num.item())  # the variable-length return value forces one readback
+    if k < 0:
+        raise RuntimeError("nms: a device-side wait of the single-launch kernel timed out (num_keep = -1): the GPU's "
+                           "compute units were held by other work for seconds; no result was produced")
+    return keep[:k]
 
 
 def nms_batched(boxes, scores, seg_offsets, max_n, threshold):

@@ -552,6 +552,69 @@ def test_nms_single_launch_and_three_launch_paths(fused):
         _lib.tuning_set("nms_fused", 0)
 
 
+def test_nms_single_launch_timeout_is_reported_not_silently_wrong():
+    """a wait of the single-launch kernel that runs out of its polling budget must not publish a
+    keep set built from unpublished rows.  Fault injection: the sort workgroups publish a wrong token, the budget is a
+    few hundred polls -> every consumer wait times out -> num_keep = -1 and an all-zero keep mask per segment, and the
+    reference-named `nms` raises instead of returning indices."""
+    from maskrcnn_benchmark import _lib
+    segs = synth.rpn_nms_segments()[:4]
+    boxes = np.concatenate([b for b, _ in segs])
+    scores = np.concatenate([s for _, s in segs])
+    offs = np.cumsum([0] + [len(s) for _, s in segs]).astype(np.int32)
+    tb, ts, to = _t(boxes), _t(scores), _t(offs)
+    try:
+        _lib.tuning_set("nms_fault", 1)
+        _lib.tuning_set("nms_spin_budget", 200)
+        km, num = _C().nms_batched_mask(tb, ts, to, 2000, 0.7)
+        torch.cuda.synchronize()
+        assert (num.cpu().numpy() == -1).all(), num
+        assert not km.cpu().numpy().any()
+        with pytest.raises(RuntimeError, match="timed out"):
+            _C().nms(_t(segs[0][0]), _t(segs[0][1]), 0.7)
+    finally:
+        _lib.tuning_set("nms_fault", 0)
+        _lib.tuning_set("nms_spin_budget", 0)
+    # and the very next launch on the same workspace allocator is correct again
+    keep, num = _C().nms_batched(tb, ts, to, 2000, 0.7)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    for i, (b, sc) in enumerate(segs):
+        ref = oracle.nms(b, sc, 0.7)
+        assert num[i] == len(ref)
+        np.testing.assert_array_equal(keep[offs[i]:offs[i] + num[i]], ref)
+
+
+@pytest.mark.parametrize("fused", [0, 3])
+def test_nms_single_launch_under_concurrent_stream_load(fused):
+    """the single-launch kernel's workgroups wait for each other: both dispatch orders (0: scans right behind the sorts
+    when the device is otherwise empty, 3: scans last) stay bit-exact while ANOTHER stream keeps the compute units busy"""
+    from maskrcnn_benchmark import _lib
+    segs = synth.rpn_nms_segments()
+    boxes = np.concatenate([b for b, _ in segs])
+    scores = np.concatenate([s for _, s in segs])
+    offs = np.cumsum([0] + [len(s) for _, s in segs]).astype(np.int32)
+    tb, ts, to = _t(boxes), _t(scores), _t(offs)
+    refs = [oracle.nms(b, sc, 0.7) for b, sc in segs]
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    try:
+        _lib.tuning_set("nms_fused", fused)
+        outs = []
+        for rep in range(6):
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    a = torch.tanh(a @ a * 1e-4)          # long-running GEMMs that fill the chip
+            outs.append(_C().nms_batched(tb, ts, to, 2000, 0.7))
+        torch.cuda.synchronize()
+        for keep, num in outs:
+            keep, num = keep.cpu().numpy(), num.cpu().numpy()
+            for i, ref in enumerate(refs):
+                assert num[i] == len(ref), (fused, i, num[i])
+                np.testing.assert_array_equal(keep[offs[i]:offs[i] + num[i]], ref)
+    finally:
+        _lib.tuning_set("nms_fused", 0)
+
+
 def test_nms_threshold_boundary_is_exact():
     """Pairs whose IoU is EXACTLY the threshold, one ulp above and one ulp below it, and degenerate unions (negative
     "areas", huge coordinates) must come out as the reference's `inter / union >= thr` (nms_cpu.cpp:59-60) does: the
