@@ -747,10 +747,21 @@ def _fused_dcn_forward(input, weight, offset, mask, bias, out, kH, kW, padH, pad
 # channel-fastest, the GEMMs are plain library GEMMs on those layouts, the input gradient uses the transposed
 # sampling operator + a GEMM instead of the col2im scatter.  Served shapes: conv groups == 1, deformable_group == 1,
 # channel counts that are power-of-two multiples of a 16-byte vector (all model shapes).
-def _nhwc_ok(input, weight, group, dg):
+def _nhwc_ok(input, weight, group, dg, geom=None):
+    """channels-last pipeline applicable?  With `geom` (kH, kW, padH, padW, dH, dW, dilH, dilW, dg) the backward's index
+    plan is checked too (empty batches and shapes beyond its 32-bit limits return 0 bytes): callers then take the
+    reference-layout kernels BEFORE anything is launched instead of failing half way."""
     if group != 1 or dg != 1 or input.dtype not in _lib.DTYPE_CODE or _lib.tuning_get("dcn_nhwc") == 2:
         return False
-    return bool(lib.detops_deformable_nhwc_supported(_lib.DTYPE_CODE[input.dtype], input.size(1), weight.size(0), dg))
+    if input.numel() == 0:
+        return False
+    if not lib.detops_deformable_nhwc_supported(_lib.DTYPE_CODE[input.dtype], input.size(1), weight.size(0), dg):
+        return False
+    if geom is not None:
+        B, C, H, W = input.shape
+        if int(lib.detops_deformable_transposed_sample_workspace_bytes(B, C, H, W, *geom)) == 0:
+            return False
+    return True
 
 
 def _to_nhwc(x):
@@ -852,12 +863,12 @@ def deform_conv_backward_all(input, offset, mask, weight, grad_output, kH, kW, p
     -> (grad_input, grad_offset, grad_mask, grad_weight, grad_bias), None where not asked for / not applicable;
     returns None when the shape is outside the channels-last plan (the caller then uses the reference entry points)."""
     _dcn_check("deform_conv_backward_all", input, offset, weight, grad_output)
-    if not _nhwc_ok(input, weight, group, deformable_group):
+    geom = (kH, kW, padH, padW, dH, dW, dilH, dilW, deformable_group)
+    if not _nhwc_ok(input, weight, group, deformable_group, geom):
         return None
     input, offset, weight, grad_output = input.contiguous(), offset.contiguous(), weight.contiguous(), grad_output.contiguous()
     if mask is not None:
         mask = mask.contiguous()
-    geom = (kH, kW, padH, padW, dH, dW, dilH, dilW, deformable_group)
     B, C, H, W = input.shape
     Cout = weight.size(0)
     xT = _to_nhwc(input)
@@ -932,7 +943,8 @@ def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset,
                           dilationW, group, deformable_group)
     B, C = input.shape[:2]
     Cout = weight.size(0)
-    if gradInput.is_contiguous() and gradOffset.is_contiguous() and _nhwc_ok(input, weight, group, deformable_group):
+    if gradInput.is_contiguous() and gradOffset.is_contiguous() and _nhwc_ok(
+            input, weight, group, deformable_group, (kH, kW, padH, padW, dH, dW, dilationH, dilationW, deformable_group)):
         _nhwc_backward(input, weight, offset, None, gradOutput, gradInput, gradOffset, None, None, None,
                        (kH, kW, padH, padW, dH, dW, dilationH, dilationW, deformable_group))
         return 1
@@ -1043,7 +1055,7 @@ def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, colu
     geom = (kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w,
             deformable_group)
     if (grad_input.is_contiguous() and grad_weight.is_contiguous() and grad_offset.is_contiguous() and grad_mask.is_contiguous()
-            and _nhwc_ok(input, weight, group, deformable_group)):
+            and _nhwc_ok(input, weight, group, deformable_group, geom)):
         _nhwc_backward(input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight,
                        grad_bias if with_bias else None, geom)
         return

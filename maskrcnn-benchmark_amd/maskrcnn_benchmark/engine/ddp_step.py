@@ -42,7 +42,8 @@ class OverlappedSGD(torch.optim.Optimizer):
         self.deferred = False  # True while BucketedDataParallel applies the updates during backward
         # torch.amp.GradScaler.step() then hands `grad_scale` / `found_inf` over as attributes and does NOT read
         # found_inf back to the host: the fused kernel unscales and skips on the device (no sync in the fp16 step)
-        self._step_supports_amp_scaling = _FUSED_SGD and all(
+        # (only the fused path takes grad_scale / found_inf: momentum != 0 in every group, fp32 parameters on the GPU)
+        self._step_supports_amp_scaling = _FUSED_SGD and all(g["momentum"] != 0 for g in self.param_groups) and all(
             p.is_cuda and p.dtype == torch.float32 for g in self.param_groups for p in g["params"])
 
     @torch.no_grad()
@@ -75,7 +76,7 @@ class OverlappedSGD(torch.optim.Optimizer):
                 bufs = []
                 for p, gr in zip(ps, grads):
                     st = self.state[p]
-                    if "momentum_buffer" not in st:
+                    if st.get("momentum_buffer") is None:   # absent, or None in a torch.optim.SGD checkpoint saved before its first step
                         st["momentum_buffer"] = torch.zeros_like(gr, dtype=p.dtype)
                     bufs.append(st["momentum_buffer"])
                 torch._fused_sgd_(ps, grads, bufs, weight_decay=wd, momentum=mom, lr=lr, dampening=0.0, nesterov=False,
@@ -87,7 +88,7 @@ class OverlappedSGD(torch.optim.Optimizer):
                 bufs, fresh = [], []
                 for p, gr in zip(ps, grads):
                     st = self.state[p]
-                    if "momentum_buffer" not in st:
+                    if st.get("momentum_buffer") is None:
                         st["momentum_buffer"] = torch.clone(gr).detach()
                         fresh.append(True)
                     else:
@@ -151,12 +152,18 @@ class BucketedDataParallel(torch.nn.Module):
     Not supported, on purpose: gradient accumulation over several backward passes, trained buffers, parameters
     of a rank that change `requires_grad` after wrapping."""
 
-    def __init__(self, module, optimizer=None, bucket_cap_mb=25, process_group=None, overlap_optimizer=True):
+    def __init__(self, module, optimizer=None, bucket_cap_mb=25, process_group=None, overlap_optimizer=True,
+                 error_on_unused=False):
         super(BucketedDataParallel, self).__init__()
         self.module = module
         self.process_group = process_group if process_group is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.process_group)
         self.optimizer = optimizer if isinstance(optimizer, OverlappedSGD) else None
+        # A parameter without a gradient on THIS rank may have one on another: its slice is sent as zeros and the averaged
+        # gradient is then treated like any other — weight decay and momentum apply (torch.optim.SGD skips a parameter
+        # whose grad is None, which a rank cannot know about the other ranks without a read-back).  error_on_unused=True
+        # raises instead, like torch DDP without find_unused_parameters.
+        self.error_on_unused = bool(error_on_unused)
         self.overlap_optimizer = bool(overlap_optimizer) and self.optimizer is not None
         if self.optimizer is not None:
             self.optimizer.deferred = self.overlap_optimizer
@@ -196,7 +203,8 @@ class BucketedDataParallel(torch.nn.Module):
             by_kind.setdefault((t.dtype, t.device), []).append(t)
         for group in by_kind.values():
             flat = torch.cat([t.reshape(-1) for t in group])
-            dist.broadcast(flat, 0, group=self.process_group)   # group-local rank 0 == global rank 0 for WORLD
+            src = 0 if self.process_group is None else dist.get_global_rank(self.process_group, 0)   # broadcast takes a GLOBAL rank
+            dist.broadcast(flat, src, group=self.process_group)
             at = 0
             with torch.no_grad():
                 for t in group:
@@ -222,6 +230,9 @@ class BucketedDataParallel(torch.nn.Module):
     def _launch(self, b):
         grads = [p.grad for p in b.params]
         if any(g is None for g in grads):       # only on the flush path
+            if self.error_on_unused:
+                raise RuntimeError("BucketedDataParallel(error_on_unused=True): %d parameter(s) of a bucket received no "
+                                   "gradient in this backward pass" % sum(g is None for g in grads))
             for v, g in zip(b.views, grads):
                 v.copy_(g) if g is not None else v.zero_()
         else:

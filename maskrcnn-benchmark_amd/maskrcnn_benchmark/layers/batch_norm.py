@@ -39,11 +39,14 @@ class FrozenBatchNorm2d(nn.Module):
         self._folded = None
 
     def folded(self):
-        """(scale, bias) fp32 [C]: scale = weight * rsqrt(var), bias = bias - mean * scale.  Cached; the check on the hot
-        path is the sum of the four buffers' version counters (in-place writes, `load_state_dict`) — a replaced buffer
-        object (`.to()`, `.cuda()`, assignment) drops the cache through `_apply` / `__setattr__`."""
+        """(scale, bias) fp32 [C]: scale = weight * rsqrt(var), bias = bias - mean * scale.  Cached; the key checked on
+        the hot path is the four buffers' version counters (in-place writes, `load_state_dict`) AND their storage addresses
+        (`buf.data = x`, `module._buffers[name] = t`, which bypass `__setattr__` / `_apply`).  The one write no key can
+        see is an in-place write through the `.data` alias (`buf.data.copy_(x)` bumps no counter and moves nothing):
+        call `invalidate()` after it."""
         b = self._buffers      # (nn.Module.__getattr__ costs ~0.5 us per buffer access)
-        version = b["weight"]._version + b["bias"]._version + b["running_mean"]._version + b["running_var"]._version
+        w, bi, m, v = b["weight"], b["bias"], b["running_mean"], b["running_var"]
+        version = (w._version + bi._version + m._version + v._version, w.data_ptr(), bi.data_ptr(), m.data_ptr(), v.data_ptr())
         f = self._folded
         if f is None or f[0] != version:
             with torch.no_grad():
@@ -51,6 +54,10 @@ class FrozenBatchNorm2d(nn.Module):
                 bias = self.bias.float() - self.running_mean.float() * scale
             f = self._folded = (version, scale.contiguous(), bias.contiguous())
         return f[1], f[2]
+
+    def invalidate(self):
+        """drop the cached folded scale / bias (needed only after in-place writes through `.data`, see folded())"""
+        self._folded = None
 
     def _apply(self, fn, *args, **kwargs):
         self._folded = None

@@ -557,3 +557,29 @@ def test_mask_head_shared_box_features_uses_global_rows_for_every_image():
     seen.clear()
     head(feats, props, None)
     assert seen["x"].flatten().tolist() == [0, 1, 5, 6]
+
+
+def test_frozen_bn_folded_cache_follows_every_replacement_path():
+    """the cached folded scale / bias must notice in-place writes (version counters), `.data = x` and direct
+    `_buffers[...]` replacement (storage addresses); in-place writes through the `.data` alias are the documented case
+    for invalidate()."""
+    from maskrcnn_benchmark.layers.batch_norm import FrozenBatchNorm2d
+    bn = FrozenBatchNorm2d(4)
+
+    def expect():
+        scale = bn.weight * bn.running_var.rsqrt()
+        return scale, bn.bias - bn.running_mean * scale
+
+    def check():
+        s, b = bn.folded()
+        es, eb = expect()
+        assert torch.equal(s, es) and torch.equal(b, eb)
+
+    check()
+    bn.weight.mul_(2.0); check()                                  # in-place: version counter
+    bn.running_var.data = torch.full((4,), 4.0); check()          # .data = x: storage address
+    bn._buffers["bias"] = torch.full((4,), 0.5); check()          # direct replacement: storage address
+    bn.running_mean = torch.full((4,), 0.25); check()             # assignment: __setattr__
+    bn.load_state_dict({k: v * 3 for k, v in bn.state_dict().items()}); check()
+    bn.running_mean.data.copy_(torch.full((4,), 7.0))             # invisible to any key ...
+    bn.invalidate(); check()                                      # ... hence invalidate()
