@@ -174,6 +174,40 @@ def bench_roi_sets(C, iters, model_npz=None, only_sets=None, only_heads=None, wh
     return out
 
 
+def bench_targets(C, iters):
+    """IoU + Matcher and the balanced sampler at the RPN's shape (2 images x 268,569 anchors of the 800 x 1344 pyramid,
+    <= 20 ground-truth boxes) and at the box head's (2 x ~2,020 proposals); bytes: boxes + matched indices."""
+    out = []
+    rng = np.random.RandomState(9)
+    anchors = []
+    for stride in (4, 8, 16, 32, 64):        # the RPN's anchor grid of a padded 800 x 1344 image: 3 ratios per location
+        hh, ww = -(-800 // stride), -(-1344 // stride)
+        ys, xs = np.meshgrid(np.arange(hh) * stride, np.arange(ww) * stride, indexing="ij")
+        for r in (0.5, 1.0, 2.0):
+            w_, h_ = 8 * stride / np.sqrt(r), 8 * stride * np.sqrt(r)
+            anchors.append(np.stack([xs - w_ / 2, ys - h_ / 2, xs + w_ / 2, ys + h_ / 2], -1).reshape(hh * ww, 1, 4))
+    per_level = [np.concatenate(anchors[3 * l:3 * l + 3], 1).reshape(-1, 4) for l in range(5)]
+    rpn_anchors = np.concatenate(per_level).astype(np.float32)
+    assert rpn_anchors.shape[0] == 268569
+    for tag, K, M, B, lq in (("rpn 2x268569 anchors", 268569, 20, 256, True), ("box head 2x2020 proposals", 2020, 20, 512, False)):
+        x1 = rng.uniform(0, 1200, (K,)); y1 = rng.uniform(0, 700, (K,))
+        s_ = np.exp(rng.uniform(np.log(16), np.log(512), (K,)))
+        boxes = torch.from_numpy(np.stack([x1, y1, x1 + s_, y1 + s_ * rng.uniform(0.5, 2, (K,))], 1).astype(np.float32)).cuda()
+        if K == 268569:
+            boxes = torch.from_numpy(rpn_anchors).cuda()
+        gx = rng.uniform(0, 1000, (2, M)); gy = rng.uniform(0, 600, (2, M)); gs = rng.uniform(30, 400, (2, M))
+        gt = torch.from_numpy(np.stack([gx, gy, gx + gs, gy + gs], 2).astype(np.float32)).cuda()
+        valid = torch.ones(2, M, dtype=torch.bool, device="cuda")
+        valid[1, 12:] = False
+        us = dev_time_us(lambda: C.match_boxes(gt, valid, boxes, 0.7, 0.3, lq), iters)
+        out.append(_entry(f"match_boxes (IoU + Matcher, low-quality rule {'on' if lq else 'off'}) {tag}", us, 16 * K + 2 * 8 * K))
+        matched = C.match_boxes(gt, valid, boxes, 0.7, 0.3, lq)
+        labels = (matched >= 0).float() - (matched == -2).float()
+        us = dev_time_us(lambda: C.sample_labels(labels, B, B // 2, with_list=not lq), iters)
+        out.append(_entry(f"sample_labels B={B} {tag}", us, 2 * K * (4 + 2)))
+    return out
+
+
 def bench_nms(C, iters):
     out = []
     for n, uniform in [(819, False), (2000, False), (2000, True), (6000, False)]:
@@ -438,6 +472,8 @@ def main():
         res += bench_roi_align(C, args.iters, which=("fwd",))
     if not only or "nms" in only:
         res += bench_nms(C, args.iters)
+    if not only or "targets" in only:
+        res += bench_targets(C, args.iters)
     if not only or "frozen_bn" in only:
         res += bench_frozen_bn(C, args.iters)
     if not only or "focal" in only:
