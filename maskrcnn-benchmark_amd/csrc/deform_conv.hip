@@ -57,6 +57,25 @@ __device__ __forceinline__ void atomic_add_t(__hip_bfloat16* p, float v) {
   } while (old != assumed);
 }
 
+// Two adjacent elements (p 4-byte aligned for the 16-bit types) raised by (v0, v1): ONE hardware atomic for half / bf16
+// (global_atomic_pk_add_f16 / _bf16, gfx950) instead of two compare-and-swap loops on the containing dword.
+__device__ __forceinline__ void atomic_add2_t(float* p, float v0, float v1) { atomicAdd(p, v0); atomicAdd(p + 1, v1); }
+#ifdef DETOPS_CPU_EMU
+__device__ __forceinline__ void atomic_add2_t(__half* p, float v0, float v1) { atomic_add_t(p, v0); atomic_add_t(p + 1, v1); }
+__device__ __forceinline__ void atomic_add2_t(__hip_bfloat16* p, float v0, float v1) { atomic_add_t(p, v0); atomic_add_t(p + 1, v1); }
+#else
+__device__ __forceinline__ void atomic_add2_t(__half* p, float v0, float v1) {
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  const h2v v = {static_cast<_Float16>(v0), static_cast<_Float16>(v1)};
+  __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2v*)(p), v);
+}
+__device__ __forceinline__ void atomic_add2_t(__hip_bfloat16* p, float v0, float v1) {
+  typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+  const b2v v = {static_cast<__bf16>(v0), static_cast<__bf16>(v1)};
+  __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) b2v*)(p), v);
+}
+#endif
+
 struct Geom {
   int B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dg, Ho, Wo;
 };
@@ -593,6 +612,12 @@ struct EllOverflow {
   float w;
 };
 
+#ifdef DETOPS_CPU_EMU
+__device__ __forceinline__ int slot_fetch_add(int32_t* p) { return atomicAdd(p, 1); }
+#else
+__device__ __forceinline__ int slot_fetch_add(int32_t* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 col2im_ell_fill_kernel(const T* __restrict__ offset, const T* __restrict__ mask, Geom g, int64_t npoints,
@@ -612,13 +637,19 @@ col2im_ell_fill_kernel(const T* __restrict__ offset, const T* __restrict__ mask,
   if (mask) m = ld(mask + ((static_cast<size_t>(q.b) * g.dg + dgi) * K + q.tap) * HWo + q.pix);
   const int32_t colidx = q.tap * (g.B * HWo) + q.b * HWo + q.pix;
   const size_t img = static_cast<size_t>(q.b) * g.dg + dgi;
+  // the four slot requests first (independent relaxed atomics: four round trips in flight instead of one after the
+  // other), then the four record stores
+  int pos[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    pos[t] = -1;
+    if (tgt[t] >= 0) pos[t] = slot_fetch_add(counter + (img * K + q.tap) * HW + tgt[t]);   // counter: [img][tap][pixel]
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if (tgt[t] < 0) continue;
-    const size_t cslot = (img * K + q.tap) * HW + tgt[t];          // counter: [img][tap][pixel]
-    const int pos = atomicAdd(counter + cslot, 1);
-    if (pos < kEllCap) {
-      const size_t e = ((img * K + q.tap) * kEllCap + pos) * HW + tgt[t];   // [img][tap][slot][pixel]
+    if (pos[t] < kEllCap) {
+      const size_t e = ((img * K + q.tap) * kEllCap + pos[t]) * HW + tgt[t];   // [img][tap][slot][pixel]
       ent[e] = EllEntry{colidx, wgt[t] * m};
     } else {
       const int o = atomicAdd(ovf_count, 1);
@@ -1442,13 +1473,15 @@ sampleT_overflow_kernel(const T* __restrict__ gT, const int32_t* __restrict__ ov
                         int ovf_cap, T* __restrict__ S_T, Geom g, int Cout) {
   const int n = min(*ovf_count, ovf_cap);
   const int HWo = g.Ho * g.Wo, K = g.kh * g.kw;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < static_cast<int64_t>(n) * Cout;
+  const int half_c = Cout / 2;                    // channel pairs: one packed atomic each (Cout is even in the plan)
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < static_cast<int64_t>(n) * half_c;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const int e = static_cast<int>(i / Cout);
-    const int co = static_cast<int>(i - static_cast<int64_t>(e) * Cout);
+    const int e = static_cast<int>(i / half_c);
+    const int co = 2 * static_cast<int>(i - static_cast<int64_t>(e) * half_c);
     const EllOverflow o = ovf[e];                 // li = b * H * W + pixel (dg == 1), colidx = tap * B * HWo + q
     const int tap = o.colidx / (g.B * HWo), q = o.colidx - tap * (g.B * HWo);
-    atomic_add_t(S_T + (static_cast<size_t>(o.li) * K + tap) * Cout + co, o.w * ld(gT + static_cast<size_t>(q) * Cout + co));
+    const T* src = gT + static_cast<size_t>(q) * Cout + co;
+    atomic_add2_t(S_T + (static_cast<size_t>(o.li) * K + tap) * Cout + co, o.w * ld(src), o.w * ld(src + 1));
   }
 }
 
