@@ -59,9 +59,10 @@ struct RingWs {
   int4* lists;       // [num_tiles][cap] {roi * C * bins, roi * table bytes, fy0 | ny << 16, fx0 | nx << 16}, ascending ROI index
   float* tabs;       // [K][Hmax * PPH + Wmax * PPW], then 16 bytes of zeros
   float* partials;   // [slot_cap][chunks][256 pixels][CT]
+  long long* timeline;   // diagnosis only (roi_bwd_debug & 64): [grid.y][chunks] {start, end, hits, unit}
 };
 
-struct RingLayout { size_t off_arrive, off_heads, off_extras, off_lists, off_tabs, off_partials, zero_bytes, total; };
+struct RingLayout { size_t off_arrive, off_heads, off_extras, off_lists, off_tabs, off_partials, off_timeline, zero_bytes, total; };
 
 struct RoiExtent {
   int b;
@@ -444,6 +445,9 @@ roi_align_bwd_ring_kernel(Levels L, RingPlan P, RingWs ws, const float* __restri
 
   // ---- which unit?  the extra segments of split tiles come first in the grid (they are the long chains)
   int* s_tick = reinterpret_cast<int*>(s_ent + kEntRound);          // arrival ticket of a split tile
+#ifndef DETOPS_CPU_EMU
+  const long long t_start = (P.debug & 64) ? static_cast<long long>(wall_clock64()) : 0ll;
+#endif
   f2v acc[CT / 2];
   {
     // grid = (chunks, extras + tiles): linear workgroup id = unit * chunks + chunk, i.e. workgroup b still runs chunk
@@ -474,6 +478,12 @@ roi_align_bwd_ring_kernel(Levels L, RingPlan P, RingWs ws, const float* __restri
     for (int i = 0; i < G::NIG; ++i) goff_u[i] = static_cast<unsigned>(min(gch[i], C - 1 - c0) * (G::BINS * 4)) + grest[i];
     wy0 = y0 + 2 * wave;                                             // the wave's two rows: wy0, wy0 + 1
     if (tid == 0) { DETOPS_STAT("bwdr.units", 1); DETOPS_STAT("bwdr.hits", n); }
+#ifndef DETOPS_CPU_EMU
+    struct TimelineExit {   // written when the unit leaves, whichever path it takes
+      long long* slot; long long t0; int n, tile, seg; bool on;
+      __device__ ~TimelineExit() { if (on) { slot[0] = t0; slot[1] = static_cast<long long>(wall_clock64()); slot[2] = n; slot[3] = tile * 16 + seg; } }
+    } timeline_exit{ws.timeline + 4 * (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x), t_start, n, tile, seg, (P.debug & 64) && tid == 0};
+#endif
 #pragma unroll
     for (int c = 0; c < CT / 2; ++c) acc[c] = f2v{0.f, 0.f};
 
@@ -548,6 +558,7 @@ roi_align_bwd_ring_kernel(Levels L, RingPlan P, RingWs ws, const float* __restri
             }
           }
           DETOPS_WAVE_SYNC();
+          // (exec-masking these reads for lanes the ROI does not reach was measured: no gain, 1.45 -> 1.5 us per hit)
           {
             const float* tp = tr + min(xlo, PW - 1) * G::TS;
   #pragma unroll
@@ -1327,6 +1338,9 @@ bool ring_plan(const Levels& L, int N, int C, int K, int PH, int PW, RingPlan& P
   lay.off_tabs = o;     o = up(o + sizeof(float) * static_cast<size_t>(K) *
                                    (static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(P.Wmax) * P.PPW) + 16);   // + the zero piece
   lay.off_partials = o; o = up(o + sizeof(float) * static_cast<size_t>(P.slot_cap) * P.chunks * (kGTH * kGTW) * CT);
+  lay.off_timeline = o;
+  if (detops_tuning().roi_bwd_debug & 64)     // diagnosis: {start, end, hits, unit} per workgroup (tools/gpu/ring_timeline.py)
+    o = up(o + 32 * static_cast<size_t>(P.extra_cap + P.num_tiles) * P.chunks);
   lay.total = o;
   return true;
 }
@@ -1347,7 +1361,7 @@ int run_backward_ring(const Levels& L, const float* rois, const int32_t* levels_
   RingWs ws{reinterpret_cast<int*>(base), reinterpret_cast<int*>(base + lay.off_arrive),
             reinterpret_cast<int4*>(base + lay.off_heads), reinterpret_cast<int2*>(base + lay.off_extras),
             reinterpret_cast<int4*>(base + lay.off_lists), reinterpret_cast<float*>(base + lay.off_tabs),
-            reinterpret_cast<float*>(base + lay.off_partials)};
+            reinterpret_cast<float*>(base + lay.off_partials), reinterpret_cast<long long*>(base + lay.off_timeline)};
   DETOPS_HIP_TRY(hipMemsetAsync(base, 0, lay.zero_bytes, st));
   hipLaunchKernelGGL(roi_bwd_prep_kernel, dim3(static_cast<unsigned>(P.tab_blocks + ceil_div64(P.num_tiles, kPrepTiles))), dim3(kBlock), 0, st,
                      L, P, ws, rois, levels_in, K, C, PH, PW, sr);
