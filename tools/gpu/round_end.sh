@@ -30,7 +30,11 @@ if has trace; then
   fi; el trace
 fi
 if has opbench; then
-  timeout 600 python tools/opbench.py --iters 50 --json $O/opbench.json < /dev/null > $O/opbench.log 2>&1; grep -E "roi_align_(fwd|bwd) fpn|nms batched|frozen_bn|focal|match|dcn block" $O/opbench.log | cut -c1-150 | head -40; el opbench
+  timeout 600 python tools/opbench.py --iters 50 --json $O/opbench.json < /dev/null > $O/opbench.log 2>&1; grep -E "roi_align_(fwd|bwd) (fpn|cfg1)|nms batched|frozen_bn|focal|match_boxes|sample_labels|dcn_block" $O/opbench.log | cut -c1-150 | head -60; el opbench
+  # the > L3 variant (4 img/GPU: 365.6 MB of maps against the 256 MiB Infinity Cache)
+  timeout 300 python tools/opbench.py --only roi_sets --sets model-random-init --images 4 --iters 30 < /dev/null > $O/roi_align_l3_variant.log 2>&1; grep roi_align $O/roi_align_l3_variant.log | cut -c1-150; el l3-variant
+  timeout 200 python tools/gpu/cfg1_bwd.py 0 50 < /dev/null > $O/cfg1_bwd.log 2>&1; grep cfg1 $O/cfg1_bwd.log; el cfg1
+  timeout 200 python tools/gpu/ring_timeline.py model-random-init < /dev/null > $O/ring_timeline.txt 2>&1; head -8 $O/ring_timeline.txt; el timeline
 fi
 if has pmc; then
   PM="python tools/opbench.py --only roi_sets --heads box --dir bwd --iters 5 --sets model-random-init"
@@ -41,6 +45,16 @@ if has pmc; then
     timeout 150 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$n -o x -- $PM < /dev/null > $O/pmc_$n.log 2>&1
   done
   python tools/pmc_diag.py /tmp/pmc_sq /tmp/pmc_sq2 /tmp/pmc_tcc /tmp/pmc_fw /tmp/pmc_ww > $O/roi_align_bwd_ring_pmc.txt 2>&1; grep -v "roi_order" $O/roi_align_bwd_ring_pmc.txt | head -40; el pmc-ring
+  for d in fwd; do
+    PF="python tools/opbench.py --only roi_sets --heads box --dir $d --iters 5 --sets model-random-init"
+    for pass in "sq:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+                "sq2:SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+                "tcc:TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "fw:FETCH_SIZE" "ww:WRITE_SIZE"; do
+      n=${pass%%:*}; c=${pass#*:}; rm -rf /tmp/pmcf_$n
+      timeout 150 rocprofv3 --pmc $c --output-format csv -d /tmp/pmcf_$n -o x -- $PF < /dev/null > $O/pmcf_$n.log 2>&1
+    done
+    python tools/pmc_diag.py /tmp/pmcf_sq /tmp/pmcf_sq2 /tmp/pmcf_tcc /tmp/pmcf_fw /tmp/pmcf_ww > $O/roi_align_fwd_pmc.txt 2>&1; grep -A28 "roi_align_fwd_dma" $O/roi_align_fwd_pmc.txt | head -32; el pmc-fwd
+  done
   TR="python tools/opbench.py --only roi_align_fpn,frozen_bn,nms,dcn_block --iters 5"
   rm -rf /tmp/tr_f /tmp/tr_w
   timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/tr_f -o x -- $TR < /dev/null > $O/traffic_fetch.log 2>&1
