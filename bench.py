@@ -526,7 +526,11 @@ def main():
     progress("model + %d device batches ready" % len(batches))
     losses = None
     ddp_mode = "overlapped-sgd-hook" if (distributed or args.force_ddp) else "single"
+    call_counter = None
     for i in range(args.warmup):
+        if i == args.warmup - 1 and not args.no_kernel_timing:
+            call_counter = _C.KernelTimer(count_only=True)   # how often is each entry point called per step?  (no events)
+            _C.KERNEL_TIMER = call_counter
         try:
             losses = step(*batches[i % len(batches)])
             torch.cuda.synchronize(device)
@@ -546,10 +550,16 @@ def main():
             losses = step(*batches[i % len(batches)])
             torch.cuda.synchronize(device)
         progress("warm-up step %d done" % (i + 1))
-    # The kernel timers cost host time (two event records per timed launch).  They run on EVERY rank so that no rank is a
-    # taxed straggler under the max-over-ranks clock (rank 0's figures are the ones reported); sampled entry points are
-    # sampled densely enough for >= 10 event pairs per name over the timed steps.
-    timer = None if args.no_kernel_timing else _C.KernelTimer(every_cap=max(1, args.steps // 10))
+    _C.KERNEL_TIMER = None
+    # The kernel timers cost device time (the event records around a timed launch drain the queue: ~30 us per timed
+    # launch in the fp32 step, ~100 us under fp16).  They run on EVERY rank so that no rank is a taxed straggler under the
+    # max-over-ranks clock (rank 0's figures are the ones reported), and every entry point is sampled with its own
+    # stride — calls per step (counted in the last warm-up step) x steps / 12 — so that each name gets >= 10 event pairs
+    # over the timed steps and not many more, whatever --steps is.
+    timer = None
+    if not args.no_kernel_timing:
+        strides = {name: max(1, (n * args.steps) // 12) for name, n in (call_counter.calls if call_counter else {}).items()}
+        timer = _C.KernelTimer(every_cap=max(1, args.steps // 10), strides=strides)
 
     def install_timer():
         _C.KERNEL_TIMER = timer

@@ -143,6 +143,22 @@ int detops_roi_align_fpn_backward_ws_f32(const float* grad_out, const float* roi
                                          int zero_grad_in, void* workspace, size_t workspace_bytes,
                                          detops_stream_t stream);
 
+/* The binned backward in two calls.  Its pre-pass (per-ROI adjoint rows + per-tile hit lists) depends on the ROIs and the
+ * map shapes only: `..._prepare_f32` may be issued at FORWARD time, on any stream, into a workspace of
+ * detops_roi_align_backward_workspace_bytes(...) bytes that the caller keeps until the backward pass; `..._prepared_f32`
+ * (same shapes, same workspace, stream-ordered after the prepare call) then launches the main kernel alone.  `prepare`
+ * returns DETOPS_EUNSUPPORTED when the shape is served by the other kernels: use detops_roi_align_fpn_backward_ws_f32. */
+int detops_roi_align_fpn_backward_prepare_f32(const float* rois, const int32_t* levels, const int* H_host,
+                                              const int* W_host, const float* scale_host, int num_levels, int N,
+                                              int C, int K, int PH, int PW, int sampling_ratio, void* workspace,
+                                              size_t workspace_bytes, detops_stream_t stream);
+
+int detops_roi_align_fpn_backward_prepared_f32(const float* grad_out, float* const* grad_inputs_host,
+                                               const int* H_host, const int* W_host, const float* scale_host,
+                                               int num_levels, int N, int C, int K, int PH, int PW,
+                                               int zero_grad_in, void* workspace, size_t workspace_bytes,
+                                               detops_stream_t stream);
+
 int detops_roi_align_fpn_backward_f32(const float* grad_out, const float* rois,
                                       const int32_t* levels, float* const* grad_inputs_host,
                                       const int* H_host, const int* W_host,

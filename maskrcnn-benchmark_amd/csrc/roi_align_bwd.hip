@@ -190,13 +190,6 @@ roi_bwd_prep_kernel(Levels L, RingPlan P, RingWs ws, const float* __restrict__ r
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   if (static_cast<int>(blockIdx.x) < P.tab_blocks) {
     const int r = static_cast<int>(blockIdx.x) * (kBlock / kWave) + wave;
-    if (blockIdx.x == 0 && tid == 0) {   // per-level store geometry for the main kernel (one scalar load instead of an 8-way select)
-#pragma unroll
-      for (int i = 0; i < DETOPS_MAX_LEVELS; ++i) {
-        const unsigned long long gp = reinterpret_cast<unsigned long long>(L.lv[i].gin);
-        reinterpret_cast<int4*>(ws.ctrl + 16)[i] = make_int4(static_cast<int>(gp & 0xffffffffu), static_cast<int>(gp >> 32), L.lv[i].H, L.lv[i].W);
-      }
-    }
     if (blockIdx.x == 0 && tid < 4)   // the zero piece behind the last ROI's rows (rows of pixels outside a footprint)
       ws.tabs[static_cast<size_t>(K) * (static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(P.Wmax) * P.PPW) + tid] = 0.f;
     if (r >= K) return;
@@ -651,10 +644,12 @@ roi_align_bwd_ring_kernel(Levels L, RingPlan P, RingWs ws, const float* __restri
     if (store) {
       // two full 128-byte rows per wave and channel, straight from the accumulators; every in-map element of the
       // tile is written exactly once (zeros where no ROI reaches)
-      const int4 lt = reinterpret_cast<const int4*>(ws.ctrl + 16)[lvl];   // {gin lo, gin hi, H, W}: written by the pre-pass
-      float* gin = reinterpret_cast<float*>((static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(lt.y))) << 32) |
-                                            static_cast<unsigned>(__builtin_amdgcn_readfirstlane(lt.x)));
-      const int H = __builtin_amdgcn_readfirstlane(lt.z), W = __builtin_amdgcn_readfirstlane(lt.w);
+      // the level's gradient map from THIS launch's arguments (wave-uniform select, once per unit): the pre-pass may
+      // have run at forward time, before the gradient maps existed
+      float* gin = L.lv[0].gin; int H = L.lv[0].H, W = L.lv[0].W;
+#pragma unroll
+      for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+        if (i == lvl) { gin = L.lv[i].gin; H = L.lv[i].H; W = L.lv[i].W; }
       if (y0 + yl < H && x0 + xl < W) {
         const size_t plane = static_cast<size_t>(H) * W;
         float* dst = gin + (static_cast<size_t>(img) * C + c0) * plane + static_cast<size_t>(y0 + yl) * W + (x0 + xl);
@@ -1346,9 +1341,11 @@ bool ring_plan(const Levels& L, int N, int C, int K, int PH, int PW, RingPlan& P
 }
 
 // -1: not applicable (no / too small workspace, shape outside the plan, underfilled launch) -> scan kernel
+// phase: 0 = pre-pass + main kernel (one call), 1 = pre-pass only (may run at forward time, on another stream: it
+// needs the ROIs and the map shapes, not the gradient), 2 = main kernel only (the workspace holds a phase-1 result)
 int run_backward_ring(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
                       int N, int C, int K, int PH, int PW, int sr, int accumulate, void* workspace,
-                      size_t workspace_bytes, bool forced, hipStream_t st) {
+                      size_t workspace_bytes, bool forced, hipStream_t st, int phase = 0) {
   if (C == 0 || N == 0) return 0;
   if (!workspace || K == 0) return -1;
   RingPlan P; RingLayout lay;
@@ -1362,9 +1359,12 @@ int run_backward_ring(const Levels& L, const float* rois, const int32_t* levels_
             reinterpret_cast<int4*>(base + lay.off_heads), reinterpret_cast<int2*>(base + lay.off_extras),
             reinterpret_cast<int4*>(base + lay.off_lists), reinterpret_cast<float*>(base + lay.off_tabs),
             reinterpret_cast<float*>(base + lay.off_partials), reinterpret_cast<long long*>(base + lay.off_timeline)};
-  DETOPS_HIP_TRY(hipMemsetAsync(base, 0, lay.zero_bytes, st));
-  hipLaunchKernelGGL(roi_bwd_prep_kernel, dim3(static_cast<unsigned>(P.tab_blocks + ceil_div64(P.num_tiles, kPrepTiles))), dim3(kBlock), 0, st,
-                     L, P, ws, rois, levels_in, K, C, PH, PW, sr);
+  if (phase != 2) {
+    DETOPS_HIP_TRY(hipMemsetAsync(base, 0, lay.zero_bytes, st));
+    hipLaunchKernelGGL(roi_bwd_prep_kernel, dim3(static_cast<unsigned>(P.tab_blocks + ceil_div64(P.num_tiles, kPrepTiles))), dim3(kBlock), 0, st,
+                       L, P, ws, rois, levels_in, K, C, PH, PW, sr);
+    if (phase == 1) return launch_status();
+  }
   const dim3 grid(static_cast<unsigned>(P.chunks), static_cast<unsigned>(P.extra_cap + P.num_tiles));
   if (PH == 7) {
     const int nr = detops_tuning().roi_bwd_ring ? detops_tuning().roi_bwd_ring : kRingSlots;
@@ -1599,6 +1599,47 @@ DETOPS_API int detops_roi_align_fpn_backward_ws_f32(
   if (K == 0 && !zero_grad_in) return 0;
   return run_backward(L, rois, levels, grad_out, N, C, K, PH, PW, sampling_ratio,
                       zero_grad_in ? 0 : 1, as_stream(stream), workspace, workspace_bytes);
+}
+
+// ---- the ring backward in two calls: the pre-pass (hit lists + adjoint rows: a function of the ROIs and the map shapes
+// only) can be issued at FORWARD time, on any stream, into a workspace the caller keeps; the backward pass then launches
+// the main kernel alone.  Returns DETOPS_EUNSUPPORTED when the ring plan does not apply (the caller uses the one-call entry).
+DETOPS_API int detops_roi_align_fpn_backward_prepare_f32(
+    const float* rois, const int32_t* levels, const int* H_host, const int* W_host, const float* scale_host,
+    int num_levels, int N, int C, int K, int PH, int PW, int sampling_ratio, void* workspace, size_t workspace_bytes,
+    detops_stream_t stream) {
+  if (bad_dims(N, C, K, PH, PW) || num_levels < 1 || num_levels > DETOPS_MAX_LEVELS || !H_host || !W_host || !scale_host)
+    return DETOPS_EINVAL;
+  if (K <= 0 || C == 0 || N == 0 || !rois || (num_levels > 1 && !levels) || !workspace) return DETOPS_EUNSUPPORTED;
+  const int impl = detops_tuning().roi_bwd_impl;
+  if (impl != 0 && impl != 1) return DETOPS_EUNSUPPORTED;
+  Levels L{};
+  L.num = num_levels;
+  for (int i = 0; i < num_levels; ++i) {
+    if (H_host[i] <= 0 || W_host[i] <= 0) return DETOPS_EINVAL;
+    L.lv[i] = Level{nullptr, nullptr, H_host[i], W_host[i], scale_host[i]};
+  }
+  const int rc = run_backward_ring(L, rois, levels, nullptr, N, C, K, PH, PW, sampling_ratio, 0, workspace, workspace_bytes,
+                                   impl == 1, as_stream(stream), 1);
+  return rc == -1 ? DETOPS_EUNSUPPORTED : rc;
+}
+
+DETOPS_API int detops_roi_align_fpn_backward_prepared_f32(
+    const float* grad_out, float* const* grad_inputs_host, const int* H_host, const int* W_host, const float* scale_host,
+    int num_levels, int N, int C, int K, int PH, int PW, int zero_grad_in, void* workspace, size_t workspace_bytes,
+    detops_stream_t stream) {
+  if (bad_dims(N, C, K, PH, PW) || num_levels < 1 || num_levels > DETOPS_MAX_LEVELS || !grad_inputs_host || !H_host ||
+      !W_host || !scale_host || !grad_out || !workspace || K <= 0)
+    return DETOPS_EINVAL;
+  Levels L{};
+  L.num = num_levels;
+  for (int i = 0; i < num_levels; ++i) {
+    if (!grad_inputs_host[i] || H_host[i] <= 0 || W_host[i] <= 0) return DETOPS_EINVAL;
+    L.lv[i] = Level{nullptr, grad_inputs_host[i], H_host[i], W_host[i], scale_host[i]};
+  }
+  const int rc = run_backward_ring(L, nullptr, nullptr, grad_out, N, C, K, PH, PW, 0, zero_grad_in ? 0 : 1, workspace,
+                                   workspace_bytes, true, as_stream(stream), 2);
+  return rc == -1 ? DETOPS_EUNSUPPORTED : rc;
 }
 
 DETOPS_API int detops_roi_align_fpn_backward_f32(

@@ -56,16 +56,24 @@ class KernelTimer(object):
     High-frequency entry points (FrozenBN: ~100 launches per step) are SAMPLED — every `every`-th call of a name
     gets an event pair, all calls are counted — so that the timer's own host cost stays out of the step."""
 
-    def __init__(self, every_cap=None):
+    def __init__(self, every_cap=None, strides=None, count_only=False):
         self.pairs = {}
         self.calls = {}
-        self.every_cap = every_cap   # upper bound on the sampling stride (short runs: enough samples per name)
+        self.every_cap = every_cap     # upper bound on the sampling stride (short runs: enough samples per name)
+        self.strides = strides or {}   # per-name sampling stride (bench.py: from the call counts of a warm-up step, so
+        self.count_only = count_only   # that every name gets ~12 event pairs over the timed steps and no more: a timed
+                                       # launch costs ~30-100 us of device time — the event records drain the queue)
 
     def span(self, name, t, every=1):
         """`name`: a string or (format, args) — kept as the key and formatted in results() (no string work per launch)"""
         n = self.calls.get(name, 0)
         self.calls[name] = n + 1
-        if self.every_cap is not None and every > self.every_cap:
+        if self.count_only:
+            return _NOSPAN
+        stride = self.strides.get(name)
+        if stride is not None:
+            every = stride
+        elif self.every_cap is not None and every > self.every_cap:
             every = self.every_cap
         return _Span(self, name, t) if n % every == 0 else _NOSPAN
 
@@ -454,15 +462,72 @@ def roi_align_fpn_forward(inputs, rois, scales, pooled_height, pooled_width, sam
     return out, levels
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """one auxiliary stream per device for work that only has to be finished by the backward pass"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _SIDE_STREAMS.get(idx)
+    if s is None:
+        s = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return s
+
+
+def roi_align_fpn_backward_prepare(rois, levels, shapes, scales, pooled_height, pooled_width, sampling_ratio):
+    """The backward's pre-pass (per-ROI adjoint rows + per-tile hit lists: a function of the ROIs and the map shapes only),
+    issued at FORWARD time on a side stream so that it is off the backward pass's critical path.  Returns an opaque
+    handle for roi_align_fpn_backward(prepared=...), or None when the shape is served by the one-call kernels."""
+    K = rois.size(0)
+    if K == 0 or not rois.is_cuda:
+        return None
+    N, C = shapes[0][:2]
+    L = len(shapes)
+    Hs = (ctypes.c_int * L)(*[s[2] for s in shapes])
+    Ws = (ctypes.c_int * L)(*[s[3] for s in shapes])
+    sc = (ctypes.c_float * L)(*[float(s) for s in scales])
+    nbytes = int(lib.detops_roi_align_backward_workspace_bytes(Hs, Ws, L, int(N), int(C), int(K), int(pooled_height), int(pooled_width)))
+    if nbytes <= 0:
+        return None
+    main = torch.cuda.current_stream(rois.device)
+    side = _side_stream(rois.device)
+    side.wait_stream(main)                       # the ROIs and their levels are produced on the main stream
+    with torch.cuda.stream(side):
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=rois.device)
+        with _timed(("roi_align_fpn_bwd_prepare[K=%d,C=%d,%dx%d]", (K, C, pooled_height, pooled_width)), rois):
+            rc = lib.detops_roi_align_fpn_backward_prepare_f32(
+                ptr(rois), ptr(levels), Hs, Ws, sc, L, int(N), int(C), int(K), int(pooled_height), int(pooled_width),
+                int(sampling_ratio), ptr(ws), nbytes, side.cuda_stream)
+        if rc == -3:                             # DETOPS_EUNSUPPORTED: the other kernels serve this shape
+            return None
+        check(rc, "roi_align_fpn_backward_prepare")
+        done = torch.cuda.Event()
+        done.record(side)
+    ws.record_stream(main)                       # used by the backward pass on the main stream
+    rois.record_stream(side)
+    levels.record_stream(side)
+    return ws, nbytes, done
+
+
 def roi_align_fpn_backward(grad, rois, levels, shapes, scales, pooled_height, pooled_width,
-                           sampling_ratio):
-    """Backward of roi_align_fpn_forward: returns one zero-initialised gradient map per level."""
+                           sampling_ratio, prepared=None):
+    """Backward of roi_align_fpn_forward: returns one zero-initialised gradient map per level.  `prepared`: the handle of
+    roi_align_fpn_backward_prepare (the pre-pass already ran): only the main kernel is launched."""
     _need_cuda("roi_align_fpn_backward", grad, rois, levels)
     grad = _f32c("roi_align_fpn_backward", grad)
     K = rois.size(0)
     gins = [torch.empty(tuple(s), dtype=torch.float32, device=grad.device) for s in shapes]
     N, C = shapes[0][:2]
     ptrs, Hs, Ws, sc = _host_arrays(gins, scales)
+    if prepared is not None:
+        ws, nbytes, done = prepared
+        with _on_device(grad):
+            torch.cuda.current_stream(grad.device).wait_event(done)
+            with _timed(("roi_align_fpn_bwd[K=%d,C=%d,%dx%d]", (K, C, pooled_height, pooled_width)), grad):
+                check(lib.detops_roi_align_fpn_backward_prepared_f32(
+                    ptr(grad), ptrs, Hs, Ws, sc, len(gins), N, C, K, pooled_height, pooled_width, 1, ptr(ws), nbytes,
+                    stream_of(grad)), "roi_align_fpn_backward(prepared)")
+        return gins
     with _on_device(grad):
         ws, nbytes = _bwd_workspace(grad.device, Hs, Ws, len(gins), N, C, K, pooled_height, pooled_width)
         with _timed(("roi_align_fpn_bwd[K=%d,C=%d,%dx%d]", (K, C, pooled_height, pooled_width)), grad):

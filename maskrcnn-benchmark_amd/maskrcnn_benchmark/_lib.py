@@ -28,6 +28,8 @@ SIGNATURES = {
         c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "detops_roi_align_fpn_backward_ws_f32": (
         c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P, c_size_t, _P]),
+    "detops_roi_align_fpn_backward_prepare_f32": (c_int, [_P] * 5 + [c_int] * 7 + [_P, c_size_t, _P]),
+    "detops_roi_align_fpn_backward_prepared_f32": (c_int, [_P] * 5 + [c_int] * 7 + [_P, c_size_t, _P]),
     "detops_roi_align_backward_ws_f32": (
         c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P, c_size_t, _P]),
     "detops_roi_align_backward_workspace_bytes": (c_size_t, [_P, _P] + [c_int] * 6),

@@ -46,6 +46,12 @@ class _ROIAlignFPN(Function):
         ctx.save_for_backward(rois, levels)
         ctx.cfg = (output_size, scales, sampling_ratio)
         ctx.shapes = [tuple(f.shape) for f in features]
+        # the backward's pre-pass needs the ROIs and the map shapes only: issued now, on a side stream, it is finished
+        # long before the backward pass asks for it (None: this shape does not use it)
+        ctx.prepared = None
+        if any(ctx.needs_input_grad[6:]) and rois.is_cuda:
+            ctx.prepared = _C.roi_align_fpn_backward_prepare(rois, levels, ctx.shapes, scales, output_size[0],
+                                                             output_size[1], sampling_ratio)
         return out
 
     @staticmethod
@@ -54,7 +60,8 @@ class _ROIAlignFPN(Function):
         rois, levels = ctx.saved_tensors
         output_size, scales, sampling_ratio = ctx.cfg
         grads = _C.roi_align_fpn_backward(grad, rois, levels, ctx.shapes, scales, output_size[0],
-                                          output_size[1], sampling_ratio)
+                                          output_size[1], sampling_ratio, prepared=ctx.prepared)
+        ctx.prepared = None
         return (None, None, None, None, None, None) + tuple(grads)
 
 

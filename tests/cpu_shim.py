@@ -41,7 +41,7 @@ def _fpn_forward(inputs, rois, scales, ph, pw, sr, k_min, k_max, canonical_scale
     return torch.from_numpy(out), torch.from_numpy(lv.astype(np.int32))
 
 
-def _fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr):
+def _fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr, prepared=None):
     r, g, lv = _np(rois.float()), _np(grad.float()), _np(levels)
     outs = []
     for l, (shp, s) in enumerate(zip(shapes, scales)):

@@ -22,6 +22,8 @@ SIGNATURES = {
     "detops_roi_align_fpn_backward_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P]),
     "detops_roi_align_fpn_backward_ws_f32": (
         c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P, ctypes.c_size_t, _P]),
+    "detops_roi_align_fpn_backward_prepare_f32": (c_int, [_P] * 5 + [c_int] * 7 + [_P, ctypes.c_size_t, _P]),
+    "detops_roi_align_fpn_backward_prepared_f32": (c_int, [_P] * 5 + [c_int] * 7 + [_P, ctypes.c_size_t, _P]),
     "detops_roi_align_backward_ws_f32": (
         c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P, ctypes.c_size_t, _P]),
     "detops_roi_align_backward_workspace_bytes": (ctypes.c_size_t, [_P, _P] + [c_int] * 6),
@@ -146,6 +148,30 @@ def _host_arrays(arrs, scales):
     Ws = (ctypes.c_int * L)(*[a.shape[3] for a in arrs])
     sc = (ctypes.c_float * L)(*[float(s) for s in scales])
     return ptrs, Hs, Ws, sc
+
+
+def roi_align_fpn_backward_two_calls(grad, rois, levels, shapes, scales, ph, pw, sr):
+    """the ring backward as prepare (forward time) + prepared (backward time): -> list of gradient maps, or None when the
+    shape is served by the one-call kernels"""
+    grad, rois = _f32(grad), _f32(rois)
+    levels = np.ascontiguousarray(levels, dtype=np.int32)
+    K = rois.shape[0]
+    gins = [np.full(s, np.nan, np.float32) for s in shapes]
+    ptrs, Hs, Ws, sc = _host_arrays(gins, scales)
+    N, C = shapes[0][:2]
+    nbytes = lib().detops_roi_align_backward_workspace_bytes(Hs, Ws, len(shapes), N, C, K, ph, pw)
+    if nbytes == 0:
+        return None
+    ws = np.full((nbytes,), 0xAB, np.uint8)
+    rc = lib().detops_roi_align_fpn_backward_prepare_f32(_p(rois), _p(levels), Hs, Ws, sc, len(shapes), N, C, K, ph, pw, sr,
+                                                         _p(ws), nbytes, None)
+    if rc == -3:
+        return None
+    assert rc == 0, rc
+    rc = lib().detops_roi_align_fpn_backward_prepared_f32(_p(grad), ptrs, Hs, Ws, sc, len(shapes), N, C, K, ph, pw, 1,
+                                                          _p(ws), nbytes, None)
+    assert rc == 0, rc
+    return gins
 
 
 def roi_align_fpn_forward(feats, rois, scales, ph, pw, sr, k_min, k_max):

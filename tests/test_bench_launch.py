@@ -82,3 +82,23 @@ def test_hw_queue_pin_and_sampling_cap():
     # the driver's --steps 20)
     spans = [t.span("frozen_bn_fwd", x, every=8) for _ in range(20)]
     assert sum(s is not _NOSPAN for s in spans) == 10
+
+
+def test_kernel_timer_per_name_strides_from_a_counted_step():
+    """bench.py's sampling plan: a counting pass (no events) over one warm-up step gives calls per step per entry point; the
+    timed region then samples every name with stride calls x steps / 12 -> >= 10 event pairs per name, few more."""
+    pytest.importorskip("torch")
+    sys.path.insert(0, os.path.join(ROOT, "maskrcnn-benchmark_amd"))
+    import torch
+    from maskrcnn_benchmark._C import KernelTimer, _NOSPAN
+    x = torch.zeros(1)
+    counter = KernelTimer(count_only=True)
+    per_step = {"frozen_bn_fwd[a]": 13, "roi_align_fpn_fwd[b]": 1, "frozen_bn_bwd[c]": 3}
+    for name, n in per_step.items():
+        assert all(counter.span(name, x, every=8) is _NOSPAN for _ in range(n))
+    steps = 20
+    strides = {name: max(1, (n * steps) // 12) for name, n in counter.calls.items()}
+    timer = KernelTimer(every_cap=2, strides=strides)
+    sampled = {name: sum(timer.span(name, x, every=8) is not _NOSPAN for _ in range(n * steps)) for name, n in per_step.items()}
+    assert all(10 <= v <= 24 for v in sampled.values()), sampled
+    assert sum(sampled.values()) < sum(per_step.values()) * steps / 4      # far fewer than "every 2nd call of everything"

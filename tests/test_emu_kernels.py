@@ -673,3 +673,26 @@ def test_emu_deform_conv_forward_fused_mfma(geom, modulated):
     f = lambda a: None if a is None else a.astype(np.float16).astype(np.float32)  # noqa: E731
     ref = oracle.deform_conv_forward(f(x), f(off), f(mask), f(wgt), f(bias), group=1, dg=g["dg"], **geo)
     assert np.abs(out.astype(np.float32) - ref).max() <= 2e-2 * np.abs(ref).max()
+
+
+def test_emu_roi_align_backward_prepare_then_prepared_equals_one_call():
+    """the ring backward in two calls (pre-pass at forward time into a kept workspace, main kernel alone at backward time)
+    gives the bits of the one-call entry point; shapes the ring plan does not serve answer DETOPS_EUNSUPPORTED"""
+    rng = np.random.RandomState(71)
+    shapes = [(2, 19, 50, 84), (2, 19, 25, 42), (2, 19, 13, 21), (2, 19, 7, 11)]
+    scales = [0.25, 0.125, 0.0625, 0.03125]
+    rois = synth.fpn_rois(seed=9, per_image=120, smin=8, smax=300)
+    rois[:, 1:] *= 0.25
+    lv = synth.level_map(rois)
+    emu.tuning_set("roi_bwd_impl", 1)      # the ring also for these small test maps
+    for ph in (7, 14):
+        g = rng.randn(rois.shape[0], 19, ph, ph).astype(np.float32)
+        one = emu.roi_align_fpn_backward(g, rois, lv, shapes, scales, ph, ph, 2)
+        two = emu.roi_align_fpn_backward_two_calls(g, rois, lv, shapes, scales, ph, ph, 2)
+        assert two is not None
+        for a, b in zip(one, two):
+            assert np.array_equal(a, b)
+    emu.tuning_set("roi_bwd_impl", 2)
+    assert emu.roi_align_fpn_backward_two_calls(g, rois, lv, shapes, scales, 14, 14, 2) is None
+    emu.tuning_set("roi_bwd_impl", 0)      # auto: these maps are an under-filled launch -> the one-call kernels
+    assert emu.roi_align_fpn_backward_two_calls(g, rois, lv, shapes, scales, 14, 14, 2) is None

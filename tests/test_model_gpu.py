@@ -283,3 +283,37 @@ def test_train_net_entry_script_runs_and_checkpoints(launcher, tmp_path):
     r2 = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, (r2.stdout + r2.stderr)[-3000:]
     assert "Loading checkpoint from" in (r2.stdout + r2.stderr)
+
+
+@pytest.mark.gpu
+def test_pooler_backward_prepared_at_forward_time_equals_one_call_backward():
+    """The fused multi-level ROIAlign issues its backward's pre-pass at FORWARD time on a side stream (modeling/poolers.py)
+    and launches only the main kernel in the backward pass: same gradients, bit for bit, as the one-call backward, also
+    when several poolers are in flight before any backward runs (box head + mask head) and across iterations."""
+    import synth
+    from maskrcnn_benchmark import _C, _lib
+    from maskrcnn_benchmark.modeling.poolers import roi_align_fpn
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    feats = [torch.randn(2, 64, h, w, device=dev, requires_grad=True) for (h, w) in synth.fpn_shapes()[:4]]
+    scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
+    rois_box = torch.from_numpy(synth.fpn_rois(per_image=512)).to(dev)
+    rois_mask = torch.from_numpy(synth.fpn_rois(per_image=128, seed=8)).to(dev)
+    for it in range(3):
+        out_b = roi_align_fpn(feats, rois_box, (7, 7), scales, 2, 2, 5)
+        out_m = roi_align_fpn(feats, rois_mask, (14, 14), scales, 2, 2, 5)
+        assert out_b.grad_fn.prepared is not None and out_m.grad_fn.prepared is not None, "the prepared path did not engage"
+        gb, gm = torch.randn_like(out_b), torch.randn_like(out_m)
+        grads = torch.autograd.grad([out_b, out_m], feats, [gb, gm])
+        lv_b = _C.roi_align_fpn_forward([f.detach() for f in feats], rois_box, scales, 7, 7, 2, 2, 5)[1]
+        lv_m = _C.roi_align_fpn_forward([f.detach() for f in feats], rois_mask, scales, 14, 14, 2, 2, 5)[1]
+        shapes = [tuple(f.shape) for f in feats]
+        ref_b = _C.roi_align_fpn_backward(gb, rois_box, lv_b, shapes, scales, 7, 7, 2)
+        ref_m = _C.roi_align_fpn_backward(gm, rois_mask, lv_m, shapes, scales, 14, 14, 2)
+        for g, rb, rm in zip(grads, ref_b, ref_m):
+            assert torch.equal(g, rb + rm)
+    # a shape the ring plan does not serve (scan kernel forced): prepare answers "unsupported", the one-call path runs
+    _lib.tuning_set("roi_bwd_impl", 2)
+    out = roi_align_fpn(feats, rois_box, (7, 7), scales, 2, 2, 5)
+    assert out.grad_fn.prepared is None
+    torch.autograd.grad(out, feats, torch.ones_like(out))
