@@ -58,23 +58,10 @@ __device__ __forceinline__ void atomic_add_t(__hip_bfloat16* p, float v) {
 }
 
 // Two adjacent elements (p 4-byte aligned for the 16-bit types) raised by (v0, v1): ONE hardware atomic for half / bf16
-// (global_atomic_pk_add_f16 / _bf16, gfx950) instead of two compare-and-swap loops on the containing dword.
+// (detops_common.h: detops_atomic_add2).
 __device__ __forceinline__ void atomic_add2_t(float* p, float v0, float v1) { atomicAdd(p, v0); atomicAdd(p + 1, v1); }
-#ifdef DETOPS_CPU_EMU
-__device__ __forceinline__ void atomic_add2_t(__half* p, float v0, float v1) { atomic_add_t(p, v0); atomic_add_t(p + 1, v1); }
-__device__ __forceinline__ void atomic_add2_t(__hip_bfloat16* p, float v0, float v1) { atomic_add_t(p, v0); atomic_add_t(p + 1, v1); }
-#else
-__device__ __forceinline__ void atomic_add2_t(__half* p, float v0, float v1) {
-  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-  const h2v v = {static_cast<_Float16>(v0), static_cast<_Float16>(v1)};
-  __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2v*)(p), v);
-}
-__device__ __forceinline__ void atomic_add2_t(__hip_bfloat16* p, float v0, float v1) {
-  typedef __bf16 b2v __attribute__((ext_vector_type(2)));
-  const b2v v = {static_cast<__bf16>(v0), static_cast<__bf16>(v1)};
-  __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) b2v*)(p), v);
-}
-#endif
+__device__ __forceinline__ void atomic_add2_t(__half* p, float v0, float v1) { detops_atomic_add2(p, v0, v1); }
+__device__ __forceinline__ void atomic_add2_t(__hip_bfloat16* p, float v0, float v1) { detops_atomic_add2(p, v0, v1); }
 
 struct Geom {
   int B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dg, Ho, Wo;
@@ -612,11 +599,7 @@ struct EllOverflow {
   float w;
 };
 
-#ifdef DETOPS_CPU_EMU
-__device__ __forceinline__ int slot_fetch_add(int32_t* p) { return atomicAdd(p, 1); }
-#else
-__device__ __forceinline__ int slot_fetch_add(int32_t* p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#endif
+__device__ __forceinline__ int slot_fetch_add(int32_t* p) { return detops_fetch_add_relaxed(p, 1); }
 
 template <typename T>
 __global__ void __launch_bounds__(kBlock)

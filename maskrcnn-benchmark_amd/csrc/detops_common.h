@@ -224,6 +224,35 @@ __device__ __forceinline__ bool spin_again(int& budget) {   // false: give up (s
 #endif
 constexpr int kSpinBudget = 1 << 22;
 
+// ---- relaxed agent-scope fetch-add (a slot request whose result nothing else is ordered against), the packed 16-bit
+// hardware atomics (two adjacent elements, 4-byte aligned: global_atomic_pk_add_f16 / _bf16 instead of two
+// compare-and-swap loops on the containing dword) and the constant 100 MHz wall clock (diagnostic timelines)
+#ifdef DETOPS_CPU_EMU
+__device__ __forceinline__ int detops_fetch_add_relaxed(int32_t* p, int v) { const int o = *p; *p = o + v; return o; }
+__device__ __forceinline__ void detops_atomic_add2(__half* p, float v0, float v1) {
+  p[0] = __float2half(__half2float(p[0]) + v0); p[1] = __float2half(__half2float(p[1]) + v1);
+}
+__device__ __forceinline__ void detops_atomic_add2(__hip_bfloat16* p, float v0, float v1) {
+  p[0] = __float2bfloat16(__bfloat162float(p[0]) + v0); p[1] = __float2bfloat16(__bfloat162float(p[1]) + v1);
+}
+__device__ __forceinline__ long long detops_wall_clock() { return 0; }
+#else
+__device__ __forceinline__ int detops_fetch_add_relaxed(int32_t* p, int v) {
+  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void detops_atomic_add2(__half* p, float v0, float v1) {
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  const h2v v = {static_cast<_Float16>(v0), static_cast<_Float16>(v1)};
+  __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) h2v*)(p), v);
+}
+__device__ __forceinline__ void detops_atomic_add2(__hip_bfloat16* p, float v0, float v1) {
+  typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+  const b2v v = {static_cast<__bf16>(v0), static_cast<__bf16>(v1)};
+  __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) b2v*)(p), v);
+}
+__device__ __forceinline__ long long detops_wall_clock() { return static_cast<long long>(wall_clock64()); }
+#endif
+
 // ---- hardware transcendental / matrix instructions and their host-emulation stand-ins
 #ifdef DETOPS_CPU_EMU
 __device__ __forceinline__ float detops_exp(float x) { return expf(x); }

@@ -438,9 +438,7 @@ roi_align_bwd_ring_kernel(Levels L, RingPlan P, RingWs ws, const float* __restri
 
   // ---- which unit?  the extra segments of split tiles come first in the grid (they are the long chains)
   int* s_tick = reinterpret_cast<int*>(s_ent + kEntRound);          // arrival ticket of a split tile
-#ifndef DETOPS_CPU_EMU
-  const long long t_start = (P.debug & 64) ? static_cast<long long>(wall_clock64()) : 0ll;
-#endif
+  const long long t_start = (P.debug & 64) ? detops_wall_clock() : 0ll;
   f2v acc[CT / 2];
   {
     // grid = (chunks, extras + tiles): linear workgroup id = unit * chunks + chunk, i.e. workgroup b still runs chunk
@@ -471,12 +469,10 @@ roi_align_bwd_ring_kernel(Levels L, RingPlan P, RingWs ws, const float* __restri
     for (int i = 0; i < G::NIG; ++i) goff_u[i] = static_cast<unsigned>(min(gch[i], C - 1 - c0) * (G::BINS * 4)) + grest[i];
     wy0 = y0 + 2 * wave;                                             // the wave's two rows: wy0, wy0 + 1
     if (tid == 0) { DETOPS_STAT("bwdr.units", 1); DETOPS_STAT("bwdr.hits", n); }
-#ifndef DETOPS_CPU_EMU
     struct TimelineExit {   // written when the unit leaves, whichever path it takes
       long long* slot; long long t0; int n, tile, seg; bool on;
-      __device__ ~TimelineExit() { if (on) { slot[0] = t0; slot[1] = static_cast<long long>(wall_clock64()); slot[2] = n; slot[3] = tile * 16 + seg; } }
+      __device__ ~TimelineExit() { if (on) { slot[0] = t0; slot[1] = detops_wall_clock(); slot[2] = n; slot[3] = tile * 16 + seg; } }
     } timeline_exit{ws.timeline + 4 * (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x), t_start, n, tile, seg, (P.debug & 64) && tid == 0};
-#endif
 #pragma unroll
     for (int c = 0; c < CT / 2; ++c) acc[c] = f2v{0.f, 0.f};
 
