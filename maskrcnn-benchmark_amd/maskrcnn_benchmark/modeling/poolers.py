@@ -36,6 +36,9 @@ class LevelMapper(object):
         return lvl.to(torch.int64) - self.k_min
 
 
+PREPARE_BACKWARD_AT_FORWARD = False   # see _ROIAlignFPN.forward
+
+
 class _ROIAlignFPN(Function):
     """autograd glue of the fused multi-level ROIAlign."""
 
@@ -46,10 +49,12 @@ class _ROIAlignFPN(Function):
         ctx.save_for_backward(rois, levels)
         ctx.cfg = (output_size, scales, sampling_ratio)
         ctx.shapes = [tuple(f.shape) for f in features]
-        # the backward's pre-pass needs the ROIs and the map shapes only: issued now, on a side stream, it is finished
-        # long before the backward pass asks for it (None: this shape does not use it)
+        # The backward's pre-pass needs the ROIs and the map shapes only and CAN be issued now, on a side stream
+        # (PREPARE_BACKWARD_AT_FORWARD).  Off by default — measured (profiles/r04_rejected_experiments.txt): the backward
+        # entry drops from 106 to 92 us, but a second busy hardware queue next to the saturated compute queue costs the
+        # STEP +0.5-0.9 ms in fp32 and +4 ms under bf16 autocast.
         ctx.prepared = None
-        if any(ctx.needs_input_grad[6:]) and rois.is_cuda:
+        if PREPARE_BACKWARD_AT_FORWARD and any(ctx.needs_input_grad[6:]) and rois.is_cuda:
             ctx.prepared = _C.roi_align_fpn_backward_prepare(rois, levels, ctx.shapes, scales, output_size[0],
                                                              output_size[1], sampling_ratio)
         return out

@@ -286,13 +286,15 @@ def test_train_net_entry_script_runs_and_checkpoints(launcher, tmp_path):
 
 
 @pytest.mark.gpu
-def test_pooler_backward_prepared_at_forward_time_equals_one_call_backward():
-    """The fused multi-level ROIAlign issues its backward's pre-pass at FORWARD time on a side stream (modeling/poolers.py)
-    and launches only the main kernel in the backward pass: same gradients, bit for bit, as the one-call backward, also
+def test_pooler_backward_prepared_at_forward_time_equals_one_call_backward(monkeypatch):
+    """The fused multi-level ROIAlign CAN issue its backward's pre-pass at FORWARD time on a side stream (modeling/poolers.py:
+    PREPARE_BACKWARD_AT_FORWARD) and launch only the main kernel in the backward pass: same gradients, bit for bit, as the one-call backward, also
     when several poolers are in flight before any backward runs (box head + mask head) and across iterations."""
     import synth
     from maskrcnn_benchmark import _C, _lib
+    from maskrcnn_benchmark.modeling import poolers
     from maskrcnn_benchmark.modeling.poolers import roi_align_fpn
+    monkeypatch.setattr(poolers, "PREPARE_BACKWARD_AT_FORWARD", True)     # off by default (it costs a second hardware queue)
     dev = torch.device("cuda")
     torch.manual_seed(3)
     feats = [torch.randn(2, 64, h, w, device=dev, requires_grad=True) for (h, w) in synth.fpn_shapes()[:4]]
