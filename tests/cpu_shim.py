@@ -121,7 +121,7 @@ def _emu_patches():
                                             [float(s) for s in scales], ph, pw, sr, k_min, k_max)
         return torch.from_numpy(out), torch.from_numpy(lv)
 
-    def fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr):
+    def fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr, prepared=None):
         outs = emu.roi_align_fpn_backward(_np(grad.float()), _np(rois.float()), _np(levels), [tuple(s) for s in shapes],
                                           [float(s) for s in scales], ph, pw, sr)
         return [torch.from_numpy(o) for o in outs]
