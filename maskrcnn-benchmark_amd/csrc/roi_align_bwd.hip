@@ -1393,6 +1393,9 @@ bool acc_plan(int N, int C, int H, int W, int K, int PH, int PW, AccPlan& P, siz
   if (static_cast<int64_t>(K) * C * PH * PW > 0xfffffff0ll) return false;
   P = AccPlan{};
   P.H = H; P.W = W; P.HWp = (H * W + 3) & ~3;
+  // ring + two T buffers + the map + the round's row tables must fit the CU's LDS (14x14 bins on a 31 x 15 map: 182 KB)
+  const size_t lds = PH == 7 ? AccGeom<7, 7, kRingCT>::lds_bytes(4, H, W, P.HWp) : AccGeom<14, 14, kRingCT>::lds_bytes(3, H, W, P.HWp);
+  if (lds > 150 * 1024) return false;
   P.chunks = static_cast<int>(ceil_div64(C, kRingCT));
   // ROI-list split: ~2 workgroups per CU (measured on cfg-1: 16 / 32 / 64 groups -> 50 / 33 / 37 us), one round
   // (8 ROIs) or more per workgroup

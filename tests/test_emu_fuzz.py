@@ -39,13 +39,22 @@ def test_emu_fuzz_roi_align(seed):
     g = rng.randn(K, C, ph, pw).astype(np.float32)
     ref = oracle.roi_align_backward(g, rois, scale, ph, pw, N, C, H, W, sr, acc64=True)
     tol = 2e-5 * max(1.0, np.abs(ref).max())
-    impls = [("scan", 2), ("atomic", 3)] + ([("ring", 1)] if (ph, pw) in ((7, 7), (14, 14)) else [])
+    impls = [("scan", 2), ("atomic", 3)] + ([("ring", 1), ("acc", 4)] if (ph, pw) in ((7, 7), (14, 14)) else [])
     for name, impl in impls:
         emu.tuning_set("roi_bwd_impl", impl)
         if impl == 1:
             emu.tuning_set("roi_bwd_seg", 8 + seed % 3)        # split whatever is crowded
+        if impl == 4:
+            emu.tuning_set("roi_bwd_groups", [0, 1, 3][seed % 3])   # auto / one group (direct store) / three partial maps
+        emu.stats(reset=True)
         got = emu.roi_align_backward(g, rois, scale, ph, pw, N, C, H, W, sr)
         assert np.abs(got - ref).max() <= tol, name
+        if impl == 4:   # maps beyond 32 x 32 (or beyond the LDS budget) fall through to the scan kernel
+            if H > 32 or W > 32:
+                assert emu.stats().get("bwda.units", 0) == 0, (H, W)
+            elif ph == 7:
+                assert emu.stats().get("bwda.units", 0) > 0, (H, W)
+            emu.tuning_set("roi_bwd_groups", 0)
     if seed % 3 == 0:
         emu.tuning_set("roi_bwd_impl", 2)
         emu.tuning_set("roi_bwd_groups", 5)

@@ -262,6 +262,66 @@ def test_roi_align_adjoint_and_linearity_full_size(bwd_impl):
     torch.testing.assert_close(b12, 0.5 * b1 + b2, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_roi_align_backward_acc_and_two_call_ring_random_shapes(seed):
+    """random small maps (acc kernel: the map lives in LDS; 1-3 images, odd channel counts, ROIs outside / degenerate /
+    slivers, 1 .. 400 ROIs, every group count) and random pyramids through the ring backward in ONE call and in TWO
+    (pre-pass at forward time): within 2e-5 of the fp64-accumulated oracle, two-call == one-call bit for bit"""
+    from maskrcnn_benchmark import _lib
+    rng = np.random.RandomState(4000 + seed)
+    N = int(rng.randint(1, 4))
+    C = int(rng.choice([1, 5, 16, 37, 64]))
+    H, W = int(rng.randint(1, 33)), int(rng.randint(1, 33))
+    K = int(rng.choice([1, 2, 9, 65, 400]))
+    ph = [7, 14][seed % 2]
+    sr = int(rng.choice([0, 1, 2]))
+    scale = float(rng.choice([1.0, 0.25, 0.0625]))
+    iw, ih = W / scale, H / scale
+    x1 = rng.uniform(-0.3 * iw, 1.1 * iw, K); y1 = rng.uniform(-0.3 * ih, 1.1 * ih, K)
+    w = np.exp(rng.uniform(np.log(0.5), np.log(1.5 * iw), K)); h = np.exp(rng.uniform(np.log(0.5), np.log(1.5 * ih), K))
+    rois = np.stack([rng.randint(0, N, K), x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+    if K > 2:
+        rois[0, 3:] = rois[0, 1:3]
+        rois[1, 1:] = [-1e4, -1e4, -9e3, -9e3]
+    g = rng.randn(K, C, ph, ph).astype(np.float32)
+    ref = oracle.roi_align_backward(g, rois, scale, ph, ph, N, C, H, W, sr, acc64=True)
+    tol = 2e-5 * max(1.0, np.abs(ref).max())
+    try:
+        _lib.tuning_set("roi_bwd_impl", 4)
+        for groups in (0, 1, 7):
+            _lib.tuning_set("roi_bwd_groups", groups)
+            got = _C().roi_align_backward(_t(g), _t(rois), scale, ph, ph, N, C, H, W, sr).cpu().numpy()
+            assert np.abs(got - ref).max() <= tol, groups
+            again = _C().roi_align_backward(_t(g), _t(rois), scale, ph, ph, N, C, H, W, sr).cpu().numpy()
+            assert np.array_equal(got, again)          # no atomics: run-to-run identical
+    finally:
+        _lib.tuning_set("roi_bwd_groups", 0)
+        _lib.tuning_set("roi_bwd_impl", 0)
+    # a pyramid through the ring kernel, one call vs prepare + prepared
+    Cp = int(rng.choice([8, 24, 40]))
+    shapes = [(2, Cp, 50 + seed, 84 - seed), (2, Cp, 25, 42), (2, Cp, 13, 21)]
+    scales = [0.25, 0.125, 0.0625]
+    Kp = int(rng.choice([3, 120, 500]))
+    pr = synth.fpn_rois(seed=seed, per_image=(Kp + 1) // 2, smin=8, smax=300)[:Kp]
+    pr[:, 1:] *= 0.25
+    lv = np.minimum(synth.level_map(pr), 2).astype(np.int32)
+    gp = rng.randn(Kp, Cp, ph, ph).astype(np.float32)
+    try:
+        _lib.tuning_set("roi_bwd_impl", 1)
+        one = _C().roi_align_fpn_backward(_t(gp), _t(pr), _t(lv), shapes, scales, ph, ph, 2)
+        prepared = _C().roi_align_fpn_backward_prepare(_t(pr), _t(lv), shapes, scales, ph, ph, 2)
+        assert prepared is not None
+        two = _C().roi_align_fpn_backward(_t(gp), _t(pr), _t(lv), shapes, scales, ph, ph, 2, prepared=prepared)
+        for l, (a, b) in enumerate(zip(one, two)):
+            assert torch.equal(a, b)
+            sel = lv == l
+            N_, C_, H_, W_ = shapes[l]
+            refl = oracle.roi_align_backward(gp[sel], pr[sel], scales[l], ph, ph, N_, C_, H_, W_, 2, acc64=True) if sel.any() else np.zeros(shapes[l], np.float32)
+            assert np.abs(a.cpu().numpy() - refl).max() <= 2e-5 * max(1.0, np.abs(refl).max())
+    finally:
+        _lib.tuning_set("roi_bwd_impl", 0)
+
+
 def test_roi_align_backward_edge_cases(bwd_impl):
     C = _C()
     gin = C.roi_align_backward(torch.zeros(0, 3, 7, 7, device=DEV), torch.zeros(0, 5, device=DEV), 0.5,
