@@ -286,6 +286,11 @@ def test_roi_align_backward_acc_and_two_call_ring_random_shapes(seed):
     g = rng.randn(K, C, ph, ph).astype(np.float32)
     ref = oracle.roi_align_backward(g, rois, scale, ph, ph, N, C, H, W, sr, acc64=True)
     tol = 2e-5 * max(1.0, np.abs(ref).max())
+    # the acc plan's LDS budget (roi_align_bwd.hip acc_plan: ring + two T buffers + map + row tables <= 150 KB); shapes
+    # beyond it take the scan kernel, whose ROI-list split adds with atomics (seed 1: 14x14 bins on 23 x 27 -> 170 KB)
+    nring, pad = (4, 8) if ph == 7 else (3, 16)
+    lds = 4 * (nring * 4 * (64 if ph == 7 else 256) * 4 + 2 * H * pad * 20 + 16 * ((H * W + 3) & ~3) + 8 * (H + W) * pad) + 144
+    acc_runs = lds <= 150 * 1024
     try:
         _lib.tuning_set("roi_bwd_impl", 4)
         for groups in (0, 1, 7):
@@ -293,7 +298,7 @@ def test_roi_align_backward_acc_and_two_call_ring_random_shapes(seed):
             got = _C().roi_align_backward(_t(g), _t(rois), scale, ph, ph, N, C, H, W, sr).cpu().numpy()
             assert np.abs(got - ref).max() <= tol, groups
             again = _C().roi_align_backward(_t(g), _t(rois), scale, ph, ph, N, C, H, W, sr).cpu().numpy()
-            assert np.array_equal(got, again)          # no atomics: run-to-run identical
+            assert np.array_equal(got, again) or not acc_runs          # no atomics: run-to-run identical
     finally:
         _lib.tuning_set("roi_bwd_groups", 0)
         _lib.tuning_set("roi_bwd_impl", 0)
