@@ -1,0 +1,54 @@
+// LDS-DMA issue / completion rate probe (gfx950): how fast does ONE wave's stream of global_load_lds_dwordx4 retire, and
+// what does the access pattern cost?  Each wave issues N instructions (1 KiB each) back to back, then waits vmcnt(0).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+__device__ __forceinline__ void dma16(const float* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+// pattern 0: lane-contiguous 1 KiB; 1: 13 row pieces of 80 bytes at a 268800-byte stride (channel planes), unaligned start
+template <int PATTERN>
+__global__ void __launch_bounds__(64) probe(const float* src, long long* ticks, int n, int span_kb, float* sink) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  typedef __attribute__((address_space(3))) float* lds_fptr_t;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_fptr_t)lds)));
+  unsigned voff;
+  if (PATTERN == 0) voff = lane * 16;
+  else { const int ch = lane / 5, v = lane % 5; voff = ch * 268800u + v * 16u + 12u; }
+  const size_t wg_stride = (PATTERN == 0 ? 1024 : 13 * 268800ull) / 4;
+  const float* base = src + (static_cast<size_t>(blockIdx.x) * 7919 % 97) * wg_stride;
+  const long long t0 = wall_clock64();
+  for (int i = 0; i < n; ++i) {
+    const float* p = base + static_cast<size_t>(i) * (PATTERN == 0 ? 256 * 256 : 336);   // a new row / block every instruction
+    dma16(p, voff, lds0 + (i % span_kb) * 1024);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const long long t1 = wall_clock64();
+  if (lane == 0) ticks[blockIdx.x] = t1 - t0;
+  if (sink) sink[blockIdx.x * 64 + lane] = lds[lane];
+}
+int main() {
+  const size_t bytes = 1ull << 30;
+  float* src; hipMalloc(&src, bytes); hipMemset(src, 0, bytes);
+  long long* ticks; hipMalloc(&ticks, 8 * 4096);
+  std::vector<long long> h(4096);
+  for (int pattern = 0; pattern < 2; ++pattern)
+    for (int waves_per_cu : {1, 4, 8})
+      for (int n : {8, 32, 128}) {
+        const int grid = 256 * waves_per_cu;
+        for (int rep = 0; rep < 2; ++rep) {
+          if (pattern == 0) hipLaunchKernelGGL(probe<0>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
+          else hipLaunchKernelGGL(probe<1>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
+          hipDeviceSynchronize();
+        }
+        hipMemcpy(h.data(), ticks, 8 * grid, hipMemcpyDeviceToHost);
+        double s = 0; for (int i = 0; i < grid; ++i) s += h[i];
+        const double us = s / grid / 100.0;
+        printf("pattern %d waves/CU %d n %3d: %.2f us per wave = %.0f ns per instruction, %.1f KB/us per CU\n", pattern, waves_per_cu, n, us,
+               us * 1000 / n, n * waves_per_cu / us);
+      }
+  return 0;
+}
