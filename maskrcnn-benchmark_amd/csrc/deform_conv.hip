@@ -73,6 +73,7 @@ struct Sample {
   int i1, i2, i3, i4;      // flat indices h*W+w, -1 when that tap is outside
   float w1, w2, w3, w4;    // hh*hw, hh*lw, lh*hw, lh*lw
   float lh, lw;
+  int hl, wl;              // floor(h_im), floor(w_im): the low corner (may lie outside the map)
   bool inside;             // h_im > -1 && w_im > -1 && h_im < H && w_im < W   (:236)
 };
 
@@ -82,6 +83,7 @@ __device__ __forceinline__ Sample make_sample(float h_im, float w_im, int H, int
              (w_im < static_cast<float>(W));
   const int h_low = static_cast<int>(floorf(h_im)), w_low = static_cast<int>(floorf(w_im));
   const int h_high = h_low + 1, w_high = w_low + 1;
+  s.hl = h_low; s.wl = w_low;
   s.lh = h_im - static_cast<float>(h_low);
   s.lw = w_im - static_cast<float>(w_low);
   const float hh = 1.f - s.lh, hw = 1.f - s.lw;
@@ -581,7 +583,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255);
 // rocprofv3 of the CSR pipeline above (profiles/r01e_opbench_kernel_stats.csv) shows that at layer2 size
 // the index build is a third of the time (count 47 + fill 90 + sort 150 us of 817) and that the gather
 // reads its per-pixel entry lists with one cache line per lane.  Here the inverted index is a fixed-width
-// table instead: every (pixel, tap) owns kEllCap slots stored pixel-fastest ([b*dg][tap][slot][pixel]),
+// table instead: every (pixel, tap) owns kEllCap slots, one 64-byte record ([b*dg][tap][pixel][slot]),
 // so ONE pass fills it (slot = atomicAdd on the (pixel, tap) counter), a coalesced pass sorts each
 // slot column by column index (deterministic summation order), and the gather reads counters and
 // entries coalesced across the wave.  The rare (pixel, tap) with more than kEllCap contributions
@@ -632,7 +634,7 @@ col2im_ell_fill_kernel(const T* __restrict__ offset, const T* __restrict__ mask,
   for (int t = 0; t < 4; ++t) {
     if (tgt[t] < 0) continue;
     if (pos[t] < kEllCap) {
-      const size_t e = ((img * K + q.tap) * kEllCap + pos[t]) * HW + tgt[t];   // [img][tap][slot][pixel]
+      const size_t e = ((img * K + q.tap) * HW + tgt[t]) * kEllCap + pos[t];   // [img][tap][pixel][slot]
       ent[e] = EllEntry{colidx, wgt[t] * m};
     } else {
       const int o = atomicAdd(ovf_count, 1);
@@ -650,12 +652,12 @@ col2im_ell_sort_kernel(const int32_t* __restrict__ counter, int64_t ncols, int H
   if (n < 2) return;
   const int64_t it = i / HW;             // img * K + tap
   const int pix = static_cast<int>(i - it * HW);
-  EllEntry* ee = ent + static_cast<size_t>(it) * kEllCap * HW + pix;
+  EllEntry* ee = ent + (static_cast<size_t>(it) * HW + pix) * kEllCap;
   int32_t k[kEllCap];
   float w[kEllCap];
 #pragma unroll
   for (int j = 0; j < kEllCap; ++j) {
-    const EllEntry r = j < n ? ee[static_cast<size_t>(j) * HW] : EllEntry{0x7fffffff, 0.f};
+    const EllEntry r = j < n ? ee[j] : EllEntry{0x7fffffff, 0.f};
     k[j] = r.idx;
     w[j] = r.w;
   }
@@ -672,7 +674,7 @@ col2im_ell_sort_kernel(const int32_t* __restrict__ counter, int64_t ncols, int H
   }
 #pragma unroll
   for (int j = 0; j < kEllCap; ++j)
-    if (j < n) ee[static_cast<size_t>(j) * HW] = EllEntry{k[j], w[j]};
+    if (j < n) ee[j] = EllEntry{k[j], w[j]};
 }
 
 template <typename T>
@@ -703,11 +705,11 @@ col2im_ell_gather_kernel(const T* __restrict__ col, const int32_t* __restrict__ 
     const T* cbase = col + static_cast<size_t>(cs) * chan_stride;
     for (int tap = 0; tap < K; ++tap) {
       const int n = live ? min(counter[(img * K + tap) * HW + p], kEllCap) : 0;
-      const EllEntry* ee = ent + (img * K + tap) * kEllCap * HW + p;
+      const EllEntry* ee = ent + ((img * K + tap) * HW + p) * kEllCap;
       for (int j = 0; j < kEllCap; ++j) {
         if (__ballot(j < n) == 0ull) break;        // wave-uniform trip count
         if (j < n) {
-          const EllEntry r = ee[static_cast<size_t>(j) * HW];
+          const EllEntry r = ee[j];
           const int32_t ci = r.idx;
           const float w = r.w;
           const T* cp = cbase + ci;
@@ -773,6 +775,191 @@ inline bool ell_plan(const Geom& g, EllPlan& P) {
   return true;
 }
 
+// ------------------------------------------------------------------------------------ ELL index, tile-owner build
+// The scatter build above asks a global counter for every tap of every sampling point (1.2 M returning atomics on
+// [tap][pixel] counters at the layer2 size), then a second launch sorts the slots.  Here a workgroup OWNS one
+// (image, kernel tap, 16 x 32 input tile): it scans the sampling points whose undisplaced position lies within
+// kEllM pixels of the tile (learned offsets are small: the window catches all but the far tail), keeps the bilinear
+// corners that land inside its tile in LDS lists, sorts every pixel's <= 8 entries and writes the counter and the
+// pixel's whole 64-byte record ONCE — no global atomics with return, no clear, no sort launch, every sector of the
+// table written in full.  Every corner is handled exactly once: by the workgroup of the tile it lands in when that
+// workgroup's window covers the point (`ell_covers`, the same predicate on both sides), otherwise by the point's HOME
+// workgroup (the tile of its undisplaced position, clamped into the map), which appends it to the overflow list the
+// atomic kernel adds later.
+// Measured (layer2 size, fp16, index build + gather + overflow): 146 -> 129 us.  The window scan costs 8 us and the
+// record write 10 us; what is left is the slot requests — LDS atomics WITH RETURN are slow on this hardware (~15 cycles
+// per requesting lane and CU; branch-free issue of a point's four requests changes nothing), so a wave compacts the
+// corners that are its tile's own through ballots first and requests slots 64 lanes dense (141 -> 129 us).
+constexpr int kEllTH = 16, kEllTW = 32;   // input tile (pixels); small maps use 8 rows
+constexpr int kEllM = 8;                  // displacement margin scanned around a tile
+constexpr int kEllThreads = 256;          // few, fat waves: the slot requests are per wave instruction
+constexpr int kEllQueue = 128;            // records a wave queues before it requests slots for 64 of them
+
+__device__ __forceinline__ bool ell_covers(int zy, int zx, int y0, int x0, int th) {
+  return zy >= y0 - kEllM && zy < y0 + th + kEllM && zx >= x0 - kEllM && zx < x0 + kEllTW + kEllM;
+}
+__device__ __forceinline__ int ceil_div_signed(int a, int s) { return a >= 0 ? (a + s - 1) / s : -((-a) / s); }
+
+template <typename T>
+__global__ void __launch_bounds__(kEllThreads)
+ell_build_kernel(const T* __restrict__ offset, const T* __restrict__ mask, Geom g, int th, int tiles_x,
+                 int32_t* __restrict__ counter, EllEntry* __restrict__ ent, int32_t* __restrict__ ovf_count,
+                 EllOverflow* __restrict__ ovf, int ovf_cap) {
+  __shared__ int s_cnt[kEllTH * kEllTW];
+  __shared__ int s_queue[(kEllThreads / 64) * 3 * kEllQueue];
+  __shared__ EllEntry s_ent[kEllCap][kEllTH * kEllTW];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int th_log2 = th == 8 ? 3 : 4;
+  const int ty = static_cast<int>(blockIdx.x) / tiles_x, tx = static_cast<int>(blockIdx.x) - ty * tiles_x;
+  const int tap = blockIdx.y;
+  const int img = blockIdx.z, b = img / g.dg, dgi = img - b * g.dg;
+  const int y0 = ty * th, x0 = tx * kEllTW;
+  const int npx = th * kEllTW;
+  const int K = g.kh * g.kw, HW = g.H * g.W, HWo = g.Ho * g.Wo;
+  for (int l = tid; l < npx; l += nthr) s_cnt[l] = 0;
+  __syncthreads();
+  const int ky = tap / g.kw, kx = tap - ky * g.kw;
+  // output pixels whose undisplaced (clamped) position can fall inside the window: a superset, each is tested exactly
+  const int by_ = g.pad_h - ky * g.dil_h, bx_ = g.pad_w - kx * g.dil_w;
+  int oy_lo = (y0 - kEllM <= 0) ? 0 : max(0, ceil_div_signed(y0 - kEllM + by_, g.stride_h));
+  int oy_hi = (y0 + th + kEllM >= g.H) ? g.Ho : min(g.Ho, ceil_div_signed(y0 + th + kEllM + by_, g.stride_h));
+  int ox_lo = (x0 - kEllM <= 0) ? 0 : max(0, ceil_div_signed(x0 - kEllM + bx_, g.stride_w));
+  int ox_hi = (x0 + kEllTW + kEllM >= g.W) ? g.Wo : min(g.Wo, ceil_div_signed(x0 + kEllTW + kEllM + bx_, g.stride_w));
+  const int ncx = max(0, ox_hi - ox_lo), ncy = max(0, oy_hi - oy_lo);
+  const size_t lbase = static_cast<size_t>(img) * HW;
+  auto spill = [&](int tgt, int32_t colidx, float w) {
+    const int o = atomicAdd(ovf_count, 1);
+    if (o < ovf_cap) ovf[o] = EllOverflow{static_cast<int32_t>(lbase + tgt), colidx, w};
+  };
+  // Slot requests are LDS atomics with return: ~500 cycles per wave instruction on this hardware whatever the number of
+  // active lanes.  So a wave first COMPACTS the corners that are this tile's own into its private queue (ballot + lane
+  // prefix, no atomics) and requests slots 64 lanes dense: a third of the atomic instructions.
+  const int lane = tid & 63;
+  int* qbase = s_queue + (tid >> 6) * (3 * kEllQueue);           // this wave's queue: [l | column index | weight bits] x kEllQueue
+  int qn = 0;                                                     // records queued (wave-uniform)
+  auto drain = [&](int take) {                                    // the oldest `take` (<= 64) records request their slots
+    DETOPS_WAVE_SYNC();
+    if (lane < take) {
+      const int l = qbase[lane], ci = qbase[kEllQueue + lane];
+      const float w = __int_as_float(qbase[2 * kEllQueue + lane]);
+      const int pos = atomicAdd(&s_cnt[l], 1);
+      if (pos < kEllCap) s_ent[pos][l] = EllEntry{ci, w};
+      else {
+        const int py = y0 + l / kEllTW, px = x0 + (l & (kEllTW - 1));
+        spill(py * g.W + px, ci, w);
+      }
+    }
+    DETOPS_WAVE_SYNC();
+    const int rest = qn - take;                                   // <= 64: move it to the front
+    int m0 = 0, m1 = 0, m2 = 0;
+    if (lane < rest) { m0 = qbase[take + lane]; m1 = qbase[kEllQueue + take + lane]; m2 = qbase[2 * kEllQueue + take + lane]; }
+    DETOPS_WAVE_SYNC();
+    if (lane < rest) { qbase[lane] = m0; qbase[kEllQueue + lane] = m1; qbase[2 * kEllQueue + lane] = m2; }
+    qn = rest;
+  };
+  const int ncand = ncy * ncx;
+  for (int i0 = 0; i0 < ncand; i0 += nthr) {                      // wave-uniform trip count (ballots inside)
+    const int i = i0 + tid;
+    const int r = i / max(ncx, 1);
+    const int oy = oy_lo + r, ox = ox_lo + (i - r * ncx);
+    const int zy = min(max(oy * g.stride_h - by_, 0), g.H - 1), zx = min(max(ox * g.stride_w - bx_, 0), g.W - 1);
+    bool live = i < ncand && ell_covers(zy, zx, y0, x0, th);
+    const bool home = zy >= y0 && zy < y0 + th && zx >= x0 && zx < x0 + kEllTW;
+    Point q;
+    q.b = b; q.tap = tap; q.ho = live ? oy : 0; q.wo = live ? ox : 0; q.pix = q.ho * g.Wo + q.wo;
+    const Sample s = point_sample(q, g, dgi, offset);
+    live = live && s.inside;
+    float m = 1.f;
+    if (mask) m = ld(mask + ((static_cast<size_t>(b) * g.dg + dgi) * K + tap) * HWo + q.pix);
+    const int32_t colidx = tap * (g.B * HWo) + b * HWo + q.pix;
+    const int tgt[4] = {s.i1, s.i2, s.i3, s.i4};
+    const float wgt[4] = {s.w1 * m, s.w2 * m, s.w3 * m, s.w4 * m};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int cy = s.hl + (t >> 1), cx = s.wl + (t & 1);        // corner coordinates from the sample's floor
+      const bool valid = live && tgt[t] >= 0;
+      const bool mine = valid && cy >= y0 && cy < y0 + th && cx >= x0 && cx < x0 + kEllTW;
+      const unsigned long long mk = __ballot(mine);
+      if (mine) {
+        const int at = qn + __popcll(mk & ((1ull << lane) - 1ull));
+        qbase[at] = (cy - y0) * kEllTW + (cx - x0);
+        qbase[kEllQueue + at] = colidx;
+        qbase[2 * kEllQueue + at] = __float_as_int(wgt[t]);
+      }
+      qn += __popcll(mk);
+      if (qn >= 64) drain(64);
+      if (valid && !mine && home && !ell_covers(zy, zx, (cy >> th_log2) << th_log2, (cx / kEllTW) * kEllTW, th))
+        spill(tgt[t], colidx, wgt[t]);                            // displaced beyond the window of the tile it lands in
+    }
+  }
+  if (qn > 0) drain(qn);
+  __syncthreads();
+  // every pixel's entries by column index (same summation order every run), counters and slots out in full rows
+  const size_t col0 = (static_cast<size_t>(img) * K + tap) * HW;
+  EllEntry* ebase = ent + (static_cast<size_t>(img) * K + tap) * HW * kEllCap;   // [pixel][slot]: one 64-byte record per pixel
+  for (int l = tid; l < npx; l += nthr) {
+    const int py = y0 + l / kEllTW, px = x0 + (l & (kEllTW - 1));
+    if (py >= g.H || px >= g.W) continue;
+    const int cnt = s_cnt[l];
+    const int n = min(cnt, kEllCap);
+    int32_t k[kEllCap];
+    float w[kEllCap];
+#pragma unroll
+    for (int j = 0; j < kEllCap; ++j) {
+      const EllEntry e = j < n ? s_ent[j][l] : EllEntry{0x7fffffff, 0.f};
+      k[j] = e.idx; w[j] = e.w;
+    }
+    if (n >= 2) {
+#pragma unroll
+      for (int r = 0; r < kEllCap; ++r) {
+#pragma unroll
+        for (int j = (r & 1); j + 1 < kEllCap; j += 2) {
+          const bool sw = k[j] > k[j + 1];
+          const int32_t ka = sw ? k[j + 1] : k[j], kb = sw ? k[j] : k[j + 1];
+          const float wa = sw ? w[j + 1] : w[j], wb = sw ? w[j] : w[j + 1];
+          k[j] = ka; k[j + 1] = kb; w[j] = wa; w[j + 1] = wb;
+        }
+      }
+    }
+    const int pix = py * g.W + px;
+    counter[col0 + pix] = cnt;
+    // the whole record, used slots or not: four 16-byte stores, every 64-byte sector of the table written in full
+    float4* rec = reinterpret_cast<float4*>(ebase + static_cast<size_t>(pix) * kEllCap);
+#pragma unroll
+    for (int j = 0; j < kEllCap; j += 2)
+      rec[j / 2] = make_float4(__int_as_float(k[j]), w[j], __int_as_float(k[j + 1]), w[j + 1]);
+  }
+}
+
+// Builds counters + slots (+ the overflow list) of the inverted index for one call.  `dcn_ell_build` = 1 keeps the
+// scatter build (A/B).
+template <typename T>
+int ell_build(const void* offset, const void* mask, const Geom& g, const EllPlan& P, int32_t* count, int32_t* ovf_count,
+              EllEntry* ent, EllOverflow* ovf, size_t clear_bytes, hipStream_t st_) {
+  if (detops_tuning().dcn_ell_build == 1) {
+    DETOPS_HIP_TRY(hipMemsetAsync(count, 0, clear_bytes, st_));   // counters + overflow counter
+    const dim3 pgrid(static_cast<unsigned>(ceil_div64(P.npoints_per_dg, kBlock)), static_cast<unsigned>(g.dg));
+    hipLaunchKernelGGL(col2im_ell_fill_kernel<T>, pgrid, dim3(kBlock), 0, st_, static_cast<const T*>(offset),
+                       static_cast<const T*>(mask), g, P.npoints_per_dg, count, ent, ovf_count, ovf, P.ovf_cap);
+    hipLaunchKernelGGL(col2im_ell_sort_kernel, dim3(static_cast<unsigned>(ceil_div64(P.ncols, kBlock))), dim3(kBlock),
+                       0, st_, static_cast<const int32_t*>(count), P.ncols, g.H * g.W, ent);
+    return launch_status();
+  }
+  DETOPS_HIP_TRY(hipMemsetAsync(ovf_count, 0, sizeof(int32_t), st_));
+  const int K = g.kh * g.kw;
+  const int tiles_x = static_cast<int>(ceil_div64(g.W, kEllTW));
+  int th = kEllTH;
+  if (ceil_div64(g.H, th) * tiles_x * K * g.B * g.dg < 2 * kNumCU) th = 8;   // small maps: more, smaller workgroups
+  const int nthr = kEllThreads;
+  const int tiles_y = static_cast<int>(ceil_div64(g.H, th));
+  if (K > 65535 || static_cast<int64_t>(g.B) * g.dg > 65535) return DETOPS_EUNSUPPORTED;
+  hipLaunchKernelGGL(ell_build_kernel<T>, dim3(static_cast<unsigned>(tiles_x * tiles_y), static_cast<unsigned>(K),
+                                               static_cast<unsigned>(g.B * g.dg)),
+                     dim3(nthr), 0, st_, static_cast<const T*>(offset), static_cast<const T*>(mask), g, th, tiles_x,
+                     count, ent, ovf_count, ovf, P.ovf_cap);
+  return launch_status();
+}
+
 template <typename T>
 int col2im_ell_t(const void* col, const void* offset, const void* mask, void* grad_im, const Geom& g,
                  const EllPlan& P, void* ws, hipStream_t st_) {
@@ -782,13 +969,7 @@ int col2im_ell_t(const void* col, const void* offset, const void* mask, void* gr
   int32_t* ovf_count = reinterpret_cast<int32_t*>(w + P.off_ovf_count);
   EllEntry* ent = reinterpret_cast<EllEntry*>(w + P.off_ent);
   EllOverflow* ovf = reinterpret_cast<EllOverflow*>(w + P.off_ovf);
-  DETOPS_HIP_TRY(hipMemsetAsync(count, 0, P.off_ent - P.off_count, st_));   // counters + overflow counter
-  const dim3 pgrid(static_cast<unsigned>(ceil_div64(P.npoints_per_dg, kBlock)), static_cast<unsigned>(g.dg));
-  hipLaunchKernelGGL(col2im_ell_fill_kernel<T>, pgrid, dim3(kBlock), 0, st_, static_cast<const T*>(offset),
-                     static_cast<const T*>(mask), g, P.npoints_per_dg, count, ent, ovf_count, ovf,
-                     P.ovf_cap);
-  hipLaunchKernelGGL(col2im_ell_sort_kernel, dim3(static_cast<unsigned>(ceil_div64(P.ncols, kBlock))), dim3(kBlock),
-                     0, st_, static_cast<const int32_t*>(count), P.ncols, g.H * g.W, ent);
+  { const int rc = ell_build<T>(offset, mask, g, P, count, ovf_count, ent, ovf, P.off_ent - P.off_count, st_); if (rc) return rc; }
   const int cpg = g.C / g.dg;
   const int64_t pix_blocks = ceil_div64(static_cast<int64_t>(g.H) * g.W, kBlock) * g.B;
   int cc = cpg;
@@ -1420,12 +1601,12 @@ sampleT_gather_kernel(const T* __restrict__ gT, const int32_t* __restrict__ coun
   for (int tap = 0; tap < K; ++tap) {
     const size_t col = (static_cast<size_t>(b) * K + tap) * HW + p;             // counter: [img][tap][pixel]
     const int n = min(counter[col], kEllCap);
-    const EllEntry* ee = ent + (static_cast<size_t>(b) * K + tap) * kEllCap * HW + p;
+    const EllEntry* ee = ent + ((static_cast<size_t>(b) * K + tap) * HW + p) * kEllCap;
     int32_t qi[kEllCap];
     float wi[kEllCap];
 #pragma unroll
     for (int j = 0; j < kEllCap; ++j) {            // the (<= 8) entries: same addresses across the pixel group
-      const EllEntry r = j < n ? ee[static_cast<size_t>(j) * HW] : EllEntry{tap * (g.B * HWo), 0.f};
+      const EllEntry r = j < n ? ee[j] : EllEntry{tap * (g.B * HWo), 0.f};
       qi[j] = r.idx - tap * (g.B * HWo);           // column index -> b * Ho * Wo + pix
       wi[j] = r.w;
     }
@@ -1518,12 +1699,7 @@ int sampleT_t(const void* gT, const void* offset, const void* mask, void* S_T, c
   int32_t* ovf_count = reinterpret_cast<int32_t*>(w + P.off_ovf_count);
   EllEntry* ent = reinterpret_cast<EllEntry*>(w + P.off_ent);
   EllOverflow* ovf = reinterpret_cast<EllOverflow*>(w + P.off_ovf);
-  DETOPS_HIP_TRY(hipMemsetAsync(count, 0, P.off_ent - P.off_count, st_));   // counters + overflow counter
-  hipLaunchKernelGGL(col2im_ell_fill_kernel<T>, dim3(static_cast<unsigned>(ceil_div64(P.npoints_per_dg, kBlock)), 1u), dim3(kBlock),
-                     0, st_, static_cast<const T*>(offset), static_cast<const T*>(mask), g, P.npoints_per_dg, count, ent,
-                     ovf_count, ovf, P.ovf_cap);
-  hipLaunchKernelGGL(col2im_ell_sort_kernel, dim3(static_cast<unsigned>(ceil_div64(P.ncols, kBlock))), dim3(kBlock), 0, st_,
-                     static_cast<const int32_t*>(count), P.ncols, g.H * g.W, ent);
+  { const int rc = ell_build<T>(offset, mask, g, P, count, ovf_count, ent, ovf, P.off_ent - P.off_count, st_); if (rc) return rc; }
   hipLaunchKernelGGL(sampleT_gather_kernel<T>, dim3(static_cast<unsigned>(ceil_div64(npix, m.ppb))), dim3(kBlock), 0, st_,
                      static_cast<const T*>(gT), static_cast<const int32_t*>(count), static_cast<const EllEntry*>(ent),
                      static_cast<T*>(S_T), g, Cout, m.sub, m.nv, npix);

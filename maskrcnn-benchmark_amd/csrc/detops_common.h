@@ -308,6 +308,7 @@ struct DetopsTuning {
   int dcn_fused;           // 0 auto | 1 force | 2 off
   int dcn_gather_xcd;      // 0 auto (XCD-contiguous block order) | 1 plain block order
   int dcn_nhwc;            // 0 auto (channels-last pipeline where supported) | 2 off (reference-layout kernels)
+  int dcn_ell_build;       // inverted index of the deformable-conv input gradient: 0 tile-owner build (LDS lists) | 1 scatter build (global atomics + sort launch)
 };
 DetopsTuning& detops_tuning();
 

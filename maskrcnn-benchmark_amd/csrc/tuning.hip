@@ -17,7 +17,7 @@ const Key kKeys[] = {
     {"dcn_col2im", &DetopsTuning::dcn_col2im},           {"dcn_fused", &DetopsTuning::dcn_fused},
     {"dcn_gather_xcd", &DetopsTuning::dcn_gather_xcd},   {"dcn_nhwc", &DetopsTuning::dcn_nhwc},
     {"nms_fused", &DetopsTuning::nms_fused},             {"roi_fwd_records", &DetopsTuning::roi_fwd_records},
-    {"roi_fwd_ct", &DetopsTuning::roi_fwd_ct},
+    {"roi_fwd_ct", &DetopsTuning::roi_fwd_ct},           {"dcn_ell_build", &DetopsTuning::dcn_ell_build},
     {"nms_fault", &DetopsTuning::nms_fault},             {"nms_spin_budget", &DetopsTuning::nms_spin_budget},
     {"roi_bwd_split", &DetopsTuning::roi_bwd_split},     {"roi_bwd_maxseg", &DetopsTuning::roi_bwd_maxseg},
     {"roi_bwd_extras", &DetopsTuning::roi_bwd_extras},

@@ -90,7 +90,7 @@ def lib():
 
 
 TUNING_KEYS = ("roi_bwd_impl", "roi_bwd_seg", "nms_fault", "nms_spin_budget", "roi_bwd_ring", "roi_bwd_ct", "roi_bwd_split", "roi_bwd_maxseg", "roi_bwd_extras", "roi_bwd_groups", "roi_bwd_scan_ct", "roi_bwd_debug", "roi_fwd_impl", "roi_fwd_records", "roi_fwd_ct",
-               "roi_fwd_order", "roi_fwd_order_mink", "dcn_col2im", "dcn_fused", "dcn_gather_xcd", "dcn_nhwc", "nms_fused")
+               "roi_fwd_order", "roi_fwd_order_mink", "dcn_col2im", "dcn_fused", "dcn_gather_xcd", "dcn_nhwc", "dcn_ell_build", "nms_fused")
 
 
 def tuning_set(key, value):

@@ -590,6 +590,38 @@ def test_emu_deformable_col2im_ell_overflow():
         np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref).max()), err_msg=mode)
 
 
+@pytest.mark.parametrize("case", [dict(B=1, C=3, H=37, W=70, k=3, stride=1, pad=1, dil=1, dg=1, sigma=2.0),      # several 16 x 32 tiles
+                                  dict(B=2, C=2, H=21, W=45, k=3, stride=1, pad=1, dil=1, dg=1, sigma=12.0),     # most taps leave the scan window
+                                  dict(B=1, C=4, H=40, W=41, k=3, stride=2, pad=3, dil=3, dg=2, sigma=5.0),      # stride, dilation, two offset groups
+                                  dict(B=1, C=2, H=19, W=33, k=1, stride=1, pad=0, dil=1, dg=1, sigma=9.0),      # 1 x 1 kernel
+                                  dict(B=1, C=2, H=50, W=40, k=3, stride=1, pad=6, dil=6, dg=1, sigma=3.0)])     # padding beyond the margin
+def test_emu_deformable_index_tile_owner_build(case):
+    """the tile-owner build of the inverted index (LDS lists, no global atomics): maps of several tiles, displacements
+    far beyond the scanned window (those corners go through the overflow list), strides / dilations / padding — same
+    gradient as the oracle and as the scatter build it replaces, run-to-run identical when nothing overflows"""
+    g = case
+    rng = np.random.RandomState(17)
+    k, p_, s_, d, dg = g["k"], g["pad"], g["stride"], g["dil"], g["dg"]
+    Ho = (g["H"] + 2 * p_ - (d * (k - 1) + 1)) // s_ + 1
+    Wo = (g["W"] + 2 * p_ - (d * (k - 1) + 1)) // s_ + 1
+    off = (rng.randn(g["B"], 2 * dg * k * k, Ho, Wo) * g["sigma"]).astype(np.float32)
+    mask = rng.uniform(0.2, 1.0, (g["B"], dg * k * k, Ho, Wo)).astype(np.float32)
+    geo = dict(kh=k, kw=k, pad=(p_, p_), stride=(s_, s_), dil=(d, d), dg=dg)
+    gcol = rng.randn(g["C"] * k * k, g["B"] * Ho * Wo).astype(np.float32)
+    shape = (g["B"], g["C"], g["H"], g["W"])
+    ref = oracle.deformable_col2im(gcol, off, mask, *shape, **geo)
+    tol = dict(rtol=1e-4, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    out = emu.deformable_col2im(gcol, off, mask, *shape, mode="ell", **geo)
+    np.testing.assert_allclose(out, ref, **tol)
+    try:
+        emu.tuning_set("dcn_ell_build", 1)
+        np.testing.assert_allclose(emu.deformable_col2im(gcol, off, mask, *shape, mode="ell", **geo), ref, **tol)
+    finally:
+        emu.tuning_set("dcn_ell_build", 0)
+    if g["sigma"] <= 3.0:
+        assert np.array_equal(out, emu.deformable_col2im(gcol, off, mask, *shape, mode="ell", **geo))
+
+
 # ================================================================================ deformable conv, channels-last pipeline
 @pytest.mark.parametrize("geom", [dict(B=2, C=64, H=9, W=11, Cout=128, k=3, pad=1, stride=1, dil=1),
                                   dict(B=1, C=128, H=12, W=10, Cout=64, k=3, pad=2, stride=2, dil=2),
