@@ -1,85 +1,50 @@
 // detops_common.h — shared host/device helpers for libdetops_gfx950 (gfx950 / CDNA4 only).
 #pragma once
-#ifdef DETOPS_CPU_EMU  // tests/emu: the kernels compiled as host C++ (logic checks without a GPU)
-#include "hip_cpu_emu.h"
+#include <stdint.h>
+
+typedef unsigned long long detops_u64;
+constexpr int kSpinBudget = 1 << 22;   // polls before a wait on another workgroup's flag gives up
+
+// ---- the device primitives.  This is the ONE place in the library sources that knows about the host emulation
+// (tests/emu compiles the kernels as host C++ for logic checks without a GPU): there, every name defined between
+// here and the #endif comes from tests/emu/detops_emu_shims.h instead.
+#ifdef DETOPS_CPU_EMU
+#include "detops_emu_shims.h"
 #else
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
-#endif
-#include <stdint.h>
-
-#include "detops.h"
-
-#define DETOPS_API extern "C" __attribute__((visibility("default")))
-
-static inline hipStream_t as_stream(detops_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
-
-static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
-
-// Launch epilogue: surfaces launch-configuration errors as the function's return code.
-static inline int launch_status() { return static_cast<int>(hipGetLastError()); }
-
-#define DETOPS_HIP_TRY(expr)                       \
-  do {                                             \
-    hipError_t _e = (expr);                        \
-    if (_e != hipSuccess) return static_cast<int>(_e); \
-  } while (0)
 
 // Dynamically sized LDS of a kernel, as `T name[]` (16-byte aligned).
-#ifdef DETOPS_CPU_EMU
-#define DETOPS_DYNAMIC_LDS(T, name) T* name = reinterpret_cast<T*>(emu::dynamic_lds())
-#else
 #define DETOPS_DYNAMIC_LDS(T, name) extern __shared__ __align__(16) T name[]
-#endif
 
 // Work counters of the host emulation (tests/emu): compiled out of the device build.
-#ifdef DETOPS_CPU_EMU
-#define DETOPS_STAT(name, n) emu::stat(name, n)
-#else
 #define DETOPS_STAT(name, n) ((void)0)
-#endif
 
 // Resident workgroups per CU of a kernel at a block size / dynamic LDS size (sizes persistent grids; the
 // value is advisory and only affects speed).  Host emulation: a fixed 4.
-#ifdef DETOPS_CPU_EMU
-#define DETOPS_OCCUPANCY(out, kernel, block, lds) ((out) = 4)
-#else
 #define DETOPS_OCCUPANCY(out, kernel, block, lds)                                                         \
   do {                                                                                                    \
     int _n = 0;                                                                                           \
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&_n, reinterpret_cast<const void*>(kernel), (block), (lds)) == hipSuccess && _n > 0) \
       (out) = _n;                                                                                         \
   } while (0)
-#endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() lowers to `s_waitcnt vmcnt(0) lgkmcnt(0);
 // s_barrier`: it drains every outstanding GLOBAL load and store of the wave first, which serialises a
 // software pipeline (prefetch loads in flight across the barrier, fire-and-forget result stores).  Use only
 // where no thread reads global memory another thread of the workgroup wrote before the barrier.
-#ifdef DETOPS_CPU_EMU
-#define DETOPS_LDS_BARRIER() __syncthreads()
-#else
 #define DETOPS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#endif
 
 // Scheduling pin: the four values must be in registers here, so every load that produces them has been ISSUED
 // before this point (hipcc's scheduler otherwise serialises LDS reads one `s_waitcnt lgkmcnt(0)` at a time to
 // save registers).  No instruction is emitted.
-#ifdef DETOPS_CPU_EMU
-#define DETOPS_PIN4(a, b, c, d) ((void)0)
-#else
 #define DETOPS_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
-#endif
 
 // Ordering point for LDS data handed from some lanes of a wave to other lanes of the SAME wave (no other wave
 // touches the region): the hardware executes a wave's LDS operations in order, so only the compiler must be kept
 // from moving the reads above the writes.  The emulation runs lanes as fibers and needs a real rendezvous.
-#ifdef DETOPS_CPU_EMU
-#define DETOPS_WAVE_SYNC() ((void)__ballot(1))
-#else
 #define DETOPS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-#endif
 
 // ---- LDS-DMA (gfx950 global_load_lds_dwordx4): 16 bytes per lane, global (per-lane, dword-aligned address) ->
 // LDS (wave-uniform base + lane * 16).
@@ -93,20 +58,6 @@ static inline int launch_status() { return static_cast<int>(hipGetLastError()); 
 //                 control flow so that every wave's count is known).
 // Host emulation: glds16 copies at once; glds16_async QUEUES the copy and DETOPS_VMCNT_WAIT applies all but the
 // newest n instructions' copies — a read that is not covered by a wait sees stale LDS, as on the device.
-#ifdef DETOPS_CPU_EMU
-__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
-  float* d = lds_wave_base + 4 * (threadIdx.x & 63);
-  d[0] = g[0]; d[1] = g[1]; d[2] = g[2]; d[3] = g[3];
-}
-__device__ __forceinline__ void glds16_async(bool active, const float* g, float* lds_wave_base) {
-  emu::dma_issue(active, g, lds_wave_base + 4 * (threadIdx.x & 63));
-}
-__device__ __forceinline__ void glds16_async_so(bool active, const float* sbase, unsigned voff_bytes, float* lds_wave_base) {
-  emu::dma_issue(active, reinterpret_cast<const float*>(reinterpret_cast<const char*>(sbase) + voff_bytes),
-                 lds_wave_base + 4 * (threadIdx.x & 63));
-}
-#define DETOPS_VMCNT_WAIT(n) emu::dma_wait(n)
-#else
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -131,28 +82,19 @@ __device__ __forceinline__ void glds16_async_so(bool active, const float* sbase,
                  : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(dst) : "memory");
 }
 #define DETOPS_VMCNT_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
-#endif
 
 // ---- write-through (sc1) 16-byte global store and its matching load: partial results handed to ANOTHER workgroup
 // inside one launch (cdna_hip_programming.md Guideline 16, "sc1 slab stores"): the store bypasses the XCD's
 // non-coherent L2, DETOPS_VMCNT_WAIT(0) + a barrier + a relaxed agent-scope atomic then publishes it.
-#ifdef DETOPS_CPU_EMU
-__device__ __forceinline__ void store_f4_wt(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-#else
 __device__ __forceinline__ void store_f4_wt(float* p, float4 v) {
   typedef float f4v __attribute__((ext_vector_type(4)));
   const f4v d = {v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
 }
-#endif
 
 // Acquire at agent scope (buffer_inv sc1: drops this CU's L1 lines) — executed by ONE lane of the workgroup that
 // is about to read another workgroup's published partial results, followed by a barrier.
-#ifdef DETOPS_CPU_EMU
-#define DETOPS_ACQUIRE_AGENT() ((void)0)
-#else
 #define DETOPS_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
-#endif
 
 // ---- flags between workgroups of ONE launch (producer has a LOWER blockIdx than every consumer: workgroups are
 // dispatched in index order, so a waiting workgroup only ever waits for resident or finished ones).  Producer:
@@ -160,25 +102,6 @@ __device__ __forceinline__ void store_f4_wt(float* p, float4 v) {
 // Consumer: spin on flag_load (acquire, agent scope: other XCDs' L2 lines are invalidated) -> plain loads.
 // Spins are bounded (a wedged producer must not hang the device); the emulation runs workgroups one after another,
 // so there a flag that is not already set is a design error and aborts.
-typedef unsigned long long detops_u64;
-#ifdef DETOPS_CPU_EMU
-__device__ __forceinline__ void detops_release_agent() {}
-__device__ __forceinline__ void flag_store(detops_u64* p, detops_u64 v) { *p = v; }
-__device__ __forceinline__ void flag_store_relaxed(detops_u64* p, detops_u64 v) { *p = v; }
-__device__ __forceinline__ detops_u64 flag_load(const detops_u64* p) { return *p; }
-__device__ __forceinline__ int flag_load(const int* p) { return *p; }
-__device__ __forceinline__ void flag_add(int* p, int v) { *p += v; }
-__device__ __forceinline__ detops_u64 flag_peek(const detops_u64* p) { return *p; }
-__device__ __forceinline__ int flag_peek(const int* p) { return *p; }
-__device__ __forceinline__ void store_u64_wt(detops_u64* p, detops_u64 v) { *p = v; }
-__device__ __forceinline__ void store_u32_wt(void* p, unsigned v) { *static_cast<unsigned*>(p) = v; }
-__device__ __forceinline__ float load_f32_coherent(const float* p) { return *p; }
-__device__ __forceinline__ bool spin_again(int& budget) {
-  (void)budget;
-  fprintf(stderr, "emu: a workgroup waits for a flag no earlier workgroup has set\n");
-  abort();
-}
-#else
 __device__ __forceinline__ void detops_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
 __device__ __forceinline__ void flag_store(detops_u64* p, detops_u64 v) {
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -221,22 +144,10 @@ __device__ __forceinline__ bool spin_again(int& budget) {   // false: give up (s
   __builtin_amdgcn_s_sleep(64);
   return --budget > 0;
 }
-#endif
-constexpr int kSpinBudget = 1 << 22;
 
 // ---- relaxed agent-scope fetch-add (a slot request whose result nothing else is ordered against), the packed 16-bit
 // hardware atomics (two adjacent elements, 4-byte aligned: global_atomic_pk_add_f16 / _bf16 instead of two
 // compare-and-swap loops on the containing dword) and the constant 100 MHz wall clock (diagnostic timelines)
-#ifdef DETOPS_CPU_EMU
-__device__ __forceinline__ int detops_fetch_add_relaxed(int32_t* p, int v) { const int o = *p; *p = o + v; return o; }
-__device__ __forceinline__ void detops_atomic_add2(__half* p, float v0, float v1) {
-  p[0] = __float2half(__half2float(p[0]) + v0); p[1] = __float2half(__half2float(p[1]) + v1);
-}
-__device__ __forceinline__ void detops_atomic_add2(__hip_bfloat16* p, float v0, float v1) {
-  p[0] = __float2bfloat16(__bfloat162float(p[0]) + v0); p[1] = __float2bfloat16(__bfloat162float(p[1]) + v1);
-}
-__device__ __forceinline__ long long detops_wall_clock() { return 0; }
-#else
 __device__ __forceinline__ int detops_fetch_add_relaxed(int32_t* p, int v) {
   return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -251,37 +162,44 @@ __device__ __forceinline__ void detops_atomic_add2(__hip_bfloat16* p, float v0, 
   __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) b2v*)(p), v);
 }
 __device__ __forceinline__ long long detops_wall_clock() { return static_cast<long long>(wall_clock64()); }
-#endif
 
 // ---- hardware transcendental / matrix instructions and their host-emulation stand-ins
-#ifdef DETOPS_CPU_EMU
-__device__ __forceinline__ float detops_exp(float x) { return expf(x); }
-__device__ __forceinline__ float detops_log(float x) { return logf(x); }
-#define DETOPS_MFMA_32x32x16_F16(a, b, c) emu_mfma_f32_32x32x16<decltype(a), _Float16>(a, b, c)
-#define DETOPS_MFMA_32x32x16_BF16(a, b, c) emu_mfma_f32_32x32x16<decltype(a), __bf16>(a, b, c)
-#else
 __device__ __forceinline__ float detops_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float detops_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }   // v_log_f32 is log2
 #define DETOPS_MFMA_32x32x16_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #define DETOPS_MFMA_32x32x16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-#endif
 
 // Workgroups of `kernel` (block size, dynamic LDS) the current device holds at once; -1 when unknown and in the host
 // emulation (which runs workgroups one after another).
 template <typename K>
 static inline int detops_resident_workgroups(K kernel, int block, size_t lds) {
-#ifdef DETOPS_CPU_EMU
-  (void)kernel; (void)block; (void)lds;
-  return -1;
-#else
   int dev = 0, cus = 0, per_cu = 1;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     return -1;
   DETOPS_OCCUPANCY(per_cu, kernel, block, lds);
   return cus * per_cu;
-#endif
 }
+#endif   // DETOPS_CPU_EMU
+
+#include "detops.h"
+
+#define DETOPS_API extern "C" __attribute__((visibility("default")))
+
+static inline hipStream_t as_stream(detops_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Launch epilogue: surfaces launch-configuration errors as the function's return code.
+static inline int launch_status() { return static_cast<int>(hipGetLastError()); }
+
+#define DETOPS_HIP_TRY(expr)                       \
+  do {                                             \
+    hipError_t _e = (expr);                        \
+    if (_e != hipSuccess) return static_cast<int>(_e); \
+  } while (0)
+
+
 
 // ---- tuning / test switches (read once at library load from DETOPS_TUNING="key=value,...", or set through
 // detops_tuning_set(); never read from the environment on the launch path)
