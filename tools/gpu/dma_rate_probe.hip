@@ -8,7 +8,9 @@ __device__ __forceinline__ void dma16(const float* sbase, unsigned voff, unsigne
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
-// pattern 0: lane-contiguous 1 KiB; 1: 13 row pieces of 80 bytes at a 268800-byte stride (channel planes), unaligned start
+// pattern 0: lane-contiguous 1 KiB; 1: 13 row pieces of 80 bytes at a 268800-byte stride (channel planes), unaligned start (the
+// forward kernel's shape); 2: the same pieces starting on 128-byte boundaries (one line each); 3: pattern 1 re-reading the SAME
+// addresses every instruction (L1 hits after the first); 4: 64 separate 16-byte pieces in 64 different lines
 template <int PATTERN>
 __global__ void __launch_bounds__(64) probe(const float* src, long long* ticks, int n, int span_kb, float* sink) {
   extern __shared__ float lds[];
@@ -17,12 +19,13 @@ __global__ void __launch_bounds__(64) probe(const float* src, long long* ticks, 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_fptr_t)lds)));
   unsigned voff;
   if (PATTERN == 0) voff = lane * 16;
-  else { const int ch = lane / 5, v = lane % 5; voff = ch * 268800u + v * 16u + 12u; }
-  const size_t wg_stride = (PATTERN == 0 ? 1024 : 13 * 268800ull) / 4;
-  const float* base = src + (static_cast<size_t>(blockIdx.x) * 7919 % 97) * wg_stride;
+  else if (PATTERN == 4) voff = lane * 268800u + 12u;
+  else { const int ch = lane / 5, v = lane % 5; voff = ch * 268800u + v * 16u + (PATTERN == 2 ? 0u : 12u); }
+  const size_t wg_stride = (PATTERN == 0 ? 1024 : (PATTERN == 4 ? 64 : 13) * 268800ull) / 4;
+  const float* base = src + (static_cast<size_t>(blockIdx.x) * 7919 % (PATTERN == 4 ? 13 : 97)) * wg_stride;   // all reads stay inside the 1 GiB buffer
   const long long t0 = wall_clock64();
   for (int i = 0; i < n; ++i) {
-    const float* p = base + static_cast<size_t>(i) * (PATTERN == 0 ? 256 * 256 : 336);   // a new row / block every instruction
+    const float* p = base + static_cast<size_t>(PATTERN == 3 ? 0 : i) * (PATTERN == 0 ? 256 * 256 : (PATTERN == 2 ? 352 : 336));   // a new row / block every instruction (pattern 2: 1408-byte rows keep the 128-byte alignment)
     dma16(p, voff, lds0 + (i % span_kb) * 1024);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -35,13 +38,16 @@ int main() {
   float* src; hipMalloc(&src, bytes); hipMemset(src, 0, bytes);
   long long* ticks; hipMalloc(&ticks, 8 * 4096);
   std::vector<long long> h(4096);
-  for (int pattern = 0; pattern < 2; ++pattern)
+  for (int pattern = 0; pattern < 5; ++pattern)
     for (int waves_per_cu : {1, 4, 8})
-      for (int n : {8, 32, 128}) {
+      for (int n : {32, 128}) {
         const int grid = 256 * waves_per_cu;
         for (int rep = 0; rep < 2; ++rep) {
           if (pattern == 0) hipLaunchKernelGGL(probe<0>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
-          else hipLaunchKernelGGL(probe<1>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
+          else if (pattern == 1) hipLaunchKernelGGL(probe<1>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
+          else if (pattern == 2) hipLaunchKernelGGL(probe<2>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
+          else if (pattern == 3) hipLaunchKernelGGL(probe<3>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
+          else hipLaunchKernelGGL(probe<4>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
           hipDeviceSynchronize();
         }
         hipMemcpy(h.data(), ticks, 8 * grid, hipMemcpyDeviceToHost);
