@@ -872,6 +872,41 @@ def test_deformable_kernels_vs_oracle_fp32(gi, modulated):
         _close(gmask, rgmask, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(rgmask).max()))
 
 
+@pytest.mark.parametrize("case", [dict(B=1, C=3, H=37, W=70, k=3, stride=1, pad=1, dil=1, dg=1, sigma=2.0),
+                                  dict(B=2, C=2, H=21, W=45, k=3, stride=1, pad=1, dil=1, dg=1, sigma=12.0),
+                                  dict(B=1, C=4, H=40, W=41, k=3, stride=2, pad=3, dil=3, dg=2, sigma=5.0),
+                                  dict(B=1, C=2, H=19, W=33, k=1, stride=1, pad=0, dil=1, dg=1, sigma=9.0),
+                                  dict(B=1, C=2, H=50, W=40, k=3, stride=1, pad=6, dil=6, dg=1, sigma=3.0)])
+def test_deformable_index_tile_owner_build_on_device(case):
+    """the tile-owner build of the inverted index on the device (LDS lists, ballot-compacted slot requests): maps of
+    several tiles, displacements far beyond the scanned window (overflow list), strides / dilations / padding — the
+    oracle's gradient, and the scatter build's (tuning dcn_ell_build = 1)"""
+    C = _C()
+    g = case
+    rng = np.random.RandomState(17)
+    k, p_, s_, d, dg = g["k"], g["pad"], g["stride"], g["dil"], g["dg"]
+    Ho = (g["H"] + 2 * p_ - (d * (k - 1) + 1)) // s_ + 1
+    Wo = (g["W"] + 2 * p_ - (d * (k - 1) + 1)) // s_ + 1
+    off = (rng.randn(g["B"], 2 * dg * k * k, Ho, Wo) * g["sigma"]).astype(np.float32)
+    mask = rng.uniform(0.2, 1.0, (g["B"], dg * k * k, Ho, Wo)).astype(np.float32)
+    geo = (k, k, p_, p_, s_, s_, d, d, dg)
+    ogeo = dict(kh=k, kw=k, pad=(p_, p_), stride=(s_, s_), dil=(d, d), dg=dg)
+    gcol = rng.randn(g["C"] * k * k, g["B"] * Ho * Wo).astype(np.float32)
+    shape = (g["B"], g["C"], g["H"], g["W"])
+    ref = oracle.deformable_col2im(gcol, off, mask, *shape, **ogeo)
+    tol = dict(rtol=1e-4, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    try:
+        _tune("dcn_col2im", 3)
+        for build in (0, 1):
+            _tune("dcn_ell_build", build)
+            gim = torch.zeros(*shape, device=DEV)
+            C.deformable_col2im(_t(gcol), _t(off), _t(mask), gim, *geo)
+            _close(gim, ref, **tol)
+    finally:
+        _tune("dcn_ell_build", 0)
+        _tune("dcn_col2im", 0)
+
+
 @pytest.mark.parametrize("gi", [0, 1])
 @pytest.mark.parametrize("modulated", [False, True])
 def test_deform_conv_layers_end_to_end_fp32(gi, modulated):
