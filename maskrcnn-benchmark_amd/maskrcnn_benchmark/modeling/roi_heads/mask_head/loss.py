@@ -88,8 +88,12 @@ class MaskRCNNLossComputation(object):
         pos = labels > 0
         if mask_targets.numel() == 0:
             return mask_logits.sum() * 0
-        idx = torch.arange(labels.numel(), device=dev)
-        logits = mask_logits[idx, labels.clamp(min=0)].float()
+        # the class plane of every ROI by gather (reference: mask_logits[positive_inds, labels_pos], loss.py:137-139): its
+        # backward is a scatter, where advanced indexing's is a sort-based index_put that leaves the device idle for
+        # 0.1-0.2 ms per step (profiles/r04z_bench_f32_step_breakdown.txt: the gaps behind indexing_backward_kernel)
+        M = mask_logits.shape[-1]
+        cls = labels.clamp(min=0)[:, None, None, None].expand(-1, 1, mask_logits.shape[-2], M)
+        logits = mask_logits.gather(1, cls).squeeze(1).float()
         bce = F.binary_cross_entropy_with_logits(logits, mask_targets, reduction="none")
         denom = (pos.sum() * bce[0].numel()).clamp(min=1).to(torch.float32)
         return torch.where(pos[:, None, None], bce, torch.zeros_like(bce)).sum() / denom
