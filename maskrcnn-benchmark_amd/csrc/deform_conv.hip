@@ -1604,11 +1604,16 @@ sampleT_gather_kernel(const T* __restrict__ gT, const int32_t* __restrict__ coun
     const EllEntry* ee = ent + ((static_cast<size_t>(b) * K + tap) * HW + p) * kEllCap;
     int32_t qi[kEllCap];
     float wi[kEllCap];
+    // the pixel's whole 64-byte record in four 16-byte loads (same addresses across the pixel group); slots >= n may
+    // hold anything (the scatter build leaves them unwritten): they are replaced before use
+    const float4* rec = reinterpret_cast<const float4*>(ee);
 #pragma unroll
-    for (int j = 0; j < kEllCap; ++j) {            // the (<= 8) entries: same addresses across the pixel group
-      const EllEntry r = j < n ? ee[j] : EllEntry{tap * (g.B * HWo), 0.f};
-      qi[j] = r.idx - tap * (g.B * HWo);           // column index -> b * Ho * Wo + pix
-      wi[j] = r.w;
+    for (int j = 0; j < kEllCap; j += 2) {
+      const float4 r = rec[j / 2];
+      qi[j] = (j < n ? __float_as_int(r.x) : tap * (g.B * HWo)) - tap * (g.B * HWo);   // column index -> b * Ho * Wo + pix
+      wi[j] = j < n ? r.y : 0.f;
+      qi[j + 1] = (j + 1 < n ? __float_as_int(r.z) : tap * (g.B * HWo)) - tap * (g.B * HWo);
+      wi[j + 1] = j + 1 < n ? r.w : 0.f;
     }
     T* dst = S_T + (static_cast<size_t>(gp) * K + tap) * Cout;
     for (int k = 0; k < nv; ++k) {
