@@ -880,6 +880,8 @@ def _w_tap_major(weight):
 
 
 def _nhwc_forward(input, weight, offset, mask, bias, out, geom):
+    """-> (xT, colT): the channel-fastest copy of the input and the column matrix, which the backward pass of the same
+    layer needs again (deform_conv_backward_all(saved=...))"""
     B, C, H, W = input.shape
     Cout = weight.size(0)
     xT = _to_nhwc(input)
@@ -888,6 +890,7 @@ def _nhwc_forward(input, weight, offset, mask, bias, out, geom):
               out=out.view(B, Cout, -1))
     if bias is not None:
         out += bias.to(out.dtype).view(1, -1, 1, 1)
+    return xT, colT
 
 
 def _nhwc_backward(input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight, grad_bias,
@@ -917,13 +920,18 @@ def _nhwc_backward(input, weight, offset, mask, grad_output, grad_input, grad_of
 
 
 def deform_conv_backward_all(input, offset, mask, weight, grad_output, kH, kW, padH, padW, dH, dW, dilH, dilW, group,
-                             deformable_group, need_input=True, need_weight=True, need_bias=False):
+                             deformable_group, need_input=True, need_weight=True, need_bias=False, saved=None):
     """Extension (not a name of the reference's `_C`): every gradient of one deformable convolution (v1: mask None;
     v2: modulated) from ONE pass over the channels-last pipeline.  The reference API (deform_conv_backward_input +
     deform_conv_backward_parameters, kept above) asks for them in two calls, each of which must rebuild the
     channel-fastest copies of the input and of the output gradient and accumulates into caller-zeroed tensors:
     per layer that is two extra transposes, three fills and an accumulate — about a third of the launches of a
     host-bound step (R-101 + DCN under fp16).
+
+    `saved` = what the forward pass of the same layer kept (`keep=[]` of deform_conv_forward /
+    modulated_deform_conv_forward: the channel-fastest input copy and the column matrix): neither is rebuilt then
+    (one transpose and one im2col launch less per layer: 35-55 us of device time at the cfg-5 shapes, for 9x the
+    layer input in memory until its backward pass has run).
 
     -> (grad_input, grad_offset, grad_mask, grad_weight, grad_bias), None where not asked for / not applicable;
     returns None when the shape is outside the channels-last plan (the caller then uses the reference entry points)."""
@@ -936,7 +944,7 @@ def deform_conv_backward_all(input, offset, mask, weight, grad_output, kH, kW, p
         mask = mask.contiguous()
     B, C, H, W = input.shape
     Cout = weight.size(0)
-    xT = _to_nhwc(input)
+    xT, colT = saved if saved is not None else (_to_nhwc(input), None)
     gT = _to_nhwc(grad_output)                                   # [B, Ho*Wo, Cout]
     g2 = gT.view(-1, Cout)
     grad_input = grad_offset = grad_mask = grad_weight = grad_bias = None
@@ -950,7 +958,8 @@ def deform_conv_backward_all(input, offset, mask, weight, grad_output, kH, kW, p
         W2T = weight.permute(1, 2, 3, 0).reshape(C, -1)          # [C, K*Cout]
         grad_input = torch.bmm(W2T.unsqueeze(0).expand(B, -1, -1), S_T.view(B, H * W, -1).transpose(1, 2)).view(B, C, H, W)
     if need_weight:
-        colT = _im2col_nhwc(xT, offset, mask, B, C, H, W, geom)  # [B*Ho*Wo, K*C]
+        if colT is None:
+            colT = _im2col_nhwc(xT, offset, mask, B, C, H, W, geom)  # [B*Ho*Wo, K*C]
         grad_weight = torch.mm(g2.t(), colT).view(Cout, kH, kW, C).permute(0, 3, 1, 2).contiguous()
     if need_bias:
         grad_bias = g2.sum(0)
@@ -968,9 +977,11 @@ def _grouped_weight_times_cols(weight, col, group, out):
 
 
 def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH,
-                        dilationW, dilationH, group, deformable_group, im2col_step):
+                        dilationW, dilationH, group, deformable_group, im2col_step, keep=None):
     """reference csrc/deform_conv.h:11-42 / csrc/cuda/deform_conv_cuda.cu:158-266.
-    Writes `output` in place; note the W-before-H argument order.  Returns 1."""
+    Writes `output` in place; note the W-before-H argument order.  Returns 1.
+    `keep` (extension): a list that receives what deform_conv_backward_all(saved=...) can reuse, when the
+    channels-last pipeline served the call."""
     _dcn_check("deform_conv_forward", input, weight, offset, output)
     input, offset, weight = input.contiguous(), offset.contiguous(), weight.contiguous()
     Ho, Wo = _shape_check(input, offset, None, weight, kH, kW, dH, dW, padH, padW, dilationH,
@@ -984,7 +995,9 @@ def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW
                                                   dilationH, dilationW, group, deformable_group):
         return 1
     if out.is_contiguous() and _nhwc_ok(input, weight, group, deformable_group):
-        _nhwc_forward(input, weight, offset, None, None, out, (kH, kW, padH, padW, dH, dW, dilationH, dilationW, deformable_group))
+        kept = _nhwc_forward(input, weight, offset, None, None, out, (kH, kW, padH, padW, dH, dW, dilationH, dilationW, deformable_group))
+        if keep is not None:
+            keep.append(kept)
         return 1
     for b0 in range(0, B, im2col_step):
         sl = slice(b0, b0 + im2col_step)
@@ -1058,8 +1071,9 @@ def deform_conv_backward_parameters(input, offset, gradOutput, gradWeight, colum
 
 def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, output, columns, kernel_h,
                                   kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
-                                  group, deformable_group, with_bias):
+                                  group, deformable_group, with_bias, keep=None):
     """reference csrc/deform_conv.h:115-149 / deform_conv_cuda.cu:496-575 (H-before-W order).
+    `keep` (extension): see deform_conv_forward.
     The reference loops per image; one im2col + one GEMM per group over the whole batch gives the
     same sums."""
     _dcn_check("modulated_deform_conv_forward", input, weight, offset, mask, output)
@@ -1082,8 +1096,10 @@ def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, outpu
                                                   dilation_h, dilation_w, group, deformable_group):
         return
     if out.is_contiguous() and _nhwc_ok(input, weight, group, deformable_group):
-        _nhwc_forward(input, weight, offset, mask, bias if with_bias else None, out,
-                      (kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w, deformable_group))
+        kept = _nhwc_forward(input, weight, offset, mask, bias if with_bias else None, out,
+                             (kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w, deformable_group))
+        if keep is not None:
+            keep.append(kept)
         return
     col = deformable_im2col(input, offset, mask, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w,
                             dilation_h, dilation_w, deformable_group)

@@ -34,10 +34,14 @@ class DeformConvFunction(Function):
             raise NotImplementedError
         step = min(ctx.im2col_step, input.shape[0])
         assert (input.shape[0] % step) == 0, "im2col step must divide batchsize"
+        # a layer that will be differentiated keeps its channel-fastest input copy and column matrix for its backward
+        # pass (one transpose + one im2col launch less there)
+        keep = [] if any(ctx.needs_input_grad[:3]) else None
         _C.deform_conv_forward(input, weight, offset, output, ctx.bufs_[0], ctx.bufs_[1],
                                weight.size(3), weight.size(2), ctx.stride[1], ctx.stride[0],
                                ctx.padding[1], ctx.padding[0], ctx.dilation[1], ctx.dilation[0],
-                               ctx.groups, ctx.deformable_groups, step)
+                               ctx.groups, ctx.deformable_groups, step, keep=keep)
+        ctx.kept_ = keep[0] if keep else None
         return output
 
     @staticmethod
@@ -58,7 +62,9 @@ class DeformConvFunction(Function):
         fused = _C.deform_conv_backward_all(input, offset, None, weight, grad_output, weight.size(2), weight.size(3),
                                             ctx.padding[0], ctx.padding[1], ctx.stride[0], ctx.stride[1],
                                             ctx.dilation[0], ctx.dilation[1], ctx.groups, ctx.deformable_groups,
-                                            need_input=need_in, need_weight=ctx.needs_input_grad[2])
+                                            need_input=need_in, need_weight=ctx.needs_input_grad[2],
+                                            saved=getattr(ctx, "kept_", None))
+        ctx.kept_ = None
         if fused is not None:
             return (fused[0], fused[1], fused[3], None, None, None, None, None, None)
         if need_in:
@@ -102,11 +108,13 @@ class ModulatedDeformConvFunction(Function):
             ctx.save_for_backward(input, offset, mask, weight, bias)
         output = input.new_empty(ModulatedDeformConvFunction._infer_shape(ctx, input, weight))
         ctx._bufs = [input.new_empty(0), input.new_empty(0)]
+        keep = [] if needs_grad else None
         _C.modulated_deform_conv_forward(input.contiguous(), weight, bias, ctx._bufs[0], offset, mask,
                                          output, ctx._bufs[1], weight.shape[2], weight.shape[3],
                                          ctx.stride, ctx.stride, ctx.padding, ctx.padding,
                                          ctx.dilation, ctx.dilation, ctx.groups,
-                                         ctx.deformable_groups, ctx.with_bias)
+                                         ctx.deformable_groups, ctx.with_bias, keep=keep)
+        ctx.kept_ = keep[0] if keep else None
         return output
 
     @staticmethod
@@ -118,7 +126,9 @@ class ModulatedDeformConvFunction(Function):
         (grad_output,) = _same_dtype(input, grad_output)
         fused = _C.deform_conv_backward_all(input, offset, mask, weight, grad_output, weight.shape[2], weight.shape[3],
                                             ctx.padding, ctx.padding, ctx.stride, ctx.stride, ctx.dilation, ctx.dilation,
-                                            ctx.groups, ctx.deformable_groups, need_bias=ctx.with_bias)
+                                            ctx.groups, ctx.deformable_groups, need_bias=ctx.with_bias,
+                                            saved=getattr(ctx, "kept_", None))
+        ctx.kept_ = None
         if fused is not None:
             return fused + (None, None, None, None, None)
         grad_input = torch.zeros_like(input)
