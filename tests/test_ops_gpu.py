@@ -1040,6 +1040,33 @@ def test_deform_conv_cfg5_layer4_half_fwd_bwd(dtype):
         assert np.abs(got.float().cpu().numpy() - want).max() <= 2e-2 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("modulated", [False, True])
+def test_deform_conv_backward_with_kept_forward_copies_equals_rebuild(modulated):
+    """layers that will be differentiated keep the channel-fastest input copy and the column matrix of their forward pass
+    (`keep=` / `saved=`): the backward pass with them equals the one that rebuilds both"""
+    C = _C()
+    Cc, H, W = CFG5_SHAPES[1]
+    x, off, mask, wgt = synth.dcn_inputs(2, Cc, H, W, Cc, 3, 1, modulated, seed=21)
+    dt = torch.float16
+    tx, toff, tw = (_t(a).to(dt) for a in (x, off, wgt * 0.25))
+    tm = _t(mask).to(dt) if modulated else None
+    out = torch.empty(2, Cc, H, W, device=DEV, dtype=dt)
+    e = torch.empty(0, device=DEV, dtype=dt)
+    keep = []
+    if modulated:
+        C.modulated_deform_conv_forward(tx, tw, torch.zeros(Cc, device=DEV, dtype=dt), e, toff, tm, out, e, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, False, keep=keep)
+    else:
+        C.deform_conv_forward(tx, tw, toff, out, e, e, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 2, keep=keep)
+    assert len(keep) == 1 and keep[0][1].shape == (2 * H * W, 9 * Cc)       # the channels-last pipeline served it
+    go = torch.randn(2, Cc, H, W, device=DEV).to(dt)
+    a = C.deform_conv_backward_all(tx, toff, tm, tw, go, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, saved=keep[0])
+    b = C.deform_conv_backward_all(tx, toff, tm, tw, go, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
+    for p_, q_ in zip(a, b):
+        assert (p_ is None) == (q_ is None)
+        if p_ is not None:     # (pile-ups beyond the index's 8 slots are added by atomics: not bit-reproducible run to run)
+            torch.testing.assert_close(p_.float(), q_.float(), rtol=2e-3, atol=2e-3 * float(q_.float().abs().max()))
+
+
 # ============================================================================ fused FrozenBN
 @pytest.mark.parametrize("shape", [(2, 8, 25, 42), (1, 5, 7, 9), (2, 16, 40, 64), (3, 4, 1, 1)])
 @pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True), (False, True)])
