@@ -356,6 +356,9 @@ def pin_hip_queues():
     queue (overlap with backward) without the many-queue penalty; an explicit setting in the environment wins.  Read by
     the HIP runtime at initialisation: must run before the first torch.cuda call."""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", HW_QUEUES_DEFAULT)
+    # kernel arguments in device memory: this image's runtime default, pinned because the step is ~1500 dependent launches
+    # (HIP_FORCE_DEV_KERNARG = 0 measured: fp32 39.0 -> 41.0 ms, bf16 22.1 -> 24.2 ms per step, profiles/r04ak_env_knobs.txt)
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     return os.environ["GPU_MAX_HW_QUEUES"]
 
 
@@ -596,7 +599,7 @@ def main():
             "losses": {k: round(v, 4) for k, v in loss_vals.items()},
             "max_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
             "miopen": {"search": bool(torch.backends.cudnn.benchmark), "db": miopen_db},
-            "hip": {"GPU_MAX_HW_QUEUES": hw_queues},
+            "hip": {"GPU_MAX_HW_QUEUES": hw_queues, "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
             "kernel_timers": ("all ranks" if distributed else "rank 0") if timer is not None else "off",
             "ddp": ddp_mode,
             # host time to ENQUEUE the timed steps (rank 0): close to ms_per_step = the host is the limiter

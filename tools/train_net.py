@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "maskrcnn-benchmark_amd"))
 # two busy streams per rank (compute, RCCL): two HIP hardware queues — see bench.py::pin_hip_queues for the measurement;
 # read by the HIP runtime at initialisation, an explicit setting in the environment wins
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (bench.py::pin_hip_queues)
 
 import torch  # noqa: E402
 
