@@ -82,6 +82,7 @@ class AnchorGenerator(nn.Module):
         self.cell_anchors = BufferList(cells)
         self.straddle_thresh = straddle_thresh
         self._grid_cache = {}
+        self._vis_cache = {}          # insertion-ordered: least recently used first
 
     def num_anchors_per_location(self):
         return [len(c) for c in self.cell_anchors]
@@ -112,7 +113,20 @@ class AnchorGenerator(nn.Module):
 
     def add_visibility_to(self, boxlist):
         w, h = boxlist.size
-        boxlist.add_field("visibility", self.visibility(boxlist.bbox, w, h))
+        boxlist.add_field("visibility", self._cached_visibility(boxlist.bbox, w, h))
+
+    def _cached_visibility(self, anchors, image_width, image_height):
+        """visibility is a function of (the cached per-level anchor tensor, the image size): seven elementwise launches
+        per (image, level) and step when recomputed — 70 per step at 2 images x 5 levels.  Bounded cache (real data
+        brings many image sizes): least recently used entries go first."""
+        key = (anchors.data_ptr(), tuple(anchors.shape), str(anchors.device), int(image_width), int(image_height))
+        hit = self._vis_cache.pop(key, None)
+        if hit is None or hit[0] is not anchors:
+            hit = (anchors, self.visibility(anchors, image_width, image_height))
+            while len(self._vis_cache) >= 256:
+                self._vis_cache.pop(next(iter(self._vis_cache)))
+        self._vis_cache[key] = hit
+        return hit[1]
 
     def forward(self, image_list, feature_maps):
         per_level = self.cached_grid_anchors([f.shape[-2:] for f in feature_maps])

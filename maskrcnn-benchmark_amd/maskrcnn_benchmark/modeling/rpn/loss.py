@@ -73,18 +73,39 @@ class RPNLossComputation(object):
         self.generate_labels_func = generate_labels_func
         self.discard_cases = ["not_visibility", "between_thresholds"]
 
+    # The per-level anchor tensors and their visibility masks are cached objects of the anchor generator (one per grid /
+    # image size): their concatenations are cached here on the identity of the parts (bounded), instead of two cat
+    # launches + a stack per step.
+    def _cat_cached(self, parts, build):
+        cache = self.__dict__.setdefault("_cat_cache", {})     # (subclasses have their own __init__)
+        key = tuple(id(p) for p in parts)
+        hit = cache.pop(key, None)
+        if hit is None or any(a is not b for a, b in zip(hit[0], parts)):
+            hit = (tuple(parts), build(parts))
+            while len(cache) >= 64:
+                cache.pop(next(iter(cache)))
+        cache[key] = hit
+        return hit[1]
+
+    def _all_anchors(self, level_boxlists):
+        return self._cat_cached([b.bbox for b in level_boxlists], lambda ps: torch.cat(ps, dim=0))
+
+    def _visibility(self, anchors):
+        parts = [b.get_field("visibility") for per_image in anchors for b in per_image]
+        n = len(anchors)
+        return self._cat_cached(parts, lambda ps: torch.stack([torch.cat(ps[i * len(ps) // n:(i + 1) * len(ps) // n], dim=0)
+                                                               for i in range(n)], dim=0))
+
     def _match(self, anchors, targets):
         """-> (labels [N,A] float 1/0/-1, matched_idxs [N,A] int64, padded gt [N,M,4], all anchors [A,4])."""
-        all_anchors = torch.cat([b.bbox for b in anchors[0]], dim=0)
+        all_anchors = self._all_anchors(anchors[0])
         dev = all_anchors.device
         gt, row_valid, extra = pad_targets(targets, dev, self.copied_fields)
         matched = match_batched(self.proposal_matcher, gt, row_valid, all_anchors)
         labels = self.generate_labels_func(matched, extra).to(torch.float32)
         labels = torch.where(matched == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(labels), labels)
         if "not_visibility" in self.discard_cases:
-            vis = torch.stack([torch.cat([b.get_field("visibility") for b in per_image], dim=0)
-                               for per_image in anchors], dim=0)
-            labels = torch.where(vis, labels, labels.new_full((), -1.0))
+            labels = torch.where(self._visibility(anchors), labels, labels.new_full((), -1.0))
         if "between_thresholds" in self.discard_cases:
             labels = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, labels.new_full((), -1.0), labels)
         return labels, matched, gt, all_anchors
