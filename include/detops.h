@@ -413,6 +413,21 @@ int detops_sample_labels(const void* labels, int label_dtype, int N, int n, int 
 int detops_mask_targets(const void* masks, int mask_dtype, const int64_t* mask_index, const float* boxes,
                         int G, int H, int W, int P, int M, float* out, detops_stream_t stream);
 
+/* detops_rpn_decode_f32 — the box path of RPN proposal selection for one feature level
+ *   (modeling/rpn/inference.py:75-110: gather of the pre-NMS top-k anchors' deltas, BoxCoder.decode —
+ *   modeling/box_coder.py:61-95 —, clip_to_image(remove_empty=False) — structures/bounding_box.py:202-213 —,
+ *   remove_small_boxes — structures/boxlist_ops.py:34-50 — as a mask): ~35 ATen launches per level in the reference.
+ *   box_regression [N, 4A, H, W] fp32 (the head's own layout), topk_idx / topk_scores [N, k] (positions in the
+ *   (y, x, a) order of permute_and_flatten, modeling/rpn/utils.py:9-13), anchors [A*H*W, 4] in that order,
+ *   image_hw [N, 2] = (height, width) fp32.  Writes boxes [N][.][4] and scores [N][.] at the caller's column offset
+ *   (row strides in elements), and this level's slice of the NMS input: nms_boxes [N*k, 4], nms_scores [N*k]
+ *   (boxes smaller than min_size are moved far away with score -1), ok [N*k] uint8. */
+int detops_rpn_decode_f32(const float* box_regression, const int64_t* topk_idx, const float* topk_scores,
+                          const float* anchors, const float* image_hw, int N, int A, int H, int W, int k,
+                          float wx, float wy, float ww, float wh, float bbox_xform_clip, float min_size,
+                          float* boxes, int64_t boxes_row_stride, float* scores, int64_t scores_row_stride,
+                          float* nms_boxes, float* nms_scores, uint8_t* ok, detops_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused FrozenBatchNorm2d affine (+ residual) (+ ReLU) — the elementwise tail of every backbone
  * convolution: layers/batch_norm.py:19-31 (`x * scale + bias`), then `F.relu_`, and in the

@@ -538,6 +538,54 @@ rpn_loss_scale_kernel(RpnLevels L, int A, int N, const float* __restrict__ up_ob
   }
 }
 
+// ------------------------------------------------------------------------------------------ RPN proposal decode
+// One launch per feature level for the box path of RPNPostProcessor.forward_for_single_feature_map
+// (modeling/rpn/inference.py:75-110): gather the selected anchors' deltas from the head output in ITS layout
+// [N, 4A, H, W] (no permuted copy), BoxCoder.decode (modeling/box_coder.py:61-95), clip_to_image(remove_empty = False)
+// (structures/bounding_box.py:202-213) and remove_small_boxes (structures/boxlist_ops.py:34-50) as a mask — ~35 elementwise
+// launches per level as an ATen composition.  Same operations in the same order in fp32, contraction off.
+//   idx [N, k]: positions in the (y, x, a) anchor order of permute_and_flatten (modeling/rpn/utils.py:9-13)
+// writes  boxes_im [N][*][4] / scores_im [N][*] at the level's column offset of the image-major result (row strides
+//         given), and the level's slice of the level-major NMS input: nms_boxes [N * k, 4], nms_scores [N * k] (boxes
+//         failing min_size moved far away with score -1: they must not take part in NMS), ok [N * k]
+__global__ void __launch_bounds__(kBlock)
+rpn_decode_kernel(const float* __restrict__ reg, const int64_t* __restrict__ idx, const float* __restrict__ scores,
+                  const float* __restrict__ anchors, const float* __restrict__ image_hw, int N, int A, int H, int W, int k,
+                  float wx, float wy, float ww, float wh, float xform_clip, float min_size,
+                  float* __restrict__ boxes_im, int64_t boxes_row_stride, float* __restrict__ scores_im,
+                  int64_t scores_row_stride, float* __restrict__ nms_boxes, float* __restrict__ nms_scores,
+                  uint8_t* __restrict__ ok_out) {
+#pragma clang fp contract(off)
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= static_cast<int64_t>(N) * k) return;
+  const int n = static_cast<int>(t / k), j = static_cast<int>(t - static_cast<int64_t>(n) * k);
+  const int64_t i = idx[t];
+  const int a = static_cast<int>(i % A);
+  const int64_t pos = i / A;
+  const int y = static_cast<int>(pos / W), x = static_cast<int>(pos - static_cast<int64_t>(y) * W);
+  const size_t plane = static_cast<size_t>(H) * W;
+  const float* r = reg + (static_cast<size_t>(n) * 4 * A + 4 * a) * plane + static_cast<size_t>(y) * W + x;
+  const float4 an = reinterpret_cast<const float4*>(anchors)[i];
+  const float w = an.z - an.x + 1.f, h = an.w - an.y + 1.f;
+  const float cx = an.x + 0.5f * w, cy = an.y + 0.5f * h;
+  const float dx = r[0] / wx, dy = r[plane] / wy;
+  const float dw = fminf(r[2 * plane] / ww, xform_clip), dh = fminf(r[3 * plane] / wh, xform_clip);
+  const float pcx = dx * w + cx, pcy = dy * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw - 1.f, y2 = pcy + 0.5f * ph - 1.f;
+  const float hx = image_hw[2 * n + 1] - 1.f, hy = image_hw[2 * n] - 1.f;
+  x1 = fminf(fmaxf(x1, 0.f), hx); y1 = fminf(fmaxf(y1, 0.f), hy);
+  x2 = fminf(fmaxf(x2, 0.f), hx); y2 = fminf(fmaxf(y2, 0.f), hy);
+  const float bw = x2 - x1 + 1.f, bh = y2 - y1 + 1.f;
+  const bool ok = bw >= min_size && bh >= min_size;
+  const float s = scores[t];
+  reinterpret_cast<float4*>(boxes_im + static_cast<size_t>(n) * boxes_row_stride)[j] = make_float4(x1, y1, x2, y2);
+  scores_im[static_cast<size_t>(n) * scores_row_stride + j] = s;
+  reinterpret_cast<float4*>(nms_boxes)[t] = ok ? make_float4(x1, y1, x2, y2) : make_float4(-1e6f, -1e6f, -1e6f + 1.f, -1e6f + 1.f);
+  nms_scores[t] = ok ? s : -1.f;
+  ok_out[t] = ok ? 1 : 0;
+}
+
 }  // namespace
 
 DETOPS_API size_t detops_match_boxes_workspace_bytes(int N, int M) {
@@ -565,6 +613,23 @@ DETOPS_API int detops_match_boxes_f32(const float* gt_boxes, const uint8_t* gt_v
   if (allow_low_quality_matches)
     hipLaunchKernelGGL(match_kernel<1>, grid, dim3(kBlock), 0, st, gt_boxes, gt_valid, boxes, boxes_batched, M, K,
                        high_threshold, low_threshold, allow_low_quality_matches, best, matched_idxs);
+  return launch_status();
+}
+
+DETOPS_API int detops_rpn_decode_f32(const float* box_regression, const int64_t* topk_idx, const float* topk_scores,
+                                     const float* anchors, const float* image_hw, int N, int A, int H, int W, int k,
+                                     float wx, float wy, float ww, float wh, float bbox_xform_clip, float min_size,
+                                     float* boxes, int64_t boxes_row_stride, float* scores, int64_t scores_row_stride,
+                                     float* nms_boxes, float* nms_scores, uint8_t* ok, detops_stream_t stream) {
+  if (N < 0 || A <= 0 || H <= 0 || W <= 0 || k < 0) return DETOPS_EINVAL;
+  if (N == 0 || k == 0) return 0;
+  if (!box_regression || !topk_idx || !topk_scores || !anchors || !image_hw || !boxes || !scores || !nms_boxes ||
+      !nms_scores || !ok || boxes_row_stride < 4 * static_cast<int64_t>(k) || scores_row_stride < k)
+    return DETOPS_EINVAL;
+  const int64_t total = static_cast<int64_t>(N) * k;
+  hipLaunchKernelGGL(rpn_decode_kernel, dim3(static_cast<unsigned>(ceil_div64(total, kBlock))), dim3(kBlock), 0, as_stream(stream),
+                     box_regression, topk_idx, topk_scores, anchors, image_hw, N, A, H, W, k, wx, wy, ww, wh, bbox_xform_clip,
+                     min_size, boxes, boxes_row_stride, scores, scores_row_stride, nms_boxes, nms_scores, ok);
   return launch_status();
 }
 

@@ -356,6 +356,38 @@ def mask_targets(masks, mask_index, boxes, discretization_size):
     return out
 
 
+def rpn_decode(box_regression, topk_idx, topk_scores, anchors, image_hw, weights, bbox_xform_clip, min_size,
+               boxes, scores, col, nms_boxes, nms_scores, ok, off):
+    """Box path of RPN proposal selection for one level in ONE launch (extension; reference
+    modeling/rpn/inference.py:75-110 + box_coder.py:61-95): decodes the top-k anchors straight from the head output
+    [N,4A,H,W] and writes boxes[:, col:col+k] / scores[:, col:col+k] of the image-major result and rows
+    [off, off+N*k) of the level-major NMS input (nms_boxes, nms_scores, ok uint8)."""
+    _need_cuda("rpn_decode", box_regression, topk_idx, topk_scores, anchors, image_hw, boxes, scores)
+    reg = _f32c("rpn_decode", box_regression)
+    topk_scores = _f32c("rpn_decode", topk_scores)
+    anchors = _f32c("rpn_decode", anchors)
+    topk_idx = topk_idx.contiguous()
+    N, A4, H, W = reg.shape
+    k = topk_idx.size(1)
+    if topk_idx.dtype != torch.int64 or A4 % 4 or anchors.size(0) != (A4 // 4) * H * W or image_hw.shape != (N, 2):
+        raise ValueError("rpn_decode: inconsistent arguments")
+    for t in (boxes, scores, nms_boxes, nms_scores, ok):
+        if not t.is_contiguous():
+            raise ValueError("rpn_decode: outputs must be contiguous")
+    if boxes.dtype != torch.float32 or scores.dtype != torch.float32 or ok.dtype != torch.uint8 \
+            or col + k > boxes.size(1) or off + N * k > nms_scores.numel():
+        raise ValueError("rpn_decode: outputs do not fit")
+    if N * k == 0:
+        return
+    wx, wy, ww, wh = (float(w) for w in weights)
+    with _on_device(reg), _timed(("rpn_decode[N=%d,k=%d]", (N, k)), reg):
+        check(lib.detops_rpn_decode_f32(
+            ptr(reg), ptr(topk_idx), ptr(topk_scores), ptr(anchors), ptr(image_hw), N, A4 // 4, H, W, k, wx, wy, ww, wh,
+            float(bbox_xform_clip), float(min_size), boxes.data_ptr() + 16 * col, 4 * boxes.size(1),
+            scores.data_ptr() + 4 * col, scores.size(1), nms_boxes.data_ptr() + 16 * off, nms_scores.data_ptr() + 4 * off,
+            ok.data_ptr() + off, stream_of(reg)), "rpn_decode")
+
+
 # ------------------------------------------------------------------------------------------ ROIAlign
 def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
     """reference csrc/ROIAlign.h:11-25 -> [K,C,PH,PW]."""

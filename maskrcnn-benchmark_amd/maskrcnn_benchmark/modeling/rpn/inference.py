@@ -36,6 +36,7 @@ class RPNPostProcessor(torch.nn.Module):
         self.fpn_post_nms_top_n = post_nms_top_n if fpn_post_nms_top_n is None else fpn_post_nms_top_n
         self.fpn_post_nms_per_batch = fpn_post_nms_per_batch
         self._seg_cache = {}
+        self.fused_decode = True  # device tensors: one _C.rpn_decode launch per level instead of the ATen composition
 
     # ------------------------------------------------------------------ per level (batched over images)
     def _level_candidates(self, level_anchors, objectness, box_regression, image_sizes):
@@ -74,25 +75,54 @@ class RPNPostProcessor(torch.nn.Module):
             return self._select(anchors_per_level, [o.float() for o in objectness],
                                 [r.float() for r in box_regression], image_sizes, training)
 
+    def _candidates_fused(self, anchors_per_level, objectness, box_regression, image_sizes):
+        """The device path of `_level_candidates` + the NMS-input assembly below: per level a sigmoid, a top-k and ONE
+        `_C.rpn_decode` launch that reads the head output in its own layout and writes straight into the image-major
+        result and the level-major NMS input (no permuted copy of the regression, no per-level concatenation)."""
+        N = objectness[0].shape[0]
+        dev = objectness[0].device
+        ks = [min(self.pre_nms_top_n, o.shape[1] * o.shape[2] * o.shape[3]) for o in objectness]
+        K = sum(ks)
+        boxes = torch.empty((N, K, 4), dtype=torch.float32, device=dev)
+        scores = torch.empty((N, K), dtype=torch.float32, device=dev)
+        flat_boxes = torch.empty((N * K, 4), dtype=torch.float32, device=dev)
+        flat_scores = torch.empty((N * K,), dtype=torch.float32, device=dev)
+        flat_ok = torch.empty((N * K,), dtype=torch.uint8, device=dev)
+        image_hw = device_constant([[h, w] for (h, w) in image_sizes], torch.float32, dev)
+        col = 0
+        for a, o, r, k in zip(anchors_per_level, objectness, box_regression, ks):
+            A, H, W = o.shape[1:]
+            s, idx = permute_and_flatten(o, N, A, 1, H, W).view(N, -1).sigmoid().topk(k, dim=1, sorted=True)
+            _C.rpn_decode(r, idx, s, a, image_hw, self.box_coder.weights, self.box_coder.bbox_xform_clip, self.min_size,
+                          boxes, scores, col, flat_boxes, flat_scores, flat_ok, N * col)
+            col += k
+        return ks, boxes, scores, flat_boxes, flat_scores, flat_ok.view(torch.bool)
+
     def _select(self, anchors_per_level, objectness, box_regression, image_sizes, training):
         N = objectness[0].shape[0]
-        boxes, scores, oks = [], [], []
-        for a, o, r in zip(anchors_per_level, objectness, box_regression):
-            b, s, ok = self._level_candidates(a, o, r, image_sizes)
-            boxes.append(b)
-            scores.append(s)
-            oks.append(ok)
-        ks = [b.shape[1] for b in boxes]
-        dev = boxes[0].device
-        # one segmented NMS over all (level, image) problems
-        flat_boxes = torch.cat([b.reshape(-1, 4) for b in boxes], dim=0)
-        flat_scores = torch.cat([s.reshape(-1) for s in scores], dim=0)
-        flat_ok = torch.cat([k.reshape(-1) for k in oks], dim=0)
-        if self.min_size > 0:
-            # removed boxes must not take part in NMS: move them far away with the lowest score
-            far = device_constant([-1e6, -1e6, -1e6 + 1, -1e6 + 1], flat_boxes.dtype, flat_boxes.device)
-            flat_boxes = torch.where(flat_ok[:, None], flat_boxes, far)
-            flat_scores = torch.where(flat_ok, flat_scores, flat_scores.new_full((), -1.0))
+        dev = objectness[0].device
+        if dev.type == "cuda" and self.fused_decode:
+            ks, boxes, scores, flat_boxes, flat_scores, flat_ok = self._candidates_fused(
+                anchors_per_level, objectness, box_regression, image_sizes)
+        else:
+            boxes, scores, oks = [], [], []
+            for a, o, r in zip(anchors_per_level, objectness, box_regression):
+                b, s, ok = self._level_candidates(a, o, r, image_sizes)
+                boxes.append(b)
+                scores.append(s)
+                oks.append(ok)
+            ks = [b.shape[1] for b in boxes]
+            # one segmented NMS over all (level, image) problems
+            flat_boxes = torch.cat([b.reshape(-1, 4) for b in boxes], dim=0)
+            flat_scores = torch.cat([s.reshape(-1) for s in scores], dim=0)
+            flat_ok = torch.cat([k.reshape(-1) for k in oks], dim=0)
+            if self.min_size > 0:
+                # removed boxes must not take part in NMS: move them far away with the lowest score
+                far = device_constant([-1e6, -1e6, -1e6 + 1, -1e6 + 1], flat_boxes.dtype, flat_boxes.device)
+                flat_boxes = torch.where(flat_ok[:, None], flat_boxes, far)
+                flat_scores = torch.where(flat_ok, flat_scores, flat_scores.new_full((), -1.0))
+            boxes = torch.cat(boxes, dim=1)
+            scores = torch.cat(scores, dim=1)
         keep, _ = _C.nms_batched_mask(flat_boxes, flat_scores, self._segments(ks, N, dev), max(ks),
                                       self.nms_thresh)
         keep = keep & flat_ok
@@ -103,8 +133,6 @@ class RPNPostProcessor(torch.nn.Module):
             if self.post_nms_top_n < k:  # keep the first post_nms_top_n survivors (score order)
                 v = v & (v.cumsum(dim=1) <= self.post_nms_top_n)
             valid.append(v)
-        boxes = torch.cat(boxes, dim=1)
-        scores = torch.cat(scores, dim=1)
         valid = torch.cat(valid, dim=1)
         if len(ks) > 1:
             valid = self._select_over_all_levels(scores, valid, training)

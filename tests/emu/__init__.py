@@ -37,6 +37,7 @@ SIGNATURES = {
     "detops_sample_labels": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, _P, _P, _P, _P, _P,
                                      ctypes.c_size_t, _P]),
     "detops_mask_targets": (c_int, [_P, c_int, _P, _P] + [c_int] * 5 + [_P, _P]),
+    "detops_rpn_decode_f32": (c_int, [_P] * 5 + [c_int] * 5 + [c_float] * 6 + [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, _P, _P]),
     "detops_rpn_loss_workspace_bytes": (ctypes.c_size_t, []),
     "detops_rpn_loss_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
                                     _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
@@ -250,6 +251,24 @@ def mask_targets(masks, mask_index, boxes, M):
     rc = lib().detops_mask_targets(_p(masks), code, _p(mask_index), _p(boxes), G, H, W, P, M, _p(out), None)
     assert rc == 0, rc
     return out
+
+
+def rpn_decode(box_regression, topk_idx, topk_scores, anchors, image_hw, weights, xform_clip, min_size):
+    """-> boxes [N,k,4], scores [N,k], nms_boxes [N*k,4], nms_scores [N*k], ok [N*k] bool for one level."""
+    reg, sc, an, hw = _f32(box_regression), _f32(topk_scores), _f32(anchors), _f32(image_hw)
+    idx = np.ascontiguousarray(topk_idx, dtype=np.int64)
+    N, A4, H, W = reg.shape
+    A, k = A4 // 4, idx.shape[1]
+    boxes = np.full((N, k, 4), np.nan, np.float32)
+    scores = np.full((N, k), np.nan, np.float32)
+    nb = np.full((N * k, 4), np.nan, np.float32)
+    ns = np.full((N * k,), np.nan, np.float32)
+    ok = np.full((N * k,), 7, np.uint8)
+    rc = lib().detops_rpn_decode_f32(_p(reg), _p(idx), _p(sc), _p(an), _p(hw), N, A, H, W, k, *[float(w) for w in weights],
+                                     float(xform_clip), float(min_size), _p(boxes), 4 * k, _p(scores), k, _p(nb), _p(ns),
+                                     _p(ok), None)
+    assert rc == 0, rc
+    return boxes, scores, nb, ns, ok.astype(bool)
 
 
 # ---------------------------------------------------------------------------------- deformable conv

@@ -168,3 +168,34 @@ def test_rpn_loss_fused_full_size_equals_torch_composite_and_autograd():
             torch.testing.assert_close(a, r, rtol=1e-5, atol=1e-8)
         lo2, lb2 = _C.rpn_loss(obj, box, anchors, matched, pos, neg, gt, beta, weights)
         assert float(lo2) == float(lo) and float(lb2) == float(lb)   # fixed-order sums
+
+
+@pytest.mark.parametrize("training,min_size", [(True, 0), (False, 16)])
+def test_rpn_proposal_selection_with_the_fused_decode_is_bit_equal_to_the_aten_composition(training, min_size):
+    """RPNPostProcessor._select at the BASELINE shape (5 FPN levels of an 800 x 1344 batch, 2000 / 1000 pre-NMS
+    candidates per level): the one-launch-per-level decode (_C.rpn_decode) against the per-level ATen composition
+    (gather, BoxCoder.decode, clip, min-size mask, concatenations) — boxes, scores and the post-NMS validity mask
+    all identical (tests/test_emu_targets.py holds the same kernel against the CPU composite)."""
+    from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+    from maskrcnn_benchmark.modeling.rpn.anchor_generator import AnchorGenerator
+    from maskrcnn_benchmark.modeling.rpn.inference import RPNPostProcessor
+    strides = (4, 8, 16, 32, 64)
+    ag = AnchorGenerator(sizes=((32,), (64,), (128,), (256,), (512,)), anchor_strides=strides)
+    shapes = [(-(-800 // s), -(-1344 // s)) for s in strides]
+    anchors = [a.to(DEV) for a in ag.grid_anchors(shapes)]
+    g = torch.Generator().manual_seed(3)
+    N, A = 2, 3
+    obj = [torch.randn(N, A, h, w, generator=g).to(DEV) for h, w in shapes]
+    reg = [(torch.randn(N, 4 * A, h, w, generator=g) * 0.5).to(DEV) for h, w in shapes]
+    reg[2][0, 2::4] += 5.0
+    sizes = [(800, 1344), (771, 1203)]
+    top = 2000 if training else 1000
+    post = RPNPostProcessor(top, top, 0.7, min_size, BoxCoder((1.0, 1.0, 1.0, 1.0)), fpn_post_nms_top_n=top)
+    out = {}
+    for fused in (True, False):
+        post.fused_decode = fused
+        out[fused] = post._select(anchors, obj, reg, sizes, training)
+    for a, b in zip(out[True], out[False]):
+        assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)
+    boxes, scores, valid = out[True]
+    assert 0 < int(valid.sum()) <= (top if training else N * top)
