@@ -428,6 +428,25 @@ int detops_rpn_decode_f32(const float* box_regression, const int64_t* topk_idx, 
                           float* boxes, int64_t boxes_row_stride, float* scores, int64_t scores_row_stride,
                           float* nms_boxes, float* nms_scores, uint8_t* ok, detops_stream_t stream);
 
+/* detops_match_labels — Matcher output -> training labels (modeling/rpn/loss.py:70-88 and
+ *   roi_heads/box_head/loss.py:56-72 of the reference: the clamp / gather / three masked assignments per image):
+ *   matched [N, K] int64; gt_labels [N, M] int64 or NULL (NULL: every match labels 1, the RPN rule);
+ *   valid [N, K] uint8 or NULL (anchor visibility / proposal validity: false -> -1).
+ *   out [N, K]: float32 (out_dtype 0) or int64 (out_dtype 1);  >= 0 -> class, -1 -> 0, -2 -> -1. */
+int detops_match_labels(const int64_t* matched, const int64_t* gt_labels, const uint8_t* valid, int N, int K, int M,
+                        int out_dtype, void* out, detops_stream_t stream);
+
+/* detops_roi_head_targets_f32 — the box head's sampled slots (roi_heads/box_head/loss.py:56-110: labels, BoxCoder.encode of
+ *   the matched ground truth — modeling/box_coder.py:27-51 —, the per-image indexing by the sampled positions):
+ *   boxes [N, K, 4], matched [N, K], gt_boxes [N, M, 4], gt_labels [N, M], valid [N, K] or NULL, idx / slot_valid [N, B]
+ *   (detops_sample_labels' slot list), objectness [N, K] or NULL -> per slot: box [N, B, 4], label [N, B] int64 (-1 for an
+ *   unfilled slot), regression target [N, B, 4], matched index [N, B], objectness [N, B] (out_objectness may be NULL). */
+int detops_roi_head_targets_f32(const float* boxes, const int64_t* matched, const float* gt_boxes, const int64_t* gt_labels,
+                                const uint8_t* valid, const int64_t* idx, const uint8_t* slot_valid, const float* objectness,
+                                int N, int K, int M, int B, float wx, float wy, float ww, float wh, float* out_boxes,
+                                int64_t* out_labels, float* out_regression_targets, int64_t* out_matched,
+                                float* out_objectness, detops_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused FrozenBatchNorm2d affine (+ residual) (+ ReLU) — the elementwise tail of every backbone
  * convolution: layers/batch_norm.py:19-31 (`x * scale + bias`), then `F.relu_`, and in the

@@ -586,6 +586,59 @@ rpn_decode_kernel(const float* __restrict__ reg, const int64_t* __restrict__ idx
   ok_out[t] = ok ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------ labels / head targets
+// Matcher output -> training labels in ONE launch (the where / eq / full_like chains of modeling/rpn/loss.py:108-118 and
+// roi_heads/box_head/loss.py:56-72):  matched >= 0 -> the matched ground truth's class (1 without classes),
+// BELOW_LOW_THRESHOLD (-1) -> 0, BETWEEN_THRESHOLDS (-2) -> -1, and -1 wherever `valid` (anchor visibility / proposal
+// validity) is false.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+match_labels_kernel(const int64_t* __restrict__ matched, const int64_t* __restrict__ gt_labels,
+                    const uint8_t* __restrict__ valid, int64_t total, int K, int M, T* __restrict__ out) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= total) return;
+  const int64_t m = matched[t];
+  T v = static_cast<T>(-1);
+  if (m >= 0) v = gt_labels ? static_cast<T>(gt_labels[(t / K) * M + m]) : static_cast<T>(1);
+  else if (m == -1) v = static_cast<T>(0);
+  if (valid && !valid[t]) v = static_cast<T>(-1);
+  out[t] = v;
+}
+
+// The sampled slots of the box head in ONE launch (roi_heads/box_head/loss.py:56-110 of the reference does this per
+// image with ~25 indexing launches after encoding ALL proposals): slot (n, j) takes proposal i = idx[n][j] and gets its
+// box, class label (as above; -1 for an unfilled slot), BoxCoder.encode(matched gt, box) (box_coder.py:27-51),
+// matched index and objectness.
+__global__ void __launch_bounds__(kBlock)
+roi_head_targets_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ matched, const float* __restrict__ gt,
+                        const int64_t* __restrict__ gt_labels, const uint8_t* __restrict__ valid,
+                        const int64_t* __restrict__ idx, const uint8_t* __restrict__ slot_valid,
+                        const float* __restrict__ objectness, int N, int K, int M, int B, float wx, float wy, float ww,
+                        float wh, float* __restrict__ out_boxes, int64_t* __restrict__ out_labels,
+                        float* __restrict__ out_reg, int64_t* __restrict__ out_matched, float* __restrict__ out_obj) {
+#pragma clang fp contract(off)
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (t >= static_cast<int64_t>(N) * B) return;
+  const int n = static_cast<int>(t / B);
+  int64_t i = idx[t];
+  i = i < 0 ? 0 : (i >= K ? K - 1 : i);
+  const size_t src = static_cast<size_t>(n) * K + i;
+  const int64_t m = matched[src];
+  const float4 b = reinterpret_cast<const float4*>(boxes)[src];
+  const float4 g = reinterpret_cast<const float4*>(gt)[static_cast<size_t>(n) * M + (m < 0 ? 0 : m)];
+  int64_t label = -1;
+  if (slot_valid[t] && (!valid || valid[src])) label = m >= 0 ? gt_labels[static_cast<size_t>(n) * M + m] : (m == -1 ? 0 : -1);
+  const float ew = b.z - b.x + 1.f, eh = b.w - b.y + 1.f;
+  const float ex = b.x + 0.5f * ew, ey = b.y + 0.5f * eh;
+  const float gw = g.z - g.x + 1.f, gh = g.w - g.y + 1.f;
+  const float gx = g.x + 0.5f * gw, gy = g.y + 0.5f * gh;
+  reinterpret_cast<float4*>(out_boxes)[t] = b;
+  reinterpret_cast<float4*>(out_reg)[t] = make_float4(wx * (gx - ex) / ew, wy * (gy - ey) / eh, ww * logf(gw / ew), wh * logf(gh / eh));
+  out_labels[t] = label;
+  out_matched[t] = m;
+  if (out_obj) out_obj[t] = objectness ? objectness[src] : 0.f;
+}
+
 }  // namespace
 
 DETOPS_API size_t detops_match_boxes_workspace_bytes(int N, int M) {
@@ -630,6 +683,40 @@ DETOPS_API int detops_rpn_decode_f32(const float* box_regression, const int64_t*
   hipLaunchKernelGGL(rpn_decode_kernel, dim3(static_cast<unsigned>(ceil_div64(total, kBlock))), dim3(kBlock), 0, as_stream(stream),
                      box_regression, topk_idx, topk_scores, anchors, image_hw, N, A, H, W, k, wx, wy, ww, wh, bbox_xform_clip,
                      min_size, boxes, boxes_row_stride, scores, scores_row_stride, nms_boxes, nms_scores, ok);
+  return launch_status();
+}
+
+DETOPS_API int detops_match_labels(const int64_t* matched, const int64_t* gt_labels, const uint8_t* valid, int N, int K,
+                                   int M, int out_dtype, void* out, detops_stream_t stream) {
+  if (N < 0 || K < 0 || M < 0 || (out_dtype != 0 && out_dtype != 1)) return DETOPS_EINVAL;
+  const int64_t total = static_cast<int64_t>(N) * K;
+  if (total == 0) return 0;
+  if (!matched || !out || (gt_labels && M == 0)) return DETOPS_EINVAL;
+  const dim3 grid(static_cast<unsigned>(ceil_div64(total, kBlock)));
+  if (out_dtype == 0)
+    hipLaunchKernelGGL(match_labels_kernel<float>, grid, dim3(kBlock), 0, as_stream(stream), matched, gt_labels, valid, total, K,
+                       M, static_cast<float*>(out));
+  else
+    hipLaunchKernelGGL(match_labels_kernel<int64_t>, grid, dim3(kBlock), 0, as_stream(stream), matched, gt_labels, valid, total,
+                       K, M, static_cast<int64_t*>(out));
+  return launch_status();
+}
+
+DETOPS_API int detops_roi_head_targets_f32(const float* boxes, const int64_t* matched, const float* gt_boxes,
+                                           const int64_t* gt_labels, const uint8_t* valid, const int64_t* idx,
+                                           const uint8_t* slot_valid, const float* objectness, int N, int K, int M, int B,
+                                           float wx, float wy, float ww, float wh, float* out_boxes, int64_t* out_labels,
+                                           float* out_regression_targets, int64_t* out_matched, float* out_objectness,
+                                           detops_stream_t stream) {
+  if (N < 0 || K < 0 || M < 0 || B < 0) return DETOPS_EINVAL;
+  if (N == 0 || B == 0) return 0;
+  if (K == 0 || M == 0 || !boxes || !matched || !gt_boxes || !gt_labels || !idx || !slot_valid || !out_boxes || !out_labels ||
+      !out_regression_targets || !out_matched)
+    return DETOPS_EINVAL;
+  const int64_t total = static_cast<int64_t>(N) * B;
+  hipLaunchKernelGGL(roi_head_targets_kernel, dim3(static_cast<unsigned>(ceil_div64(total, kBlock))), dim3(kBlock), 0,
+                     as_stream(stream), boxes, matched, gt_boxes, gt_labels, valid, idx, slot_valid, objectness, N, K, M, B, wx, wy,
+                     ww, wh, out_boxes, out_labels, out_regression_targets, out_matched, out_objectness);
   return launch_status();
 }
 

@@ -40,6 +40,21 @@ def _f32c(name, t):
     return t.contiguous()
 
 
+def on_device(t):
+    """True when `t` takes the HIP operators of this module (the model code asks this instead of `t.is_cuda`, so the
+    host-emulation tests can drive the same branches with CPU tensors)."""
+    return t.is_cuda
+
+
+def _u8(name, t):
+    """bool / uint8 mask -> contiguous uint8 (a bool tensor is reinterpreted, not converted: no launch)."""
+    if t.dtype == torch.bool:
+        return t.contiguous().view(torch.uint8)
+    if t.dtype != torch.uint8:
+        raise RuntimeError("%s: expected a bool or uint8 mask, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
 def _on_device(t):
     """Context: `t`'s device is current for the launch (a shared no-op object in the usual case — the tensor lives
     on the current device — so the launch path allocates nothing)."""
@@ -264,7 +279,7 @@ def match_boxes(gt_boxes, gt_valid, boxes, high_threshold, low_threshold, allow_
     _need_cuda("match_boxes", gt_boxes, gt_valid, boxes)
     gt_boxes = _f32c("match_boxes", gt_boxes)
     boxes = _f32c("match_boxes", boxes)
-    valid = gt_valid.to(torch.uint8).contiguous() if gt_valid.dtype != torch.uint8 else gt_valid.contiguous()
+    valid = _u8("match_boxes", gt_valid)
     N, M = gt_boxes.shape[:2]
     batched = boxes.dim() == 3
     K = boxes.shape[-2]
@@ -354,6 +369,76 @@ def mask_targets(masks, mask_index, boxes, discretization_size):
             check(lib.detops_mask_targets(ptr(m), code, ptr(mask_index), ptr(boxes), G, H, W, P, M, ptr(out),
                                           stream_of(boxes)), "mask_targets")
     return out
+
+
+def match_labels(matched, gt_labels=None, valid=None, dtype=torch.int64):
+    """Matcher output [N,K] -> labels in one launch (extension; reference modeling/rpn/loss.py:70-88,
+    roi_heads/box_head/loss.py:56-72): matched >= 0 -> gt_labels[n, matched] (1 when gt_labels is None), -1 -> 0,
+    -2 -> -1, and -1 where `valid` [N,K] is false.  dtype float32 or int64."""
+    _need_cuda("match_labels", matched, gt_labels, valid)
+    if matched.dtype != torch.int64 or matched.dim() != 2 or dtype not in (torch.float32, torch.int64):
+        raise ValueError("match_labels: matched must be [N, K] int64 and dtype float32 / int64")
+    matched = matched.contiguous()
+    N, K = matched.shape
+    M = 0
+    if gt_labels is not None:
+        gt_labels = gt_labels.to(torch.int64).contiguous()
+        M = gt_labels.size(1)
+        if gt_labels.size(0) != N:
+            raise ValueError("match_labels: gt_labels must be [N, M]")
+    if valid is not None:
+        valid = _u8("match_labels", valid)
+        if valid.shape != matched.shape:
+            raise ValueError("match_labels: valid must be [N, K]")
+    out = torch.empty((N, K), dtype=dtype, device=matched.device)
+    if N * K:
+        with _on_device(matched), _timed(("match_labels[N=%d,K=%d]", (N, K)), matched):
+            check(lib.detops_match_labels(ptr(matched), ptr(gt_labels) if gt_labels is not None else None,
+                                          ptr(valid) if valid is not None else None, N, K, M,
+                                          0 if dtype == torch.float32 else 1, ptr(out), stream_of(matched)), "match_labels")
+    return out
+
+
+def roi_head_targets(boxes, matched, gt_boxes, gt_labels, valid, idx, slot_valid, objectness, weights):
+    """The box head's sampled slots in one launch (extension; reference roi_heads/box_head/loss.py:56-110):
+    boxes [N,K,4], matched [N,K], gt_boxes [N,M,4], gt_labels [N,M], valid [N,K] | None, idx / slot_valid [N,B],
+    objectness [N,K] | None -> (boxes [N,B,4], labels [N,B] int64, regression_targets [N,B,4], matched [N,B],
+    objectness [N,B] | None)."""
+    _need_cuda("roi_head_targets", boxes, matched, gt_boxes, gt_labels, valid, idx, slot_valid, objectness)
+    boxes = _f32c("roi_head_targets", boxes)
+    gt_boxes = _f32c("roi_head_targets", gt_boxes)
+    matched, idx = matched.contiguous(), idx.contiguous()
+    gt_labels = gt_labels.to(torch.int64).contiguous()
+    slot_valid = _u8("roi_head_targets", slot_valid)
+    N, K = matched.shape
+    M, B = gt_boxes.size(1), idx.size(1)
+    if matched.dtype != torch.int64 or idx.dtype != torch.int64 or boxes.shape != (N, K, 4) or gt_boxes.shape != (N, M, 4) \
+            or gt_labels.shape != (N, M) or idx.shape != (N, B) or slot_valid.shape != (N, B):
+        raise ValueError("roi_head_targets: inconsistent arguments")
+    if valid is not None:
+        valid = _u8("roi_head_targets", valid)
+        if valid.shape != (N, K):
+            raise ValueError("roi_head_targets: valid must be [N, K]")
+    if objectness is not None:
+        objectness = _f32c("roi_head_targets", objectness)
+        if objectness.shape != (N, K):
+            raise ValueError("roi_head_targets: objectness must be [N, K]")
+    dev = boxes.device
+    ob = torch.empty((N, B, 4), dtype=torch.float32, device=dev)
+    oreg = torch.empty((N, B, 4), dtype=torch.float32, device=dev)
+    ol = torch.empty((N, B), dtype=torch.int64, device=dev)
+    om = torch.empty((N, B), dtype=torch.int64, device=dev)
+    oo = torch.empty((N, B), dtype=torch.float32, device=dev) if objectness is not None else None
+    if N * B:
+        if K == 0 or M == 0:
+            raise ValueError("roi_head_targets: no proposals / ground truth rows to take the slots from")
+        wx, wy, ww, wh = (float(w) for w in weights)
+        with _on_device(boxes), _timed(("roi_head_targets[N=%d,B=%d]", (N, B)), boxes):
+            check(lib.detops_roi_head_targets_f32(
+                ptr(boxes), ptr(matched), ptr(gt_boxes), ptr(gt_labels), ptr(valid) if valid is not None else None, ptr(idx),
+                ptr(slot_valid), ptr(objectness) if objectness is not None else None, N, K, M, B, wx, wy, ww, wh, ptr(ob),
+                ptr(ol), ptr(oreg), ptr(om), ptr(oo) if oo is not None else None, stream_of(boxes)), "roi_head_targets")
+    return ob, ol, oreg, om, oo
 
 
 def rpn_decode(box_regression, topk_idx, topk_scores, anchors, image_hw, weights, bbox_xform_clip, min_size,

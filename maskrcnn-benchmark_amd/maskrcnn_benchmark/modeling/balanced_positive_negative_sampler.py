@@ -26,9 +26,9 @@ class BalancedPositiveNegativeSampler(object):
         B = self.batch_size_per_image
         max_pos = int(B * self.positive_fraction)
         n = labels.shape[-1]
-        if labels.is_cuda and labels.dim() == 2 and B <= 512:
+        from maskrcnn_benchmark import _C
+        if _C.on_device(labels) and labels.dim() == 2 and B <= 512:
             # hashed-key threshold filter + a small per-image sort (csrc/targets.hip) instead of four argsorts
-            from maskrcnn_benchmark import _C
             return _C.sample_labels(labels, B, max_pos)
         pos = labels >= 1
         neg = labels == 0
@@ -67,8 +67,8 @@ class BalancedPositiveNegativeSampler(object):
         first, then negatives; `valid` is False for slots that could not be filled (fewer than B
         candidates).  No host synchronisation."""
         B = self.batch_size_per_image
-        if labels.is_cuda and labels.dim() == 2 and B <= 512:
-            from maskrcnn_benchmark import _C
+        from maskrcnn_benchmark import _C
+        if _C.on_device(labels) and labels.dim() == 2 and B <= 512:
             _, _, idx, valid = _C.sample_labels(labels, B, int(B * self.positive_fraction), with_list=True)
             return idx, valid
         pos_mask, neg_mask = self._masks(labels)

@@ -7,6 +7,7 @@ from maskrcnn_benchmark.structures.image_list import to_image_list
 
 from ..backbone import build_backbone
 from ..roi_heads.roi_heads import build_roi_heads
+from ..rpn.loss import begin_step
 from ..rpn.rpn import build_rpn
 
 
@@ -20,6 +21,7 @@ class GeneralizedRCNN(nn.Module):
     def forward(self, images, targets=None):
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")
+        begin_step()   # the padded-target batch is shared by the callers of ONE forward, never across forwards
         images = to_image_list(images)
         features = self.backbone(images.tensors)
         proposals, proposal_losses = self.rpn(images, features, targets)

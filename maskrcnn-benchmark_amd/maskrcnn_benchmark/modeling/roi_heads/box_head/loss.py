@@ -8,9 +8,12 @@ smooth-L1 (beta 1) on the positives' class-specific deltas, summed / #sampled.
 The sampled set has a FIXED length (BATCH_SIZE_PER_IMAGE slots per image, positives first,
 unfilled slots flagged invalid and label -1) so the head runs with static shapes and no `nonzero`.
 """
+import os
+
 import torch
 from torch.nn import functional as F
 
+from maskrcnn_benchmark import _C
 from maskrcnn_benchmark.modeling.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
 from maskrcnn_benchmark.modeling.box_coder import BoxCoder
 from maskrcnn_benchmark.modeling.matcher import Matcher
@@ -19,9 +22,17 @@ from maskrcnn_benchmark.modeling.utils import cat
 from maskrcnn_benchmark.structures.bounding_box import BoxList
 
 
+_FUSED = os.environ.get("DETOPS_ROI_TARGETS", "fused") != "torch"   # A/B switch: the PyTorch composite on the GPU
+
+
 def stack_proposals(proposals):
     """list[BoxList] (possibly different lengths, optional "valid" field) -> boxes [N,K,4],
-    valid [N,K]."""
+    valid [N,K].  Lists that are the rows of one batch (the training RPN hands its proposals over like that,
+    `BoxList.batch_rows`) are returned as that batch: no copy."""
+    rows = [getattr(p, "batch_rows", None) for p in proposals]
+    if rows[0] is not None and all(r is not None and r[0] is rows[0][0] and r[1] == i for i, r in enumerate(rows)) \
+            and rows[0][0]["boxes"].shape[0] == len(proposals):
+        return rows[0][0]["boxes"], rows[0][0]["valid"]
     K = max(len(p) for p in proposals)
     dev = proposals[0].bbox.device
     boxes = torch.zeros((len(proposals), K, 4), dtype=torch.float32, device=dev)
@@ -52,8 +63,42 @@ class FastRCNNLossComputation(object):
         matched_gt = torch.gather(gt, 1, matched.clamp(min=0)[:, :, None].expand(-1, -1, 4))
         return labels, self.box_coder.encode(matched_gt, boxes), matched
 
+    def _subsample_fused(self, proposals, boxes, valid, targets):
+        """`subsample` with three launches behind the matcher (csrc/targets.hip: labels of all proposals, the sampler, the
+        sampled slots' boxes / labels / encoded targets / matched indices / objectness) in place of the label chain, the
+        encode of ALL proposals and the per-image indexing of every field."""
+        gt, row_valid, extra = pad_targets(targets, boxes.device, ("labels",))
+        matched = match_batched(self.proposal_matcher, gt, row_valid, boxes)
+        labels = _C.match_labels(matched, extra["labels"], valid, torch.int64)
+        idx, slot_valid = self.fg_bg_sampler.sample_fixed(labels)
+        objectness = None
+        if all(p.has_field("objectness") for p in proposals):
+            rows = getattr(proposals[0], "batch_rows", None)
+            if rows is not None and rows[0]["boxes"] is boxes and "objectness" in rows[0]:
+                objectness = rows[0]["objectness"]
+            else:
+                objectness = boxes.new_zeros(boxes.shape[:2])
+                for i, p in enumerate(proposals):
+                    objectness[i, :len(p)] = p.get_field("objectness")
+        b, lab, reg, mat, obj = _C.roi_head_targets(boxes, matched, gt, extra["labels"], valid, idx, slot_valid, objectness,
+                                                    self.box_coder.weights)
+        out = []
+        for i, p in enumerate(proposals):
+            bl = BoxList(b[i], p.size, mode="xyxy")
+            bl.add_field("labels", lab[i])
+            bl.add_field("regression_targets", reg[i])
+            bl.add_field("matched_idxs", mat[i])
+            bl.add_field("valid", slot_valid[i])
+            if obj is not None:
+                bl.add_field("objectness", obj[i])
+            out.append(bl)
+        return out
+
     def subsample(self, proposals, targets):
         boxes, valid = stack_proposals(proposals)
+        if _C.on_device(boxes) and _FUSED and boxes.shape[1] > 0:
+            self._proposals = self._subsample_fused(proposals, boxes, valid, targets)
+            return self._proposals
         labels, regression_targets, matched = self.prepare_targets(boxes, valid, targets)
         idx, slot_valid = self.fg_bg_sampler.sample_fixed(labels)
         out = []

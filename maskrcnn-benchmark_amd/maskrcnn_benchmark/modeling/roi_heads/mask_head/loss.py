@@ -35,9 +35,9 @@ def project_masks_on_boxes(masks, mask_index, boxes, discretization_size):
     instance each ROI crops), boxes [P,4] xyxy -> [P,M,M] float32 targets."""
     M = discretization_size
     G, H, W = masks.shape
-    if masks.is_cuda:
+    from maskrcnn_benchmark import _C
+    if _C.on_device(masks):
         # one workgroup per ROI, ATen's CPU operation order (csrc/targets.hip): bit-equal to the reference's path
-        from maskrcnn_benchmark import _C
         return _C.mask_targets(masks, mask_index, boxes, M)
     b = boxes.round().to(torch.int64)
     xmin = b[:, 0].clamp(min=0, max=W - 1)

@@ -15,8 +15,9 @@ from .roi_mask_predictors import make_roi_mask_predictor
 
 
 def keep_only_positive_boxes(boxes, max_positives=None):
-    """list[BoxList] with "labels" -> (positive-slot BoxLists, per-image slot indices).  With
-    `max_positives` the result has exactly that many slots per image (positives-first inputs)."""
+    """list[BoxList] with "labels" -> (positive-slot BoxLists, per-image slot indices: an index tensor, or a slice when
+    `max_positives` is given).  With `max_positives` the result has exactly that many slots per image (positives-first
+    inputs)."""
     assert isinstance(boxes, (list, tuple)) and isinstance(boxes[0], BoxList)
     assert boxes[0].has_field("labels")
     out, inds = [], []
@@ -24,7 +25,7 @@ def keep_only_positive_boxes(boxes, max_positives=None):
         if max_positives is None:
             sel = (b.get_field("labels") > 0).nonzero().squeeze(1)
         else:
-            sel = torch.arange(min(max_positives, len(b)), device=b.bbox.device)
+            sel = slice(0, min(max_positives, len(b)))   # views of the first slots: no indexing launches
         out.append(b[sel])
         inds.append(sel)
     return out, inds
@@ -53,6 +54,8 @@ class ROIMaskHead(torch.nn.Module):
             # reference concatenates per-image boolean masks, mask_head.py:60-63)
             rows, base = [], 0
             for sel, b in zip(positive_inds, all_proposals):
+                if isinstance(sel, slice):
+                    sel = torch.arange(sel.start, sel.stop, device=b.bbox.device)
                 rows.append(sel + base)
                 base += len(b)
             x = features[torch.cat(rows, dim=0)]

@@ -101,7 +101,7 @@ class RPNPostProcessor(torch.nn.Module):
     def _select(self, anchors_per_level, objectness, box_regression, image_sizes, training):
         N = objectness[0].shape[0]
         dev = objectness[0].device
-        if dev.type == "cuda" and self.fused_decode:
+        if _C.on_device(objectness[0]) and self.fused_decode:
             ks, boxes, scores, flat_boxes, flat_scores, flat_ok = self._candidates_fused(
                 anchors_per_level, objectness, box_regression, image_sizes)
         else:
@@ -161,6 +161,22 @@ class RPNPostProcessor(torch.nn.Module):
         per_level = [b.bbox for b in anchors[0]]
         boxes, scores, valid = self.select(per_level, objectness, box_regression, image_sizes, self.training)
         out = []
+        if self.training and targets is not None and _C.on_device(boxes):
+            # add_gt_proposals for the whole batch: the padded ground truth (rows beyond an image's count are far-away
+            # boxes flagged invalid) joins every image's candidates with three concatenations; the lists handed to the
+            # box head are rows of these tensors and say so (`batch_rows`), so its sampler takes the batch as it is
+            from .loss import pad_targets
+            gt, row_valid, _ = pad_targets(targets, boxes.device)
+            batch = {"boxes": torch.cat([boxes, gt.to(boxes.dtype)], dim=1),
+                     "objectness": torch.cat([scores, scores.new_ones(row_valid.shape)], dim=1),
+                     "valid": torch.cat([valid, row_valid], dim=1)}
+            for i, (h, w) in enumerate(image_sizes):
+                bl = BoxList(batch["boxes"][i], (w, h), mode="xyxy")
+                bl.add_field("objectness", batch["objectness"][i])
+                bl.add_field("valid", batch["valid"][i])
+                bl.batch_rows = (batch, i)
+                out.append(bl)
+            return out
         for i, (h, w) in enumerate(image_sizes):
             if self.training:
                 b, s, v = boxes[i], scores[i], valid[i]

@@ -14,6 +14,7 @@ import os
 import torch
 from torch.nn import functional as F
 
+from maskrcnn_benchmark import _C
 from maskrcnn_benchmark.modeling.matcher import Matcher
 from maskrcnn_benchmark.structures.boxlist_ops import box_iou_matrix
 
@@ -24,9 +25,40 @@ from .utils import concat_box_prediction_layers
 _FUSED = os.environ.get("DETOPS_RPN_LOSS", "fused") != "torch"   # A/B switch: the PyTorch composite on the GPU
 
 
+# The RPN loss, the proposal selector (ground truth appended to the proposals) and the box head all pad the SAME targets of a
+# step: the padded batch is kept for the duration of one detector forward (`begin_step` drops it — the detector calls it on
+# entry, so a batch that is fed again, as a benchmark does, is padded again like a fresh one).  A hit needs the same BoxList
+# objects with untouched tensors (identity + tensor version), so a stale entry can never be served.
+_PADDED = {}
+
+
+def begin_step():
+    _PADDED.clear()
+
+
+def _targets_stamp(targets, device, fields):
+    return (str(device), tuple(fields)) + tuple(
+        (id(t), id(t.bbox), t.bbox._version) + tuple((id(t.get_field(f)), t.get_field(f)._version) for f in fields)
+        for t in targets)
+
+
 def pad_targets(targets, device, fields=()):
     """list[BoxList] -> (boxes [N,M,4] (padding rows = a far-away unit box), row_valid [N,M] bool,
-    {field: [N,M]}) with M = max number of ground-truth boxes; host-side sizes only, no sync."""
+    {field: [N,M]}) with M = max number of ground-truth boxes; host-side sizes only, no sync.
+    The result is shared by the callers of one step (see `begin_step`): treat it as read-only."""
+    fields = tuple(fields)
+    stamp = _targets_stamp(targets, device, fields)
+    hit = _PADDED.get(stamp)
+    if hit is not None and all(a is b for a, b in zip(hit[0], targets)):
+        return hit[1]
+    out = _pad_targets(targets, device, fields)
+    if len(_PADDED) >= 4:
+        _PADDED.clear()
+    _PADDED[stamp] = (list(targets), out)   # the references keep the ids of the stamp alive
+    return out
+
+
+def _pad_targets(targets, device, fields):
     N = len(targets)
     M = max(max(len(t) for t in targets), 1)
     boxes = torch.full((N, M, 4), -1e5, dtype=torch.float32, device=device)
@@ -47,9 +79,8 @@ def pad_targets(targets, device, fields=()):
 def match_batched(matcher, gt_boxes, row_valid, boxes):
     """IoU + Matcher for a batch: gt_boxes [N,M,4], boxes [N,K,4] (or [K,4] shared) -> matched_idxs
     [N,K] int64 (>= 0 index into the image's gt rows, -1 / -2 as in Matcher)."""
-    if boxes.is_cuda:
+    if _C.on_device(boxes):
         # fused IoU + Matcher kernel (csrc/targets.hip): the [N, M, K] quality matrix is never materialised
-        from maskrcnn_benchmark import _C
         return _C.match_boxes(gt_boxes, row_valid, boxes, matcher.high_threshold, matcher.low_threshold,
                               matcher.allow_low_quality_matches)
     if boxes.dim() == 2:
@@ -102,6 +133,11 @@ class RPNLossComputation(object):
         dev = all_anchors.device
         gt, row_valid, extra = pad_targets(targets, dev, self.copied_fields)
         matched = match_batched(self.proposal_matcher, gt, row_valid, all_anchors)
+        if _C.on_device(matched) and _FUSED and self.generate_labels_func is generate_rpn_labels \
+                and "between_thresholds" in self.discard_cases:
+            # the masked assignments below in one launch
+            vis = self._visibility(anchors) if "not_visibility" in self.discard_cases else None
+            return _C.match_labels(matched, None, vis, torch.float32), matched, gt, all_anchors
         labels = self.generate_labels_func(matched, extra).to(torch.float32)
         labels = torch.where(matched == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(labels), labels)
         if "not_visibility" in self.discard_cases:

@@ -157,12 +157,63 @@ def _emu_patches():
             "frozen_bn_act_backward": bn_bwd}
 
 
+def _emu_device_patches():
+    """The target-assignment / proposal kernels of csrc/targets.hip under the host emulation, plus `on_device` -> True:
+    the model takes the branches it takes on the GPU (fused labels, sampler, sampled-slot targets, proposal decode,
+    batched hand-over of the proposals) with CPU tensors."""
+    import emu
+    seed = [0]
+
+    def match_boxes(gt_boxes, gt_valid, boxes, high, low, allow_lq):
+        return torch.from_numpy(emu.match_boxes(_np(gt_boxes), _np(gt_valid), _np(boxes), float(high), float(low), bool(allow_lq)))
+
+    def sample_labels(labels, B, max_pos, with_list=False, seed_=None):
+        seed[0] += 1
+        pos, neg, idx, val = emu.sample_labels(_np(labels), int(B), int(max_pos), seed=seed[0] if seed_ is None else seed_)
+        out = (torch.from_numpy(pos), torch.from_numpy(neg))
+        return out + (torch.from_numpy(idx), torch.from_numpy(val)) if with_list else out
+
+    def match_labels(matched, gt_labels=None, valid=None, dtype=torch.int64):
+        return torch.from_numpy(emu.match_labels(_np(matched), None if gt_labels is None else _np(gt_labels),
+                                                 None if valid is None else _np(valid),
+                                                 np.float32 if dtype == torch.float32 else np.int64))
+
+    def roi_head_targets(boxes, matched, gt_boxes, gt_labels, valid, idx, slot_valid, objectness, weights):
+        out = emu.roi_head_targets(_np(boxes), _np(matched), _np(gt_boxes), _np(gt_labels), None if valid is None else _np(valid),
+                                   _np(idx), _np(slot_valid), None if objectness is None else _np(objectness), weights)
+        return tuple(None if o is None else torch.from_numpy(o) for o in out)
+
+    def rpn_decode(box_regression, topk_idx, topk_scores, anchors, image_hw, weights, clip, min_size, boxes, scores, col,
+                   nms_boxes, nms_scores, ok, off):
+        b, s, nb, ns, okk = emu.rpn_decode(_np(box_regression), _np(topk_idx), _np(topk_scores), _np(anchors), _np(image_hw),
+                                           weights, clip, min_size)
+        N, k = s.shape
+        boxes[:, col:col + k] = torch.from_numpy(b)
+        scores[:, col:col + k] = torch.from_numpy(s)
+        nms_boxes[off:off + N * k] = torch.from_numpy(nb)
+        nms_scores[off:off + N * k] = torch.from_numpy(ns)
+        ok[off:off + N * k] = torch.from_numpy(okk.astype(np.uint8))
+
+    def mask_targets(masks, mask_index, boxes, M):
+        m = _np(masks)
+        if m.dtype not in (np.uint8, np.float32, np.bool_):
+            m = m.astype(np.uint8)
+        return torch.from_numpy(emu.mask_targets(m, _np(mask_index), _np(boxes), int(M)))
+
+    return {"on_device": lambda t: True, "match_boxes": match_boxes, "sample_labels": sample_labels,
+            "match_labels": match_labels, "roi_head_targets": roi_head_targets, "rpn_decode": rpn_decode,
+            "mask_targets": mask_targets}
+
+
 @contextlib.contextmanager
 def install(backend="oracle"):
-    """backend = "oracle" (C restatement) or "emu" (the HIP sources under the host emulation)."""
+    """backend = "oracle" (C restatement), "emu" (the HIP sources under the host emulation) or "emu-device" (emu + the
+    model's device-only branches, see `_emu_device_patches`)."""
     patches = dict(_PATCHES)
-    if backend == "emu":
+    if backend in ("emu", "emu-device"):
         patches.update(_emu_patches())
+    if backend == "emu-device":
+        patches.update(_emu_device_patches())
     saved = {k: getattr(_C, k) for k in patches}
     try:
         for k, v in patches.items():

@@ -37,6 +37,8 @@ SIGNATURES = {
     "detops_sample_labels": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, _P, _P, _P, _P, _P,
                                      ctypes.c_size_t, _P]),
     "detops_mask_targets": (c_int, [_P, c_int, _P, _P] + [c_int] * 5 + [_P, _P]),
+    "detops_match_labels": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "detops_roi_head_targets_f32": (c_int, [_P] * 8 + [c_int] * 4 + [c_float] * 4 + [_P] * 6),
     "detops_rpn_decode_f32": (c_int, [_P] * 5 + [c_int] * 5 + [c_float] * 6 + [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, _P, _P]),
     "detops_rpn_loss_workspace_bytes": (ctypes.c_size_t, []),
     "detops_rpn_loss_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
@@ -251,6 +253,38 @@ def mask_targets(masks, mask_index, boxes, M):
     rc = lib().detops_mask_targets(_p(masks), code, _p(mask_index), _p(boxes), G, H, W, P, M, _p(out), None)
     assert rc == 0, rc
     return out
+
+
+def match_labels(matched, gt_labels=None, valid=None, dtype=np.int64):
+    matched = np.ascontiguousarray(matched, dtype=np.int64)
+    N, K = matched.shape
+    gl = None if gt_labels is None else np.ascontiguousarray(gt_labels, dtype=np.int64)
+    va = None if valid is None else np.ascontiguousarray(valid).view(np.uint8)
+    out = np.full((N, K), 77, dtype)
+    rc = lib().detops_match_labels(_p(matched), None if gl is None else _p(gl), None if va is None else _p(va), N, K,
+                                   0 if gl is None else gl.shape[1], 0 if np.dtype(dtype) == np.float32 else 1, _p(out), None)
+    assert rc == 0, rc
+    return out
+
+
+def roi_head_targets(boxes, matched, gt, gt_labels, valid, idx, slot_valid, objectness, weights):
+    boxes, gt = _f32(boxes), _f32(gt)
+    matched, idx, gl = (np.ascontiguousarray(a, dtype=np.int64) for a in (matched, idx, gt_labels))
+    sv = np.ascontiguousarray(slot_valid).view(np.uint8)
+    va = None if valid is None else np.ascontiguousarray(valid).view(np.uint8)
+    ob = None if objectness is None else _f32(objectness)
+    N, K = matched.shape
+    M, B = gt.shape[1], idx.shape[1]
+    o_b = np.full((N, B, 4), np.nan, np.float32)
+    o_r = np.full((N, B, 4), np.nan, np.float32)
+    o_l = np.full((N, B), 77, np.int64)
+    o_m = np.full((N, B), 77, np.int64)
+    o_o = None if ob is None else np.full((N, B), np.nan, np.float32)
+    rc = lib().detops_roi_head_targets_f32(_p(boxes), _p(matched), _p(gt), _p(gl), None if va is None else _p(va), _p(idx),
+                                           _p(sv), None if ob is None else _p(ob), N, K, M, B, *[float(w) for w in weights],
+                                           _p(o_b), _p(o_l), _p(o_r), _p(o_m), None if o_o is None else _p(o_o), None)
+    assert rc == 0, rc
+    return o_b, o_l, o_r, o_m, o_o
 
 
 def rpn_decode(box_regression, topk_idx, topk_scores, anchors, image_hw, weights, xform_clip, min_size):

@@ -199,3 +199,102 @@ def test_rpn_proposal_selection_with_the_fused_decode_is_bit_equal_to_the_aten_c
         assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)
     boxes, scores, valid = out[True]
     assert 0 < int(valid.sum()) <= (top if training else N * top)
+
+
+def test_match_labels_and_sampled_slot_targets_equal_the_aten_composition_on_the_device():
+    """_C.match_labels / _C.roi_head_targets at the box-head size (2 x 2020 proposals, 512 slots) against the ATen
+    composition on the same device: labels, boxes, matched indices and objectness identical, encoded targets to the
+    last place (division / log in one kernel vs separate ATen kernels)."""
+    from maskrcnn_benchmark import _C
+    from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+    rng = np.random.RandomState(31)
+    N, K, M, B = 2, 2020, 20, 512
+    weights = (10.0, 10.0, 5.0, 5.0)
+    gt = torch.from_numpy(_gt(rng, N, M)).to(DEV)
+    boxes = torch.from_numpy(_gt(rng, N, K)).to(DEV)
+    boxes[:, :M * 20] = gt.repeat(1, 20, 1) + torch.from_numpy(rng.uniform(-8, 8, (N, M * 20, 4)).astype(np.float32)).to(DEV)
+    boxes[..., 2:] = torch.maximum(boxes[..., 2:], boxes[..., :2] + 1)
+    gl = torch.from_numpy(rng.randint(1, 81, (N, M)).astype(np.int64)).to(DEV)
+    gvalid = torch.ones((N, M), dtype=torch.bool, device=DEV)
+    valid = torch.from_numpy(rng.rand(N, K) < 0.9).to(DEV)
+    obj = torch.from_numpy(rng.rand(N, K).astype(np.float32)).to(DEV)
+    matched = _C.match_boxes(gt, gvalid, boxes, 0.5, 0.5, False)
+    matched[0, 5:9] = Matcher.BETWEEN_THRESHOLDS
+    ref = torch.gather(gl, 1, matched.clamp(min=0))
+    ref = torch.where(matched == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(ref), ref)
+    ref = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, torch.full_like(ref, -1), ref)
+    ref = torch.where(valid, ref, torch.full_like(ref, -1))
+    labels = _C.match_labels(matched, gl, valid, torch.int64)
+    assert torch.equal(labels, ref) and int((labels > 0).sum()) > 100
+    rpn = torch.where(valid & (matched != Matcher.BETWEEN_THRESHOLDS), (matched >= 0).float(), torch.full((), -1.0, device=DEV))
+    assert torch.equal(_C.match_labels(matched, None, valid, torch.float32), rpn)
+    _, _, idx, slot_valid = _C.sample_labels(labels, B, 128, with_list=True, seed=4)
+    ob, ol, oreg, om, oo = _C.roi_head_targets(boxes, matched, gt, gl, valid, idx, slot_valid, obj, weights)
+    reg = BoxCoder(weights).encode(torch.gather(gt, 1, matched.clamp(min=0)[:, :, None].expand(-1, -1, 4)), boxes)
+    for i in range(N):
+        sel = idx[i]
+        assert torch.equal(ob[i], boxes[i][sel]) and torch.equal(om[i], matched[i][sel]) and torch.equal(oo[i], obj[i][sel])
+        assert torch.equal(ol[i], torch.where(slot_valid[i], labels[i][sel], torch.full_like(sel, -1)))
+        assert torch.allclose(oreg[i], reg[i][sel], rtol=2e-6, atol=2e-6)
+    assert int((ol > 0).sum()) > 50 and int((ol == 0).sum()) > 50
+    assert _C.roi_head_targets(boxes, matched, gt, gl, None, idx, slot_valid, None, weights)[4] is None
+
+
+def test_rpn_to_box_head_hand_over_on_the_device_equals_the_per_image_composition(monkeypatch):
+    """training RPNPostProcessor.forward + FastRCNNLossComputation.subsample on the device (fused decode, batched
+    ground-truth hand-over, fused labels / sampled-slot targets) against the same modules with every device branch
+    switched off (ATen compositions on the same tensors), with the device generator re-seeded so both draw the same
+    sampled subsets."""
+    from maskrcnn_benchmark import _C
+    from maskrcnn_benchmark.engine.bench_step import load_cfg
+    from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+    from maskrcnn_benchmark.modeling.roi_heads.box_head import loss as box_loss
+    from maskrcnn_benchmark.modeling.rpn.anchor_generator import AnchorGenerator
+    from maskrcnn_benchmark.modeling.rpn.inference import RPNPostProcessor
+    from maskrcnn_benchmark.modeling.rpn.loss import begin_step
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    from maskrcnn_benchmark.structures.image_list import ImageList
+    strides = (4, 8, 16, 32, 64)
+    sizes = [(800, 1344), (771, 1203)]
+    ag = AnchorGenerator(sizes=((32,), (64,), (128,), (256,), (512,)), anchor_strides=strides)
+    feats = [torch.zeros(2, 1, -(-800 // s), -(-1344 // s), device=DEV) for s in strides]
+    anchors = ag(ImageList(torch.zeros(2, 3, 800, 1344, device=DEV), sizes), feats)
+    g = torch.Generator().manual_seed(8)
+    obj = [torch.randn(2, 3, f.shape[2], f.shape[3], generator=g).to(DEV) for f in feats]
+    reg = [(torch.randn(2, 12, f.shape[2], f.shape[3], generator=g) * 0.3).to(DEV) for f in feats]
+    rng = np.random.RandomState(2)
+    targets = []
+    for (h, w), m in zip(sizes, (7, 12)):
+        t = BoxList(torch.from_numpy(_gt(rng, 1, m, w, h)[0]).clamp(min=0).to(DEV), (w, h), mode="xyxy")
+        t.add_field("labels", torch.from_numpy(rng.randint(1, 81, m).astype(np.int64)).to(DEV))
+        targets.append(t)
+    post = RPNPostProcessor(2000, 2000, 0.7, 0, BoxCoder((1.0, 1.0, 1.0, 1.0)), fpn_post_nms_top_n=2000).train()
+    ev = box_loss.make_roi_box_loss_evaluator(load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml"))
+
+    def run():
+        begin_step()
+        props = post(anchors, obj, reg, targets)
+        boxes, valid = box_loss.stack_proposals(props)
+        torch.cuda.manual_seed(77)
+        return props, boxes, valid, ev.subsample(props, targets)
+    props, boxes, valid, out = run()
+    assert boxes is props[0].batch_rows[0]["boxes"] and boxes.shape == (2, 5 * 2000 + 12, 4)
+    post.fused_decode = False
+    monkeypatch.setattr(box_loss, "_FUSED", False)
+    on = _C.on_device
+    monkeypatch.setattr(_C, "on_device", lambda t: False)
+    rprops = post(anchors, obj, reg, targets)
+    monkeypatch.setattr(_C, "on_device", on)                    # matcher + sampler kernels again; the rest stays composite
+    assert all(getattr(p, "batch_rows", None) is None for p in rprops)
+    rboxes, rvalid = box_loss.stack_proposals(rprops)
+    torch.cuda.manual_seed(77)
+    ref = ev.subsample(rprops, targets)
+    assert torch.equal(valid, rvalid) and int(valid.sum()) == 2000 + 19
+    assert torch.equal(boxes[valid], rboxes[valid])
+    for o, r in zip(out, ref):
+        assert set(o.fields()) == set(r.fields())
+        for f in ("labels", "matched_idxs", "valid", "objectness"):
+            assert torch.equal(o.get_field(f), r.get_field(f)), f
+        assert torch.equal(o.bbox, r.bbox)
+        assert torch.allclose(o.get_field("regression_targets"), r.get_field("regression_targets"), rtol=2e-6, atol=2e-6)
+        assert int((o.get_field("labels") > 0).sum()) >= 7
