@@ -29,17 +29,33 @@ def T(a, dev="cpu"):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-@pytest.fixture(params=["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+class _Dev(str):
+    """a device string that also names the cpu_shim backend serving the HIP-only operators"""
+    backend = "oracle"
+
+
+def _emu_device():
+    d = _Dev("cpu")
+    d.backend = "emu-device"
+    return d
+
+
+@pytest.fixture(params=["cpu", pytest.param(_emu_device(), id="cpu-device-branches"), pytest.param("cuda", marks=pytest.mark.gpu)])
 def dev(request):
-    """The reference-generated fixtures are checked twice: on the CPU (host logic; HIP-only operators
-    replaced by the oracle through cpu_shim) and, in the `-m gpu` suite, on the device through the real
-    HIP kernels (no shim)."""
-    return request.param
+    """The reference-generated fixtures are checked three times: on the CPU (host logic; HIP-only operators
+    replaced by the oracle through cpu_shim); on the CPU with the model taking its DEVICE branches (fused label /
+    sampler / sampled-slot / decode launches, served by the HIP sources under the host emulation: cpu_shim backend
+    "emu-device"); and, in the `-m gpu` suite, on the device through the real HIP kernels (no shim)."""
+    if getattr(request.param, "backend", None) == "emu-device":
+        with cpu_shim.install("emu-device"):     # for the whole test: target assignment runs outside `_shim` blocks
+            yield request.param
+    else:
+        yield request.param
 
 
 def _shim(dev):
     import contextlib
-    return cpu_shim.install() if dev == "cpu" else contextlib.nullcontext()
+    return cpu_shim.install(getattr(dev, "backend", "oracle")) if dev == "cpu" else contextlib.nullcontext()
 
 
 def N_(t):

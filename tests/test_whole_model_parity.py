@@ -63,8 +63,13 @@ def test_state_dict_keys_equal_the_reference_and_load_strict(name):
 
 
 @pytest.mark.parametrize("name", ["mask_rcnn", "retinanet"])
-@pytest.mark.parametrize("dev", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("dev", ["cpu", "cpu-device-branches", pytest.param("cuda", marks=pytest.mark.gpu)])
 def test_losses_equal_the_reference_with_its_weights(name, dev, monkeypatch):
+    # "cpu-device-branches": CPU tensors, but the model takes the branches it takes on the GPU (fused labels / sampler /
+    # sampled-slot targets / proposal decode / batched proposal hand-over), served by the HIP sources under the host emulation
+    backend = "oracle"
+    if dev == "cpu-device-branches":
+        dev, backend = "cpu", "emu-device"
     cfg, model, ref_sd, il, targets, ref_losses = _build(name, dev)
     model.load_state_dict(ref_sd, strict=True)
     model.to(dev).train()
@@ -72,7 +77,7 @@ def test_losses_equal_the_reference_with_its_weights(name, dev, monkeypatch):
         import maskrcnn_benchmark.layers.sigmoid_focal_loss as sfl
         monkeypatch.setattr(sfl.SigmoidFocalLoss, "forward",
                             lambda self, l, t: sfl.sigmoid_focal_loss_sum(l.float(), t, self.gamma, self.alpha))
-    with (cpu_shim.install() if dev == "cpu" else contextlib.nullcontext()):
+    with (cpu_shim.install(backend) if dev == "cpu" else contextlib.nullcontext()):
         with torch.no_grad():
             losses = model(il.to(dev), [t.to(dev) for t in targets])
     got = {k: float(v) for k, v in losses.items()}
