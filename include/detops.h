@@ -447,6 +447,27 @@ int detops_roi_head_targets_f32(const float* boxes, const int64_t* matched, cons
                                 int64_t* out_labels, float* out_regression_targets, int64_t* out_matched,
                                 float* out_objectness, detops_stream_t stream);
 
+/* ---- ROI-head losses: value and gradient in one pass (csrc/head_loss.hip) ------------------------------------------------
+ * detops_fastrcnn_loss_f32 — FastRCNNLossComputation.__call__ (roi_heads/box_head/loss.py:140-193 of the reference):
+ *   class_logits [R, C], box_regression [R, D] (D = 4C, or >= 8 with cls_agnostic: columns 4..7), labels [R] int64
+ *   (-1 = not sampled), regression_targets [R, 4].  losses2 = {cross_entropy(sum over labels >= 0), smooth_l1(beta) summed
+ *   over labels > 0 on the class's four columns} / max(#(labels >= 0), 1).  grad_logits [R, C] and grad_box [R, D] receive
+ *   d losses2[0] / d class_logits and d losses2[1] / d box_regression (every element written).
+ * detops_mask_loss_f32 — MaskRCNNLossComputation.__call__ (roi_heads/mask_head/loss.py:113-143): mask_logits [P, C, M, M],
+ *   labels [P] int64 (> 0 = positive), mask_targets [P, M, M] -> loss1 = mean BCE-with-logits between each positive ROI's
+ *   class plane and its target (0 without positives); grad_logits [P, C, M, M] fully written.
+ * detops_head_loss_backward_f32 — grad_a *= upstream_a[0], grad_b *= upstream_b[0] (device scalars), in place, one launch. */
+size_t detops_fastrcnn_loss_workspace_bytes(int R);
+int detops_fastrcnn_loss_f32(const float* class_logits, const float* box_regression, const int64_t* labels,
+                             const float* regression_targets, int R, int C, int D, int cls_agnostic, float beta,
+                             float* grad_logits, float* grad_box, float* losses2, void* workspace, size_t workspace_bytes,
+                             detops_stream_t stream);
+size_t detops_mask_loss_workspace_bytes(int P);
+int detops_mask_loss_f32(const float* mask_logits, const int64_t* labels, const float* mask_targets, int P, int C, int M,
+                         float* grad_logits, float* loss1, void* workspace, size_t workspace_bytes, detops_stream_t stream);
+int detops_head_loss_backward_f32(float* grad_a, int64_t count_a, const float* upstream_a, float* grad_b, int64_t count_b,
+                                  const float* upstream_b, detops_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused FrozenBatchNorm2d affine (+ residual) (+ ReLU) — the elementwise tail of every backbone
  * convolution: layers/batch_norm.py:19-31 (`x * scale + bias`), then `F.relu_`, and in the

@@ -272,6 +272,94 @@ def rpn_loss(objectness, box_regression, anchors, matched_idxs, pos_mask, neg_ma
     return lo, lb
 
 
+# ------------------------------------------------------------------------------------------ ROI-head losses
+class _HeadLoss(torch.autograd.Function):
+    """Shared autograd glue of the fused ROI-head losses (csrc/head_loss.hip): forward stores d loss / d input next to the
+    values, backward scales the stored gradients by the upstream scalars in one launch."""
+
+    @staticmethod
+    def forward(ctx, kind, aux, *inputs):
+        grads, out = _HEAD_LOSS[kind](aux, *inputs)
+        ctx.grads, ctx.n_in = grads, len(inputs)
+        return tuple(out[i] for i in range(out.numel()))
+
+    @staticmethod
+    def backward(ctx, *ups):
+        grads = ctx.grads
+        if grads is None:
+            raise RuntimeError("head loss: backward called twice (the stored gradients are scaled in place)")
+        dev = grads[0].device
+        up = [(u if u is not None else torch.zeros((), device=dev)).reshape(1).float().contiguous() for u in ups]
+        a, b = grads[0], (grads[1] if len(grads) > 1 else None)
+        with _on_device(a):
+            check(lib.detops_head_loss_backward_f32(ptr(a), a.numel(), ptr(up[0]), ptr(b), b.numel() if b is not None else 0,
+                                                    ptr(up[1]) if b is not None else None, stream_of(a)), "head_loss_backward")
+        ctx.grads = None
+        return (None, None) + tuple(grads) + (None,) * (ctx.n_in - len(grads))
+
+
+def _fastrcnn_loss_forward(aux, class_logits, box_regression, labels, regression_targets):
+    cls_agnostic, beta = aux
+    R, C = class_logits.shape
+    D = box_regression.size(1)
+    dev = class_logits.device
+    gl, gb = torch.empty_like(class_logits), torch.empty_like(box_regression)
+    out = torch.empty((2,), dtype=torch.float32, device=dev)
+    nbytes = int(lib.detops_fastrcnn_loss_workspace_bytes(R))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    with _on_device(class_logits), _timed(("fastrcnn_loss[R=%d,C=%d]", (R, C)), class_logits):
+        check(lib.detops_fastrcnn_loss_f32(ptr(class_logits), ptr(box_regression), ptr(labels), ptr(regression_targets), R, C, D,
+                                           int(bool(cls_agnostic)), float(beta), ptr(gl), ptr(gb), ptr(out), ptr(ws), nbytes,
+                                           stream_of(class_logits)), "fastrcnn_loss")
+    return (gl, gb), out
+
+
+def _mask_loss_forward(aux, mask_logits, labels, mask_targets):
+    P, C, M, _ = mask_logits.shape
+    dev = mask_logits.device
+    g = torch.empty_like(mask_logits)
+    out = torch.empty((1,), dtype=torch.float32, device=dev)
+    nbytes = int(lib.detops_mask_loss_workspace_bytes(P))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    with _on_device(mask_logits), _timed(("mask_loss[P=%d,C=%d,M=%d]", (P, C, M)), mask_logits):
+        check(lib.detops_mask_loss_f32(ptr(mask_logits), ptr(labels), ptr(mask_targets), P, C, M, ptr(g), ptr(out), ptr(ws), nbytes,
+                                       stream_of(mask_logits)), "mask_loss")
+    return (g,), out
+
+
+_HEAD_LOSS = {"fastrcnn": _fastrcnn_loss_forward, "mask": _mask_loss_forward}
+
+
+def fastrcnn_loss(class_logits, box_regression, labels, regression_targets, cls_agnostic=False, beta=1.0):
+    """Box-head loss, value + gradient in one pass (extension; reference roi_heads/box_head/loss.py:140-193):
+    class_logits [R,C], box_regression [R,4C] (or [R,>=8] class-agnostic), labels [R] int64 (-1 = not sampled),
+    regression_targets [R,4] -> (classification_loss, box_loss), both / max(#sampled, 1)."""
+    _need_cuda("fastrcnn_loss", class_logits, box_regression, labels, regression_targets)
+    class_logits, box_regression = _f32c("fastrcnn_loss", class_logits), _f32c("fastrcnn_loss", box_regression)
+    regression_targets = _f32c("fastrcnn_loss", regression_targets)
+    labels = labels.to(torch.int64).contiguous()
+    R, C = class_logits.shape
+    D = box_regression.size(1)
+    if R == 0 or labels.shape != (R,) or regression_targets.shape != (R, 4) or box_regression.size(0) != R \
+            or (D < 8 if cls_agnostic else D != 4 * C):
+        raise ValueError("fastrcnn_loss: inconsistent arguments")
+    return _HeadLoss.apply("fastrcnn", (bool(cls_agnostic), float(beta)), class_logits, box_regression, labels,
+                           regression_targets)
+
+
+def mask_loss(mask_logits, labels, mask_targets):
+    """Mask-head loss, value + gradient in one pass (extension; reference roi_heads/mask_head/loss.py:113-143):
+    mask_logits [P,C,M,M], labels [P] int64 (> 0 = positive), mask_targets [P,M,M] -> mean BCE-with-logits of the
+    positives' class planes (0 without positives)."""
+    _need_cuda("mask_loss", mask_logits, labels, mask_targets)
+    mask_logits, mask_targets = _f32c("mask_loss", mask_logits), _f32c("mask_loss", mask_targets)
+    labels = labels.to(torch.int64).contiguous()
+    P, C, M, M2 = mask_logits.shape
+    if P == 0 or M != M2 or labels.shape != (P,) or mask_targets.shape != (P, M, M):
+        raise ValueError("mask_loss: inconsistent arguments")
+    return _HeadLoss.apply("mask", None, mask_logits, labels, mask_targets)[0]
+
+
 # ------------------------------------------------------------------------------------------ target assignment
 def match_boxes(gt_boxes, gt_valid, boxes, high_threshold, low_threshold, allow_low_quality_matches):
     """Fused IoU + Matcher (extension; reference structures/boxlist_ops.py:53-89 + modeling/matcher.py:42-112):

@@ -30,7 +30,7 @@ class DeformConvFunction(Function):
         output = input.new_empty(DeformConvFunction._output_size(input, weight, ctx.padding,
                                                                   ctx.dilation, ctx.stride))
         ctx.bufs_ = [input.new_empty(0), input.new_empty(0)]  # columns, ones (API compatibility)
-        if not input.is_cuda:
+        if not _C.on_device(input):
             raise NotImplementedError
         step = min(ctx.im2col_step, input.shape[0])
         assert (input.shape[0] % step) == 0, "im2col step must divide batchsize"
@@ -49,7 +49,7 @@ class DeformConvFunction(Function):
     def backward(ctx, grad_output):
         input, offset, weight = ctx.saved_tensors
         grad_input = grad_offset = grad_weight = None
-        if not grad_output.is_cuda:
+        if not _C.on_device(grad_output):
             raise NotImplementedError
         (grad_output,) = _same_dtype(input, grad_output)
         step = min(ctx.im2col_step, input.shape[0])
@@ -99,7 +99,7 @@ class ModulatedDeformConvFunction(Function):
         ctx.with_bias = bias is not None
         if not ctx.with_bias:
             bias = input.new_empty(1)  # fake tensor
-        if not input.is_cuda:
+        if not _C.on_device(input):
             raise NotImplementedError
         # decided on the ORIGINAL arguments: a .to(dtype) copy made under no-grad reports requires_grad=False
         needs_grad = weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad
@@ -120,7 +120,7 @@ class ModulatedDeformConvFunction(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        if not grad_output.is_cuda:
+        if not _C.on_device(grad_output):
             raise NotImplementedError
         input, offset, mask, weight, bias = ctx.saved_tensors
         (grad_output,) = _same_dtype(input, grad_output)

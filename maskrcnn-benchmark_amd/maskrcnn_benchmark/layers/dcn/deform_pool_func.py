@@ -15,7 +15,7 @@ class DeformRoIPoolingFunction(Function):
         ctx.cfg = (no_trans, spatial_scale, out_channels, group_size, out_size,
                    out_size if part_size is None else part_size, sample_per_part, trans_std)
         assert 0.0 <= trans_std <= 1.0
-        if not data.is_cuda:
+        if not _C.on_device(data):
             raise NotImplementedError
         n = rois.shape[0]
         output = data.new_empty(n, out_channels, out_size, out_size)
@@ -29,7 +29,7 @@ class DeformRoIPoolingFunction(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        if not grad_output.is_cuda:
+        if not _C.on_device(grad_output):
             raise NotImplementedError
         data, rois, offset = ctx.saved_tensors
         grad_input = torch.zeros_like(data)

@@ -64,9 +64,9 @@ class SigmoidFocalLoss(nn.Module):
         self.alpha = alpha
 
     def forward(self, logits, targets):
-        if not logits.is_cuda:
+        if not _C.on_device(logits):
             raise RuntimeError("SigmoidFocalLoss: Not implemented on the CPU (HIP-only build)")
-        with torch.autocast(device_type="cuda", enabled=False):
+        with torch.autocast(device_type=logits.device.type, enabled=False):
             return sigmoid_focal_loss_sum(logits.float(), targets, self.gamma, self.alpha)
 
     def __repr__(self):

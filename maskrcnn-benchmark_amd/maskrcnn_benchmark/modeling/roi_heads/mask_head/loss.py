@@ -12,6 +12,7 @@ once on the device with four gathers, never leaving the GPU.
 import torch
 from torch.nn import functional as F
 
+from maskrcnn_benchmark import _C
 from maskrcnn_benchmark.modeling.matcher import Matcher
 
 
@@ -35,7 +36,6 @@ def project_masks_on_boxes(masks, mask_index, boxes, discretization_size):
     instance each ROI crops), boxes [P,4] xyxy -> [P,M,M] float32 targets."""
     M = discretization_size
     G, H, W = masks.shape
-    from maskrcnn_benchmark import _C
     if _C.on_device(masks):
         # one workgroup per ROI, ATen's CPU operation order (csrc/targets.hip): bit-equal to the reference's path
         return _C.mask_targets(masks, mask_index, boxes, M)
@@ -88,6 +88,10 @@ class MaskRCNNLossComputation(object):
         pos = labels > 0
         if mask_targets.numel() == 0:
             return mask_logits.sum() * 0
+        from ..box_head import loss as box_loss
+        if box_loss._FUSED_LOSS and _C.on_device(mask_logits):
+            # value + gradient in one pass (csrc/head_loss.hip; opt-in, see box_head/loss.py)
+            return _C.mask_loss(mask_logits.float(), labels, mask_targets)
         # the class plane of every ROI by gather (reference: mask_logits[positive_inds, labels_pos], loss.py:137-139): its
         # backward is a scatter, where advanced indexing's is a sort-based index_put that leaves the device idle for
         # 0.1-0.2 ms per step (profiles/r04z_bench_f32_step_breakdown.txt: the gaps behind indexing_backward_kernel)

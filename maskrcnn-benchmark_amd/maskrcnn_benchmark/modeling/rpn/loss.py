@@ -155,11 +155,10 @@ class RPNLossComputation(object):
         return labels, regression_targets
 
     def __call__(self, anchors, objectness, box_regression, targets):
-        if objectness[0].is_cuda and len(objectness) <= 8 and _FUSED:
+        if _C.on_device(objectness[0]) and len(objectness) <= 8 and _FUSED:
             # one launch over the head outputs in their own layout (csrc/targets.hip::rpn_loss_kernel): no permute /
             # cat of the 5 levels, no [N, A, 4] regression targets, no masked reductions — and none of their
             # autograd mirrors
-            from maskrcnn_benchmark import _C
             labels, matched, gt, all_anchors = self._match(anchors, targets)
             pos, neg = self.fg_bg_sampler._masks(labels)
             # half-precision head outputs (autocast): the loss is evaluated in fp32 like the composite below

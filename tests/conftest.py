@@ -48,3 +48,24 @@ def _reset_library_tuning():
         import emu as _e  # key list only
         for k in _e.TUNING_KEYS:
             lib_mod.lib.detops_tuning_set(k.encode(), 0)
+
+
+_C_SURFACE = {}
+_C_MODULE = []
+
+
+@pytest.fixture(autouse=True)
+def _operator_surface_is_restored():
+    """tests that swap entries of `maskrcnn_benchmark._C` (tests/cpu_shim.py, monkeypatch) must leave the module as they
+    found it: a leftover stand-in would silently serve every later test"""
+    mod = sys.modules.get("maskrcnn_benchmark._C")
+    if mod is not None and not _C_MODULE and hasattr(mod, "on_device"):
+        _C_MODULE.append(mod)
+        _C_SURFACE.update({k: v for k, v in vars(mod).items() if callable(v) or k == "lib"})
+    yield
+    if _C_MODULE:
+        mod = _C_MODULE[0]
+        changed = [k for k, v in _C_SURFACE.items() if vars(mod).get(k) is not v]
+        for k in changed:
+            setattr(mod, k, _C_SURFACE[k])
+        assert not changed, "left patched after the test: %s" % changed

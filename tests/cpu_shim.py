@@ -7,6 +7,7 @@ with implementations that run the oracle (oracle/detops_oracle.c) on numpy copie
 tests/ imports this module.
 """
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -200,20 +201,88 @@ def _emu_device_patches():
             m = m.astype(np.uint8)
         return torch.from_numpy(emu.mask_targets(m, _np(mask_index), _np(boxes), int(M)))
 
-    return {"on_device": lambda t: True, "match_boxes": match_boxes, "sample_labels": sample_labels,
+    class _EmuHeadLoss(torch.autograd.Function):
+        """the autograd contract of _C._HeadLoss with the kernels of csrc/head_loss.hip under the host emulation"""
+
+        @staticmethod
+        def forward(ctx, kind, aux, *inputs):
+            ctx.kind, ctx.aux, ctx.n_in = kind, aux, len(inputs)
+            ctx.save_for_backward(*inputs)
+            if kind == "fastrcnn":
+                lc, lb, _, _ = emu.fastrcnn_loss(*[_np(t) for t in inputs], aux[0], aux[1])
+                return torch.tensor(lc), torch.tensor(lb)
+            return (torch.tensor(emu.mask_loss(*[_np(t) for t in inputs])[0]),)
+
+        @staticmethod
+        def backward(ctx, *ups):
+            args = [_np(t) for t in ctx.saved_tensors]
+            up = [0.0 if u is None else float(u) for u in ups]
+            if ctx.kind == "fastrcnn":
+                _, _, gl, gb = emu.fastrcnn_loss(*args, ctx.aux[0], ctx.aux[1], upstream=(up[0], up[1]))
+                return (None, None, torch.from_numpy(gl), torch.from_numpy(gb), None, None)
+            return (None, None, torch.from_numpy(emu.mask_loss(*args, upstream=up[0])[1]), None, None)
+
+    class _EmuRpnLoss(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, L, meta, *heads):
+            anchors, matched, pos, neg, gt, beta, weights = meta
+            lo, lb, gobj, gbox = emu.rpn_loss([_np(t) for t in heads[:L]], [_np(t) for t in heads[L:]], anchors, matched, pos, neg,
+                                              gt, beta, weights)
+            ctx.grads = [torch.from_numpy(g) for g in gobj], [torch.from_numpy(g) for g in gbox]
+            return torch.tensor(lo), torch.tensor(lb)
+
+        @staticmethod
+        def backward(ctx, uo, ub):
+            uo = 0.0 if uo is None else float(uo)
+            ub = 0.0 if ub is None else float(ub)
+            return (None, None) + tuple(g * uo for g in ctx.grads[0]) + tuple(g * ub for g in ctx.grads[1])
+
+    def rpn_loss(objectness, box_regression, anchors, matched_idxs, pos_mask, neg_mask, gt_boxes, beta, weights):
+        meta = (_np(anchors), _np(matched_idxs), _np(pos_mask), _np(neg_mask), _np(gt_boxes), float(beta), tuple(weights))
+        return _EmuRpnLoss.apply(len(objectness), meta, *[t.float() for t in list(objectness) + list(box_regression)])
+
+    def fastrcnn_loss(class_logits, box_regression, labels, regression_targets, cls_agnostic=False, beta=1.0):
+        return _EmuHeadLoss.apply("fastrcnn", (bool(cls_agnostic), float(beta)), class_logits.float(), box_regression.float(),
+                                  labels, regression_targets)
+
+    def mask_loss(mask_logits, labels, mask_targets):
+        return _EmuHeadLoss.apply("mask", None, mask_logits.float(), labels, mask_targets)[0]
+
+    return {"on_device": lambda t: True, "rpn_loss": rpn_loss, "fastrcnn_loss": fastrcnn_loss, "mask_loss": mask_loss, "match_boxes": match_boxes, "sample_labels": sample_labels,
             "match_labels": match_labels, "roi_head_targets": roi_head_targets, "rpn_decode": rpn_decode,
             "mask_targets": mask_targets}
 
 
+def _emu_lib_patches():
+    """The PRODUCT's own `_C` wrappers (argument checks, marshalling, workspaces, autograd functions) on CPU tensors: the
+    library handle they call is the host-emulation build of the same HIP sources (same C ABI, host pointers), the
+    CUDA-only guards are lifted and `on_device` says yes.  Nothing of `_C`'s operator surface is replaced."""
+    import ctypes
+
+    import emu
+    from maskrcnn_benchmark import _lib
+    emu.lib()                                   # builds tests/emu/libdetops_emu.so when needed
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(emu.__file__)), "libdetops_emu.so"))
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:                      # the two *_cpu_* entry points and detops_version exist in the device build only
+            fn.restype, fn.argtypes = res, args
+    return {"lib": lib, "_need_cuda": lambda name, *tensors: None, "stream_of": lambda t: None,
+            "_on_device": lambda t: _C._NOSPAN, "on_device": lambda t: True}
+
+
 @contextlib.contextmanager
 def install(backend="oracle"):
-    """backend = "oracle" (C restatement), "emu" (the HIP sources under the host emulation) or "emu-device" (emu + the
-    model's device-only branches, see `_emu_device_patches`)."""
+    """backend = "oracle" (C restatement), "emu" (the HIP sources under the host emulation), "emu-device" (emu + the
+    model's device-only branches, see `_emu_device_patches`) or "emu-lib" (the product's own `_C` wrappers over the
+    emulation library, see `_emu_lib_patches`)."""
     patches = dict(_PATCHES)
     if backend in ("emu", "emu-device"):
         patches.update(_emu_patches())
     if backend == "emu-device":
         patches.update(_emu_device_patches())
+    if backend == "emu-lib":
+        patches = _emu_lib_patches()
     saved = {k: getattr(_C, k) for k in patches}
     try:
         for k, v in patches.items():

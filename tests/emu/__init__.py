@@ -39,6 +39,11 @@ SIGNATURES = {
     "detops_mask_targets": (c_int, [_P, c_int, _P, _P] + [c_int] * 5 + [_P, _P]),
     "detops_match_labels": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "detops_roi_head_targets_f32": (c_int, [_P] * 8 + [c_int] * 4 + [c_float] * 4 + [_P] * 6),
+    "detops_fastrcnn_loss_workspace_bytes": (ctypes.c_size_t, [c_int]),
+    "detops_fastrcnn_loss_f32": (c_int, [_P] * 4 + [c_int] * 4 + [c_float] + [_P] * 4 + [ctypes.c_size_t, _P]),
+    "detops_mask_loss_workspace_bytes": (ctypes.c_size_t, [c_int]),
+    "detops_mask_loss_f32": (c_int, [_P] * 3 + [c_int] * 3 + [_P] * 3 + [ctypes.c_size_t, _P]),
+    "detops_head_loss_backward_f32": (c_int, [_P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _P]),
     "detops_rpn_decode_f32": (c_int, [_P] * 5 + [c_int] * 5 + [c_float] * 6 + [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, _P, _P]),
     "detops_rpn_loss_workspace_bytes": (ctypes.c_size_t, []),
     "detops_rpn_loss_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float,
@@ -285,6 +290,42 @@ def roi_head_targets(boxes, matched, gt, gt_labels, valid, idx, slot_valid, obje
                                            _p(o_b), _p(o_l), _p(o_r), _p(o_m), None if o_o is None else _p(o_o), None)
     assert rc == 0, rc
     return o_b, o_l, o_r, o_m, o_o
+
+
+def fastrcnn_loss(class_logits, box_regression, labels, regression_targets, cls_agnostic=False, beta=1.0, upstream=(1.0, 1.0)):
+    """-> (classification loss, box loss, d/d class_logits, d/d box_regression) with the backward scaling applied."""
+    lg, bx, tg = _f32(class_logits), _f32(box_regression), _f32(regression_targets)
+    lab = np.ascontiguousarray(labels, dtype=np.int64)
+    R, C = lg.shape
+    D = bx.shape[1]
+    gl = np.full((R, C), np.nan, np.float32)
+    gb = np.full((R, D), np.nan, np.float32)
+    out = np.full((2,), np.nan, np.float32)
+    nbytes = lib().detops_fastrcnn_loss_workspace_bytes(R)
+    ws = np.full((nbytes,), 0xAB, np.uint8)
+    rc = lib().detops_fastrcnn_loss_f32(_p(lg), _p(bx), _p(lab), _p(tg), R, C, D, int(cls_agnostic), float(beta), _p(gl), _p(gb),
+                                        _p(out), _p(ws), nbytes, None)
+    assert rc == 0, rc
+    ua, ub = np.float32([upstream[0]]), np.float32([upstream[1]])
+    rc = lib().detops_head_loss_backward_f32(_p(gl), gl.size, _p(ua), _p(gb), gb.size, _p(ub), None)
+    assert rc == 0, rc
+    return out[0], out[1], gl, gb
+
+
+def mask_loss(mask_logits, labels, mask_targets, upstream=1.0):
+    lg, tg = _f32(mask_logits), _f32(mask_targets)
+    lab = np.ascontiguousarray(labels, dtype=np.int64)
+    P, C, M, _ = lg.shape
+    g = np.full(lg.shape, np.nan, np.float32)
+    out = np.full((1,), np.nan, np.float32)
+    nbytes = lib().detops_mask_loss_workspace_bytes(P)
+    ws = np.full((nbytes,), 0xAB, np.uint8)
+    rc = lib().detops_mask_loss_f32(_p(lg), _p(lab), _p(tg), P, C, M, _p(g), _p(out), _p(ws), nbytes, None)
+    assert rc == 0, rc
+    ua = np.float32([upstream])
+    rc = lib().detops_head_loss_backward_f32(_p(g), g.size, _p(ua), None, 0, None, None)
+    assert rc == 0, rc
+    return out[0], g
 
 
 def rpn_decode(box_regression, topk_idx, topk_scores, anchors, image_hw, weights, xform_clip, min_size):

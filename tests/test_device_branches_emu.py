@@ -160,14 +160,15 @@ def test_tiny_mask_rcnn_trains_through_the_device_branches(monkeypatch):
     torch.manual_seed(0)
     model = build_detection_model(cfg).train()
     calls = {}
-    with cpu_shim.install("emu-device"):
+    # (the counting wrappers are undone INSIDE the install block: undone after it they would re-install the shims they wrap)
+    with cpu_shim.install("emu-device"), monkeypatch.context() as mp:
         for name in ("match_boxes", "sample_labels", "match_labels", "roi_head_targets", "rpn_decode", "mask_targets"):
             fn = getattr(_C, name)
 
             def counted(*a, _fn=fn, _name=name, **k):
                 calls[_name] = calls.get(_name, 0) + 1
                 return _fn(*a, **k)
-            monkeypatch.setattr(_C, name, counted)
+            mp.setattr(_C, name, counted)
         losses = model(images, list(targets))
         sum(losses.values()).backward()
     assert calls == {"match_boxes": 2, "sample_labels": 2, "match_labels": 2, "roi_head_targets": 1, "rpn_decode": 5,
@@ -176,3 +177,40 @@ def test_tiny_mask_rcnn_trains_through_the_device_branches(monkeypatch):
     for k, v in losses.items():
         assert torch.isfinite(v) and 0 <= float(v.detach()) < 10, (k, float(v.detach()))
     assert sum(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters()) > 10
+
+
+@pytest.mark.parametrize("backend", ["emu-device", "emu-lib"])
+def test_tiny_mask_rcnn_with_the_fused_head_losses_equals_the_aten_losses(backend, monkeypatch):
+    """DETOPS_HEAD_LOSS=fused (opt-in): the value + gradient kernels of csrc/head_loss.hip in the detector — same losses
+    and same parameter gradients as the ATen compositions (same weights, same batch, same sampler draws).
+    "emu-lib": through the product's own `_C.fastrcnn_loss` / `_C.mask_loss` autograd functions (and every other `_C`
+    wrapper of the model) over the emulation library."""
+    from maskrcnn_benchmark.data.synthetic import BatchCollator, SyntheticCOCODataset
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    from maskrcnn_benchmark.modeling.roi_heads.box_head import loss as box_loss
+    cfg = _cfg(["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 100, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 150,
+                "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 32, "MODEL.RESNETS.RES2_OUT_CHANNELS", 16,
+                "MODEL.RESNETS.WIDTH_PER_GROUP", 4, "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 16,
+                "MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM", 32, "MODEL.ROI_MASK_HEAD.CONV_LAYERS", (16, 16)])
+    ds = SyntheticCOCODataset(length=2, height=96, width=128, with_masks=True, min_objects=2, max_objects=4)
+    images, targets, _ = BatchCollator(32)([ds[0], ds[1]])
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(box_loss, "_FUSED_LOSS", fused)
+        torch.manual_seed(0)
+        model = build_detection_model(cfg).train()
+        calls = []
+        _C._SAMPLER_CALLS[0] = 0      # without a device generator the sampler seeds come from this per-process counter
+        with cpu_shim.install(backend), monkeypatch.context() as mp:
+            for name in ("fastrcnn_loss", "mask_loss"):
+                mp.setattr(_C, name, (lambda *a, _fn=getattr(_C, name), _n=name, **k: (calls.append(_n), _fn(*a, **k))[1]))
+            # the emulated sampler's seed counter restarts with every install(): both runs draw the same subsets
+            losses = model(images, list(targets))
+            sum(v * w for v, w in zip(losses.values(), (1.0, 0.7, 1.3, 0.9, 1.1))).backward()
+        assert sorted(calls) == (["fastrcnn_loss", "mask_loss"] if fused else [])
+        res[fused] = ({k: v.item() for k, v in losses.items()}, [p.grad.clone() for p in model.parameters() if p.grad is not None])
+    for k, v in res[False][0].items():
+        assert abs(res[True][0][k] - v) <= 1e-5 * max(1.0, abs(v)), (k, res[True][0][k], v)
+    assert len(res[True][1]) == len(res[False][1]) > 10
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * max(1.0, float(b.abs().max())))

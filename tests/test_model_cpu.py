@@ -34,20 +34,23 @@ class _Dev(str):
     backend = "oracle"
 
 
-def _emu_device():
+def _emu(backend):
     d = _Dev("cpu")
-    d.backend = "emu-device"
+    d.backend = backend
     return d
 
 
-@pytest.fixture(params=["cpu", pytest.param(_emu_device(), id="cpu-device-branches"), pytest.param("cuda", marks=pytest.mark.gpu)])
+@pytest.fixture(params=["cpu", pytest.param(_emu("emu-device"), id="cpu-device-branches"),
+                        pytest.param(_emu("emu-lib"), id="cpu-product-wrappers"), pytest.param("cuda", marks=pytest.mark.gpu)])
 def dev(request):
-    """The reference-generated fixtures are checked three times: on the CPU (host logic; HIP-only operators
+    """The reference-generated fixtures are checked four times: on the CPU (host logic; HIP-only operators
     replaced by the oracle through cpu_shim); on the CPU with the model taking its DEVICE branches (fused label /
     sampler / sampled-slot / decode launches, served by the HIP sources under the host emulation: cpu_shim backend
-    "emu-device"); and, in the `-m gpu` suite, on the device through the real HIP kernels (no shim)."""
-    if getattr(request.param, "backend", None) == "emu-device":
-        with cpu_shim.install("emu-device"):     # for the whole test: target assignment runs outside `_shim` blocks
+    "emu-device"); on the CPU through the product's own `_C` wrappers over the emulation library (backend "emu-lib":
+    nothing of `_C` replaced); and, in the `-m gpu` suite, on the device through the real HIP kernels (no shim)."""
+    backend = getattr(request.param, "backend", None)
+    if backend in ("emu-device", "emu-lib"):
+        with cpu_shim.install(backend):          # for the whole test: target assignment runs outside `_shim` blocks
             yield request.param
     else:
         yield request.param

@@ -63,17 +63,21 @@ def test_state_dict_keys_equal_the_reference_and_load_strict(name):
 
 
 @pytest.mark.parametrize("name", ["mask_rcnn", "retinanet"])
-@pytest.mark.parametrize("dev", ["cpu", "cpu-device-branches", pytest.param("cuda", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("dev", ["cpu", "cpu-device-branches", "cpu-product-wrappers", pytest.param("cuda", marks=pytest.mark.gpu)])
 def test_losses_equal_the_reference_with_its_weights(name, dev, monkeypatch):
     # "cpu-device-branches": CPU tensors, but the model takes the branches it takes on the GPU (fused labels / sampler /
     # sampled-slot targets / proposal decode / batched proposal hand-over), served by the HIP sources under the host emulation
     backend = "oracle"
     if dev == "cpu-device-branches":
         dev, backend = "cpu", "emu-device"
+    if dev == "cpu-product-wrappers":
+        # the product's own `_C` wrappers and autograd functions, every operator of the model included, over the
+        # host-emulation build of the HIP sources (cpu_shim backend "emu-lib"): nothing of `_C` is replaced
+        dev, backend = "cpu", "emu-lib"
     cfg, model, ref_sd, il, targets, ref_losses = _build(name, dev)
     model.load_state_dict(ref_sd, strict=True)
     model.to(dev).train()
-    if dev == "cpu":
+    if dev == "cpu" and backend != "emu-lib":
         import maskrcnn_benchmark.layers.sigmoid_focal_loss as sfl
         monkeypatch.setattr(sfl.SigmoidFocalLoss, "forward",
                             lambda self, l, t: sfl.sigmoid_focal_loss_sum(l.float(), t, self.gamma, self.alpha))
