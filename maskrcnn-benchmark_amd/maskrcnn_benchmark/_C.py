@@ -144,7 +144,7 @@ def nms(dets, scores, threshold):
     CPU semantics (IoU >= threshold suppresses; csrc/cpu/nms_cpu.cpp:60)."""
     if dets.numel() == 0:  # nms.h:17-18 returns an empty CPU long tensor
         return torch.empty((0,), dtype=torch.long, device="cpu")
-    on_cpu = not dets.is_cuda and not scores.is_cuda
+    on_cpu = not on_device(dets) and not on_device(scores)
     if not on_cpu:
         _need_cuda("nms", dets, scores)
     dets = _f32c("nms", dets)
@@ -564,7 +564,7 @@ def rpn_decode(box_regression, topk_idx, topk_scores, anchors, image_hw, weights
 # ------------------------------------------------------------------------------------------ ROIAlign
 def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
     """reference csrc/ROIAlign.h:11-25 -> [K,C,PH,PW]."""
-    if not input.is_cuda and not rois.is_cuda:
+    if not on_device(input) and not on_device(rois):
         return _roi_align_forward_cpu(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio)
     _need_cuda("roi_align_forward", input, rois)
     input = _f32c("roi_align_forward", input)
@@ -684,7 +684,7 @@ def roi_align_fpn_backward_prepare(rois, levels, shapes, scales, pooled_height, 
     issued at FORWARD time on a side stream so that it is off the backward pass's critical path.  Returns an opaque
     handle for roi_align_fpn_backward(prepared=...), or None when the shape is served by the one-call kernels."""
     K = rois.size(0)
-    if K == 0 or not rois.is_cuda:
+    if K == 0 or not on_device(rois):
         return None
     N, C = shapes[0][:2]
     L = len(shapes)
@@ -1415,7 +1415,7 @@ def deform_psroi_pooling_backward(out_grad, input, bbox, trans, top_count, input
         raise RuntimeError("Output shape and bbox number wont match: (%d vs %d)." % (out_grad.size(0), K))
     if not (input_grad.is_contiguous() and input_grad.dtype == torch.float32):
         raise RuntimeError("%s: input_grad must be contiguous float32" % name)
-    if not no_trans and not (trans_grad.is_cuda and trans_grad.is_contiguous()
+    if not no_trans and not (on_device(trans_grad) and trans_grad.is_contiguous()
                              and trans_grad.dtype == torch.float32 and trans_grad.shape == trans.shape):
         raise RuntimeError("%s: trans_grad must be a contiguous float32 CUDA tensor shaped like trans" % name)
     with _on_device(input), _timed(("psroi_bwd[K=%d,D=%d,P=%d]", (K, output_dim, pooled_size)), input):
