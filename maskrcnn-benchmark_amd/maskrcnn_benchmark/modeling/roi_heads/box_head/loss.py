@@ -33,9 +33,14 @@ def stack_proposals(proposals):
     valid [N,K].  Lists that are the rows of one batch (the training RPN hands its proposals over like that,
     `BoxList.batch_rows`) are returned as that batch: no copy."""
     rows = [getattr(p, "batch_rows", None) for p in proposals]
-    if rows[0] is not None and all(r is not None and r[0] is rows[0][0] and r[1] == i for i, r in enumerate(rows)) \
-            and rows[0][0]["boxes"].shape[0] == len(proposals):
-        return rows[0][0]["boxes"], rows[0][0]["valid"]
+    if rows[0] is not None and all(r is not None and r[0] is rows[0][0] and r[1] == i for i, r in enumerate(rows)):
+        batch = rows[0][0]
+        bb = batch["boxes"]
+        # still the rows they were handed over as (a list whose boxes were replaced since falls through to the copy)
+        if bb.shape[0] == len(proposals) and all(
+                p.bbox.shape == bb[i].shape and p.bbox.data_ptr() == bb[i].data_ptr() and p.has_field("valid")
+                and p.get_field("valid").data_ptr() == batch["valid"][i].data_ptr() for i, p in enumerate(proposals)):
+            return bb, batch["valid"]
     K = max(len(p) for p in proposals)
     dev = proposals[0].bbox.device
     boxes = torch.zeros((len(proposals), K, 4), dtype=torch.float32, device=dev)

@@ -214,3 +214,22 @@ def test_tiny_mask_rcnn_with_the_fused_head_losses_equals_the_aten_losses(backen
     assert len(res[True][1]) == len(res[False][1]) > 10
     for a, b in zip(res[True][1], res[False][1]):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * max(1.0, float(b.abs().max())))
+
+
+def test_stack_proposals_takes_the_handed_over_batch_only_while_the_lists_are_its_rows():
+    boxes = torch.rand(2, 5, 4)
+    batch = {"boxes": boxes, "valid": torch.ones(2, 5, dtype=torch.bool), "objectness": torch.rand(2, 5)}
+    props = []
+    for i in range(2):
+        p = BoxList(boxes[i], (10, 10), mode="xyxy")
+        p.add_field("valid", batch["valid"][i])
+        p.batch_rows = (batch, i)
+        props.append(p)
+    assert stack_proposals(props)[0] is boxes
+    assert stack_proposals(props[::-1])[0] is not boxes                      # not in batch order
+    props[1].bbox = boxes[1].clone()                                         # boxes replaced after the hand-over
+    b, v = stack_proposals(props)
+    assert b is not boxes and torch.equal(b, boxes) and torch.equal(v, batch["valid"])
+    props[1].bbox = boxes[1]
+    props[1].extra_fields["valid"] = torch.zeros(5, dtype=torch.bool)       # validity replaced
+    assert not stack_proposals(props)[1][1].any()
