@@ -233,3 +233,50 @@ def test_stack_proposals_takes_the_handed_over_batch_only_while_the_lists_are_it
     props[1].bbox = boxes[1]
     props[1].extra_fields["valid"] = torch.zeros(5, dtype=torch.bool)       # validity replaced
     assert not stack_proposals(props)[1][1].any()
+
+
+@pytest.mark.parametrize("seed,sizes,counts,pre,post_n", [
+    (0, [(96, 128)], [3], 60, 80),                                   # one image
+    (1, [(96, 128), (80, 120), (64, 64)], [2, 0, 5], 50, 90),         # an image WITHOUT ground truth in the batch
+    (2, [(130, 200), (160, 192)], [9, 1], 300, 250),                  # per-batch top-n below the candidates
+    (3, [(64, 96), (64, 96)], [1, 1], 1000, 2000)])                   # k = all anchors of every level
+def test_proposals_and_box_head_sampling_fuzz_device_branches_vs_compositions(seed, sizes, counts, pre, post_n, monkeypatch):
+    """RPNPostProcessor.forward (training, ground truth appended) + FastRCNNLossComputation.subsample over random
+    batches, through the product's `_C` wrappers on the emulation library: every device branch on, against every device
+    branch off (per-level ATen decode, per-image concatenation and re-stacking, ATen label chain + encode + indexing)"""
+    from maskrcnn_benchmark.modeling.roi_heads.box_head import loss as box_loss
+    rng = np.random.RandomState(100 + seed)
+    anchors, obj, reg = _rpn_inputs(rng, sizes)
+    targets = _targets(rng, sizes, counts)
+    post = RPNPostProcessor(pre, pre, 0.7, 0, BoxCoder((1.0, 1.0, 1.0, 1.0)), fpn_post_nms_top_n=post_n).train()
+    ev = make_roi_box_loss_evaluator(_cfg(["MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 64]))
+    with cpu_shim.install("emu-lib"):
+        begin_step()
+        props = post(anchors, obj, reg, targets)
+        boxes, valid = stack_proposals(props)
+        assert boxes is props[0].batch_rows[0]["boxes"]
+        _C._SAMPLER_CALLS[0] = 0
+        out = ev.subsample(props, targets)
+        # ---- the same modules with the device branches off
+        post.fused_decode = False
+        monkeypatch.setattr(box_loss, "_FUSED", False)
+        with monkeypatch.context() as mp:
+            mp.setattr(_C, "on_device", lambda t: False)
+            begin_step()
+            rprops = post(anchors, obj, reg, targets)
+        assert all(getattr(p, "batch_rows", None) is None for p in rprops)
+        rboxes, rvalid = stack_proposals(rprops)
+        _C._SAMPLER_CALLS[0] = 0
+        ref = ev.subsample(rprops, targets)
+    assert torch.equal(valid, rvalid) and int(valid.sum()) >= sum(counts)
+    assert torch.allclose(boxes[valid], rboxes[valid], rtol=1e-6, atol=4e-3)      # glibc expf vs ATen's exp: last place
+    for o, r, m in zip(out, ref, counts):
+        assert set(o.fields()) == set(r.fields())
+        for f in ("labels", "matched_idxs", "valid", "objectness"):
+            assert torch.equal(o.get_field(f), r.get_field(f)), f
+        v = o.get_field("valid")
+        assert torch.allclose(o.bbox[v], r.bbox[v], rtol=1e-6, atol=4e-3)
+        pos = o.get_field("labels") > 0
+        assert torch.allclose(o.get_field("regression_targets")[pos], r.get_field("regression_targets")[pos], rtol=1e-4, atol=1e-4)
+        assert int(pos.sum()) >= min(m, 16) and (m > 0 or not pos.any())
+        assert torch.isfinite(o.get_field("regression_targets")).all()
