@@ -145,3 +145,52 @@ def test_frozen_batch_norm_module_and_focal_loss_equal_the_torch_formulas():
     loss.backward()
     want = oracle.sigmoid_focal_loss_backward(logits, targets, np.ones_like(logits), 2.0, 0.25)
     assert np.allclose(tl.grad.numpy(), want, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("config", ["e2e_mask_rcnn_R_50_FPN_1x.yaml", "retinanet/retinanet_R-50-FPN_1x.yaml"])
+def test_detector_trains_and_detects_through_the_product_wrappers(config):
+    """TrainStep (forward, backward, fused-SGD update) for a few iterations and an eval-mode forward of the tiny detector
+    with every operator served by `_C` as shipped: falling loss, finite gradients, and the SAME detections as with the
+    oracle stand-ins (tests/cpu_shim.py default backend) from the same weights"""
+    from maskrcnn_benchmark.data.synthetic import BatchCollator, SyntheticCOCODataset
+    from maskrcnn_benchmark.engine.bench_step import load_cfg
+    from maskrcnn_benchmark.engine.ddp_step import TrainStep, make_overlapped_sgd
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    cfg = load_cfg(config, ["MODEL.DEVICE", "cpu", "MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 100, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 150,
+                            "MODEL.RPN.PRE_NMS_TOP_N_TEST", 100, "MODEL.RPN.FPN_POST_NMS_TOP_N_TEST", 60,
+                            "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 32, "MODEL.RESNETS.RES2_OUT_CHANNELS", 16,
+                            "MODEL.RESNETS.WIDTH_PER_GROUP", 4, "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 16,
+                            "MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM", 32, "MODEL.ROI_MASK_HEAD.CONV_LAYERS", (16, 16),
+                            "MODEL.ROI_HEADS.SCORE_THRESH", 0.0, "MODEL.RETINANET.INFERENCE_TH", 0.0, "SOLVER.BASE_LR", 0.002])
+    torch.manual_seed(0)
+    model = build_detection_model(cfg).train()
+    ds = SyntheticCOCODataset(length=2, height=96, width=128, with_masks=cfg.MODEL.MASK_ON, min_objects=2, max_objects=4)
+    images, targets, _ = BatchCollator(32)([ds[0], ds[1]])
+    step = TrainStep(model, make_overlapped_sgd(cfg, model), None, "float32", "cpu")
+    first = {k: v.item() for k, v in step(images, list(targets)).items()}
+    for _ in range(3):
+        last = {k: v.item() for k, v in step(images, list(targets)).items()}
+    assert all(np.isfinite(v) for v in last.values()) and sum(last.values()) < sum(first.values())
+    model.eval()
+    with torch.no_grad():
+        det = model(images)
+    # the same weights with the oracle stand-ins and the CPU compositions: inside this file's emu-lib install, hand `_C` its
+    # own library handle and device test back for the duration of the stand-in run
+    from maskrcnn_benchmark import _C, _lib
+    on, lib = _C.on_device, _C.lib
+    _C.on_device, _C.lib = (lambda t: t.is_cuda), _lib.lib
+    try:
+        with cpu_shim.install("oracle"), torch.no_grad():
+            ref = model(images)
+    finally:
+        _C.on_device, _C.lib = on, lib
+    assert len(det) == len(ref) == 2
+    for d, r in zip(det, ref):
+        assert d.has_field("scores") and d.has_field("labels") and len(d) > 0
+        assert abs(len(d) - len(r)) <= max(2, len(r) // 10)
+        k = min(len(d), len(r), 5)
+        ds_, rs_ = d.get_field("scores").sort(descending=True), r.get_field("scores").sort(descending=True)
+        assert torch.allclose(ds_[0][:k], rs_[0][:k], rtol=1e-3, atol=1e-4)
+        assert torch.allclose(d.bbox[ds_[1][:k]], r.bbox[rs_[1][:k]], rtol=1e-3, atol=5e-2)
+        if cfg.MODEL.MASK_ON:
+            assert d.has_field("mask") and d.get_field("mask").shape[0] == len(d)
