@@ -37,6 +37,7 @@ class LevelMapper(object):
 
 
 PREPARE_BACKWARD_AT_FORWARD = False   # see _ROIAlignFPN.forward
+_INDEX_COLUMNS = {}                   # Pooler.convert_to_roi_format: (lengths, dtype, device) -> [K, 1] image-index column
 
 
 class _ROIAlignFPN(Function):
@@ -96,12 +97,17 @@ class Pooler(nn.Module):
     @staticmethod
     def convert_to_roi_format(boxes):
         """list[BoxList] -> [K,5] rows (image index, x1, y1, x2, y2); the index is stored as float
-        like the reference (:78-89)."""
-        rows = []
-        for i, b in enumerate(boxes):
-            bb = b.bbox
-            rows.append(torch.cat([bb.new_full((bb.shape[0], 1), float(i)), bb], dim=1))
-        return cat(rows, dim=0)
+        like the reference (:78-89).  The index column depends on the list lengths only: it is kept per
+        (lengths, dtype, device) — two concatenations per call instead of a fill + a concatenation per image."""
+        first = boxes[0].bbox
+        key = (tuple(b.bbox.shape[0] for b in boxes), first.dtype, str(first.device))
+        col = _INDEX_COLUMNS.pop(key, None)
+        if col is None:
+            col = cat([first.new_full((n, 1), float(i)) for i, n in enumerate(key[0])], dim=0)   # on the device: no sync
+            while len(_INDEX_COLUMNS) >= 32:
+                _INDEX_COLUMNS.pop(next(iter(_INDEX_COLUMNS)))
+        _INDEX_COLUMNS[key] = col            # most recently used last
+        return torch.cat([col, cat([b.bbox for b in boxes], dim=0)], dim=1)
 
     def forward(self, x, boxes):
         rois = boxes if isinstance(boxes, torch.Tensor) else self.convert_to_roi_format(boxes)
