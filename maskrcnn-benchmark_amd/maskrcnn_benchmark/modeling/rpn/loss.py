@@ -16,6 +16,7 @@ from torch.nn import functional as F
 
 from maskrcnn_benchmark import _C
 from maskrcnn_benchmark.modeling.matcher import Matcher
+from maskrcnn_benchmark.modeling.utils import device_constant
 from maskrcnn_benchmark.structures.boxlist_ops import box_iou_matrix
 
 from ..balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
@@ -58,21 +59,45 @@ def pad_targets(targets, device, fields=()):
     return out
 
 
+_PADDING_ROWS = {}
+
+
+def _padding_rows(n, kind, device):
+    """n rows of padding — kind "box": the far-away unit box (-1e5, -1e5, -1e5 + 1, -1e5 + 1); kind "zero": int64 zeros — as
+    a slice of a constant kept on the device (rows rounded up to a power of two >= 64: one constant serves every batch)."""
+    cap = 64
+    while cap < n:
+        cap *= 2
+    key = (cap, kind, str(device))
+    rows = _PADDING_ROWS.get(key)
+    if rows is None:
+        if kind == "box":
+            rows = device_constant([[-1e5, -1e5, -1e5 + 1, -1e5 + 1]] * cap, torch.float32, device)
+        else:
+            rows = device_constant([0] * cap, torch.int64, device)
+        _PADDING_ROWS[key] = rows      # a handful of entries: (power of two, kind, device)
+    return rows[:n]
+
+
 def _pad_targets(targets, device, fields):
+    """ONE concatenation per padded tensor (each image's rows followed by its padding rows, sliced from device-resident
+    constants) and a row-validity mask that is a cached constant of the per-image counts: 1 + len(fields) launches."""
     N = len(targets)
-    M = max(max(len(t) for t in targets), 1)
-    boxes = torch.full((N, M, 4), -1e5, dtype=torch.float32, device=device)
-    boxes[:, :, 2:] = -1e5 + 1
-    row_valid = torch.zeros((N, M), dtype=torch.bool, device=device)
-    extra = {f: torch.zeros((N, M), dtype=torch.int64, device=device) for f in fields}
-    for i, t in enumerate(targets):
-        m = len(t)
-        if m == 0:
-            continue
-        boxes[i, :m] = t.convert("xyxy").bbox.to(device)
-        row_valid[i, :m] = True
-        for f in fields:
-            extra[f][i, :m] = t.get_field(f).to(device=device, dtype=torch.int64)
+    lens = [len(t) for t in targets]
+    M = max(max(lens), 1)
+    parts = {f: [] for f in ("bbox",) + tuple(fields)}
+    for t, m in zip(targets, lens):
+        if m:
+            parts["bbox"].append(t.convert("xyxy").bbox.to(device=device, dtype=torch.float32))
+            for f in fields:
+                parts[f].append(t.get_field(f).to(device=device, dtype=torch.int64))
+        if m < M:
+            parts["bbox"].append(_padding_rows(M - m, "box", device))
+            for f in fields:
+                parts[f].append(_padding_rows(M - m, "zero", device))
+    boxes = torch.cat(parts["bbox"], dim=0).view(N, M, 4)
+    row_valid = device_constant([[j < m for j in range(M)] for m in lens], torch.bool, device)
+    extra = {f: torch.cat(parts[f], dim=0).view(N, M) for f in fields}
     return boxes, row_valid, extra
 
 
