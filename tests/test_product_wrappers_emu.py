@@ -194,3 +194,65 @@ def test_detector_trains_and_detects_through_the_product_wrappers(config):
         assert torch.allclose(d.bbox[ds_[1][:k]], r.bbox[rs_[1][:k]], rtol=1e-3, atol=5e-2)
         if cfg.MODEL.MASK_ON:
             assert d.has_field("mask") and d.get_field("mask").shape[0] == len(d)
+
+
+def test_roi_pool_and_deformable_psroi_pooling_layers_equal_the_oracle():
+    """ROIPool (layers/roi_pool.py; reference :11-63) and DeformRoIPooling (layers/dcn/deform_pool_module.py; reference
+    layers/dcn/deform_pool_func.py:8-95) with their autograd functions, through `_C` as shipped"""
+    from maskrcnn_benchmark.layers import ROIPool
+    from maskrcnn_benchmark.layers.dcn.deform_pool_module import DeformRoIPooling
+    rng = np.random.RandomState(13)
+    N, C, H, W, K = 2, 6, 20, 28, 30
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    wh = rng.uniform(8, 200, (K, 2))
+    xy = rng.uniform(0, [W * 16 - 8, H * 16 - 8], (K, 2))
+    rois = np.concatenate([rng.randint(0, N, (K, 1)), xy, xy + wh], 1).astype(np.float32)
+    tx = _t(x).requires_grad_()
+    out = ROIPool((5, 4), 1.0 / 16)(tx, _t(rois))
+    ref, argmax = oracle.roi_pool_forward(x, rois, 1.0 / 16, 5, 4)
+    assert np.array_equal(out.detach().numpy(), ref)
+    g = rng.randn(*ref.shape).astype(np.float32)
+    out.backward(_t(g))
+    want = oracle.roi_pool_backward(g, rois, argmax, N, C, H, W)
+    assert np.abs(tx.grad.numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    # deformable position-sensitive pooling: output_dim 3, group 2, pooled 4, part 4, 2 samples per part, learned shifts
+    D, G, P, S, std = 3, 2, 4, 2, 0.1
+    data = rng.randn(N, D * G * G, H, W).astype(np.float32)
+    trans = (rng.randn(K, 2, P, P) * 0.5).astype(np.float32)
+    for no_trans in (True, False):
+        td, tt = _t(data).requires_grad_(), _t(trans).requires_grad_()
+        layer = DeformRoIPooling(1.0 / 16, P, D, no_trans, group_size=G, part_size=P, sample_per_part=S, trans_std=std)
+        out = layer(td, _t(rois), tt)
+        ro, rc = oracle.deform_psroi_pool_forward(data, rois, trans, no_trans, 1.0 / 16, D, G, P, P, S, std)
+        assert np.abs(out.detach().numpy() - ro).max() <= 1e-5
+        g = rng.randn(*ro.shape).astype(np.float32)
+        out.backward(_t(g))
+        dg, tg = oracle.deform_psroi_pool_backward(g, data, rois, trans, rc, no_trans, 1.0 / 16, D, G, P, P, S, std, acc64=True)
+        assert np.abs(td.grad.numpy() - dg).max() <= 1e-4 * max(1.0, np.abs(dg).max())
+        if not no_trans:
+            assert np.abs(tt.grad.numpy() - tg).max() <= 1e-4 * max(1.0, np.abs(tg).max())
+
+
+def test_deformable_detector_trains_through_the_product_wrappers():
+    """R-50-FPN with deformable convolutions in C3-C5 (the cfg-5 family, narrow): forward + backward of the detector through
+    `ModulatedDeformConvPack` / `_C.deform_conv_*` as shipped: finite losses, a finite gradient on every trainable parameter"""
+    from maskrcnn_benchmark.data.synthetic import BatchCollator, SyntheticCOCODataset
+    from maskrcnn_benchmark.engine.bench_step import load_cfg
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    cfg = load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml", ["MODEL.DEVICE", "cpu", "MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 100,
+                                                     "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 150, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 32,
+                                                     "MODEL.RESNETS.RES2_OUT_CHANNELS", 16, "MODEL.RESNETS.WIDTH_PER_GROUP", 4,
+                                                     "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 16, "MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM", 32,
+                                                     "MODEL.ROI_MASK_HEAD.CONV_LAYERS", (16, 16),
+                                                     "MODEL.RESNETS.STAGE_WITH_DCN", "(False, True, True, True)"])
+    torch.manual_seed(0)
+    model = build_detection_model(cfg).train()
+    assert sum(type(m).__name__ == "ModulatedDeformConvPack" or type(m).__name__ == "DeformConv" or "DCN" in type(m).__name__
+               for m in model.modules()) > 0
+    ds = SyntheticCOCODataset(length=2, height=96, width=128, with_masks=True, min_objects=2, max_objects=4)
+    images, targets, _ = BatchCollator(32)([ds[0], ds[1]])
+    losses = model(images, list(targets))
+    assert all(torch.isfinite(v) for v in losses.values())
+    sum(losses.values()).backward()
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in trainable) and len(trainable) > 90
