@@ -559,7 +559,9 @@ rpn_decode_kernel(const float* __restrict__ reg, const int64_t* __restrict__ idx
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (t >= static_cast<int64_t>(N) * k) return;
   const int n = static_cast<int>(t / k), j = static_cast<int>(t - static_cast<int64_t>(n) * k);
-  const int64_t i = idx[t];
+  int64_t i = idx[t];
+  const int64_t last = static_cast<int64_t>(A) * H * W - 1;
+  i = i < 0 ? 0 : (i > last ? last : i);          // a position outside the level would read outside the head output
   const int a = static_cast<int>(i % A);
   const int64_t pos = i / A;
   const int y = static_cast<int>(pos / W), x = static_cast<int>(pos - static_cast<int64_t>(y) * W);
@@ -599,7 +601,7 @@ match_labels_kernel(const int64_t* __restrict__ matched, const int64_t* __restri
   if (t >= total) return;
   const int64_t m = matched[t];
   T v = static_cast<T>(-1);
-  if (m >= 0) v = gt_labels ? static_cast<T>(gt_labels[(t / K) * M + m]) : static_cast<T>(1);
+  if (m >= 0) v = gt_labels ? (m < M ? static_cast<T>(gt_labels[(t / K) * M + m]) : static_cast<T>(-1)) : static_cast<T>(1);
   else if (m == -1) v = static_cast<T>(0);
   if (valid && !valid[t]) v = static_cast<T>(-1);
   out[t] = v;
@@ -625,9 +627,10 @@ roi_head_targets_kernel(const float* __restrict__ boxes, const int64_t* __restri
   const size_t src = static_cast<size_t>(n) * K + i;
   const int64_t m = matched[src];
   const float4 b = reinterpret_cast<const float4*>(boxes)[src];
-  const float4 g = reinterpret_cast<const float4*>(gt)[static_cast<size_t>(n) * M + (m < 0 ? 0 : m)];
+  const int64_t mg = m < 0 ? 0 : (m >= M ? M - 1 : m);     // the matched row (row 0 when there is none: value unused)
+  const float4 g = reinterpret_cast<const float4*>(gt)[static_cast<size_t>(n) * M + mg];
   int64_t label = -1;
-  if (slot_valid[t] && (!valid || valid[src])) label = m >= 0 ? gt_labels[static_cast<size_t>(n) * M + m] : (m == -1 ? 0 : -1);
+  if (slot_valid[t] && (!valid || valid[src])) label = m >= 0 ? (m < M ? gt_labels[static_cast<size_t>(n) * M + m] : -1) : (m == -1 ? 0 : -1);
   const float ew = b.z - b.x + 1.f, eh = b.w - b.y + 1.f;
   const float ex = b.x + 0.5f * ew, ey = b.y + 0.5f * eh;
   const float gw = g.z - g.x + 1.f, gh = g.w - g.y + 1.f;
