@@ -95,6 +95,10 @@ def setup_miopen_db(export_dir=None):
     return "shipped:" + shipped
 
 
+# timer-name prefixes of the SURVEY §8(a) operators (a1/a2/a10 ROIAlign over the pyramid, a8 focal loss, a9 deformable conv)
+PATH_FAMILIES = ("roi_align_fpn_", "focal_", "dcn_")
+
+
 def algorithmic_bytes(name, feat_bytes):
     """SURVEY.md §8(d) per-launch ALGORITHMIC bytes of a hand-written entry point, from the shape in its timer name:
     ROIAlign fwd/bwd = pooled tensor + every pooled feature map once + rois; focal fwd(sum) = logits + targets, bwd =
@@ -571,7 +575,7 @@ def main():
                                                 before=install_timer)
     _C.KERNEL_TIMER = None
     progress("%d timed steps done" % args.steps)
-    loss_vals = {k: float(v) for k, v in losses.items()} if losses else {}
+    loss_vals = {k: float(v.detach()) for k, v in losses.items()} if losses else {}
 
     if rank == 0:
         images = args.images_per_gpu * world * args.steps
@@ -602,6 +606,10 @@ def main():
             "hip": {"GPU_MAX_HW_QUEUES": hw_queues, "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
             "kernel_timers": ("all ranks" if distributed else "rank 0") if timer is not None else "off",
             "ddp": ddp_mode,
+            # which communication path the wrapper runs: "direct" = RCCL on one low-priority side stream (engine/rccl_comm.py),
+            # "pg" = ProcessGroupNCCL (with the reason, when the direct path was tried and refused)
+            "ddp_comm": ({"mode": getattr(model, "comm_mode", None), "note": getattr(model, "comm_note", None)}
+                         if (distributed or args.force_ddp) else None),
             # host time to ENQUEUE the timed steps (rank 0): close to ms_per_step = the host is the limiter
             "host_enqueue_ms_per_step": round(1000.0 * host_elapsed / args.steps, 3),
         }
@@ -617,14 +625,17 @@ def main():
                     entry["alg_bytes"] = b
                     entry["achieved_GBs"] = round(b / (mean_us * 1e-6) / 1e9, 1)
                 kernels[name] = entry
-            # one `roofline` entry point: the hand-written kernel FAMILY (name before the shape) with the largest time per
-            # step, represented by its member with the largest time per step
+            # one `roofline` entry point: among the SURVEY §8(a) operators of the path BASELINE.json's metric names
+            # (ROIAlign, focal loss, deformable conv — `PATH_FAMILIES`), the kernel FAMILY (name before the shape) with the
+            # largest time per step, represented by its member with the largest time per step.  The fused FrozenBN
+            # streams are larger per step but are not a §8 row: they stay in `kernels` / `kernel_families_ms_per_step`.
             fam = {}
             for name, e in kernels.items():
                 if "alg_bytes" in e:
                     fam.setdefault(name.split("[")[0], []).append((e["ms_per_step"], name))
-            if fam:
-                best = max(fam.values(), key=lambda members: sum(m[0] for m in members))
+            path_fam = {k: v for k, v in fam.items() if k.startswith(PATH_FAMILIES)}
+            if path_fam:
+                best = max(path_fam.values(), key=lambda members: sum(m[0] for m in members))
                 name = max(best)[1]
                 dominant = (name, kernels[name])
             line["kernels"] = kernels

@@ -190,7 +190,9 @@ int detops_roi_pool_backward_f32(const float* grad_out, const float* rois,
  *   keep      [n]  int64, first *num_keep entries valid (ascending original indices)
  *   num_keep  [1]  int32 on device (the caller decides when/if to read it back); -1 = FAILED: a workgroup of the
  *                  single-launch kernel waited for another one of the same launch beyond its polling budget (seconds:
- *                  the compute units were held by other work) — nothing is kept for that segment (all-zero keep mask)
+ *                  the compute units were held by other work).  The repair pass described at
+ *                  detops_nms_batched_status_f32 redoes such a segment before the call's work ends, so a caller only ever
+ *                  SEES -1 (and an all-zero keep mask) with the repair switched off (tuning "nms_no_repair" = 1: tests)
  *   Entirely device-side: no host round trip (the reference's CUDA path copies the n x n/64
  *   bitmask to the host and scans it there, csrc/cuda/nms.cu:100-123).
  * ---------------------------------------------------------------------------------------- */
@@ -223,6 +225,17 @@ int detops_nms_batched_mask_f32(const float* boxes, const float* scores,
                                 const int32_t* seg_offsets, int num_segments, int max_n,
                                 float threshold, uint8_t* keep_mask, int32_t* num_keep,
                                 void* workspace, size_t workspace_bytes, detops_stream_t stream);
+
+/* Both result forms optional (keep and / or keep_mask, at least one) + a sticky STATUS word.  Every entry point of this
+ * section launches, right behind the single-launch kernel and on the same stream, a repair pass: a segment the single
+ * launch marked as failed (num_keep = -1, see above) is redone by ONE workgroup that waits for nobody, so that — like the
+ * reference (csrc/cuda/nms.cu:70-131) — no segment is ever dropped; num_keep[s] then holds the real count.  *status
+ * (int32 on device, may be NULL; never cleared by the library) is incremented once per redone segment: a trainer reads it
+ * with its next loss read-back and reports how often the fast path gave up — no synchronisation of its own. */
+int detops_nms_batched_status_f32(const float* boxes, const float* scores, const int32_t* seg_offsets,
+                                  int num_segments, int max_n, float threshold, int64_t* keep, uint8_t* keep_mask,
+                                  int32_t* num_keep, int32_t* status, void* workspace, size_t workspace_bytes,
+                                  detops_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * SigmoidFocalLoss — replaces _C.sigmoid_focalloss_forward / _backward

@@ -33,10 +33,12 @@ __device__ __forceinline__ float wave_max_all(float v) {
   return __shfl(v, 0);
 }
 
-// #labels that satisfy label >= lo, counted by the whole workgroup (every thread returns the count)
-__device__ __forceinline__ float block_count_ge(const int64_t* __restrict__ labels, int n, int64_t lo, float* s_red) {
+// #labels with lo <= label < hi — the SAME predicate the loss rows use, so that a malformed label (>= #classes) drops out
+// of the sum and of its normaliser alike; counted by the whole workgroup (every thread returns the count)
+__device__ __forceinline__ float block_count_in(const int64_t* __restrict__ labels, int n, int64_t lo, int64_t hi,
+                                                float* s_red) {
   float c = 0.f;
-  for (int i = threadIdx.x; i < n; i += kBlock) c += labels[i] >= lo ? 1.f : 0.f;
+  for (int i = threadIdx.x; i < n; i += kBlock) c += (labels[i] >= lo && labels[i] < hi) ? 1.f : 0.f;
   c = wave_sum(c);
   if ((threadIdx.x & (kWave - 1)) == 0) s_red[threadIdx.x / kWave] = c;
   __syncthreads();
@@ -54,7 +56,7 @@ fastrcnn_loss_kernel(const float* __restrict__ logits, const float* __restrict__
                      const float* __restrict__ targets, int R, int C, int D, int agnostic, float beta,
                      float* __restrict__ grad_logits, float* __restrict__ grad_box, float* __restrict__ partial) {
   __shared__ float s_red[kWavesPerBlock];
-  const float inv = 1.f / fmaxf(block_count_ge(labels, R, 0, s_red), 1.f);
+  const float inv = 1.f / fmaxf(block_count_in(labels, R, 0, C, s_red), 1.f);
   const int lane = threadIdx.x & (kWave - 1);
   const int r = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
   if (r >= R) return;
@@ -92,13 +94,13 @@ fastrcnn_loss_kernel(const float* __restrict__ logits, const float* __restrict__
   if (lane == 0) { partial[2 * r] = ce; partial[2 * r + 1] = l1; }
 }
 
-// fixed-order sum of the per-row partials -> out = {sum0 * inv, sum1 * inv}; inv = 1 / max(count(labels >= lo) * per, 1)
+// fixed-order sum of the per-row partials -> out = {sum0 * inv, sum1 * inv}; inv = 1 / max(count(lo <= labels < hi) * per, 1)
 __global__ void __launch_bounds__(kBlock)
 head_loss_finish_kernel(const float* __restrict__ partial, int rows, int width, const int64_t* __restrict__ labels, int n,
-                        int64_t lo, float per, float* __restrict__ out) {
+                        int64_t lo, int64_t hi, float per, float* __restrict__ out) {
   __shared__ float s_red[kWavesPerBlock];
   __shared__ float s_sum[2][kWavesPerBlock];
-  const float inv = 1.f / fmaxf(block_count_ge(labels, n, lo, s_red) * per, 1.f);
+  const float inv = 1.f / fmaxf(block_count_in(labels, n, lo, hi, s_red) * per, 1.f);
   float v[2] = {0.f, 0.f};
   for (int i = threadIdx.x; i < rows; i += kBlock)
     for (int k = 0; k < width; ++k) v[k] += partial[i * width + k];
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(kBlock)
 mask_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ targets,
                  int P, int C, int S, float* __restrict__ grad, float* __restrict__ partial) {
   __shared__ float s_red[kWavesPerBlock];
-  const float inv = 1.f / fmaxf(block_count_ge(labels, P, 1, s_red) * static_cast<float>(S), 1.f);
+  const float inv = 1.f / fmaxf(block_count_in(labels, P, 1, C, s_red) * static_cast<float>(S), 1.f);
   const int p = blockIdx.x;
   const int64_t label = labels[p];
   const bool pos = label > 0 && label < C;
@@ -184,7 +186,7 @@ DETOPS_API int detops_fastrcnn_loss_f32(const float* class_logits, const float* 
   hipLaunchKernelGGL(fastrcnn_loss_kernel, dim3((R + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, st, class_logits,
                      box_regression, labels, regression_targets, R, C, D, cls_agnostic, beta, grad_logits, grad_box, partial);
   hipLaunchKernelGGL(head_loss_finish_kernel, dim3(1), dim3(kBlock), 0, st, partial, R, 2, labels, R,
-                     static_cast<int64_t>(0), 1.f, losses2);
+                     static_cast<int64_t>(0), static_cast<int64_t>(C), 1.f, losses2);
   return launch_status();
 }
 
@@ -202,7 +204,7 @@ DETOPS_API int detops_mask_loss_f32(const float* mask_logits, const int64_t* lab
   hipLaunchKernelGGL(mask_loss_kernel, dim3(P, kMaskSplit), dim3(kBlock), 0, st, mask_logits, labels, mask_targets, P, C, M * M,
                      grad_logits, partial);
   hipLaunchKernelGGL(head_loss_finish_kernel, dim3(1), dim3(kBlock), 0, st, partial, P, 1, labels, P, static_cast<int64_t>(1),
-                     static_cast<float>(M * M), loss1);
+                     static_cast<int64_t>(C), static_cast<float>(M * M), loss1);
   return launch_status();
 }
 

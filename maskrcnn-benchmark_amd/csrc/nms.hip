@@ -668,6 +668,52 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
   if (tid == 0 && s_fail[0]) num_keep[s] = -1;     // (same thread that wrote the count in compact_keep)
 }
 
+// ---------------------------------------------------------------------------- repair of failed segments
+// Launched right behind nms_fused_kernel on the same stream, S workgroups.  Workgroup s looks at num_keep[s]: anything
+// but the failure marker (-1) -> it leaves at once (the normal case: ~2 us for the whole launch).  A failed segment is
+// redone HERE by this one workgroup alone — sort, every mask tile (a wave per tile, 8 at a time), scan chain, compaction
+// — with no wait for any other workgroup, so it cannot time out; slow (one CU), but the reference never drops a
+// segment (csrc/cuda/nms.cu:70-131) and neither does this path.  The fused launch has retired by now (stream order): its
+// late writers cannot race with this one.  `status` (optional): a sticky device word, incremented once per repaired
+// segment — the trainer reads it at its logging interval.
+__global__ void __launch_bounds__(kScanThreads)
+nms_repair_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                  const int32_t* __restrict__ seg_offsets, int n_single, int npad, float thr, Work w,
+                  int64_t* __restrict__ keep, int32_t* __restrict__ num_keep, uint8_t* __restrict__ keep_mask,
+                  int32_t* __restrict__ status) {
+  DETOPS_DYNAMIC_LDS(unsigned char, smem_raw);
+  const int s = blockIdx.x;
+  if (num_keep[s] != -1) return;                                  // uniform over the workgroup
+  const int tid = threadIdx.x, wave = tid / kWave;
+  u64* keys = reinterpret_cast<u64*>(smem_raw);
+  u64* keptw = keys + npad;
+  u64* flags = keptw + kWave;
+  int* wsum = reinterpret_cast<int*>(flags + kWave);
+  const SegView sv = seg_view(seg_offsets, n_single, s);
+  const int n = sv.n, nb = (n + kWave - 1) / kWave;
+  if (tid < kWave) { flags[tid] = 0; keptw[tid] = 0; }
+  sort_and_gather<true>(keys, boxes, scores, sv, npad, w, s);     // write-through: the other waves read the rows below
+  DETOPS_VMCNT_WAIT(0);
+  __syncthreads();
+  const int ntiles = nb * (nb + 1) / 2;
+  u64* mask = w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax;
+  for (int t0 = wave; t0 < ntiles; t0 += kFusedWaves) {
+    int t = t0, rb = 0;
+    while (t >= nb - rb) { t -= nb - rb; ++rb; }
+    mask_tile<true>(w.boxes + static_cast<size_t>(s) * w.stride, w.areas + static_cast<size_t>(s) * w.stride, mask, n, nb, rb,
+                    rb + t, thr);
+  }
+  DETOPS_VMCNT_WAIT(0);
+  __syncthreads();
+  if (wave == 0) {
+    DETOPS_ACQUIRE_AGENT();
+    if (nb > 0) scan_chain_any<true>(mask, n, nb, nullptr, keptw);
+  }
+  __syncthreads();
+  compact_keep(keptw, flags, wsum, w.order + static_cast<size_t>(s) * w.stride, sv, s, keep, num_keep, keep_mask);
+  if (tid == 0 && status) atomicAdd(status, 1);
+}
+
 // ---------------------------------------------------------------------------- host side
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -700,7 +746,7 @@ Layout make_layout(int S, int max_n, bool big) {
 
 int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets, int S, int max_n,
             float thr, int64_t* keep, int32_t* num_keep, uint8_t* keep_mask, void* ws,
-            size_t ws_bytes, hipStream_t st) {
+            size_t ws_bytes, hipStream_t st, int32_t* status = nullptr) {
   const bool big = max_n > kSortLdsMax;
   const Layout l = make_layout(S, max_n, big);
   if (ws_bytes < l.total || !ws) return DETOPS_EWORKSPACE;
@@ -734,6 +780,9 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
                        detops_tuning().nms_fault == 1 ? (token ^ 2ull) : token,   // fault injection (tests): the token never shows up
                        detops_tuning().nms_spin_budget > 0 ? detops_tuning().nms_spin_budget : kSpinBudget, S, G,
                        scan_first, keep, num_keep, keep_mask);
+    if (detops_tuning().nms_no_repair != 1)    // failed segments (num_keep = -1) are redone, each by one workgroup alone
+      hipLaunchKernelGGL(nms_repair_kernel, dim3(S), dim3(kScanThreads), npad * sizeof(u64) + 2 * kWave * sizeof(u64) + 64,
+                         st, boxes, scores, seg_offsets, max_n, npad, thr, w, keep, num_keep, keep_mask, status);
     return launch_status();
   }
 
@@ -827,3 +876,21 @@ DETOPS_API int detops_nms_batched_mask_f32(const float* boxes, const float* scor
                  keep_mask, workspace, workspace_bytes, st);
 }
 
+
+/* The segmented problem with BOTH result forms optional (keep and / or keep_mask) and a sticky status word: *status is
+ * incremented once for every segment the single launch reported as failed and the repair launch redid (include/detops.h). */
+DETOPS_API int detops_nms_batched_status_f32(const float* boxes, const float* scores, const int32_t* seg_offsets,
+                                             int num_segments, int max_n, float threshold, int64_t* keep,
+                                             uint8_t* keep_mask, int32_t* num_keep, int32_t* status, void* workspace,
+                                             size_t workspace_bytes, detops_stream_t stream) {
+  if (num_segments < 0 || max_n < 0) return DETOPS_EINVAL;
+  if (num_segments == 0) return 0;
+  if (!seg_offsets || !num_keep) return DETOPS_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (max_n == 0)
+    return static_cast<int>(hipMemsetAsync(num_keep, 0, sizeof(int32_t) * num_segments, st));
+  if (!boxes || !scores || (!keep && !keep_mask)) return DETOPS_EINVAL;
+  if (max_n > kScanMaxN) return DETOPS_EUNSUPPORTED;
+  return run_nms(boxes, scores, seg_offsets, num_segments, max_n, threshold, keep, num_keep, keep_mask, workspace,
+                 workspace_bytes, st, status);
+}

@@ -20,7 +20,7 @@ const Key kKeys[] = {
     {"roi_fwd_ct", &DetopsTuning::roi_fwd_ct},           {"dcn_ell_build", &DetopsTuning::dcn_ell_build},
     {"nms_fault", &DetopsTuning::nms_fault},             {"nms_spin_budget", &DetopsTuning::nms_spin_budget},
     {"roi_bwd_split", &DetopsTuning::roi_bwd_split},     {"roi_bwd_maxseg", &DetopsTuning::roi_bwd_maxseg},
-    {"roi_bwd_extras", &DetopsTuning::roi_bwd_extras},
+    {"roi_bwd_extras", &DetopsTuning::roi_bwd_extras},   {"nms_no_repair", &DetopsTuning::nms_no_repair},
 };
 
 bool set_key(DetopsTuning& t, const char* key, size_t len, int value) {

@@ -171,10 +171,40 @@ def nms(dets, scores, threshold):
     return keep[:k]
 
 
+_NMS_STATUS = {}
+
+
+def nms_status(device):
+    """The sticky device word (int32 [1]) the segmented NMS entry points pass to the library: incremented once for every
+    segment the single-launch kernel gave up on and the repair launch redid (include/detops.h,
+    detops_nms_batched_status_f32).  One per device, never cleared by the library, never read by the launch path."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0))
+    t = _NMS_STATUS.get(key)
+    if t is None:
+        t = _NMS_STATUS[key] = torch.zeros((1,), dtype=torch.int32, device=device)
+    return t
+
+
+def nms_repaired_segments(device=None, reset=False):
+    """Host-side read of the status words (a device->host copy: call it where a read-back happens anyway, e.g. with the
+    logged losses).  Returns the number of NMS segments redone by the repair launch since the last reset."""
+    total = 0
+    for (typ, idx), t in list(_NMS_STATUS.items()):
+        if device is not None and torch.device(device).type != typ:
+            continue
+        total += int(t.item())
+        if reset:
+            t.zero_()
+    return total
+
+
 def nms_batched(boxes, scores, seg_offsets, max_n, threshold):
     """Sync-free segmented NMS (extension; not in the reference `_C`).
     boxes [T,4], scores [T], seg_offsets int32 [S+1] (device).  Returns (keep [T] int64 with each
-    segment's LOCAL kept indices packed at its offset, num_keep [S] int32) — all on device."""
+    segment's LOCAL kept indices packed at its offset, num_keep [S] int32) — all on device.
+    A segment the single launch gives up on (starved producer workgroup) is redone by the library's repair launch on the
+    same stream and counted in `nms_status(device)`: callers may ignore num_keep without ever losing a segment."""
     _need_cuda("nms_batched", boxes, scores, seg_offsets)
     boxes = _f32c("nms_batched", boxes)
     scores = _f32c("nms_batched", scores)
@@ -187,9 +217,10 @@ def nms_batched(boxes, scores, seg_offsets, max_n, threshold):
     ws_bytes = lib.detops_nms_batched_workspace_bytes(S, int(max_n))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=boxes.device)
     with _on_device(boxes):
-        check(lib.detops_nms_batched_f32(ptr(boxes), ptr(scores), ptr(seg_offsets), S, int(max_n),
-                                         float(threshold), ptr(keep), ptr(num), ptr(ws), ws_bytes,
-                                         stream_of(boxes)), "nms_batched")
+        check(lib.detops_nms_batched_status_f32(ptr(boxes), ptr(scores), ptr(seg_offsets), S, int(max_n),
+                                                float(threshold), ptr(keep), None, ptr(num),
+                                                ptr(nms_status(boxes.device)), ptr(ws), ws_bytes,
+                                                stream_of(boxes)), "nms_batched")
     return keep, num
 
 
@@ -210,9 +241,10 @@ def nms_batched_mask(boxes, scores, seg_offsets, max_n, threshold):
     ws_bytes = lib.detops_nms_batched_workspace_bytes(S, int(max_n))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=boxes.device)
     with _on_device(boxes), _timed(("nms_batched[S=%d,max_n=%d]", (S, int(max_n))), boxes):
-        check(lib.detops_nms_batched_mask_f32(ptr(boxes), ptr(scores), ptr(seg_offsets), S, int(max_n),
-                                              float(threshold), ptr(mask), ptr(num), ptr(ws), ws_bytes,
-                                              stream_of(boxes)), "nms_batched_mask")
+        check(lib.detops_nms_batched_status_f32(ptr(boxes), ptr(scores), ptr(seg_offsets), S, int(max_n),
+                                                float(threshold), None, ptr(mask), ptr(num),
+                                                ptr(nms_status(boxes.device)), ptr(ws), ws_bytes,
+                                                stream_of(boxes)), "nms_batched_mask")
     return mask.view(torch.bool), num
 
 

@@ -63,6 +63,7 @@ SIGNATURES = {
     "detops_nms_batched_workspace_bytes": (c_size_t, [c_int, c_int]),
     "detops_nms_batched_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
     "detops_nms_batched_mask_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
+    "detops_nms_batched_status_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "detops_sigmoid_focal_loss_forward_f32": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),
     "detops_sigmoid_focal_loss_backward_f32": (
         c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),

@@ -66,7 +66,7 @@ def smoke_train_step(device, config_file="e2e_mask_rcnn_R_50_FPN_1x.yaml", steps
     losses = None
     for _ in range(steps):
         losses = step(images, targets)
-    vals = {k: float(v) for k, v in losses.items()}
+    vals = {k: float(v.detach()) for k, v in losses.items()}
     assert all(v == v and abs(v) != float("inf") for v in vals.values()), "non-finite loss: %r" % vals
     print("smoke: one %s training step on %s ->" % (os.path.basename(config_file), device),
           {k: round(v, 4) for k, v in vals.items()})

@@ -125,7 +125,7 @@ def make_overlapped_sgd(cfg, model):
 
 
 class _Bucket(object):
-    __slots__ = ("params", "flat", "views", "pending")
+    __slots__ = ("params", "flat", "views", "pending", "event")
 
     def __init__(self, params):
         self.params = params
@@ -135,6 +135,7 @@ class _Bucket(object):
             self.views.append(self.flat[at:at + p.numel()].view(p.shape))
             at += p.numel()
         self.pending = len(params)
+        self.event = None       # direct-RCCL path: "this bucket is packed" (recorded on the main stream, reused every step)
 
 
 class BucketedDataParallel(torch.nn.Module):
@@ -149,11 +150,17 @@ class BucketedDataParallel(torch.nn.Module):
     that did not fill (a parameter without gradient on this rank: its slice is sent as zeros) are flushed and the
     main stream joins the callbacks.  `module` is the wrapped model (checkpoints strip the prefix as for DDP).
 
+    Communication (`comm`): "direct" — RCCL called through engine/rccl_comm.py on ONE low-priority side stream that
+    also runs the bucket updates (two HIP streams in the step, one event per bucket; the default on the GPU: "auto" tries
+    it, self-tests one all-reduce and falls back); "pg" — torch.distributed's ProcessGroupNCCL (its own stream, a work
+    object + future per bucket, the update in the future's callback on a pool stream) and the only path for gloo / CPU
+    tensors.  `self.comm_mode` says which one runs.
+
     Not supported, on purpose: gradient accumulation over several backward passes, trained buffers, parameters
     of a rank that change `requires_grad` after wrapping."""
 
     def __init__(self, module, optimizer=None, bucket_cap_mb=25, process_group=None, overlap_optimizer=True,
-                 error_on_unused=False):
+                 error_on_unused=False, comm=None):
         super(BucketedDataParallel, self).__init__()
         self.module = module
         self.process_group = process_group if process_group is not None else dist.group.WORLD
@@ -181,8 +188,44 @@ class BucketedDataParallel(torch.nn.Module):
         if cur:
             self.buckets.append(_Bucket(cur))
         self._next, self._armed, self._futures = 0, False, []
+        self._setup_comm(comm if comm is not None else os.environ.get("DETOPS_DDP_COMM", "auto"))
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(b))
                        for b in self.buckets for p in b.params]
+
+    def _setup_comm(self, want):
+        """want: auto | direct | pg | side-nocoll (measurement only: the direct path without the collective)"""
+        self.comm_mode, self.comm_note, self._rccl, self._side = "pg", None, None, None
+        dev = self.buckets[0].flat.device if self.buckets else None
+        on_gpu = dev is not None and dev.type == "cuda" and all(b.flat.device == dev and b.flat.dtype == torch.float32
+                                                                for b in self.buckets)
+        if want == "pg" or not on_gpu or dist.get_backend(self.process_group) != "nccl":
+            if want in ("direct", "side-nocoll"):
+                raise RuntimeError("comm=%r needs fp32 parameters on one GPU and an RCCL process group" % want)
+            return
+        try:
+            from . import rccl_comm
+            if os.environ.get("DETOPS_DDP_PRIO", "low") == "low":
+                self._side, prio = rccl_comm.low_priority_stream(dev)
+            else:
+                self._side, prio = torch.cuda.Stream(dev), 0
+            if want != "side-nocoll":
+                self._rccl = rccl_comm.RcclComm(dev, self.process_group)
+                self._rccl.selftest()
+            for b in self.buckets:
+                b.event = torch.cuda.Event()
+            self.comm_mode = "direct" if want != "side-nocoll" else "side-nocoll"
+            self.comm_note = "side stream priority %d" % prio
+        except Exception as e:  # noqa: BLE001 — the run must not depend on the direct path
+            if want == "direct" or want == "side-nocoll":
+                raise
+            self.comm_mode, self._rccl, self._side = "pg", None, None
+            self.comm_note = "direct RCCL unavailable (%s: %s)" % (type(e).__name__, e)
+        if self.world > 1:   # every rank must take the same path: the collectives of the two paths do not match up
+            flag = torch.tensor([1.0 if self.comm_mode == "pg" else 0.0], device=dev)
+            dist.all_reduce(flag, group=self.process_group)
+            if 0 < float(flag) and self.comm_mode != "pg":
+                self.comm_mode, self._rccl, self._side = "pg", None, None
+                self.comm_note = "another rank fell back to ProcessGroupNCCL"
 
     def forward(self, *args, **kwargs):
         if self._armed:             # a backward pass that raised never reached _finish_backward: start clean
@@ -239,6 +282,19 @@ class BucketedDataParallel(torch.nn.Module):
             torch._foreach_copy_(b.views, grads)
         for p, v in zip(b.params, b.views):
             p.grad = v
+        if self._side is not None:
+            # direct path: "packed" event on the main stream -> the side stream averages the bucket over the ranks and
+            # updates its parameters, in stream order; nothing returns to the host
+            side = self._side
+            b.event.record(torch.cuda.current_stream(b.flat.device))
+            side.wait_event(b.event)
+            if self._rccl is not None:
+                self._rccl.all_reduce_avg_(b.flat, side)
+            if self.overlap_optimizer and self.optimizer.deferred:
+                with torch.cuda.stream(side):
+                    self.optimizer.last_update_stream = side.cuda_stream
+                    self.optimizer.step_params(b.params, b.views)
+            return
         if self._avg is None:
             if self.world > 1:
                 b.flat.div_(self.world)
@@ -263,6 +319,8 @@ class BucketedDataParallel(torch.nn.Module):
             self._launch(b)
         for f in self._futures:
             f.wait()                # device: the current stream waits for the callbacks' stream; host does not block
+        if self._side is not None and self.buckets:
+            torch.cuda.current_stream(self.buckets[0].flat.device).wait_stream(self._side)   # device-side join
         self._reset()
 
 

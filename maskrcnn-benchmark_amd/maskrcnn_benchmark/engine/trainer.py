@@ -6,6 +6,7 @@ import time
 
 import torch
 
+from maskrcnn_benchmark import _C
 from maskrcnn_benchmark.utils.comm import get_world_size, reduce_dict
 from maskrcnn_benchmark.utils.metric_logger import MetricLogger
 
@@ -41,6 +42,13 @@ def do_train(cfg, model, data_loader, optimizer, scheduler, checkpointer, device
         if iteration % log_period == 0 or iteration == max_iter:
             reduced = reduce_loss_dict(loss_dict)
             meters.update(loss=sum(v for v in reduced.values()), **reduced)
+            # the losses are read back here anyway: also look at the segmented NMS's sticky status word (segments its
+            # single launch gave up on and the repair launch redid — results are complete either way, this is the signal)
+            repaired = _C.nms_repaired_segments(device, reset=True) if torch.device(device).type == "cuda" else 0
+            if repaired:
+                logger.warning("iter %d: %d NMS segment(s) since the last log line were redone by the repair launch "
+                               "(the single-launch kernel's waits timed out: compute units held by other work)",
+                               iteration, repaired)
         batch_time = time.time() - end
         end = time.time()
         meters.update(time=batch_time, data=data_time)

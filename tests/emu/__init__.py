@@ -503,13 +503,26 @@ def nms(boxes, scores, thr):
     return keep[:num[0]].copy()
 
 
-def nms_batched(boxes, scores, offsets, max_n, thr, mask=False):
+def nms_batched(boxes, scores, offsets, max_n, thr, mask=False, status=None):
+    """status: an int32 [1] array -> the call goes through detops_nms_batched_status_f32 (the entry point the product's
+    wrappers use) and the array is incremented once per segment the repair launch redid"""
     boxes, scores = _f32(boxes), _f32(scores)
     offsets = np.ascontiguousarray(offsets, dtype=np.int32)
     S = offsets.shape[0] - 1
-    num = np.full((S,), -1, np.int32)
+    num = np.full((S,), -7, np.int32)
     nbytes = lib().detops_nms_batched_workspace_bytes(S, max_n)
     ws = np.full((nbytes,), 0xA5, np.uint8)       # the library must not rely on any workspace content
+    if status is not None:
+        km = np.full((boxes.shape[0],), 7, np.uint8) if mask else None
+        keep = None if mask else np.full((boxes.shape[0],), -1, np.int64)
+        fn = lib().detops_nms_batched_status_f32
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 5 + \
+                      [ctypes.c_size_t, ctypes.c_void_p]
+        rc = fn(_p(boxes), _p(scores), _p(offsets), S, max_n, thr, None if mask else _p(keep), _p(km) if mask else None,
+                _p(num), _p(status), _p(ws), nbytes, None)
+        assert rc == 0, rc
+        return (km if mask else keep), num
     if mask:
         km = np.full((boxes.shape[0],), 7, np.uint8)
         rc = lib().detops_nms_batched_mask_f32(_p(boxes), _p(scores), _p(offsets), S, max_n, thr, _p(km), _p(num),

@@ -273,6 +273,45 @@ def test_emu_nms_single_launch_and_three_launch_paths(fused):
         assert np.array_equal(emu.nms(b, sc, 0.6), oracle.nms(b, sc, 0.6))
 
 
+def test_emu_nms_failed_segments_are_redone_by_the_repair_launch():
+    """VERDICT r04 "missing" #4: the single launch's failure marker must not turn into "this segment proposes nothing".
+    Fault injection (the sort workgroups publish a wrong token, test-sized polling budget -> every consumer wait gives
+    up): with the repair launch (the default) every segment comes out exactly as without the fault and the sticky status
+    word counts them; with it switched off the marker (num_keep = -1, all-zero mask) is what the caller sees."""
+    sizes = (300, 0, 65, 1000, 1, 2049)
+    segs = [synth.nms_boxes(n, seed=70 + i) if n else (np.zeros((0, 4), np.float32), np.zeros(0, np.float32))
+            for i, n in enumerate(sizes)]
+    segs[3] = _nms_chain(1000, 25)
+    boxes = np.concatenate([x for x, _ in segs])
+    scores = np.concatenate([y for _, y in segs])
+    offs = np.cumsum([0] + [len(y) for _, y in segs]).astype(np.int32)
+    status = np.zeros(1, np.int32)
+    good_keep, good_num = emu.nms_batched(boxes, scores, offs, 2049, 0.7, status=status)
+    good_mask, _ = emu.nms_batched(boxes, scores, offs, 2049, 0.7, mask=True, status=status)
+    assert status[0] == 0
+    try:
+        emu.tuning_set("nms_fault", 1)
+        emu.tuning_set("nms_spin_budget", 200)
+        keep, num = emu.nms_batched(boxes, scores, offs, 2049, 0.7, status=status)
+        assert status[0] == len(sizes)
+        km, num2 = emu.nms_batched(boxes, scores, offs, 2049, 0.7, mask=True, status=status)
+        assert status[0] == 2 * len(sizes)
+        assert np.array_equal(num, good_num) and np.array_equal(num2, good_num)
+        assert np.array_equal(km, good_mask)
+        for i, (x, y) in enumerate(segs):
+            ref = oracle.nms(x, y, 0.7) if len(y) else np.zeros(0, np.int64)
+            assert num[i] == len(ref)
+            assert np.array_equal(keep[offs[i]:offs[i] + num[i]], ref)
+        km0, num0 = emu.nms_batched(boxes, scores, offs, 2049, 0.7, mask=True)          # old entry point, NULL status
+        assert np.array_equal(km0, good_mask) and np.array_equal(num0, good_num)
+        emu.tuning_set("nms_no_repair", 1)
+        km, num = emu.nms_batched(boxes, scores, offs, 2049, 0.7, mask=True, status=status)
+        assert (num == -1).all() and not km.any() and status[0] == 2 * len(sizes)
+    finally:
+        for k in ("nms_fault", "nms_spin_budget", "nms_no_repair"):
+            emu.tuning_set(k, 0)
+
+
 def test_emu_nms_threshold_boundary_is_exact():
     """Pairs whose IoU is EXACTLY the threshold, one ulp above and one ulp below it, and degenerate unions (negative
     "areas", huge coordinates) must come out as the reference's `inter / union >= thr` (nms_cpu.cpp:59-60) does: the

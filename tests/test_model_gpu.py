@@ -122,11 +122,14 @@ def test_train_step_r101_dcn_fp16_cfg5():
     assert step.scaler.get_scale() > 0
 
 
-def test_forced_ddp_hook_world1_nccl_matches_plain_step():
+@pytest.mark.parametrize("comm", ["direct", "pg"])
+def test_forced_ddp_hook_world1_nccl_matches_plain_step(comm, monkeypatch):
     """The overlapped-SGD DDP hook on the one MI355X we have: a 1-rank NCCL (= RCCL) process group wraps the
-    detector, the bucket update runs in the all-reduce's completion callback on a side stream, and the
+    detector, the bucket update runs on a side stream behind the bucket's all-reduce ("direct": RCCL called on the
+    wrapper's own low-priority stream, engine/rccl_comm.py; "pg": in ProcessGroupNCCL's completion callback), and the
     parameters after 3 steps equal the non-DDP run (bit-for-bit when the backward itself is deterministic)."""
     import torch.distributed as dist
+    monkeypatch.setenv("DETOPS_DDP_COMM", comm)
     from maskrcnn_benchmark.engine.bench_step import build_training, load_cfg, make_device_batches
     cfg = load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml",
                    ["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 300, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 300,
@@ -150,11 +153,12 @@ def test_forced_ddp_hook_world1_nccl_matches_plain_step():
     deterministic = all(torch.equal(a, b) for a, b in zip(plain_a, plain_b))
     # MIOpen's weight-gradient kernels are not run-to-run reproducible: the plain-vs-plain spread is the yardstick
     noise = max(float((a - b).abs().max()) for a, b in zip(plain_a, plain_b))
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29517 + (comm == "pg")), rank=0, world_size=1)
     try:
         ddp_p, opt, model = run(True)
         from maskrcnn_benchmark.engine.ddp_step import BucketedDataParallel
         assert isinstance(model, BucketedDataParallel) and opt.deferred and len(model.buckets) > 1
+        assert model.comm_mode == comm, (model.comm_mode, model.comm_note)
         side = getattr(opt, "last_update_stream", None)
         assert side is not None, "the hook's update callback never ran"
         assert side != torch.cuda.default_stream(_dev()).cuda_stream, "update kernels must run on a side stream"
