@@ -40,6 +40,10 @@ constexpr int kSpinBudget = 1 << 22;   // polls before a wait on another workgro
 // before this point (hipcc's scheduler otherwise serialises LDS reads one `s_waitcnt lgkmcnt(0)` at a time to
 // save registers).  No instruction is emitted.
 #define DETOPS_PIN4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define DETOPS_PIN6(a, b, c, d, e, f) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
+// the same for three values, one of which only SOME paths below use: the compiler can neither sink that load under the
+// branch nor wait for the three one by one — the requests go out together, one round trip
+#define DETOPS_KEEP_TOGETHER3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 
 // Ordering point for LDS data handed from some lanes of a wave to other lanes of the SAME wave (no other wave
 // touches the region): the hardware executes a wave's LDS operations in order, so only the compiler must be kept

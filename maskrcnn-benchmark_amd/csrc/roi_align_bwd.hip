@@ -498,25 +498,29 @@ roi_align_bwd_ring_kernel(Levels L, RingPlan P, RingWs ws, const float* __restri
         else DETOPS_VMCNT_WAIT(0);
         DETOPS_LDS_BARRIER();                                        // every wave's pieces of hit j; walk j - 1 is over everywhere
         if (j + NR - 1 < nr) issue(j + NR - 1, islot);
-        const int eyp = __builtin_amdgcn_readfirstlane(s_ent[j].z);  // fy0 | ny << 16
         const float* sb = ring + slot * G::SLOT_FLOATS;
         slot = (slot + 1 == NR) ? 0 : slot + 1;
         islot = (islot + 1 == NR) ? 0 : islot + 1;
         if (P.debug & 1) continue;
-        // ---- walk hit j
+        // ---- walk hit j.  The entry word and this pixel's two row heads are requested TOGETHER, before the first
+        // test looks at any of them (one LDS round trip in front of the walk instead of three dependent ones; the
+        // kernel is bound by these chains, not by issue slots: SQ_WAIT_ANY 0.5 at 16 waves per CU)
+        const float* ayp = sb + (G::GP + G::AXP) * 4 + yl * G::PPH;    // this pixel's AY row / AX row (compact)
+        const float* axp = sb + G::GP * 4 + xl * G::PPW;
+        int eyp_v = s_ent[j].z;                                        // fy0 | ny << 16
+        float4 hy = *reinterpret_cast<const float4*>(ayp);
+        float4 hx = *reinterpret_cast<const float4*>(axp);
+        DETOPS_KEEP_TOGETHER3(eyp_v, hy.x, hx.x);
+        const int eyp = __builtin_amdgcn_readfirstlane(eyp_v);
         const int efy0 = eyp & 0xffff, eny = eyp >> 16;
         if (efy0 + eny - 1 < wy0 || efy0 > wy0 + 1) continue;          // this ROI misses the wave's two rows
         if (lane == 0) DETOPS_STAT("bwdr.wave_hits", 1);
-        const float* ayp = sb + (G::GP + G::AXP) * 4 + yl * G::PPH;    // this pixel's AY row / AX row (compact)
-        const float* axp = sb + G::GP * 4 + xl * G::PPW;
-        const float4 hy = *reinterpret_cast<const float4*>(ayp);
-        const float4 hx = *reinterpret_cast<const float4*>(axp);
         const int hyb = __float_as_int(hy.x), hxb = __float_as_int(hx.x);   // first bin | other axis' longest range << 8 | count << 16
       const int ny = hyb >> 16, xlo = hxb & 0xff, nx = hxb >> 16;
       const int r1 = lane >> 5, l5 = lane & 31;
       const int q = l5 % G::NP, cl = l5 / G::NP;
-      const float* ay1 = sb + (G::GP + G::AXP) * 4 + (2 * wave + r1) * G::PPH;
-      const float4 hy1 = *reinterpret_cast<const float4*>(ay1);
+      const float* ay1 = ayp;                                          // (2 * wave + r1 == yl: the same row)
+      const float4 hy1 = hy;
       const int ylo1 = __float_as_int(hy1.x) & 0xff;
       float* tw = strip + wave * (2 * G::PWP * G::TS);
       const float* tr = tw + (lane >> 5) * G::PWP * G::TS;
@@ -529,24 +533,26 @@ roi_align_bwd_ring_kernel(Levels L, RingPlan P, RingWs ws, const float* __restri
         // ---- common case: <= 3 bins per axis — straight-line, weights from the staged heads
         const int na = na_, nb = nb_;
         DETOPS_WAVE_SYNC();                                          // the previous hit's pass-2 reads of the strip are done
+          // pass 1, branch-free: all three bin rows of every round are requested before the first product is formed
+          // (weights beyond the row's own range are stored as zeros, indices clamped into the staged block): one LDS
+          // round trip for the pass instead of one per (round, row) behind scalar branches
+          (void)na;
+          float4 g4[G::ROUNDS][3];
+  #pragma unroll
+          for (int k = 0; k < G::ROUNDS; ++k) {
+            const int c = min(k * G::CPR + cl, CT - 1);
+            const float* gc = sb + (c * PH * G::NP + q) * 4;
+  #pragma unroll
+            for (int a = 0; a < 3; ++a) g4[k][a] = *reinterpret_cast<const float4*>(gc + min(ylo1 + a, PH - 1) * (G::NP * 4));
+          }
+          if (G::ROUNDS == 2) DETOPS_PIN6(g4[0][0].x, g4[0][1].x, g4[0][2].x, g4[G::ROUNDS - 1][0].x, g4[G::ROUNDS - 1][1].x, g4[G::ROUNDS - 1][2].x);
   #pragma unroll
           for (int k = 0; k < G::ROUNDS; ++k) {
             const int c = k * G::CPR + cl;
+            f2v t0 = pk_fma(hy1.y, g4[k][0].x, g4[k][0].y, f2v{0.f, 0.f}), t1 = pk_fma(hy1.y, g4[k][0].z, g4[k][0].w, f2v{0.f, 0.f});
+            t0 = pk_fma(hy1.z, g4[k][1].x, g4[k][1].y, t0); t1 = pk_fma(hy1.z, g4[k][1].z, g4[k][1].w, t1);
+            t0 = pk_fma(hy1.w, g4[k][2].x, g4[k][2].y, t0); t1 = pk_fma(hy1.w, g4[k][2].z, g4[k][2].w, t1);
             if (c < CT) {
-              const float* gc = sb + (c * PH * G::NP + q) * 4;
-              f2v t0 = f2v{0.f, 0.f}, t1 = f2v{0.f, 0.f};
-              {
-                const float4 g4 = *reinterpret_cast<const float4*>(gc + min(ylo1, PH - 1) * (G::NP * 4));
-                t0 = pk_fma(hy1.y, g4.x, g4.y, t0); t1 = pk_fma(hy1.y, g4.z, g4.w, t1);
-              }
-              if (na >= 2) {
-                const float4 g4 = *reinterpret_cast<const float4*>(gc + min(ylo1 + 1, PH - 1) * (G::NP * 4));
-                t0 = pk_fma(hy1.z, g4.x, g4.y, t0); t1 = pk_fma(hy1.z, g4.z, g4.w, t1);
-              }
-              if (na >= 3) {
-                const float4 g4 = *reinterpret_cast<const float4*>(gc + min(ylo1 + 2, PH - 1) * (G::NP * 4));
-                t0 = pk_fma(hy1.w, g4.x, g4.y, t0); t1 = pk_fma(hy1.w, g4.z, g4.w, t1);
-              }
               float* td = tw + (r1 * G::PWP + min(4 * q, PW - 4)) * G::TS + c;   // bin columns off(q) .. off(q) + 3
               td[0] = t0.x; td[G::TS] = t0.y; td[2 * G::TS] = t1.x; td[3 * G::TS] = t1.y;
             }

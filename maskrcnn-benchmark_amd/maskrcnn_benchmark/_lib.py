@@ -10,7 +10,9 @@ import os
 import torch  # noqa: F401  — loads the HIP runtime (libamdhip64) this library links against
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdetops_gfx950.so")
+# DETOPS_LIB_PATH: another build of the SAME library (same ABI version, checked below) — same-box A/B measurements of a
+# kernel change (tools/gpu/ab_build.sh puts the previous commit's build next to the current one)
+LIB_PATH = os.environ.get("DETOPS_LIB_PATH") or os.path.join(_HERE, "lib", "libdetops_gfx950.so")
 
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 

@@ -171,7 +171,8 @@ class BucketedDataParallel(torch.nn.Module):
         # whose grad is None, which a rank cannot know about the other ranks without a read-back).  error_on_unused=True
         # raises instead, like torch DDP without find_unused_parameters.
         self.error_on_unused = bool(error_on_unused)
-        self.overlap_optimizer = bool(overlap_optimizer) and self.optimizer is not None
+        self.overlap_optimizer = (bool(overlap_optimizer) and self.optimizer is not None
+                                  and os.environ.get("DETOPS_DDP_OVERLAP", "1") != "0")
         if self.optimizer is not None:
             self.optimizer.deferred = self.overlap_optimizer
         # RCCL averages inside the collective; gloo (CPU tests) has no AVG: pre-divide there
@@ -204,8 +205,13 @@ class BucketedDataParallel(torch.nn.Module):
             return
         try:
             from . import rccl_comm
-            if os.environ.get("DETOPS_DDP_PRIO", "low") == "low":
+            prio_want = os.environ.get("DETOPS_DDP_PRIO", "normal")
+            if prio_want == "low":
                 self._side, prio = rccl_comm.low_priority_stream(dev)
+            elif prio_want == "high":
+                self._side, prio = torch.cuda.Stream(dev, priority=-1), -1
+            elif prio_want == "main":     # measurement only: no second stream at all
+                self._side, prio = torch.cuda.current_stream(dev), 0
             else:
                 self._side, prio = torch.cuda.Stream(dev), 0
             if want != "side-nocoll":

@@ -14,6 +14,8 @@
 #define DETOPS_PIN4(a, b, c, d) ((void)0)
 
 #define DETOPS_WAVE_SYNC() ((void)__ballot(1))
+#define DETOPS_KEEP_TOGETHER3(a, b, c) ((void)0)
+#define DETOPS_PIN6(a, b, c, d, e, f) ((void)0)
 
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
   float* d = lds_wave_base + 4 * (threadIdx.x & 63);

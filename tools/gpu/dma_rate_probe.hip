@@ -2,6 +2,7 @@
 // what does the access pattern cost?  Each wave issues N instructions (1 KiB each) back to back, then waits vmcnt(0).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 __device__ __forceinline__ void dma16(const float* sbase, unsigned voff, unsigned lds_addr) {
   unsigned keep;
@@ -11,6 +12,33 @@ __device__ __forceinline__ void dma16(const float* sbase, unsigned voff, unsigne
 // pattern 0: lane-contiguous 1 KiB; 1: 13 row pieces of 80 bytes at a 268800-byte stride (channel planes), unaligned start (the
 // forward kernel's shape); 2: the same pieces starting on 128-byte boundaries (one line each); 3: pattern 1 re-reading the SAME
 // addresses every instruction (L1 hits after the first); 4: 64 separate 16-byte pieces in 64 different lines
+// patterns 5 / 6 (round 5): the ring BACKWARD's gradient staging.  A hit's operand is grad_out[roi, c0 : c0 + 32, 7, 7]: ONE
+// contiguous, 16-byte aligned block of 6272 bytes.  5 = how the ring kernel reads it today: 448 pieces (channel, bin row,
+// piece q) at byte (c * 49 + r * 7 + (q ? 3 : 0)) * 4 — 4-byte aligned, overlapping pairs, so that a bin row sits in two
+// aligned 16-byte LDS slots; 6 = the same block as a LINEAR copy of 392 aligned pieces.  ROI blocks are drawn from a
+// 51 MB tensor (1024 ROIs x 256 channels), instruction i of a wave = 64 consecutive pieces of block (i / 7).
+template <int PATTERN>
+__global__ void __launch_bounds__(64) probe_bwd(const float* src, long long* ticks, int n, int span_kb, float* sink) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  typedef __attribute__((address_space(3))) float* lds_fptr_t;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_fptr_t)lds)));
+  const long long t0 = wall_clock64();
+  for (int i = 0; i < n; ++i) {
+    const unsigned roi = (blockIdx.x * 2654435761u + (i / 7) * 40503u) % 1024u;
+    const float* base = src + (static_cast<size_t>(roi) * 8 + (blockIdx.x & 7)) * 1568;      // 6272-byte block
+    const int p = (i % 7) * 64 + lane;
+    unsigned voff;
+    if (PATTERN == 5) { const int c = p / 14, rem = p % 14, r = rem / 2, q = rem % 2; voff = (c * 49 + r * 7 + (q ? 3 : 0)) * 4; }
+    else voff = min(p, 391) * 16;
+    dma16(base, voff, lds0 + (i % span_kb) * 1024);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const long long t1 = wall_clock64();
+  if (lane == 0) ticks[blockIdx.x] = t1 - t0;
+  if (sink) sink[blockIdx.x * 64 + lane] = lds[lane];
+}
+
 template <int PATTERN>
 __global__ void __launch_bounds__(64) probe(const float* src, long long* ticks, int n, int span_kb, float* sink) {
   extern __shared__ float lds[];
@@ -36,10 +64,11 @@ __global__ void __launch_bounds__(64) probe(const float* src, long long* ticks, 
 int main() {
   const size_t bytes = 1ull << 30;
   float* src; hipMalloc(&src, bytes); hipMemset(src, 0, bytes);
-  long long* ticks; hipMalloc(&ticks, 8 * 4096);
-  std::vector<long long> h(4096);
-  for (int pattern = 0; pattern < 5; ++pattern)
-    for (int waves_per_cu : {1, 4, 8})
+  long long* ticks; hipMalloc(&ticks, 8 * 8192);
+  std::vector<long long> h(8192);
+  const int first = getenv("PROBE_FIRST") ? atoi(getenv("PROBE_FIRST")) : 0;
+  for (int pattern = first; pattern < 7; ++pattern)
+    for (int waves_per_cu : {1, 4, 8, 16})
       for (int n : {32, 128}) {
         const int grid = 256 * waves_per_cu;
         for (int rep = 0; rep < 2; ++rep) {
@@ -47,6 +76,8 @@ int main() {
           else if (pattern == 1) hipLaunchKernelGGL(probe<1>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
           else if (pattern == 2) hipLaunchKernelGGL(probe<2>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
           else if (pattern == 3) hipLaunchKernelGGL(probe<3>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
+          else if (pattern == 5) hipLaunchKernelGGL(probe_bwd<5>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
+          else if (pattern == 6) hipLaunchKernelGGL(probe_bwd<6>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
           else hipLaunchKernelGGL(probe<4>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
           hipDeviceSynchronize();
         }
