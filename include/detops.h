@@ -565,6 +565,25 @@ int detops_deformable_transposed_sample(const void* gT, const void* offset, cons
                               int dil_h, int dil_w, int deformable_group, void* workspace, size_t workspace_bytes,
                               detops_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The data-parallel step's bucket kernels (csrc/optim.hip) — replace, per gradient bucket of engine/ddp_step.py, the
+ * multi-tensor copy into the bucket and torch.optim.SGD's update (reference: tools/train_net.py:45-54 wraps the model in
+ * DistributedDataParallel, engine/trainer.py:93-99 `optimizer.step()`, solver/build.py:7-20 the two hyper-parameter
+ * groups).  A bucket is three flat fp32 arrays of one layout: parameters, gradients, momentum.
+ *   detops_pack_f32: dst[dst_offsets[i] .. + counts[i]) = srcs[i][0 .. counts[i]) for i < n <= detops_pack_max_tensors();
+ *     srcs / counts / dst_offsets are HOST arrays (the pointers travel in the kernel arguments), srcs[i] device pointers.
+ *   detops_sgd_momentum_flat_f32: for every element  g' = g + wd * p;  m = momentum * m + g';  p = p - lr * m
+ *     (torch.optim.SGD with dampening 0, no Nesterov; the momentum array starts as zeros, which makes the first step
+ *     m = g' like torch's), with (lr, wd) = the weights' pair on [0, split) and the biases' pair on [split, n);
+ *     split a multiple of 4, all three arrays 16-byte aligned.
+ * ---------------------------------------------------------------------------------------- */
+int detops_pack_max_tensors(void);
+int detops_pack_f32(const void* const* srcs, const int64_t* counts, const int64_t* dst_offsets, int n, float* dst,
+                    detops_stream_t stream);
+int detops_sgd_momentum_flat_f32(float* params, const float* grads, float* momentum_buf, int64_t n, int64_t split,
+                                 float lr_weights, float wd_weights, float lr_biases, float wd_biases, float momentum,
+                                 detops_stream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -248,6 +248,57 @@ def nms_batched_mask(boxes, scores, seg_offsets, max_n, threshold):
     return mask.view(torch.bool), num
 
 
+# ------------------------------------------------------------------------------------------ data-parallel bucket kernels
+_PACK_MAX = [0]
+
+
+def pack_into(dst, tensors, offsets, stream=None):
+    """dst (flat fp32) [offsets[i] : offsets[i] + tensors[i].numel()] = tensors[i] — the gradients of a bucket in ONE launch
+    per 48 tensors (csrc/optim.hip; reference: DistributedDataParallel's bucket copies, tools/train_net.py:45-54).
+    `stream`: a torch.cuda stream (default: the current one)."""
+    _need_cuda("pack_into", dst, *tensors)
+    if not _PACK_MAX[0]:
+        _PACK_MAX[0] = int(lib.detops_pack_max_tensors())
+    if dst.dtype != torch.float32 or not dst.is_contiguous():
+        raise RuntimeError("pack_into: a contiguous fp32 destination is required")
+    st = stream_of(dst) if stream is None else stream.cuda_stream
+    n_all = len(tensors)
+    with _on_device(dst):
+        for i0 in range(0, n_all, _PACK_MAX[0]):
+            part = list(tensors[i0:i0 + _PACK_MAX[0]])
+            n = len(part)
+            srcs = (ctypes.c_void_p * n)()
+            cnts = (ctypes.c_int64 * n)()
+            offs = (ctypes.c_int64 * n)()
+            for j, t in enumerate(part):
+                if t.dtype != torch.float32 or t.device != dst.device:
+                    raise RuntimeError("pack_into: fp32 tensors on the destination's device are required")
+                if not t.is_contiguous():
+                    t = t.contiguous()
+                    part[j] = t          # keep the copy alive until the launch is enqueued
+                srcs[j], cnts[j], offs[j] = t.data_ptr(), t.numel(), int(offsets[i0 + j])
+                if offs[j] < 0 or offs[j] + cnts[j] > dst.numel():
+                    raise RuntimeError("pack_into: slice %d leaves the destination" % (i0 + j))
+            check(lib.detops_pack_f32(srcs, cnts, offs, n, ptr(dst), st), "pack_f32")
+    return dst
+
+
+def sgd_momentum_flat_(params, grads, momentum_buf, split, lr_weights, wd_weights, lr_biases, wd_biases, momentum, stream=None):
+    """torch.optim.SGD(momentum, dampening 0) over a whole flat bucket in one pass (csrc/optim.hip; reference
+    solver/build.py:7-20 + engine/trainer.py:98 `optimizer.step()`): elements [0, split) take the weights' (lr, wd), the
+    rest the biases'.  In place on `params` and `momentum_buf`."""
+    _need_cuda("sgd_momentum_flat_", params, grads, momentum_buf)
+    for t in (params, grads, momentum_buf):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != params.numel():
+            raise RuntimeError("sgd_momentum_flat_: three contiguous fp32 arrays of one length are required")
+    st = stream_of(params) if stream is None else stream.cuda_stream
+    with _on_device(params):
+        check(lib.detops_sgd_momentum_flat_f32(ptr(params), ptr(grads), ptr(momentum_buf), params.numel(), int(split),
+                                               float(lr_weights), float(wd_weights), float(lr_biases), float(wd_biases),
+                                               float(momentum), st), "sgd_momentum_flat")
+    return params
+
+
 # ------------------------------------------------------------------------------------------ RPN loss
 class _RpnLoss(torch.autograd.Function):
     """Fused RPN loss (extension; reference modeling/rpn/loss.py:92-127): one launch evaluates both losses from the

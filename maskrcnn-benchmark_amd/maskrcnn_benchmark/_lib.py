@@ -57,6 +57,9 @@ SIGNATURES = {
     "detops_mask_loss_workspace_bytes": (c_size_t, [c_int]),
     "detops_mask_loss_f32": (c_int, [_P] * 3 + [c_int] * 3 + [_P] * 3 + [c_size_t, _P]),
     "detops_head_loss_backward_f32": (c_int, [_P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _P]),
+    "detops_pack_max_tensors": (c_int, []),
+    "detops_pack_f32": (c_int, [_P, _P, _P, c_int, _P, _P]),
+    "detops_sgd_momentum_flat_f32": (c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64] + [c_float] * 5 + [_P]),
     "detops_rpn_decode_f32": (c_int, [_P] * 5 + [c_int] * 5 + [c_float] * 6 + [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, _P, _P]),
     "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),
     "detops_roi_pool_backward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),

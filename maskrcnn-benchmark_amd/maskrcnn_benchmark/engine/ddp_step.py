@@ -26,6 +26,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from maskrcnn_benchmark import _C
+
 _FUSED_SGD = hasattr(torch, "_fused_sgd_") and os.environ.get("DETOPS_FUSED_SGD", "1") != "0"
 
 
@@ -125,17 +127,32 @@ def make_overlapped_sgd(cfg, model):
 
 
 class _Bucket(object):
-    __slots__ = ("params", "flat", "views", "pending", "event")
+    """One gradient bucket: `flat` (the all-reduced gradients) with a view per parameter.  Layout: the optimizer's first
+    group (weights) first, then the others (biases), every slot starting on a 64-float (256-byte) boundary — `split` is
+    where the biases begin; padding belongs to nobody and stays zero.  `flat_p` / `flat_m` (native update path only):
+    the parameters themselves and their momentum in the SAME layout, so that the bucket's SGD update is one streaming
+    pass over three flat arrays (csrc/optim.hip)."""
+    __slots__ = ("params", "flat", "views", "pending", "event", "offsets", "split", "flat_p", "flat_m")
 
-    def __init__(self, params):
+    ALIGN = 64
+
+    def __init__(self, params, is_bias=None):
+        if is_bias is not None:
+            params = [p for p in params if not is_bias(p)] + [p for p in params if is_bias(p)]
         self.params = params
-        self.flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
-        self.views, at = [], 0
+        self.offsets, at, self.split = [], 0, None
         for p in params:
-            self.views.append(self.flat[at:at + p.numel()].view(p.shape))
-            at += p.numel()
+            if is_bias is not None and self.split is None and is_bias(p):
+                self.split = at
+            self.offsets.append(at)
+            at += -(-p.numel() // self.ALIGN) * self.ALIGN
+        if self.split is None:
+            self.split = at
+        self.flat = torch.zeros(at, dtype=params[0].dtype, device=params[0].device)
+        self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, params)]
         self.pending = len(params)
         self.event = None       # direct-RCCL path: "this bucket is packed" (recorded on the main stream, reused every step)
+        self.flat_p = self.flat_m = None
 
 
 class BucketedDataParallel(torch.nn.Module):
@@ -180,14 +197,16 @@ class BucketedDataParallel(torch.nn.Module):
         self._sync_module_states()
         cap = max(int(bucket_cap_mb * 1024 * 1024), 1)
         self.buckets, cur, cur_bytes = [], [], 0
+        group_of = self.optimizer._group_of if self.optimizer is not None else {}
+        is_bias = (lambda q: group_of.get(q, 0) != 0) if self.optimizer is not None else None
         for p in reversed([p for p in module.parameters() if p.requires_grad]):
             if cur and (cur_bytes + p.numel() * p.element_size() > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
-                self.buckets.append(_Bucket(cur))
+                self.buckets.append(_Bucket(cur, is_bias))
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += p.numel() * p.element_size()
         if cur:
-            self.buckets.append(_Bucket(cur))
+            self.buckets.append(_Bucket(cur, is_bias))
         self._next, self._armed, self._futures = 0, False, []
         self._setup_comm(comm if comm is not None else os.environ.get("DETOPS_DDP_COMM", "auto"))
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(b))
@@ -196,6 +215,7 @@ class BucketedDataParallel(torch.nn.Module):
     def _setup_comm(self, want):
         """want: auto | direct | pg | side-nocoll (measurement only: the direct path without the collective)"""
         self.comm_mode, self.comm_note, self._rccl, self._side = "pg", None, None, None
+        self._native_update = False
         dev = self.buckets[0].flat.device if self.buckets else None
         on_gpu = dev is not None and dev.type == "cuda" and all(b.flat.device == dev and b.flat.dtype == torch.float32
                                                                 for b in self.buckets)
@@ -226,12 +246,54 @@ class BucketedDataParallel(torch.nn.Module):
                 raise
             self.comm_mode, self._rccl, self._side = "pg", None, None
             self.comm_note = "direct RCCL unavailable (%s: %s)" % (type(e).__name__, e)
+        if self._side is not None and os.environ.get("DETOPS_DDP_NATIVE", "1") != "0":
+            self._make_flat_parameters()
+            if self._native_update:
+                self.comm_note += ", flat buckets: native pack + SGD kernels"
         if self.world > 1:   # every rank must take the same path: the collectives of the two paths do not match up
             flag = torch.tensor([1.0 if self.comm_mode == "pg" else 0.0], device=dev)
             dist.all_reduce(flag, group=self.process_group)
             if 0 < float(flag) and self.comm_mode != "pg":
                 self.comm_mode, self._rccl, self._side = "pg", None, None
                 self.comm_note = "another rank fell back to ProcessGroupNCCL"
+
+    @torch.no_grad()
+    def _make_flat_parameters(self):
+        """Native update path (direct mode, overlapped fp32 SGD with momentum, at most two hyper-parameter groups): every
+        bucket's parameters and momentum buffers MOVE into flat arrays laid out like its gradient array — `p.data` and
+        the optimizer's `momentum_buffer` become views of them (state_dict / load_state_dict / checkpoints are unaffected:
+        they go through the views).  A parameter re-allocated afterwards (`model.to(...)`, `.data = ...`) would leave its
+        bucket: `_launch` checks the addresses."""
+        opt = self.optimizer
+        if opt is None or not self.overlap_optimizer or len(opt.param_groups) > 2:
+            return
+        moms = set(g["momentum"] for g in opt.param_groups)
+        if len(moms) != 1 or 0 in moms or any(g.get("nesterov") or g.get("dampening") for g in opt.param_groups):
+            return
+        for b in self.buckets:
+            b.flat_p, b.flat_m = torch.zeros_like(b.flat), torch.zeros_like(b.flat)
+            for p, o in zip(b.params, b.offsets):
+                pv = b.flat_p[o:o + p.numel()].view(p.shape)
+                pv.copy_(p.data)
+                p.data = pv
+                mv = b.flat_m[o:o + p.numel()].view(p.shape)
+                old = opt.state[p].get("momentum_buffer")
+                if old is not None:
+                    mv.copy_(old)
+                opt.state[p]["momentum_buffer"] = mv
+        self._native_update = True
+
+    @torch.no_grad()
+    def _adopt_momentum(self, b):
+        """the optimizer's momentum buffers of this bucket -> views of its flat momentum array (values kept)"""
+        for p, o in zip(b.params, b.offsets):
+            mv = b.flat_m[o:o + p.numel()].view(p.shape)
+            old = self.optimizer.state[p].get("momentum_buffer")
+            if old is None:
+                mv.zero_()
+            elif old.data_ptr() != mv.data_ptr():
+                mv.copy_(old)
+            self.optimizer.state[p]["momentum_buffer"] = mv
 
     def forward(self, *args, **kwargs):
         if self._armed:             # a backward pass that raised never reached _finish_backward: start clean
@@ -278,10 +340,18 @@ class BucketedDataParallel(torch.nn.Module):
     @torch.no_grad()
     def _launch(self, b):
         grads = [p.grad for p in b.params]
-        if any(g is None for g in grads):       # only on the flush path
-            if self.error_on_unused:
-                raise RuntimeError("BucketedDataParallel(error_on_unused=True): %d parameter(s) of a bucket received no "
-                                   "gradient in this backward pass" % sum(g is None for g in grads))
+        missing = any(g is None for g in grads)
+        if missing and self.error_on_unused:    # only on the flush path
+            raise RuntimeError("BucketedDataParallel(error_on_unused=True): %d parameter(s) of a bucket received no "
+                               "gradient in this backward pass" % sum(g is None for g in grads))
+        if self._side is not None:              # one launch per 48 tensors, pointer table in the kernel arguments
+            if missing:
+                for v, g in zip(b.views, grads):
+                    if g is None:
+                        v.zero_()
+            have = [(g, o) for g, o in zip(grads, b.offsets) if g is not None]
+            _C.pack_into(b.flat, [g for g, _ in have], [o for _, o in have])
+        elif missing:
             for v, g in zip(b.views, grads):
                 v.copy_(g) if g is not None else v.zero_()
         else:
@@ -297,9 +367,22 @@ class BucketedDataParallel(torch.nn.Module):
             if self._rccl is not None:
                 self._rccl.all_reduce_avg_(b.flat, side)
             if self.overlap_optimizer and self.optimizer.deferred:
-                with torch.cuda.stream(side):
-                    self.optimizer.last_update_stream = side.cuda_stream
-                    self.optimizer.step_params(b.params, b.views)
+                self.optimizer.last_update_stream = side.cuda_stream
+                if self._native_update:
+                    first = b.params[0]
+                    if first.data_ptr() != b.flat_p.data_ptr() + 4 * b.offsets[0]:
+                        raise RuntimeError("BucketedDataParallel: a parameter was re-allocated after wrapping (model.to(...)?): "
+                                           "its storage is no longer the bucket's")
+                    mb = self.optimizer.state[first].get("momentum_buffer")
+                    if mb is None or mb.data_ptr() != b.flat_m.data_ptr() + 4 * b.offsets[0]:
+                        self._adopt_momentum(b)     # optimizer.load_state_dict() replaced the state tensors
+                    gs = self.optimizer.param_groups
+                    gw, gb = gs[0], gs[-1]
+                    _C.sgd_momentum_flat_(b.flat_p, b.flat, b.flat_m, b.split, gw["lr"], gw["weight_decay"], gb["lr"],
+                                          gb["weight_decay"], gw["momentum"], stream=side)
+                else:
+                    with torch.cuda.stream(side):
+                        self.optimizer.step_params(b.params, b.views)
             return
         if self._avg is None:
             if self.world > 1:

@@ -688,3 +688,22 @@ def rpn_loss(objectness, box_regression, anchors, matched, pos, neg, gt, beta, w
     rc = lib().detops_rpn_loss_backward_f32(arr(gobj), arr(gbox), Hs, Ws, L, A, N, T, _p(uo), _p(ub), _p(out3[2:]), None)
     assert rc == 0, rc
     return float(out3[0]), float(out3[1]), gobj, gbox
+
+
+# ---------------------------------------------------------------------------------- data-parallel bucket kernels (optim.hip)
+def pack(dst, arrays, offsets):
+    """dst[offsets[i] : offsets[i] + arrays[i].size] = arrays[i] through detops_pack_f32 (<= detops_pack_max_tensors per call)"""
+    n = len(arrays)
+    arrays = [_f32(a).reshape(-1) for a in arrays]
+    srcs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays])
+    cnts = (ctypes.c_int64 * n)(*[a.size for a in arrays])
+    offs = (ctypes.c_int64 * n)(*[int(o) for o in offsets])
+    rc = lib().detops_pack_f32(srcs, cnts, offs, n, _p(dst), None)
+    return rc
+
+
+def sgd_momentum_flat(p, g, m, split, lr_w, wd_w, lr_b, wd_b, momentum):
+    fn = lib().detops_sgd_momentum_flat_f32
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int64] + [ctypes.c_float] * 5 + [ctypes.c_void_p]
+    return fn(_p(p), _p(g), _p(m), p.size, int(split), lr_w, wd_w, lr_b, wd_b, momentum, None)

@@ -134,6 +134,71 @@ def test_overlapped_sgd_single_process_equals_torch_sgd():
         torch.testing.assert_close(a, c, rtol=1e-6, atol=1e-7)
 
 
+def test_flat_bucket_parameters_and_native_kernels_equal_torch_sgd():
+    """The native update path of BucketedDataParallel (direct RCCL mode on the GPU) without a GPU: the layout logic is
+    device-agnostic, the two kernels of csrc/optim.hip run under the host emulation on the SAME memory (`.numpy()` of a
+    CPU tensor).  Parameters and momentum buffers become views of flat arrays (weights first, biases behind `split`,
+    64-float slots); three steps of pack + flat SGD per bucket equal torch.optim.SGD with the reference's two parameter
+    groups; `state_dict()` is unchanged in keys and values; an `optimizer.load_state_dict()` (which replaces the state
+    tensors) is adopted back into the flat momentum array."""
+    sys.path.insert(0, PKG)
+    sys.path.insert(0, HERE)
+    import emu
+    from maskrcnn_benchmark.engine.ddp_step import BucketedDataParallel, make_overlapped_sgd
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        m1, m2 = _toy(3), _toy(3)
+        o1 = make_overlapped_sgd(_cfg(), m1)
+        keys_before = list(m1.state_dict().keys())
+        ddp = BucketedDataParallel(m1, o1, bucket_cap_mb=0.004)
+        assert 2 <= len(ddp.buckets) and ddp.comm_mode == "pg" and not ddp._native_update
+        ddp._make_flat_parameters()
+        assert ddp._native_update
+        for h in ddp._hooks:      # the test drives the buckets by hand
+            h.remove()
+        for b in ddp.buckets:
+            assert b.split % 64 == 0 and all(o % 64 == 0 for o in b.offsets)
+            for p_, o in zip(b.params, b.offsets):
+                assert p_.data_ptr() == b.flat_p.data_ptr() + 4 * o
+                assert o1.state[p_]["momentum_buffer"].data_ptr() == b.flat_m.data_ptr() + 4 * o
+                assert (o1._group_of[p_] != 0) == (o >= b.split)
+        assert list(m1.state_dict().keys()) == keys_before
+        for a, c in zip(m1.state_dict().values(), m2.state_dict().values()):
+            assert torch.equal(a, c)
+        w = [p_ for n, p_ in m2.named_parameters() if "bias" not in n]
+        bs = [p_ for n, p_ in m2.named_parameters() if "bias" in n]
+        o2 = torch.optim.SGD([{"params": w, "lr": 0.05, "weight_decay": 0.01}, {"params": bs, "lr": 0.1, "weight_decay": 0.0}],
+                             lr=0.05, momentum=0.9)
+
+        def native_step():
+            gw, gb = o1.param_groups[0], o1.param_groups[-1]
+            for b in ddp.buckets:
+                assert emu.pack(b.flat.numpy(), [p_.grad.numpy() for p_ in b.params], b.offsets) == 0
+                assert emu.sgd_momentum_flat(b.flat_p.numpy(), b.flat.numpy(), b.flat_m.numpy(), b.split, gw["lr"],
+                                             gw["weight_decay"], gb["lr"], gb["weight_decay"], gw["momentum"]) == 0
+        for it in range(5):
+            if it == 3:           # a checkpoint resume replaces the optimizer's state tensors
+                o1.load_state_dict(__import__("copy").deepcopy(o1.state_dict()))
+                b0 = ddp.buckets[0]
+                assert o1.state[b0.params[0]]["momentum_buffer"].data_ptr() != b0.flat_m.data_ptr() + 4 * b0.offsets[0]
+                for b in ddp.buckets:
+                    ddp._adopt_momentum(b)
+            x, y = _data(0, it)
+            m1.zero_grad(set_to_none=True)
+            ((m1(x) - y) ** 2).mean().backward()
+            native_step()
+            o2.zero_grad()
+            ((m2(x) - y) ** 2).mean().backward()
+            o2.step()
+        for a, c in zip(m1.parameters(), m2.parameters()):
+            torch.testing.assert_close(a, c, rtol=2e-6, atol=2e-7)
+        for a, c in zip(m1.parameters(), m2.parameters()):
+            torch.testing.assert_close(o1.state[a]["momentum_buffer"], o2.state[c]["momentum_buffer"], rtol=2e-6, atol=2e-7)
+    finally:
+        dist.destroy_process_group()
+
+
 def _recovery_worker(rank, world, port, out_dir):
     sys.path.insert(0, PKG)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -166,11 +166,17 @@ def test_forced_ddp_hook_world1_nccl_matches_plain_step(comm, monkeypatch):
         dist.destroy_process_group()
         torch.backends.cudnn.deterministic = det0
     print("forced-DDP test: backward deterministic = %s, plain-vs-plain spread = %.3g" % (deterministic, noise))
+    # "direct" updates with the library's own flat SGD kernel (csrc/optim.hip): the same formula as torch._fused_sgd_, its
+    # roundings fused differently — equal to a few ulps per step, not bit for bit
+    slack = 0.0 if comm == "pg" else 2e-6
     for a, b in zip(plain_a, ddp_p):
-        if deterministic:
+        if deterministic and comm == "pg":
             assert torch.equal(a, b)
         else:
-            assert float((a - b).abs().max()) <= 4 * noise + 1e-7, (float((a - b).abs().max()), noise)
+            tol = 4 * noise + 1e-7 + slack * max(1.0, float(a.abs().max()))
+            assert float((a - b).abs().max()) <= tol, (float((a - b).abs().max()), noise)
+    if comm == "direct":
+        assert model._native_update and "native" in model.comm_note
 
 
 def test_overlapped_sgd_fused_kernel_equals_torch_sgd_on_device():

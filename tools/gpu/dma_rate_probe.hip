@@ -48,12 +48,15 @@ __global__ void __launch_bounds__(64) probe(const float* src, long long* ticks, 
   unsigned voff;
   if (PATTERN == 0) voff = lane * 16;
   else if (PATTERN == 4) voff = lane * 268800u + 12u;
-  else { const int ch = lane / 5, v = lane % 5; voff = ch * 268800u + v * 16u + (PATTERN == 2 ? 0u : 12u); }
+  // 7 / 8 (round 5) separate the two things pattern 1 -> 2 changed at once: 7 = every lane's 16 bytes ALIGNED but the 80-byte
+  // piece straddles a line boundary (starts 64 bytes into a line); 8 = lanes misaligned by 12 bytes as in 1, but the piece
+  // stays inside one line (12 + 80 <= 128 with rows on 128-byte boundaries)
+  else { const int ch = lane / 5, v = lane % 5; voff = ch * 268800u + v * 16u + (PATTERN == 2 ? 0u : (PATTERN == 7 ? 64u : 12u)); }
   const size_t wg_stride = (PATTERN == 0 ? 1024 : (PATTERN == 4 ? 64 : 13) * 268800ull) / 4;
   const float* base = src + (static_cast<size_t>(blockIdx.x) * 7919 % (PATTERN == 4 ? 13 : 97)) * wg_stride;   // all reads stay inside the 1 GiB buffer
   const long long t0 = wall_clock64();
   for (int i = 0; i < n; ++i) {
-    const float* p = base + static_cast<size_t>(PATTERN == 3 ? 0 : i) * (PATTERN == 0 ? 256 * 256 : (PATTERN == 2 ? 352 : 336));   // a new row / block every instruction (pattern 2: 1408-byte rows keep the 128-byte alignment)
+    const float* p = base + static_cast<size_t>(PATTERN == 3 ? 0 : i) * (PATTERN == 0 ? 256 * 256 : ((PATTERN == 2 || PATTERN == 7 || PATTERN == 8) ? 352 : 336));   // a new row / block every instruction (pattern 2: 1408-byte rows keep the 128-byte alignment)
     dma16(p, voff, lds0 + (i % span_kb) * 1024);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -67,7 +70,7 @@ int main() {
   long long* ticks; hipMalloc(&ticks, 8 * 8192);
   std::vector<long long> h(8192);
   const int first = getenv("PROBE_FIRST") ? atoi(getenv("PROBE_FIRST")) : 0;
-  for (int pattern = first; pattern < 7; ++pattern)
+  for (int pattern = first; pattern < 9; ++pattern)
     for (int waves_per_cu : {1, 4, 8, 16})
       for (int n : {32, 128}) {
         const int grid = 256 * waves_per_cu;
@@ -76,6 +79,8 @@ int main() {
           else if (pattern == 1) hipLaunchKernelGGL(probe<1>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
           else if (pattern == 2) hipLaunchKernelGGL(probe<2>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
           else if (pattern == 3) hipLaunchKernelGGL(probe<3>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
+          else if (pattern == 7) hipLaunchKernelGGL(probe<7>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
+          else if (pattern == 8) hipLaunchKernelGGL(probe<8>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
           else if (pattern == 5) hipLaunchKernelGGL(probe_bwd<5>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
           else if (pattern == 6) hipLaunchKernelGGL(probe_bwd<6>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
           else hipLaunchKernelGGL(probe<4>, dim3(grid), dim3(64), 16 * 1024, 0, src, ticks, n, 16, nullptr);
