@@ -22,13 +22,16 @@ class GeneralizedRCNN(nn.Module):
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")
         begin_step()   # the padded-target batch is shared by the callers of ONE forward, never across forwards
-        images = to_image_list(images)
-        features = self.backbone(images.tensors)
-        proposals, proposal_losses = self.rpn(images, features, targets)
-        if self.roi_heads:
-            x, result, detector_losses = self.roi_heads(features, proposals, targets)
-        else:  # RPN-only models (RetinaNet) have no ROI heads
-            x, result, detector_losses = features, proposals, {}
+        try:
+            images = to_image_list(images)
+            features = self.backbone(images.tensors)
+            proposals, proposal_losses = self.rpn(images, features, targets)
+            if self.roi_heads:
+                x, result, detector_losses = self.roi_heads(features, proposals, targets)
+            else:  # RPN-only models (RetinaNet) have no ROI heads
+                x, result, detector_losses = features, proposals, {}
+        finally:
+            begin_step()   # ... and never beyond it: nothing of this batch stays referenced after the forward (or its exception)
         if self.training:
             losses = {}
             losses.update(detector_losses)

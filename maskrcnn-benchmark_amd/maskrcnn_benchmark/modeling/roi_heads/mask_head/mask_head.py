@@ -14,19 +14,36 @@ from .roi_mask_feature_extractors import make_roi_mask_feature_extractor
 from .roi_mask_predictors import make_roi_mask_predictor
 
 
+_SLOT_INDICES = {}
+
+
+def _first_slots(n, device):
+    """arange(n) on `device`, built once per (n, device): the index tensor of "the first n slots" without a launch per step"""
+    key = (int(n), str(device))
+    t = _SLOT_INDICES.get(key)
+    if t is None:
+        if len(_SLOT_INDICES) >= 16:
+            _SLOT_INDICES.clear()
+        t = _SLOT_INDICES[key] = torch.arange(int(n), device=device)
+    return t
+
+
 def keep_only_positive_boxes(boxes, max_positives=None):
-    """list[BoxList] with "labels" -> (positive-slot BoxLists, per-image slot indices: an index tensor, or a slice when
-    `max_positives` is given).  With `max_positives` the result has exactly that many slots per image (positives-first
-    inputs)."""
+    """list[BoxList] with "labels" -> (positive-slot BoxLists, per-image slot INDEX TENSORS — the reference's return type,
+    roi_heads/mask_head/mask_head.py:15-34, usable as `sel + offset` / `torch.cat(inds)`).  With `max_positives` (positives-
+    first inputs) every image contributes exactly its first `max_positives` slots: the BoxLists are then VIEWS of the
+    proposals' tensors (no indexing launches; do not write into them) and the indices a cached arange."""
     assert isinstance(boxes, (list, tuple)) and isinstance(boxes[0], BoxList)
     assert boxes[0].has_field("labels")
     out, inds = [], []
     for b in boxes:
         if max_positives is None:
             sel = (b.get_field("labels") > 0).nonzero().squeeze(1)
+            out.append(b[sel])
         else:
-            sel = slice(0, min(max_positives, len(b)))   # views of the first slots: no indexing launches
-        out.append(b[sel])
+            n = min(max_positives, len(b))
+            sel = _first_slots(n, b.bbox.device)
+            out.append(b[slice(0, n)])
         inds.append(sel)
     return out, inds
 
@@ -54,8 +71,6 @@ class ROIMaskHead(torch.nn.Module):
             # reference concatenates per-image boolean masks, mask_head.py:60-63)
             rows, base = [], 0
             for sel, b in zip(positive_inds, all_proposals):
-                if isinstance(sel, slice):
-                    sel = torch.arange(sel.start, sel.stop, device=b.bbox.device)
                 rows.append(sel + base)
                 base += len(b)
             x = features[torch.cat(rows, dim=0)]

@@ -34,6 +34,10 @@ _PADDED = {}
 
 
 def begin_step():
+    """Drop the shared padded-target batch.  GeneralizedRCNN.forward calls it on entry AND on exit (also when the forward
+    raises).  A custom detector that drives RPNLossComputation / the box-head loss / RPNPostProcessor itself must do the
+    same around each step: the cache is keyed by object identity + tensor versions, an in-place write through `.data`
+    bumps no version and would otherwise be served stale."""
     _PADDED.clear()
 
 
@@ -63,7 +67,8 @@ _PADDING_ROWS = {}
 
 
 def _padding_rows(n, kind, device):
-    """n rows of padding — kind "box": the far-away unit box (-1e5, -1e5, -1e5 + 1, -1e5 + 1); kind "zero": int64 zeros — as
+    """n rows of padding — kind "box": the far-away unit box (-1e5, -1e5, -1e5 + 1, -1e5 + 1); kind "zero": int64 zeros;
+    "true" / "false": bool rows of the validity mask — as
     a slice of a constant kept on the device (rows rounded up to a power of two >= 64: one constant serves every batch)."""
     cap = 64
     while cap < n:
@@ -73,6 +78,8 @@ def _padding_rows(n, kind, device):
     if rows is None:
         if kind == "box":
             rows = device_constant([[-1e5, -1e5, -1e5 + 1, -1e5 + 1]] * cap, torch.float32, device)
+        elif kind in ("true", "false"):
+            rows = device_constant([kind == "true"] * cap, torch.bool, device)
         else:
             rows = device_constant([0] * cap, torch.int64, device)
         _PADDING_ROWS[key] = rows      # a handful of entries: (power of two, kind, device)
@@ -81,7 +88,7 @@ def _padding_rows(n, kind, device):
 
 def _pad_targets(targets, device, fields):
     """ONE concatenation per padded tensor (each image's rows followed by its padding rows, sliced from device-resident
-    constants) and a row-validity mask that is a cached constant of the per-image counts: 1 + len(fields) launches."""
+    constants), the row-validity mask included: 2 + len(fields) launches, no host-to-device copy."""
     N = len(targets)
     lens = [len(t) for t in targets]
     M = max(max(lens), 1)
@@ -96,7 +103,10 @@ def _pad_targets(targets, device, fields):
             for f in fields:
                 parts[f].append(_padding_rows(M - m, "zero", device))
     boxes = torch.cat(parts["bbox"], dim=0).view(N, M, 4)
-    row_valid = device_constant([[j < m for j in range(M)] for m in lens], torch.bool, device)
+    # the validity mask from device-resident pieces as well (m true rows, M - m false rows per image): a constant keyed by
+    # the per-image counts would be a fresh host build + upload for nearly every batch of a real data loader
+    row_valid = torch.cat([_padding_rows(k, kind, device) for m in lens for k, kind in ((m, "true"), (M - m, "false")) if k],
+                          dim=0).view(N, M)
     extra = {f: torch.cat(parts[f], dim=0).view(N, M) for f in fields}
     return boxes, row_valid, extra
 

@@ -174,6 +174,38 @@ def bench_roi_sets(C, iters, model_npz=None, only_sets=None, only_heads=None, wh
     return out
 
 
+def bench_roi_pool_psroi(C, iters):
+    """The two API-only pooling operators (no reference config instantiates them), once, at the box
+    head's size on the stride-16 level: ROIPool 7x7 (reference csrc/cuda/ROIPool_cuda.cu:16-202) and deformable PS-ROI
+    pooling (csrc/cuda/deform_pool_kernel_cuda.cu:53-264; 7x7 parts, 4 samples per part, 10 output channels per group)."""
+    out = []
+    H, W, Cc, K = 50, 84, 256, 512
+    feat = torch.randn(2, Cc, H, W, device="cuda")
+    rois = synth.fpn_rois(per_image=K // 2)
+    rois = _t(rois[:K])
+    fbytes = feat.numel() * 4
+    alg = 4 * K * Cc * 49 + fbytes + 20 * K
+    us = dev_time_us(lambda: C.roi_pool_forward(feat, rois, 1.0 / 16, 7, 7), iters)
+    out.append(_entry("roi_pool_fwd 512 x 256 x 7x7 on 2x256x50x84", us, alg + 4 * K * Cc * 49))      # + argmax
+    o, am = C.roi_pool_forward(feat, rois, 1.0 / 16, 7, 7)
+    g = torch.randn_like(o)
+    us = dev_time_us(lambda: C.roi_pool_backward(g, feat, rois, am, 1.0 / 16, 7, 7, 2, Cc, H, W), iters)
+    out.append(_entry("roi_pool_bwd 512 x 256 x 7x7 on 2x256x50x84", us, alg + 4 * K * Cc * 49))
+    D, P = 10, 7                                                         # C = D * P * P = 490 position-sensitive maps
+    pfeat = torch.randn(2, D * P * P, H, W, device="cuda")
+    trans = torch.randn(K, 2, P, P, device="cuda") * 0.1
+    po = torch.empty(K, D, P, P, device="cuda")
+    cnt = torch.empty_like(po)
+    palg = 2 * 4 * K * D * P * P + pfeat.numel() * 4 + 20 * K + trans.numel() * 4
+    us = dev_time_us(lambda: C.deform_psroi_pooling_forward(pfeat, rois, trans, po, cnt, 0, 1.0 / 16, D, P, P, P, 4, 0.1), iters)
+    out.append(_entry("deform_psroi_fwd 512 rois, 10 x 7x7, 4 samples/part", us, palg))
+    gi, gt = torch.zeros_like(pfeat), torch.zeros_like(trans)
+    go = torch.randn_like(po)
+    us = dev_time_us(lambda: C.deform_psroi_pooling_backward(go, pfeat, rois, trans, cnt, gi, gt, 0, 1.0 / 16, D, P, P, P, 4, 0.1), iters)
+    out.append(_entry("deform_psroi_bwd (atomic accumulate into pre-zeroed gradients)", us, palg))
+    return out
+
+
 def bench_targets(C, iters):
     """IoU + Matcher and the balanced sampler at the RPN's shape (2 images x 268,569 anchors of the 800 x 1344 pyramid,
     <= 20 ground-truth boxes) and at the box head's (2 x ~2,020 proposals); bytes: boxes + matched indices."""
@@ -470,6 +502,8 @@ def main():
             tune(k, 0)
     if "roi_align_fwd" in only:
         res += bench_roi_align(C, args.iters, which=("fwd",))
+    if not only or "pool" in only:
+        res += bench_roi_pool_psroi(C, args.iters)
     if not only or "nms" in only:
         res += bench_nms(C, args.iters)
     if not only or "targets" in only:
