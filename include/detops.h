@@ -584,6 +584,18 @@ int detops_sgd_momentum_flat_f32(float* params, const float* grads, float* momen
                                  float lr_weights, float wd_weights, float lr_biases, float wd_biases, float momentum,
                                  detops_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * FPN top-down step (csrc/fpn_topdown.hip) — replaces the pair `F.interpolate(last_inner, mode="nearest")` +
+ * `inner_lateral + inner_top_down` of reference modeling/backbone/fpn.py:59-64 (and its backward: identity towards the
+ * lateral, block sum towards the coarser map).  NCHW planes (= N * C), lateral / out [planes, H, W], top [planes, h, w];
+ * dtype DETOPS_F32 / F16 / BF16 for all tensors of a call, fp32 arithmetic; nearest index = ATen's
+ * min(int(floorf(dst * (float)in / out)), in - 1).  backward: grad_top [planes, h, w] is OVERWRITTEN.
+ * ---------------------------------------------------------------------------------------- */
+int detops_fpn_topdown_forward(const void* lateral, const void* top, void* out, int dtype, int planes, int H, int W, int h, int w,
+                               detops_stream_t stream);
+int detops_fpn_topdown_backward(const void* grad_out, void* grad_top, int dtype, int planes, int H, int W, int h, int w,
+                                detops_stream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

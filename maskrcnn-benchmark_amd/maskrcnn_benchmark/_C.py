@@ -248,6 +248,46 @@ def nms_batched_mask(boxes, scores, seg_offsets, max_n, threshold):
     return mask.view(torch.bool), num
 
 
+# ------------------------------------------------------------------------------------------ FPN top-down step
+class _UpsampleAdd(torch.autograd.Function):
+    """lateral + nearest_upsample(top) in one pass (csrc/fpn_topdown.hip; reference modeling/backbone/fpn.py:59-64)."""
+
+    @staticmethod
+    def forward(ctx, lateral, top):
+        lateral, top = lateral.contiguous(), top.contiguous()
+        N, C, H, W = lateral.shape
+        h, w = int(top.shape[2]), int(top.shape[3])
+        out = torch.empty_like(lateral)
+        with _on_device(lateral), _timed(("fpn_topdown_fwd[n=%d,e=%d]", (lateral.numel(), _ESIZE[lateral.dtype])), lateral):
+            check(lib.detops_fpn_topdown_forward(ptr(lateral), ptr(top), ptr(out), _lib.DTYPE_CODE[lateral.dtype], N * C, H, W, h, w,
+                                                 stream_of(lateral)), "fpn_topdown_forward")
+        ctx.shape = (N, C, H, W, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W, h, w = ctx.shape
+        g = g.contiguous()
+        gtop = None
+        if ctx.needs_input_grad[1]:
+            gtop = torch.empty((N, C, h, w), dtype=g.dtype, device=g.device)
+            with _on_device(g), _timed(("fpn_topdown_bwd[n=%d,e=%d]", (g.numel(), _ESIZE[g.dtype])), g):
+                check(lib.detops_fpn_topdown_backward(ptr(g), ptr(gtop), _lib.DTYPE_CODE[g.dtype], N * C, H, W, h, w, stream_of(g)),
+                      "fpn_topdown_backward")
+        return (g if ctx.needs_input_grad[0] else None), gtop
+
+
+def fpn_topdown(lateral, top):
+    """out = lateral + F.interpolate(top, size=lateral.shape[-2:], mode="nearest") (extension; the reference composes it from
+    two ATen ops, modeling/backbone/fpn.py:59-64).  [N, C, H, W] + [N, C, h, w], one dtype (fp32 / fp16 / bf16)."""
+    _need_cuda("fpn_topdown", lateral, top)
+    if lateral.dtype != top.dtype or lateral.dtype not in _lib.DTYPE_CODE:
+        raise RuntimeError("fpn_topdown: lateral and top must share one dtype (fp32 / fp16 / bf16)")
+    if lateral.dim() != 4 or top.dim() != 4 or lateral.shape[:2] != top.shape[:2]:
+        raise RuntimeError("fpn_topdown: expected [N, C, H, W] and [N, C, h, w]")
+    return _UpsampleAdd.apply(lateral, top)
+
+
 # ------------------------------------------------------------------------------------------ data-parallel bucket kernels
 _PACK_MAX = [0]
 

@@ -57,6 +57,8 @@ SIGNATURES = {
     "detops_mask_loss_workspace_bytes": (c_size_t, [c_int]),
     "detops_mask_loss_f32": (c_int, [_P] * 3 + [c_int] * 3 + [_P] * 3 + [c_size_t, _P]),
     "detops_head_loss_backward_f32": (c_int, [_P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _P]),
+    "detops_fpn_topdown_forward": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
+    "detops_fpn_topdown_backward": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "detops_pack_max_tensors": (c_int, []),
     "detops_pack_f32": (c_int, [_P, _P, _P, c_int, _P, _P]),
     "detops_sgd_momentum_flat_f32": (c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64] + [c_float] * 5 + [_P]),

@@ -4,6 +4,10 @@ RPN; P6/P7 convs for RetinaNet)."""
 import torch.nn.functional as F
 from torch import nn
 
+from maskrcnn_benchmark import _C
+
+_FUSED_TOPDOWN = __import__("os").environ.get("DETOPS_FPN_TOPDOWN", "fused") != "torch"   # A/B switch
+
 
 class FPN(nn.Module):
     def __init__(self, in_channels_list, out_channels, conv_block, top_blocks=None):
@@ -27,8 +31,12 @@ class FPN(nn.Module):
             if not inner:
                 continue
             lateral = getattr(self, inner)(feat)
-            top_down = F.interpolate(last, size=(int(lateral.shape[-2]), int(lateral.shape[-1])), mode="nearest")
-            last = lateral + top_down
+            if _FUSED_TOPDOWN and _C.on_device(lateral) and lateral.dtype == last.dtype and lateral.dtype in _C._lib.DTYPE_CODE:
+                # one streaming pass instead of interpolate + add and their full-size temporary (csrc/fpn_topdown.hip)
+                last = _C.fpn_topdown(lateral, last)
+            else:
+                top_down = F.interpolate(last, size=(int(lateral.shape[-2]), int(lateral.shape[-1])), mode="nearest")
+                last = lateral + top_down
             results.insert(0, getattr(self, layer)(last))
         if isinstance(self.top_blocks, LastLevelP6P7):
             results.extend(self.top_blocks(x[-1], results[-1]))

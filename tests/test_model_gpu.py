@@ -122,6 +122,43 @@ def test_train_step_r101_dcn_fp16_cfg5():
     assert step.scaler.get_scale() > 0
 
 
+def test_bucket_pack_and_flat_sgd_kernels_equal_torch_sgd_on_the_device():
+    """csrc/optim.hip on the device: pack of ragged gradient tensors into 64-float slots (more than one launch: 48 tensors
+    each) and three steps of the flat SGD pass against torch.optim.SGD with the reference's two parameter groups"""
+    from maskrcnn_benchmark import _C
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    sizes = [7 * 7 * 256 * 64, 64, 1, 4099, 256, 1 << 20, 2, 300] + [33 + 17 * i for i in range(60)]
+    kinds = [i % 3 == 1 for i in range(len(sizes))]                       # True = bias group
+    order = [i for i in range(len(sizes)) if not kinds[i]] + [i for i in range(len(sizes)) if kinds[i]]
+    offs, at = {}, 0
+    for i in order:
+        offs[i] = at
+        at += -(-sizes[i] // 64) * 64
+    split = offs[[i for i in order if kinds[i]][0]]
+    params = [torch.randn(s, generator=g).to(dev) for s in sizes]
+    P, M = torch.zeros(at, device=dev), torch.zeros(at, device=dev)
+    _C.pack_into(P, [params[i] for i in order], [offs[i] for i in order])
+    for i in order:
+        assert torch.equal(P[offs[i]:offs[i] + sizes[i]], params[i])
+    tp = [torch.nn.Parameter(p.clone()) for p in params]
+    lr, wd, mom = 0.02, 1e-4, 0.9
+    opt = torch.optim.SGD([{"params": [tp[i] for i in range(len(sizes)) if not kinds[i]], "lr": lr, "weight_decay": wd},
+                           {"params": [tp[i] for i in range(len(sizes)) if kinds[i]], "lr": 2 * lr, "weight_decay": 0.0}],
+                          lr=lr, momentum=mom)
+    for step in range(3):
+        grads = [torch.randn(s, generator=g).to(dev) for s in sizes]
+        G = torch.full((at,), 7.0, device=dev)
+        _C.pack_into(G, [grads[i] for i in order], [offs[i] for i in order])
+        _C.sgd_momentum_flat_(P, G, M, split, lr, wd, 2 * lr, 0.0, mom)
+        for t, gr in zip(tp, grads):
+            t.grad = gr.clone()
+        opt.step()
+        for i in order:
+            torch.testing.assert_close(P[offs[i]:offs[i] + sizes[i]], tp[i].detach(), rtol=2e-6, atol=2e-6)
+            torch.testing.assert_close(M[offs[i]:offs[i] + sizes[i]], opt.state[tp[i]]["momentum_buffer"], rtol=2e-6, atol=2e-6)
+
+
 @pytest.mark.parametrize("comm", ["direct", "pg"])
 def test_forced_ddp_hook_world1_nccl_matches_plain_step(comm, monkeypatch):
     """The overlapped-SGD DDP hook on the one MI355X we have: a 1-rank NCCL (= RCCL) process group wraps the
@@ -136,11 +173,17 @@ def test_forced_ddp_hook_world1_nccl_matches_plain_step(comm, monkeypatch):
                     "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 64])
     (images, targets), = make_device_batches(cfg, _dev(), images_per_gpu=1, num_batches=1, height=192, width=256)
 
+    # "direct" updates with the library's own flat SGD kernel (csrc/optim.hip): the same formula as torch._fused_sgd_ with
+    # its roundings fused differently — a few ulps per step.  The detector is not continuous in its weights (top-k, NMS,
+    # matcher thresholds), so ulps can become a different proposal set a step later: ONE step is compared there (same
+    # forward, same backward, only the update differs); "pg" shares torch's update and is compared over three.
+    n_steps = 1 if comm == "direct" else 3
+
     def run(force):
         torch.manual_seed(0)
         model, opt, sched, step = build_training(cfg, _dev(), force_ddp=force)
         torch.manual_seed(1)
-        for _ in range(3):
+        for _ in range(n_steps):
             step(images, targets)
         torch.cuda.synchronize()
         m = model.module if force else model
@@ -166,8 +209,6 @@ def test_forced_ddp_hook_world1_nccl_matches_plain_step(comm, monkeypatch):
         dist.destroy_process_group()
         torch.backends.cudnn.deterministic = det0
     print("forced-DDP test: backward deterministic = %s, plain-vs-plain spread = %.3g" % (deterministic, noise))
-    # "direct" updates with the library's own flat SGD kernel (csrc/optim.hip): the same formula as torch._fused_sgd_, its
-    # roundings fused differently — equal to a few ulps per step, not bit for bit
     slack = 0.0 if comm == "pg" else 2e-6
     for a, b in zip(plain_a, ddp_p):
         if deterministic and comm == "pg":

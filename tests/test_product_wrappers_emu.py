@@ -122,6 +122,51 @@ def test_nms_wrappers_equal_the_oracle_bit_exactly():
         assert np.array_equal(mask.numpy()[lo:hi], want) and int(num[i]) == int(want.sum())
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("shape", [((2, 6, 10, 16), (5, 8)), ((1, 3, 7, 9), (4, 5)), ((2, 4, 13, 21), (7, 11)), ((1, 2, 6, 6), (6, 6))])
+def test_fpn_topdown_equals_interpolate_plus_add(dtype, tol, shape):
+    """_C.fpn_topdown (csrc/fpn_topdown.hip) = lateral + F.interpolate(top, size, mode="nearest") (reference
+    modeling/backbone/fpn.py:59-64), forward and both gradients: exact 2x, odd sizes (25 -> 13-like ratios), equal sizes"""
+    from maskrcnn_benchmark import _C
+    (N, C, H, W), (h, w) = shape
+    g = torch.Generator().manual_seed(H * W + h)
+    lat = torch.randn(N, C, H, W, generator=g).to(dtype).requires_grad_()
+    top = torch.randn(N, C, h, w, generator=g).to(dtype).requires_grad_()
+    up = torch.randn(N, C, H, W, generator=g).to(dtype)
+    out = _C.fpn_topdown(lat, top)
+    out.backward(up)
+    lat2, top2 = lat.detach().float().requires_grad_(), top.detach().float().requires_grad_()
+    ref = lat2 + torch.nn.functional.interpolate(top2, size=(H, W), mode="nearest")
+    ref.backward(up.float())
+    assert torch.allclose(out.float(), ref, rtol=tol, atol=tol)
+    assert torch.equal(lat.grad, up)
+    assert torch.allclose(top.grad.float(), top2.grad, rtol=tol, atol=tol * 4)
+
+
+def test_fpn_module_uses_the_fused_topdown_step_and_equals_the_composition(monkeypatch):
+    from maskrcnn_benchmark import _C
+    from maskrcnn_benchmark.modeling.backbone import fpn as fpn_mod
+    from maskrcnn_benchmark.modeling.make_layers import conv_with_kaiming_uniform
+    torch.manual_seed(0)
+    net = fpn_mod.FPN([4, 8, 16, 32], 8, conv_with_kaiming_uniform(), fpn_mod.LastLevelMaxPool())
+    feats = [torch.randn(2, c, s, s + 2, requires_grad=True) for c, s in ((4, 32), (8, 16), (16, 8), (32, 4))]
+    calls = []
+    monkeypatch.setattr(_C, "fpn_topdown", (lambda a, b, _f=_C.fpn_topdown: (calls.append(1), _f(a, b))[1]))
+    outs = net(feats)
+    assert len(calls) == 3 and len(outs) == 5
+    sum(o.sum() for o in outs).backward()
+    grads = [f.grad.clone() for f in feats]
+    for f in feats:
+        f.grad = None
+    monkeypatch.setattr(_C, "on_device", lambda t: False)      # the ATen composition
+    ref = net(feats)
+    sum(o.sum() for o in ref).backward()
+    for a, b in zip(outs, ref):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+    for a, f in zip(grads, feats):
+        assert torch.allclose(a, f.grad, rtol=1e-5, atol=1e-5)
+
+
 def test_frozen_batch_norm_module_and_focal_loss_equal_the_torch_formulas():
     from maskrcnn_benchmark.layers import FrozenBatchNorm2d, SigmoidFocalLoss
     rng = np.random.RandomState(2)
