@@ -248,7 +248,23 @@ def _emu_device_patches():
     def mask_loss(mask_logits, labels, mask_targets):
         return _EmuHeadLoss.apply("mask", None, mask_logits.float(), labels, mask_targets)[0]
 
+    class _EmuTopDown(torch.autograd.Function):
+        """_C._UpsampleAdd's contract with the kernels of csrc/fpn_topdown.hip under the host emulation (fp32)"""
+
+        @staticmethod
+        def forward(ctx, lateral, top):
+            ctx.hw = (int(top.shape[2]), int(top.shape[3]))
+            return torch.from_numpy(emu.fpn_topdown_forward(_np(lateral.float()), _np(top.float()))).to(lateral.dtype)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g, torch.from_numpy(emu.fpn_topdown_backward(_np(g.float()), *ctx.hw)).to(g.dtype)
+
+    def fpn_topdown(lateral, top):
+        return _EmuTopDown.apply(lateral, top)
+
     return {"on_device": lambda t: True, "rpn_loss": rpn_loss, "fastrcnn_loss": fastrcnn_loss, "mask_loss": mask_loss, "match_boxes": match_boxes, "sample_labels": sample_labels,
+            "fpn_topdown": fpn_topdown,
             "match_labels": match_labels, "roi_head_targets": roi_head_targets, "rpn_decode": rpn_decode,
             "mask_targets": mask_targets}
 

@@ -707,3 +707,22 @@ def sgd_momentum_flat(p, g, m, split, lr_w, wd_w, lr_b, wd_b, momentum):
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int64] + [ctypes.c_float] * 5 + [ctypes.c_void_p]
     return fn(_p(p), _p(g), _p(m), p.size, int(split), lr_w, wd_w, lr_b, wd_b, momentum, None)
+
+
+# ---------------------------------------------------------------------------------- FPN top-down step (fpn_topdown.hip)
+def fpn_topdown_forward(lateral, top):
+    lateral, top = _f32(lateral), _f32(top)
+    N, C, H, W = lateral.shape
+    out = np.full_like(lateral, np.nan)
+    rc = lib().detops_fpn_topdown_forward(_p(lateral), _p(top), _p(out), 0, N * C, H, W, top.shape[2], top.shape[3], None)
+    assert rc == 0, rc
+    return out
+
+
+def fpn_topdown_backward(grad_out, h, w):
+    grad_out = _f32(grad_out)
+    N, C, H, W = grad_out.shape
+    gtop = np.full((N, C, h, w), np.nan, np.float32)
+    rc = lib().detops_fpn_topdown_backward(_p(grad_out), _p(gtop), 0, N * C, H, W, h, w, None)
+    assert rc == 0, rc
+    return gtop

@@ -30,7 +30,7 @@ if has trace; then
   fi; el trace
 fi
 if has opbench; then
-  timeout 600 python tools/opbench.py --iters 50 --json $O/opbench.json < /dev/null > $O/opbench.log 2>&1; grep -E "roi_align_(fwd|bwd) (fpn|cfg1)|nms batched|frozen_bn|focal|match_boxes|sample_labels|dcn_block" $O/opbench.log | cut -c1-150 | head -60; el opbench
+  timeout 600 python tools/opbench.py --iters 50 --json $O/opbench.json < /dev/null > $O/opbench.log 2>&1; grep -E "roi_align_(fwd|bwd) (fpn|cfg1)|nms batched|frozen_bn|focal|match_boxes|sample_labels|dcn_block|roi_pool|psroi" $O/opbench.log | cut -c1-150 | head -60; el opbench
   # the > L3 variant (4 img/GPU: 365.6 MB of maps against the 256 MiB Infinity Cache)
   timeout 300 python tools/opbench.py --only roi_sets --sets model-random-init --images 4 --iters 30 < /dev/null > $O/roi_align_l3_variant.log 2>&1; grep roi_align $O/roi_align_l3_variant.log | cut -c1-150; el l3-variant
   timeout 200 python tools/gpu/cfg1_bwd.py 0 50 < /dev/null > $O/cfg1_bwd.log 2>&1; grep cfg1 $O/cfg1_bwd.log; el cfg1
@@ -55,7 +55,9 @@ if has pmc; then
     done
     python tools/pmc_diag.py /tmp/pmcf_sq /tmp/pmcf_sq2 /tmp/pmcf_tcc /tmp/pmcf_fw /tmp/pmcf_ww > $O/roi_align_fwd_pmc.txt 2>&1; grep -A28 "roi_align_fwd_dma" $O/roi_align_fwd_pmc.txt | head -32; el pmc-fwd
   done
-  TR="python tools/opbench.py --only roi_align_fpn,frozen_bn,nms,dcn_block --iters 5"
+  # (the ROIAlign launches' calibrated traffic table is tools/gpu/r05j_fetch_calib.sh -> profiles/r05j_traffic.*; this pass
+  #  keeps the FrozenBN / NMS / deformable-conv rows)
+  TR="python tools/opbench.py --only frozen_bn,nms,dcn_block --iters 5"
   rm -rf /tmp/tr_f /tmp/tr_w
   timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/tr_f -o x -- $TR < /dev/null > $O/traffic_fetch.log 2>&1
   timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/tr_w -o x -- $TR < /dev/null > $O/traffic_write.log 2>&1
@@ -68,7 +70,9 @@ if has extra; then
   B="python bench.py --steps 40 --warmup 12 --no-cpu-baseline"
   timeout 300 $B --dtype bfloat16 < /dev/null > $O/bench_bf16.log 2>&1; jline $O/bench_bf16.log > $O/bench_bf16.json; brief $O/bench_bf16.log bf16; el bf16
   timeout 400 $B --config e2e_mask_rcnn_R_101_FPN_1x.yaml --dtype float16 MODEL.RESNETS.STAGE_WITH_DCN "(False, True, True, True)" < /dev/null > $O/bench_cfg5.log 2>&1; jline $O/bench_cfg5.log > $O/bench_cfg5.json; brief $O/bench_cfg5.log cfg5; el cfg5
-  timeout 300 $B --force-ddp < /dev/null > $O/bench_forceddp.log 2>&1; jline $O/bench_forceddp.log > $O/bench_forceddp.json; brief $O/bench_forceddp.log force-ddp; el force-ddp
+  timeout 300 $B < /dev/null > $O/bench_plain40.log 2>&1; jline $O/bench_plain40.log > $O/bench_plain40.json; brief $O/bench_plain40.log plain-40-steps; el plain40
+  timeout 300 $B --force-ddp < /dev/null > $O/bench_forceddp.log 2>&1; jline $O/bench_forceddp.log > $O/bench_forceddp.json; brief $O/bench_forceddp.log force-ddp-direct; el force-ddp
+  DETOPS_DDP_COMM=pg timeout 300 $B --force-ddp < /dev/null > $O/bench_forceddp_pg.log 2>&1; jline $O/bench_forceddp_pg.log > $O/bench_forceddp_pg.json; brief $O/bench_forceddp_pg.log force-ddp-pg; el force-ddp-pg
   timeout 300 $B --config e2e_faster_rcnn_R_50_FPN_1x.yaml < /dev/null > $O/bench_faster.log 2>&1; jline $O/bench_faster.log > $O/bench_faster.json; brief $O/bench_faster.log faster; el faster
   timeout 300 $B --config retinanet/retinanet_R-50-FPN_1x.yaml < /dev/null > $O/bench_retinanet.log 2>&1; jline $O/bench_retinanet.log > $O/bench_retinanet.json; brief $O/bench_retinanet.log retinanet; el retinanet
 fi
