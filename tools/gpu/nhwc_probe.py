@@ -10,7 +10,14 @@ class Bottleneck(nn.Module):
         self.c2 = nn.Conv2d(mid, mid, 3, 1, 1, bias=False)
         self.c3 = nn.Conv2d(mid, cout, 1, bias=False)
         self.down = nn.Conv2d(cin, cout, 1, stride, bias=False) if (cin != cout or stride != 1) else None
+    mixed = False   # round 5: 1x1 convolutions and block boundaries channels-last, the 3x3 convolution NCHW (Winograd); the two
+                    # layout changes around it are explicit copies here (the fused FrozenBN kernels would do them on the way)
     def forward(self, x):
+        if Bottleneck.mixed:
+            t = torch.relu(self.c1(x)).contiguous(memory_format=torch.contiguous_format)
+            t = torch.relu(self.c2(t)).contiguous(memory_format=torch.channels_last)
+            y = self.c3(t)
+            return torch.relu(y + (self.down(x) if self.down is not None else x))
         y = self.c3(torch.relu(self.c2(torch.relu(self.c1(x)))))
         return torch.relu(y + (self.down(x) if self.down is not None else x))
 
@@ -25,10 +32,18 @@ def body():
 torch.manual_seed(0)
 net = body().cuda()
 x0 = torch.randn(2, 3, 800, 1344, device="cuda")
-for dt in (torch.bfloat16, torch.float16, torch.float32):
-    for fmt in (torch.contiguous_format, torch.channels_last):
-        m = net.to(memory_format=fmt)
-        x = x0.to(memory_format=fmt).requires_grad_(True)
+for dt in (torch.float32, torch.bfloat16):
+    for fmt in (torch.contiguous_format, torch.channels_last, "mixed"):
+        Bottleneck.mixed = fmt == "mixed"
+        if fmt == "mixed":
+            m = net.to(memory_format=torch.channels_last)
+            for mod in m.modules():
+                if isinstance(mod, Bottleneck):
+                    mod.c2.to(memory_format=torch.contiguous_format)
+            x = x0.to(memory_format=torch.channels_last).requires_grad_(True)
+        else:
+            m = net.to(memory_format=fmt)
+            x = x0.to(memory_format=fmt).requires_grad_(True)
         def step():
             with torch.autocast("cuda", dtype=dt, enabled=dt != torch.float32):
                 y = m(x)
@@ -46,5 +61,10 @@ for dt in (torch.bfloat16, torch.float16, torch.float32):
         tr = sum(e.count for e in ev if "transpose" in e.key.lower())
         trt = sum(e.device_time_total for e in ev if "transpose" in e.key.lower()) / 1e3
         dev = sum(e.device_time_total for e in ev) / 1e3
-        print("%-8s %-14s wall %.2f ms/step, device-busy %.2f ms, launches %d (transposes %d = %.2f ms)" %
-              (str(dt)[6:], "channels_last" if fmt == torch.channels_last else "nchw", ms, dev, n, tr, trt), flush=True)
+        cp = sum(e.device_time_total for e in ev if "copy" in e.key.lower()) / 1e3
+        name = "mixed" if fmt == "mixed" else ("channels_last" if fmt == torch.channels_last else "nchw")
+        print("%-8s %-14s wall %.2f ms/step, device-busy %.2f ms, launches %d (transposes %d = %.2f ms; copy kernels %.2f ms)" %
+              (str(dt)[6:], name, ms, dev, n, tr, trt, cp), flush=True)
+        if fmt == "mixed":
+            for e in sorted(ev, key=lambda e: -e.device_time_total)[:14]:
+                print("      %8.3f ms  %4d x  %s" % (e.device_time_total / 1e3, e.count, e.key[:110]))
