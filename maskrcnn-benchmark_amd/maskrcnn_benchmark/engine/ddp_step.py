@@ -217,8 +217,10 @@ class BucketedDataParallel(torch.nn.Module):
         self.comm_mode, self.comm_note, self._rccl, self._side = "pg", None, None, None
         self._native_update = False
         dev = self.buckets[0].flat.device if self.buckets else None
-        on_gpu = dev is not None and dev.type == "cuda" and all(b.flat.device == dev and b.flat.dtype == torch.float32
-                                                                for b in self.buckets)
+        # (`_C.on_device`, not `.is_cuda`: the CPU suite drives this path too, over the emulated kernels and a stand-in for
+        #  librccl.so on gloo — tests/test_ddp_cpu.py)
+        on_gpu = dev is not None and _C.on_device(self.buckets[0].flat) and all(
+            b.flat.device == dev and b.flat.dtype == torch.float32 for b in self.buckets)
         if want == "pg" or not on_gpu or dist.get_backend(self.process_group) != "nccl":
             if want in ("direct", "side-nocoll"):
                 raise RuntimeError("comm=%r needs fp32 parameters on one GPU and an RCCL process group" % want)

@@ -78,9 +78,12 @@ class RcclComm(object):
         if self.rank == 0:
             self._check(self.lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
         if self.world > 1:
-            box = [bytes(uid.internal) if self.rank == 0 else None]
+            # bytes(uid): the whole 128-byte struct (a c_char array FIELD reads as a C string and stops at the first NUL)
+            box = [bytes(uid) if self.rank == 0 else None]
             dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0), group=self.group)
-            ctypes.memmove(ctypes.byref(uid), box[0], 128)
+            if not isinstance(box[0], (bytes, bytearray)) or len(box[0]) != ctypes.sizeof(_UniqueId):
+                raise RuntimeError("RCCL unique id: expected %d bytes from rank 0" % ctypes.sizeof(_UniqueId))
+            ctypes.memmove(ctypes.byref(uid), box[0], ctypes.sizeof(_UniqueId))
         self.comm = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             self._check(self.lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")

@@ -301,3 +301,160 @@ def test_detector_trains_under_ddp_hook_world2(tmp_path, config):
     assert all(v == v and abs(v) != float("inf") for v in r0["losses"].values())
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b), "ranks diverged: the averaged update must be identical on both"
+
+
+def _uid_worker(rank, world, port, out_dir):
+    """the unique-id exchange of engine/rccl_comm.py between two real ranks (gloo), with a stand-in for librccl.so that
+    records what each rank hands to ncclCommInitRank"""
+    sys.path.insert(0, PKG)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes
+    from maskrcnn_benchmark.engine import rccl_comm
+    seen = {}
+
+    class FakeLib(object):
+        def ncclGetUniqueId(self, ref):
+            raw = bytes([5, 0, 9, 0, 0, 200] + [(7 * i) % 251 for i in range(122)])      # NUL bytes early on, like a real id
+            ctypes.memmove(ref, raw, 128)
+            return 0
+
+        def ncclCommInitRank(self, comm_ref, nranks, uid, r):
+            seen["id"], seen["nranks"], seen["rank"] = bytes(uid), nranks, r
+            return 0
+
+        def ncclGetErrorString(self, rc):
+            return b"fake"
+
+    rccl_comm._load = lambda: FakeLib()
+    import contextlib
+    torch.cuda.device = lambda d: contextlib.nullcontext()         # no GPU in this test: the guard is a no-op
+    comm = rccl_comm.RcclComm(torch.device("cpu"))
+    assert (seen["nranks"], seen["rank"]) == (world, rank) and comm.world == world
+    torch.save(seen["id"], os.path.join(out_dir, "uid_%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_rccl_unique_id_reaches_every_rank_whole(tmp_path):
+    """the 128-byte ncclUniqueId of rank 0 must arrive on the other ranks byte for byte — NUL bytes included (a c_char array
+    field read as a C string would stop at the first one)"""
+    mp.spawn(_uid_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = (torch.load(os.path.join(str(tmp_path), "uid_%d.pt" % r)) for r in (0, 1))
+    assert len(a) == 128 and a == b and a[:6] == bytes([5, 0, 9, 0, 0, 200])
+
+
+class _FakeStream(object):
+    """stands in for a HIP stream on the CPU: work is executed at enqueue time, so every ordering primitive is a no-op"""
+    cuda_stream = None
+
+    def wait_event(self, ev):
+        pass
+
+    def wait_stream(self, s):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _FakeEvent(object):
+    def record(self, stream=None):
+        pass
+
+
+def _direct_worker(rank, world, port, steps, out_dir, bucket_mb):
+    """BucketedDataParallel's DIRECT path (RCCL on one side stream, flat buckets, the library's pack + SGD kernels) between
+    two real ranks without a GPU: the kernels run under the host emulation (cpu_shim "emu-lib" swaps the library handle
+    under `_C`), librccl.so is a stand-in whose ncclAllReduce averages the buffer over gloo, streams / events are no-ops."""
+    sys.path.insert(0, PKG)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes
+    import numpy as np
+    import cpu_shim
+    from maskrcnn_benchmark.engine import ddp_step, rccl_comm
+    from maskrcnn_benchmark.engine.ddp_step import BucketedDataParallel, make_overlapped_sgd
+    calls = []
+
+    class FakeLib(object):
+        def ncclGetUniqueId(self, ref):
+            ctypes.memmove(ref, bytes([3, 0, 1] + [9] * 125), 128)
+            return 0
+
+        def ncclCommInitRank(self, comm_ref, nranks, uid, r):
+            assert bytes(uid)[:3] == bytes([3, 0, 1]) and (nranks, r) == (world, rank)
+            return 0
+
+        def ncclAllReduce(self, send, recv, count, dtype, op, comm, stream):
+            assert send == recv and dtype == 7 and op == 4                      # in place, fp32, ncclAvg
+            t = torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * count).from_address(recv)))
+            dist.all_reduce(t)
+            t /= world
+            calls.append(count)
+            return 0
+
+        def ncclCommDestroy(self, comm):
+            return 0
+
+        def ncclGetErrorString(self, rc):
+            return b"fake"
+
+    import contextlib
+    rccl_comm._load = lambda: FakeLib()
+    torch.cuda.device = lambda d: contextlib.nullcontext()
+    torch.cuda.Stream = lambda *a, **k: _FakeStream()
+    torch.cuda.Event = lambda *a, **k: _FakeEvent()
+    torch.cuda.current_stream = lambda *a, **k: _FakeStream()
+    dist_get_backend = dist.get_backend
+    dist.get_backend = lambda *a, **k: "nccl"
+    model = _toy()
+    if rank:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    opt = make_overlapped_sgd(_cfg(), model)
+    with cpu_shim.install("emu-lib"):
+        ddp = BucketedDataParallel(model, opt, bucket_cap_mb=bucket_mb, comm="direct")
+        assert ddp.comm_mode == "direct" and ddp._native_update and "native" in ddp.comm_note, (ddp.comm_mode, ddp.comm_note)
+        for it in range(steps):
+            x, y = _data(rank, it)
+            opt.zero_grad(set_to_none=True)
+            ((ddp(x) - y) ** 2).mean().backward()
+            opt.step()                      # deferred: the buckets were updated inside backward
+    dist.get_backend = dist_get_backend
+    assert len(calls) == steps * len(ddp.buckets) + 1          # + the self-test at set-up
+    torch.save({"params": [p.detach().clone() for p in model.parameters()], "buckets": len(ddp.buckets)},
+               os.path.join(out_dir, "direct_%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_mb", [25, 0.002])
+def test_direct_rccl_path_with_flat_buckets_world2_equals_single_process_sgd(tmp_path, bucket_mb):
+    """the default N > 1 path of the GPU build, end to end between two ranks: identical parameters on both ranks, equal to
+    single-process torch.optim.SGD on the MEAN gradient of the two ranks' batches (one bucket / many buckets)"""
+    world, steps = 2, 4
+    mp.spawn(_direct_worker, args=(world, _free_port(), steps, str(tmp_path), bucket_mb), nprocs=world, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "direct_%d.pt" % r)) for r in (0, 1))
+    assert (r0["buckets"] == 1) if bucket_mb > 1 else (r0["buckets"] > 2)
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    sys.path.insert(0, PKG)
+    ref = _toy()
+    w = [p for n, p in ref.named_parameters() if "bias" not in n]
+    bs = [p for n, p in ref.named_parameters() if "bias" in n]
+    o = torch.optim.SGD([{"params": w, "lr": 0.05, "weight_decay": 0.01}, {"params": bs, "lr": 0.1, "weight_decay": 0.0}],
+                        lr=0.05, momentum=0.9)
+    for it in range(steps):
+        o.zero_grad()
+        loss = sum(((ref(x) - y) ** 2).mean() for x, y in (_data(r, it) for r in range(world))) / world
+        loss.backward()
+        o.step()
+    for a, c in zip(r0["params"], ref.parameters()):
+        torch.testing.assert_close(a, c.detach(), rtol=1e-5, atol=1e-6)
