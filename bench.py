@@ -676,6 +676,10 @@ def main():
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if distributed or args.force_ddp:
+        comm = getattr(model, "_rccl", None)
+        if comm is not None:        # the wrapper's own RCCL communicator (engine/rccl_comm.py): released before the process group
+            torch.cuda.synchronize(device)
+            comm.destroy()
         dist.destroy_process_group()
 
 
