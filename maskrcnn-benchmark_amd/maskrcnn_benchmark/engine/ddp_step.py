@@ -227,6 +227,11 @@ class BucketedDataParallel(torch.nn.Module):
             return
         try:
             from . import rccl_comm
+            ok = torch.tensor([1.0 if rccl_comm.available() else 0.0], device=dev)
+            if self.world > 1:          # agree BEFORE the collective communicator set-up: nobody waits for a rank that cannot join
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.process_group)
+            if float(ok) < 1.0:
+                raise RuntimeError("librccl.so (or one of its entry points) is not loadable on every rank")
             prio_want = os.environ.get("DETOPS_DDP_PRIO", "normal")
             if prio_want == "low":
                 self._side, prio = rccl_comm.low_priority_stream(dev)

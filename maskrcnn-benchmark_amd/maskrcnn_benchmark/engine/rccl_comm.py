@@ -44,6 +44,16 @@ def _load():
     return lib
 
 
+def available():
+    """Can this process call RCCL directly?  (library present, the entry points resolve.)  Checked on every rank BEFORE the
+    collective `ncclCommInitRank`, so that a rank that cannot must not leave the others waiting inside it."""
+    try:
+        lib = _load()
+        return all(hasattr(lib, n) for n in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy"))
+    except OSError:
+        return False
+
+
 def low_priority_stream(device):
     """A HIP stream of the LOWEST priority the device offers (torch.cuda.Stream(priority=) only reaches 'normal' and
     above): the command processor serves the main stream's dispatches first, so the side stream's all-reduce and update
