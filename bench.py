@@ -46,7 +46,9 @@ def parse():
     ap.add_argument("--images-per-gpu", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--channels-last", action="store_true",
+                    help="backbone + FPN on channels-last (NHWC) activations (GeneralizedRCNN.set_channels_last)")
+    ap.add_argument("--channels-last-heads", action="store_true", help="... and the RPN / ROI heads take the NHWC pyramid")
     ap.add_argument("--force-ddp", action="store_true",
                     help="N = 1 only: wrap the model in DDP over a 1-rank RCCL group so the overlapped-SGD hook "
                          "(bucket all-reduce -> update in the completion callback on a side stream) is what runs")
@@ -81,6 +83,10 @@ def setup_miopen_db(export_dir=None):
     if export_dir:
         os.makedirs(os.path.join(export_dir, "db"), exist_ok=True)
         os.makedirs(os.path.join(export_dir, "cache"), exist_ok=True)
+        seed = os.path.join(ROOT, "maskrcnn-benchmark_amd", "miopen_db")
+        if os.path.isdir(os.path.join(seed, "db")) and not os.listdir(os.path.join(export_dir, "db")):
+            # start from the shipped database: only problem keys it does not hold yet are searched
+            shutil.copytree(seed, export_dir, dirs_exist_ok=True)
         os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(export_dir, "db")
         os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = os.path.join(export_dir, "cache")
         return "export:" + export_dir
@@ -516,8 +522,8 @@ def main():
     model, optimizer, scheduler, step = build_training(cfg, device, distributed, local_rank,
                                                        force_ddp=args.force_ddp and not distributed,
                                                        bucket_cap_mb=args.bucket_mb)
-    if args.channels_last:
-        model.to(memory_format=torch.channels_last)
+    if args.channels_last or args.channels_last_heads:
+        getattr(model, "module", model).set_channels_last(True, heads=args.channels_last_heads)
     batches = make_device_batches(cfg, device, images_per_gpu=args.images_per_gpu, num_batches=2, seed=rank)
     feat_bytes = 0
     H, W = batches[0][0].tensors.shape[-2:]

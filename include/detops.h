@@ -499,6 +499,16 @@ int detops_frozen_bn_act_backward(const void* grad_y, const void* y, const float
                                   void* grad_x, void* grad_residual, int dtype, int N, int C,
                                   int HW, int relu, detops_stream_t stream);
 
+/* The same pair for channels-last activations ([rows = N*H*W, C], the channel the fastest index — what MIOpen's NHWC
+ * convolution kernels read and write without a layout transpose): same arithmetic, same rounding. */
+int detops_frozen_bn_act_forward_nhwc(const void* x, const float* scale, const float* bias,
+                                      const void* residual, void* y, int dtype, int64_t rows, int C,
+                                      int relu, detops_stream_t stream);
+
+int detops_frozen_bn_act_backward_nhwc(const void* grad_y, const void* y, const float* scale,
+                                       void* grad_x, void* grad_residual, int dtype, int64_t rows, int C,
+                                       int relu, detops_stream_t stream);
+
 /* RPN loss in one pass over the head outputs (reference modeling/rpn/loss.py:92-127 with
  * modeling/box_coder.py:27-51 and modeling/rpn/utils.py:9-45): objectness = BCE-with-logits over the sampled
  * anchors, box = smooth-L1(beta) against BoxCoder.encode(matched gt, anchor) over the sampled positives, both
@@ -595,6 +605,11 @@ int detops_fpn_topdown_forward(const void* lateral, const void* top, void* out, 
                                detops_stream_t stream);
 int detops_fpn_topdown_backward(const void* grad_out, void* grad_top, int dtype, int planes, int H, int W, int h, int w,
                                 detops_stream_t stream);
+/* channels-last form: lateral / out / grad_out [N, H, W, C], top / grad_top [N, h, w, C] */
+int detops_fpn_topdown_forward_nhwc(const void* lateral, const void* top, void* out, int dtype, int N, int C, int H, int W,
+                                    int h, int w, detops_stream_t stream);
+int detops_fpn_topdown_backward_nhwc(const void* grad_out, void* grad_top, int dtype, int N, int C, int H, int W, int h, int w,
+                                     detops_stream_t stream);
 
 #ifdef __cplusplus
 } /* extern "C" */

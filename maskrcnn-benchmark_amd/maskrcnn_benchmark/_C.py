@@ -250,30 +250,43 @@ def nms_batched_mask(boxes, scores, seg_offsets, max_n, threshold):
 
 # ------------------------------------------------------------------------------------------ FPN top-down step
 class _UpsampleAdd(torch.autograd.Function):
-    """lateral + nearest_upsample(top) in one pass (csrc/fpn_topdown.hip; reference modeling/backbone/fpn.py:59-64)."""
+    """lateral + nearest_upsample(top) in one pass (csrc/fpn_topdown.hip; reference modeling/backbone/fpn.py:59-64).
+    A channels-last lateral selects the NHWC kernels and returns channels-last tensors in both directions."""
 
     @staticmethod
     def forward(ctx, lateral, top):
-        lateral, top = lateral.contiguous(), top.contiguous()
+        nhwc = is_channels_last(lateral)
+        fmt = torch.channels_last if nhwc else torch.contiguous_format
+        lateral, top = lateral.contiguous(memory_format=fmt), top.contiguous(memory_format=fmt)
         N, C, H, W = lateral.shape
         h, w = int(top.shape[2]), int(top.shape[3])
         out = torch.empty_like(lateral)
         with _on_device(lateral), _timed(("fpn_topdown_fwd[n=%d,e=%d]", (lateral.numel(), _ESIZE[lateral.dtype])), lateral):
-            check(lib.detops_fpn_topdown_forward(ptr(lateral), ptr(top), ptr(out), _lib.DTYPE_CODE[lateral.dtype], N * C, H, W, h, w,
-                                                 stream_of(lateral)), "fpn_topdown_forward")
+            if nhwc:
+                check(lib.detops_fpn_topdown_forward_nhwc(ptr(lateral), ptr(top), ptr(out), _lib.DTYPE_CODE[lateral.dtype], N, C, H, W,
+                                                          h, w, stream_of(lateral)), "fpn_topdown_forward_nhwc")
+            else:
+                check(lib.detops_fpn_topdown_forward(ptr(lateral), ptr(top), ptr(out), _lib.DTYPE_CODE[lateral.dtype], N * C, H, W, h, w,
+                                                     stream_of(lateral)), "fpn_topdown_forward")
         ctx.shape = (N, C, H, W, h, w)
+        ctx.nhwc = nhwc
         return out
 
     @staticmethod
     def backward(ctx, g):
         N, C, H, W, h, w = ctx.shape
-        g = g.contiguous()
+        fmt = torch.channels_last if ctx.nhwc else torch.contiguous_format
+        g = g.contiguous(memory_format=fmt)
         gtop = None
         if ctx.needs_input_grad[1]:
-            gtop = torch.empty((N, C, h, w), dtype=g.dtype, device=g.device)
+            gtop = torch.empty((N, C, h, w), dtype=g.dtype, device=g.device, memory_format=fmt)
             with _on_device(g), _timed(("fpn_topdown_bwd[n=%d,e=%d]", (g.numel(), _ESIZE[g.dtype])), g):
-                check(lib.detops_fpn_topdown_backward(ptr(g), ptr(gtop), _lib.DTYPE_CODE[g.dtype], N * C, H, W, h, w, stream_of(g)),
-                      "fpn_topdown_backward")
+                if ctx.nhwc:
+                    check(lib.detops_fpn_topdown_backward_nhwc(ptr(g), ptr(gtop), _lib.DTYPE_CODE[g.dtype], N, C, H, W, h, w,
+                                                               stream_of(g)), "fpn_topdown_backward_nhwc")
+                else:
+                    check(lib.detops_fpn_topdown_backward(ptr(g), ptr(gtop), _lib.DTYPE_CODE[g.dtype], N * C, H, W, h, w, stream_of(g)),
+                          "fpn_topdown_backward")
         return (g if ctx.needs_input_grad[0] else None), gtop
 
 
@@ -972,38 +985,59 @@ def sigmoid_focalloss_backward_scalar(logits, targets, d_loss, num_classes, gamm
 
 
 # ------------------------------------------------------------------------------------------ frozen BN
+def is_channels_last(t):
+    """4-d tensor stored NHWC (and not at the same time plain-contiguous, e.g. C == 1 or H == W == 1)"""
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
+
+
 def frozen_bn_act_forward(x, scale, bias, residual, relu):
-    """Extension: y = [relu](x * scale[c] + bias[c] [+ residual]) in one pass (NCHW contiguous)."""
+    """Extension: y = [relu](x * scale[c] + bias[c] [+ residual]) in one pass.  NCHW-contiguous input -> NCHW output; a
+    channels-last (NHWC) input is processed in place of its layout and returns a channels-last output (no transpose)."""
     _need_cuda("frozen_bn_act_forward", x, scale, bias, residual)
     code = _lib.DTYPE_CODE[x.dtype]
-    x = x.contiguous()
+    nhwc = is_channels_last(x)
+    if not nhwc:
+        x = x.contiguous()
     if residual is not None:
-        residual = residual.contiguous()
         if residual.dtype != x.dtype or residual.shape != x.shape:
             raise RuntimeError("frozen_bn_act_forward: residual must match x")
+        residual = residual.contiguous(memory_format=torch.channels_last) if nhwc else residual.contiguous()
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // max(N * C, 1)
-    y = torch.empty_like(x)
+    y = torch.empty_like(x)      # preserves the memory format
     with _on_device(x), _timed(("frozen_bn_fwd[n=%d,nc=%d,e=%d,res=%d]", (x.numel(), N * C, _ESIZE[x.dtype], residual is not None)), x, every=8):
-        check(lib.detops_frozen_bn_act_forward(ptr(x), ptr(scale), ptr(bias), ptr(residual), ptr(y), code, N, C, HW,
-                                               int(bool(relu)), stream_of(x)), "frozen_bn_act_forward")
+        if nhwc:
+            check(lib.detops_frozen_bn_act_forward_nhwc(ptr(x), ptr(scale), ptr(bias), ptr(residual), ptr(y), code, N * HW, C,
+                                                        int(bool(relu)), stream_of(x)), "frozen_bn_act_forward_nhwc")
+        else:
+            check(lib.detops_frozen_bn_act_forward(ptr(x), ptr(scale), ptr(bias), ptr(residual), ptr(y), code, N, C, HW,
+                                                   int(bool(relu)), stream_of(x)), "frozen_bn_act_forward")
     return y
 
 
 def frozen_bn_act_backward(grad_y, y, scale, relu, need_residual):
-    """Extension: (grad_x, grad_residual or None) of frozen_bn_act_forward."""
+    """Extension: (grad_x, grad_residual or None) of frozen_bn_act_forward.  The layout follows the saved output `y` when
+    there is one (ReLU), otherwise the incoming gradient's."""
     _need_cuda("frozen_bn_act_backward", grad_y, scale)
     code = _lib.DTYPE_CODE[grad_y.dtype]
-    grad_y = grad_y.contiguous()
+    nhwc = is_channels_last(y) if (relu and y is not None) else is_channels_last(grad_y)
+    grad_y = grad_y.contiguous(memory_format=torch.channels_last) if nhwc else grad_y.contiguous()
     N, C = grad_y.shape[0], grad_y.shape[1]
     HW = grad_y.numel() // max(N * C, 1)
     gx = torch.empty_like(grad_y)
     gres = torch.empty_like(grad_y) if need_residual else None
     with _on_device(grad_y), _timed(("frozen_bn_bwd[n=%d,nc=%d,e=%d,res=%d,relu=%d]", (grad_y.numel(), N * C, _ESIZE[grad_y.dtype], bool(need_residual), bool(relu))),
                                      grad_y, every=8):
-        check(lib.detops_frozen_bn_act_backward(ptr(grad_y), ptr(y) if relu else None, ptr(scale), ptr(gx), ptr(gres),
-                                                code, N, C, HW, int(bool(relu)), stream_of(grad_y)),
-              "frozen_bn_act_backward")
+        if nhwc:
+            check(lib.detops_frozen_bn_act_backward_nhwc(ptr(grad_y), ptr(y) if relu else None, ptr(scale), ptr(gx), ptr(gres),
+                                                         code, N * HW, C, int(bool(relu)), stream_of(grad_y)),
+                  "frozen_bn_act_backward_nhwc")
+        else:
+            if relu and y is not None and not y.is_contiguous():
+                y = y.contiguous()
+            check(lib.detops_frozen_bn_act_backward(ptr(grad_y), ptr(y) if relu else None, ptr(scale), ptr(gx), ptr(gres),
+                                                    code, N, C, HW, int(bool(relu)), stream_of(grad_y)),
+                  "frozen_bn_act_backward")
     return gx, gres
 
 

@@ -59,6 +59,8 @@ SIGNATURES = {
     "detops_head_loss_backward_f32": (c_int, [_P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _P]),
     "detops_fpn_topdown_forward": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
     "detops_fpn_topdown_backward": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
+    "detops_fpn_topdown_forward_nhwc": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),
+    "detops_fpn_topdown_backward_nhwc": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
     "detops_pack_max_tensors": (c_int, []),
     "detops_pack_f32": (c_int, [_P, _P, _P, c_int, _P, _P]),
     "detops_sgd_momentum_flat_f32": (c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64] + [c_float] * 5 + [_P]),
@@ -85,6 +87,8 @@ SIGNATURES = {
         c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, c_size_t, _P]),
     "detops_frozen_bn_act_forward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
     "detops_frozen_bn_act_backward": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 5 + [_P]),
+    "detops_frozen_bn_act_forward_nhwc": (c_int, [_P, _P, _P, _P, _P, c_int, ctypes.c_int64, c_int, c_int, _P]),
+    "detops_frozen_bn_act_backward_nhwc": (c_int, [_P, _P, _P, _P, _P, c_int, ctypes.c_int64, c_int, c_int, _P]),
     "detops_deformable_im2col": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),
     "detops_deformable_col2im": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P]),
     "detops_deformable_col2im_workspace_bytes": (c_size_t, [c_int] * 13),

@@ -1,6 +1,7 @@
 """GeneralizedRCNN (reference modeling/detector/generalized_rcnn.py:16-65): backbone -> RPN ->
 ROI heads.  `model(images, targets)` returns a dict of losses in training and a list of BoxLists
 (detections) in eval mode."""
+import torch
 from torch import nn
 
 from maskrcnn_benchmark.structures.image_list import to_image_list
@@ -17,6 +18,22 @@ class GeneralizedRCNN(nn.Module):
         self.backbone = build_backbone(cfg)
         self.rpn = build_rpn(cfg, self.backbone.out_channels)
         self.roi_heads = build_roi_heads(cfg, self.backbone.out_channels)
+        self.channels_last = False          # see set_channels_last
+        self.channels_last_heads = False
+
+    def set_channels_last(self, on=True, heads=False):
+        """Run the backbone + FPN on channels-last (NHWC) activations: MIOpen's implicit-GEMM kernels then read and write
+        their native layout (no `batched_transpose_*` launches around them) and the fused FrozenBN / top-down kernels
+        follow the tensor's layout.  `heads=False`: the pyramid is handed to the RPN / ROI heads as NCHW (one conversion
+        per level); `heads=True`: the heads take the channels-last pyramid as it is.  Parameters, buffers and the
+        state_dict are untouched (a memory format is a stride permutation, not a shape)."""
+        fmt = torch.channels_last if on else torch.contiguous_format
+        self.backbone.to(memory_format=fmt)
+        if heads and on:
+            self.rpn.to(memory_format=fmt)
+        self.channels_last = bool(on)
+        self.channels_last_heads = bool(on and heads)
+        return self
 
     def forward(self, images, targets=None):
         if self.training and targets is None:
@@ -24,7 +41,12 @@ class GeneralizedRCNN(nn.Module):
         begin_step()   # the padded-target batch is shared by the callers of ONE forward, never across forwards
         try:
             images = to_image_list(images)
-            features = self.backbone(images.tensors)
+            x = images.tensors
+            if self.channels_last:
+                x = x.contiguous(memory_format=torch.channels_last)
+            features = self.backbone(x)
+            if self.channels_last and not self.channels_last_heads:
+                features = tuple(f.contiguous() for f in features)
             proposals, proposal_losses = self.rpn(images, features, targets)
             if self.roi_heads:
                 x, result, detector_losses = self.roi_heads(features, proposals, targets)

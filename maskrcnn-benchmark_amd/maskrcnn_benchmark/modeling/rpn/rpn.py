@@ -44,8 +44,10 @@ class RPNHead(nn.Module):
         logits, bbox_reg = [], []
         for feature in x:
             t = F.relu(self.conv(feature))
-            logits.append(self.cls_logits(t))
-            bbox_reg.append(self.bbox_pred(t))
+            # the proposal / loss kernels read the A and 4A-channel outputs in NCHW; under a channels-last pyramid these two
+            # small tensors are the only ones converted (a no-op for NCHW features)
+            logits.append(self.cls_logits(t).contiguous())
+            bbox_reg.append(self.bbox_pred(t).contiguous())
         return logits, bbox_reg
 
 

@@ -143,6 +143,64 @@ def test_fpn_topdown_equals_interpolate_plus_add(dtype, tol, shape):
     assert torch.allclose(top.grad.float(), top2.grad, rtol=tol, atol=tol * 4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [((2, 8, 10, 16), (5, 8)), ((1, 12, 7, 9), (4, 5)), ((2, 4, 13, 21), (7, 11)), ((1, 6, 6, 6), (6, 6))])
+def test_fpn_topdown_channels_last_is_bit_equal_to_the_nchw_kernels(dtype, shape):
+    """a channels-last lateral takes the NHWC kernels (detops_fpn_topdown_*_nhwc) and returns channels-last tensors; values and
+    both gradients are bit-equal to the NCHW kernels' (same arithmetic, same summation order)"""
+    from maskrcnn_benchmark import _C
+    (N, C, H, W), (h, w) = shape
+    g = torch.Generator().manual_seed(H * W + h + C)
+    lat = torch.randn(N, C, H, W, generator=g).to(dtype)
+    top = torch.randn(N, C, h, w, generator=g).to(dtype)
+    up = torch.randn(N, C, H, W, generator=g).to(dtype)
+    a, b = lat.clone().requires_grad_(), top.clone().requires_grad_()
+    ref = _C.fpn_topdown(a, b)
+    ref.backward(up)
+    cl = torch.channels_last
+    a2, b2 = lat.contiguous(memory_format=cl).requires_grad_(), top.contiguous(memory_format=cl).requires_grad_()
+    out = _C.fpn_topdown(a2, b2)
+    assert _C.is_channels_last(out)
+    out.backward(up.contiguous(memory_format=cl))
+    assert torch.equal(out, ref)
+    assert torch.equal(a2.grad, a.grad) and torch.equal(b2.grad, b.grad)
+    assert _C.is_channels_last(b2.grad) or b2.grad.is_contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C,H,W", [(8, 9, 11), (12, 5, 7), (64, 6, 10), (3, 4, 5), (2048, 2, 3)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True), (False, True)])
+def test_frozen_bn_channels_last_is_bit_equal_to_the_nchw_kernels(dtype, C, H, W, relu, res):
+    """FrozenBatchNorm2d.fused on a channels-last activation: NHWC kernels, channels-last output and gradients, bit-equal to the
+    NCHW kernels (vector widths 1-8, channel counts that are / are not powers of two, C larger than a block's span)"""
+    from maskrcnn_benchmark import _C
+    from maskrcnn_benchmark.layers import FrozenBatchNorm2d
+    rng = np.random.RandomState(C + H)
+    bn = FrozenBatchNorm2d(C)
+    bn.weight.copy_(_t(rng.rand(C).astype(np.float32) + 0.5))
+    bn.bias.copy_(_t(rng.randn(C).astype(np.float32)))
+    bn.running_mean.copy_(_t(rng.randn(C).astype(np.float32)))
+    bn.running_var.copy_(_t(rng.rand(C).astype(np.float32) + 0.2))
+    x = _t(rng.randn(2, C, H, W).astype(np.float32)).to(dtype)
+    r = _t(rng.randn(2, C, H, W).astype(np.float32)).to(dtype) if res else None
+    gy = _t(rng.randn(2, C, H, W).astype(np.float32)).to(dtype)
+    cl = torch.channels_last
+
+    def run(fmt):
+        xi = x.clone(memory_format=fmt).requires_grad_()
+        ri = r.clone(memory_format=fmt).requires_grad_() if res else None
+        y = bn.fused(xi, relu=relu, residual=ri)
+        y.backward(gy.contiguous(memory_format=fmt))
+        return y, xi.grad, (ri.grad if res else None)
+
+    y0, gx0, gr0 = run(torch.contiguous_format)
+    y1, gx1, gr1 = run(cl)
+    assert _C.is_channels_last(y1) and _C.is_channels_last(gx1)
+    assert torch.equal(y1, y0) and torch.equal(gx1, gx0)
+    if res:
+        assert torch.equal(gr1, gr0)
+
+
 def test_fpn_module_uses_the_fused_topdown_step_and_equals_the_composition(monkeypatch):
     from maskrcnn_benchmark import _C
     from maskrcnn_benchmark.modeling.backbone import fpn as fpn_mod
@@ -239,6 +297,47 @@ def test_detector_trains_and_detects_through_the_product_wrappers(config):
         assert torch.allclose(d.bbox[ds_[1][:k]], r.bbox[rs_[1][:k]], rtol=1e-3, atol=5e-2)
         if cfg.MODEL.MASK_ON:
             assert d.has_field("mask") and d.get_field("mask").shape[0] == len(d)
+
+
+@pytest.mark.parametrize("heads", [False, True])
+def test_detector_on_a_channels_last_pyramid_equals_the_nchw_run(heads):
+    """GeneralizedRCNN.set_channels_last: backbone + FPN on NHWC activations (the fused FrozenBN / top-down kernels follow
+    the layout), the pyramid handed over as NCHW (heads=False) or as it is (heads=True).  A memory format changes no value:
+    losses and parameter gradients of one training forward / backward equal the NCHW run's (CPU convolutions may pick another
+    summation order per layout: 1e-4)."""
+    from maskrcnn_benchmark.data.synthetic import BatchCollator, SyntheticCOCODataset
+    from maskrcnn_benchmark.engine.bench_step import load_cfg
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    cfg = load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml",
+                   ["MODEL.DEVICE", "cpu", "MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 100, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 150,
+                    "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 512, "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 100000,
+                    "MODEL.RESNETS.RES2_OUT_CHANNELS", 16,
+                    "MODEL.RESNETS.WIDTH_PER_GROUP", 4, "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 16,
+                    "MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM", 32, "MODEL.ROI_MASK_HEAD.CONV_LAYERS", (16, 16)])
+    torch.manual_seed(0)
+    model = build_detection_model(cfg).train()
+    ds = SyntheticCOCODataset(length=2, height=96, width=128, with_masks=True, min_objects=2, max_objects=4)
+    images, targets, _ = BatchCollator(32)([ds[0], ds[1]])
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(5)       # the samplers' keys (quotas >= candidates: take-all, but keep the streams equal anyway)
+        losses = model(images, list(targets))
+        sum(losses.values()).backward()
+        return ({k: float(v.detach()) for k, v in losses.items()},
+                {n: p.grad.detach().clone().contiguous() for n, p in model.named_parameters() if p.grad is not None})
+
+    l0, g0 = run()
+    keys = list(model.state_dict().keys())
+    model.set_channels_last(True, heads=heads)
+    assert list(model.state_dict().keys()) == keys
+    l1, g1 = run()
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-4 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        assert torch.allclose(g0[n], g1[n], rtol=1e-3, atol=1e-5), n
 
 
 def test_roi_pool_and_deformable_psroi_pooling_layers_equal_the_oracle():
