@@ -25,11 +25,35 @@ def load_cfg(config_file, opts=()):
     return cfg
 
 
-def build_training(cfg, device, distributed=False, local_rank=0, overlap_optimizer=True, force_ddp=False, bucket_cap_mb=None):
+def choose_layout(cfg, device, layout="auto"):
+    """-> "nchw" | "backbone" | "all": which part of the detector runs on channels-last (NHWC) activations
+    (GeneralizedRCNN.set_channels_last).  "auto" (overridable with DETOPS_LAYOUT): channels-last on the GPU for the fp32
+    FPN detectors without deformable convolutions — the configurations it was measured on, with the tuned MIOpen find-db
+    for the NHWC problem keys that ships in-tree (profiles/r06a_*: 37.6 -> 35.8 ms per step for e2e_mask_rcnn_R_50_FPN_1x
+    with the backbone alone); NCHW everywhere else (CPU, half precision, DCN stages: not measured / slower)."""
+    layout = os.environ.get("DETOPS_LAYOUT", layout) if layout == "auto" else layout
+    if layout in ("nchw", "backbone", "all"):
+        return layout
+    if layout != "auto":
+        raise ValueError("layout must be auto | nchw | backbone | all, got %r" % (layout,))
+    ok = (torch.device(device).type == "cuda" and cfg.DTYPE == "float32" and "FPN" in cfg.MODEL.BACKBONE.CONV_BODY
+          and not any(cfg.MODEL.RESNETS.STAGE_WITH_DCN) and cfg.MODEL.META_ARCHITECTURE == "GeneralizedRCNN")
+    return AUTO_LAYOUT if ok else "nchw"
+
+
+AUTO_LAYOUT = "backbone"
+
+
+def build_training(cfg, device, distributed=False, local_rank=0, overlap_optimizer=True, force_ddp=False, bucket_cap_mb=None,
+                   layout="auto"):
     """-> (model (DDP-wrapped when distributed), optimizer, scheduler, TrainStep).  `force_ddp` wraps
-    even at world size 1 (the process group must exist)."""
+    even at world size 1 (the process group must exist).  `layout`: see choose_layout."""
     model = build_detection_model(cfg).to(device)
     model.train()
+    layout = choose_layout(cfg, device, layout)
+    if layout != "nchw":
+        model.set_channels_last(True, heads=layout == "all")
+    model.layout = layout
     optimizer = make_overlapped_sgd(cfg, model)
     scheduler = make_lr_scheduler(cfg, optimizer)
     fp16 = cfg.DTYPE == "float16"

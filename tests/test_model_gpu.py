@@ -370,3 +370,139 @@ def test_pooler_backward_prepared_at_forward_time_equals_one_call_backward(monke
     out = roi_align_fpn(feats, rois_box, (7, 7), scales, 2, 2, 5)
     assert out.grad_fn.prepared is None
     torch.autograd.grad(out, feats, torch.ones_like(out))
+
+
+# ------------------------------------------------------------------ eval post-processing on the device
+def _canon_det(r):
+    """BoxList -> (boxes, scores, labels) in a canonical order (label, then score descending, then box)"""
+    b = r.bbox.detach().cpu().numpy()
+    s = r.get_field("scores").detach().cpu().numpy()
+    l = r.get_field("labels").detach().cpu().numpy()
+    order = np.lexsort((b[:, 3], b[:, 2], b[:, 1], b[:, 0], -s, l))
+    return b[order], s[order], l[order]
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_box_head_postprocessor_on_the_device_equals_the_reference_fixture(tag):
+    """PostProcessor.forward / filter_results (reference roi_heads/box_head/inference.py:42-149) ON THE MI355X — per-class NMS
+    as one segmented launch of the HIP kernel — against tests/golden/model_postprocess.npz, which the REFERENCE's own
+    PostProcessor produced (tests/golden/make_golden_model.py): labels bit-exact, scores <= 1e-6."""
+    from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.inference import PostProcessor
+    from maskrcnn_benchmark.structures.bounding_box import BoxList
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_postprocess.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(_dev())  # noqa: E731
+    thr, nms, dets = g["box_%s_cfg" % tag]
+    pp = PostProcessor(float(thr), float(nms), int(dets), BoxCoder((10., 10., 5., 5.)))
+    sizes = [tuple(int(v) for v in s) for s in g["box_sizes"]]
+    props = [BoxList(t(g["box_props_%d" % i]), sizes[i], mode="xyxy") for i in range(2)]
+    res = pp((t(g["box_logits"]), t(g["box_reg"])), props)
+    assert all(r.bbox.is_cuda for r in res)
+    for i, r in enumerate(res):
+        b, s, l = _canon_det(r)
+        wb, ws, wl = g["box_%s_boxes_%d" % (tag, i)], g["box_%s_scores_%d" % (tag, i)], g["box_%s_labels_%d" % (tag, i)]
+        order = np.lexsort((wb[:, 3], wb[:, 2], wb[:, 1], wb[:, 0], -ws, wl))
+        np.testing.assert_array_equal(l, wl[order])
+        np.testing.assert_allclose(s, ws[order], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(b, wb[order], rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_retinanet_postprocessor_on_the_device_equals_the_reference_fixture(tag):
+    """RetinaNetPostProcessor.forward (reference rpn/retinanet/inference.py:64-173) on the device against the fixture the
+    reference's own module produced: labels bit-exact, scores <= 1e-6."""
+    from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+    from maskrcnn_benchmark.modeling.rpn.anchor_generator import AnchorGenerator
+    from maskrcnn_benchmark.modeling.rpn.retinanet.inference import RetinaNetPostProcessor
+    from maskrcnn_benchmark.structures.image_list import ImageList
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_postprocess.npz"))
+    dev = _dev()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    H, W = (int(v) for v in g["ret_canvas"])
+    sz = tuple(tuple(s * 2 ** (k / 3.0) for k in range(3)) for s in (32, 64, 128))
+    ag = AnchorGenerator(sizes=sz, aspect_ratios=(0.5, 1.0, 2.0), anchor_strides=(8, 16, 32), straddle_thresh=-1).to(dev)
+    feats = [torch.zeros(2, 1, H // s, W // s, device=dev) for s in (8, 16, 32)]
+    il = ImageList(torch.zeros(2, 3, H, W, device=dev), [tuple(int(v) for v in s) for s in g["ret_image_sizes"]])
+    anchors = ag(il, feats)
+    thr, topn, nms, post = g["ret_%s_cfg" % tag]
+    pp = RetinaNetPostProcessor(float(thr), int(topn), float(nms), int(post), 0, 6, BoxCoder((10., 10., 5., 5.)))
+    res = pp(anchors, [t(g["ret_cls_%d" % l]) for l in range(3)], [t(g["ret_reg_%d" % l]) for l in range(3)])
+    for i, r in enumerate(res):
+        b, s, l = _canon_det(r)
+        wb, ws, wl = g["ret_%s_boxes_%d" % (tag, i)], g["ret_%s_scores_%d" % (tag, i)], g["ret_%s_labels_%d" % (tag, i)]
+        order = np.lexsort((wb[:, 3], wb[:, 2], wb[:, 1], wb[:, 0], -ws, wl))
+        np.testing.assert_array_equal(l, wl[order])
+        np.testing.assert_allclose(s, ws[order], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(b, wb[order], rtol=1e-5, atol=1e-3)
+
+
+def test_box_head_postprocessor_at_model_size_equals_per_class_oracle_nms():
+    """filter_results at the model's own size (1000 proposals x 81 classes = 80 NMS problems in one segmented launch):
+    the kept (proposal, class) INDEX SET equals a per-class loop over the CPU oracle's NMS (reference
+    roi_heads/box_head/inference.py:118-137 with csrc/cpu/nms_cpu.cpp semantics) bit-exactly, scores <= 1e-6."""
+    from maskrcnn_benchmark.modeling.box_coder import BoxCoder
+    from maskrcnn_benchmark.modeling.roi_heads.box_head.inference import PostProcessor
+    rng = np.random.RandomState(3)
+    n, C, W, H = 1000, 81, 1333, 800
+    ctr = rng.uniform([0, 0], [W, H], (n, 1, 2))
+    wh = rng.uniform(8, 300, (n, C, 2))
+    jit = rng.normal(0, 6, (n, C, 2))
+    boxes = np.concatenate([ctr + jit - wh / 2, ctr + jit + wh / 2], axis=2).astype(np.float32)      # [n, C, 4]
+    logits = rng.normal(0, 2.5, (n, C)).astype(np.float32)
+    scores = np.exp(logits - logits.max(1, keepdims=True))
+    scores = (scores / scores.sum(1, keepdims=True)).astype(np.float32)
+    pp = PostProcessor(0.05, 0.5, 100, BoxCoder((10., 10., 5., 5.)))
+    out = pp.filter_results(torch.from_numpy(boxes.reshape(n, C * 4)).to(_dev()), torch.from_numpy(scores).to(_dev()), (W, H))
+    # reference loop on the host
+    clipped = boxes.copy()
+    clipped[..., 0::2] = np.clip(clipped[..., 0::2], 0, W - 1)
+    clipped[..., 1::2] = np.clip(clipped[..., 1::2], 0, H - 1)
+    det = []
+    for c in range(1, C):
+        idx = np.nonzero(scores[:, c] > 0.05)[0]
+        if idx.size == 0:
+            continue
+        keep = oracle.nms(clipped[idx, c], scores[idx, c], 0.5)
+        det += [(float(scores[idx[k], c]), c, int(idx[k])) for k in keep]
+    det.sort(key=lambda d: -d[0])
+    if len(det) > 100:
+        thr = det[99][0]
+        det = [d for d in det if d[0] >= thr]
+    want = sorted((c, i) for _, c, i in det)
+    got_l = out.get_field("labels").cpu().numpy()
+    got_b = out.bbox.cpu().numpy()
+    got_s = out.get_field("scores").cpu().numpy()
+    assert len(got_l) == len(want)
+    # recover the proposal index of every detection from its (unique) clipped box
+    got = []
+    for b, l, s in zip(got_b, got_l, got_s):
+        i = np.nonzero((clipped[:, l] == b).all(1))[0]
+        assert i.size >= 1
+        got.append((int(l), int(i[0])))
+        assert abs(float(scores[i[0], l]) - float(s)) <= 1e-6
+    assert sorted(got) == want
+
+
+@pytest.mark.parametrize("config", ["e2e_mask_rcnn_R_50_FPN_1x.yaml", "retinanet/retinanet_R-50-FPN_1x.yaml"])
+def test_eval_forward_on_the_device_returns_finite_detections(config):
+    """eval-mode forward of the whole detector on the device (backbone -> RPN test-time selection -> box head PostProcessor ->
+    mask head post-processing / RetinaNetPostProcessor): per image a BoxList with scores, labels (and masks), all finite,
+    scores sorted into (0, 1], boxes inside the image"""
+    from maskrcnn_benchmark.engine.bench_step import load_cfg, make_device_batches
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    cfg = load_cfg(config, ["MODEL.ROI_HEADS.SCORE_THRESH", 0.0, "MODEL.RETINANET.INFERENCE_TH", 0.0])
+    torch.manual_seed(0)
+    model = build_detection_model(cfg).to(_dev()).eval()
+    (images, _), = make_device_batches(cfg, _dev(), images_per_gpu=2, num_batches=1, height=256, width=320)
+    with torch.no_grad():
+        det = model(images)
+    assert len(det) == 2
+    for d in det:
+        assert d.bbox.is_cuda and len(d) > 0
+        s = d.get_field("scores")
+        assert torch.isfinite(d.bbox).all() and torch.isfinite(s).all() and (s > 0).all() and (s <= 1).all()
+        assert d.get_field("labels").min() >= 1
+        W, H = d.size
+        assert (d.bbox[:, 0::2] <= W - 1 + 1e-3).all() and (d.bbox[:, 1::2] <= H - 1 + 1e-3).all() and (d.bbox >= 0).all()
+        if cfg.MODEL.MASK_ON:
+            assert d.get_field("mask").shape[0] == len(d)
