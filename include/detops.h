@@ -167,6 +167,35 @@ int detops_roi_align_fpn_backward_f32(const float* grad_out, const float* rois,
                                       int zero_grad_in, detops_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ROIAlign over a CHANNELS-LAST pyramid (csrc/roi_align_nhwc.hip) — the same operator as above (reference
+ * csrc/cuda/ROIAlign_cuda.cu:64-122 forward, :125-254 backward, modeling/poolers.py:91-121) for feature maps stored
+ * [N, H[l], W[l], C] (what MIOpen's implicit-GEMM convolutions read and write natively: a detector whose backbone runs
+ * channels-last needs no layout transposes around its pooler).  num_levels == 1 is the single-map operator.
+ *   forward : inputs[l] NHWC; output [K, C, PH, PW] (output_nhwc = 0) or [K, PH, PW, C] (output_nhwc = 1).  Reference
+ *             operation order with FP contraction off: bit-identical to the reference CPU kernel (and to the NCHW
+ *             kernels above) for finite inputs.  workspace (detops_roi_align_fpn_forward_nhwc_workspace_bytes(K) bytes,
+ *             may be NULL): the ROI visiting order (L2 locality only; the output does not depend on it).
+ *   backward: grad_out [K, C, PH, PW] (grad_out_nhwc = 0) or [K, PH, PW, C] (1); grad_inputs[l] NHWC, every element
+ *             written exactly once (zero_grad_in = 1) or added to (0); atomic-free, bit-reproducible run to run;
+ *             `levels` = the forward's levels_out (required when num_levels > 1); workspace REQUIRED
+ *             (detops_roi_align_fpn_backward_nhwc_workspace_bytes: per-ROI adjoint rows + per-tile hit lists).
+ * ---------------------------------------------------------------------------------------- */
+size_t detops_roi_align_fpn_forward_nhwc_workspace_bytes(int K);
+int detops_roi_align_fpn_forward_nhwc_f32(const float* const* inputs_host, const int* H_host, const int* W_host,
+                                          const float* scale_host, int num_levels, const float* rois, float* output,
+                                          int output_nhwc, int32_t* levels_out, int N, int C, int K, int PH, int PW,
+                                          int sampling_ratio, int k_min, int k_max, float canonical_scale,
+                                          float canonical_level, float eps, void* workspace, size_t workspace_bytes,
+                                          detops_stream_t stream);
+size_t detops_roi_align_fpn_backward_nhwc_workspace_bytes(const int* H_host, const int* W_host, int num_levels, int N,
+                                                          int C, int K, int PH, int PW);
+int detops_roi_align_fpn_backward_nhwc_f32(const float* grad_out, int grad_out_nhwc, const float* rois,
+                                           const int32_t* levels, float* const* grad_inputs_host, const int* H_host,
+                                           const int* W_host, const float* scale_host, int num_levels, int N, int C,
+                                           int K, int PH, int PW, int sampling_ratio, int zero_grad_in, void* workspace,
+                                           size_t workspace_bytes, detops_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * ROIPool — replaces _C.roi_pool_forward / _C.roi_pool_backward
  *   reference: csrc/ROIPool.h:11-45, csrc/cuda/ROIPool_cuda.cu:16-108 (CUDA-only there).
  *   argmax [K,C,PH,PW] int32: index h*W+w inside the channel plane, -1 for an empty bin.

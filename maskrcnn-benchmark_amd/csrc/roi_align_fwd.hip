@@ -110,55 +110,6 @@ roi_align_fwd_kernel(Levels L, const float* __restrict__ rois, const int32_t* __
 // ------------------------------------------------------------------------------------------
 constexpr int kFwdDmaWps = 5;  // waves per SIMD the register budget must allow (no staging registers)
 
-constexpr int kOrderMaxK = 4096;
-constexpr int kOrderMinK = 384;
-constexpr int kOrderLanes = 16;     // lanes that share one ROI's count
-constexpr int kOrderBlock = 1024;   // 16 waves: enough to hide the LDS read latency of the count loop
-
-__device__ __forceinline__ unsigned long long roi_order_key(const Levels& L, const float* __restrict__ rois,
-                                                            const int32_t* __restrict__ levels_in, int i) {
-  const float* roi = rois + static_cast<size_t>(i) * 5;
-  int lvl = 0;
-  if (L.num > 1) lvl = levels_in ? levels_in[i] : fpn_level(roi, L);
-  float scale = L.lv[0].scale;
-#pragma unroll
-  for (int l = 1; l < DETOPS_MAX_LEVELS; ++l)
-    if (l == lvl) scale = L.lv[l].scale;
-  const int b = static_cast<int>(roi[0]);
-  const int xc = static_cast<int>((roi[1] + roi[3]) * 0.5f * scale);
-  const int yc = static_cast<int>((roi[2] + roi[4]) * 0.0625f * scale);
-  const unsigned key = (static_cast<unsigned>(lvl & 7) << 29) | (static_cast<unsigned>(min(max(b, 0), 127)) << 22) |
-                       (static_cast<unsigned>(min(max(yc, 0), 1023)) << 12) | static_cast<unsigned>(min(max(xc, 0), 4095));
-  return (static_cast<unsigned long long>(key) << 32) | static_cast<unsigned>(i);
-}
-
-// Ranking role of the pre-pass (one 1024-thread workgroup per 64 ROIs): see roi_fwd_prep_kernel.
-__device__ __forceinline__ void roi_order_role(const Levels& L, const float* __restrict__ rois,
-                                               const int32_t* __restrict__ levels_in, int K,
-                                               int32_t* __restrict__ order, unsigned long long* keys, int block) {
-  const int tid = threadIdx.x;
-  const int Kp = (K + 2 * kOrderLanes - 1) / (2 * kOrderLanes) * (2 * kOrderLanes);   // padded with +inf keys
-  for (int i = tid; i < Kp; i += kOrderBlock)
-    keys[i] = i < K ? roi_order_key(L, rois, levels_in, i) : ~0ull;
-  __syncthreads();
-  const int r = (block * kOrderBlock + tid) / kOrderLanes;
-  const int sub = tid & (kOrderLanes - 1);
-  int cnt = 0;
-  if (r < K) {
-    const unsigned long long mine = keys[r];
-#pragma unroll 8
-    for (int j = 2 * sub; j < Kp; j += 2 * kOrderLanes) {   // one 16-byte LDS read = two keys; same address across ROIs: broadcast
-      const unsigned long long k0 = keys[j], k1 = keys[j + 1];
-      cnt += (k0 < mine ? 1 : 0) + (k1 < mine ? 1 : 0);
-    }
-  }
-  cnt += __shfl_down(cnt, 8);
-  cnt += __shfl_down(cnt, 4);
-  cnt += __shfl_down(cnt, 2);
-  cnt += __shfl_down(cnt, 1);
-  if (r < K && sub == 0) { order[cnt] = r; DETOPS_STAT("fwd.ranked_rois", 1); }
-}
-
 // Per-ROI sample records of the fast path (workspace): what EVERY channel-chunk workgroup of a ROI used to re-derive
 // (geometry, 2 x PH*SR axis taps by the reference arithmetic, the footprint bounds, per bin 4 patch offsets + 16
 // bilinear weights: ~350 VALU instructions per wave, 8 chunk workgroups per ROI = 40 % of the launch's VALU work)

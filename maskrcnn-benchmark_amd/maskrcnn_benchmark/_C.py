@@ -780,11 +780,22 @@ def _host_arrays(tensors, scales):
     return ptrs, Hs, Ws, sc
 
 
+def _nhwc_host_arrays(tensors, scales):
+    """(pointer array, H array, W array, scale array) of channels-last [N, C, H, W] tensors (stored [N, H, W, C])"""
+    return _host_arrays(tensors, scales)
+
+
 def roi_align_fpn_forward(inputs, rois, scales, pooled_height, pooled_width, sampling_ratio, k_min,
-                          k_max, canonical_scale=224.0, canonical_level=4.0, eps=1e-6):
+                          k_max, canonical_scale=224.0, canonical_level=4.0, eps=1e-6, out_channels_last=False):
     """Multi-level ROIAlign in one launch (extension): the device-side form of
-    modeling/poolers.py:91-121.  Returns (out [K,C,PH,PW], levels int32 [K])."""
+    modeling/poolers.py:91-121.  Returns (out [K,C,PH,PW], levels int32 [K]).
+    A channels-last pyramid (every level stored NHWC) is read in place by the NHWC kernels (csrc/roi_align_nhwc.hip: same
+    values, bit for bit); `out_channels_last` then returns the pooled tensor channels-last as well (for a convolutional
+    head) instead of contiguous (for the box head's FC layer)."""
     _need_cuda("roi_align_fpn_forward", rois, *inputs)
+    if all(is_channels_last(t) for t in inputs) and inputs[0].dtype == torch.float32:
+        return _roi_align_fpn_forward_nhwc(inputs, rois, scales, pooled_height, pooled_width, sampling_ratio, k_min, k_max,
+                                           canonical_scale, canonical_level, eps, out_channels_last)
     inputs = [_f32c("roi_align_fpn_forward", t) for t in inputs]
     rois = _f32c("roi_align_fpn_forward", rois)
     N, C = inputs[0].shape[:2]
@@ -800,6 +811,27 @@ def roi_align_fpn_forward(inputs, rois, scales, pooled_height, pooled_width, sam
             ptrs, Hs, Ws, sc, len(inputs), ptr(rois), ptr(out), ptr(levels), N, C, K, pooled_height,
             pooled_width, int(sampling_ratio), int(k_min), int(k_max), float(canonical_scale),
             float(canonical_level), float(eps), ptr(ws), nbytes, stream_of(rois)), "roi_align_fpn_forward")
+    return out, levels
+
+
+def _roi_align_fpn_forward_nhwc(inputs, rois, scales, pooled_height, pooled_width, sampling_ratio, k_min, k_max,
+                                canonical_scale, canonical_level, eps, out_channels_last):
+    rois = _f32c("roi_align_fpn_forward", rois)
+    N, C = inputs[0].shape[:2]
+    K = rois.size(0)
+    fmt = torch.channels_last if out_channels_last else torch.contiguous_format
+    out = torch.empty((K, C, pooled_height, pooled_width), dtype=torch.float32, device=rois.device, memory_format=fmt)
+    levels = torch.empty((K,), dtype=torch.int32, device=rois.device)
+    if K == 0:
+        return out, levels
+    ptrs, Hs, Ws, sc = _nhwc_host_arrays(inputs, scales)
+    with _on_device(rois), _timed(("roi_align_fpn_fwd[K=%d,C=%d,%dx%d]", (K, C, pooled_height, pooled_width)), rois):
+        nbytes = int(lib.detops_roi_align_fpn_forward_nhwc_workspace_bytes(int(K)))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=rois.device) if nbytes > 0 else None
+        check(lib.detops_roi_align_fpn_forward_nhwc_f32(
+            ptrs, Hs, Ws, sc, len(inputs), ptr(rois), ptr(out), int(bool(out_channels_last)), ptr(levels), N, C, K,
+            pooled_height, pooled_width, int(sampling_ratio), int(k_min), int(k_max), float(canonical_scale),
+            float(canonical_level), float(eps), ptr(ws), nbytes, stream_of(rois)), "roi_align_fpn_forward_nhwc")
     return out, levels
 
 
@@ -851,10 +883,14 @@ def roi_align_fpn_backward_prepare(rois, levels, shapes, scales, pooled_height, 
 
 
 def roi_align_fpn_backward(grad, rois, levels, shapes, scales, pooled_height, pooled_width,
-                           sampling_ratio, prepared=None):
+                           sampling_ratio, prepared=None, channels_last=False):
     """Backward of roi_align_fpn_forward: returns one zero-initialised gradient map per level.  `prepared`: the handle of
-    roi_align_fpn_backward_prepare (the pre-pass already ran): only the main kernel is launched."""
+    roi_align_fpn_backward_prepare (the pre-pass already ran): only the main kernel is launched.  `channels_last`: the
+    forward read a channels-last pyramid — the gradient maps are produced channels-last by the NHWC kernel
+    (csrc/roi_align_nhwc.hip), from a contiguous or a channels-last pooled gradient alike."""
     _need_cuda("roi_align_fpn_backward", grad, rois, levels)
+    if channels_last:
+        return _roi_align_fpn_backward_nhwc(grad, rois, levels, shapes, scales, pooled_height, pooled_width, sampling_ratio)
     grad = _f32c("roi_align_fpn_backward", grad)
     K = rois.size(0)
     gins = [torch.empty(tuple(s), dtype=torch.float32, device=grad.device) for s in shapes]
@@ -875,6 +911,27 @@ def roi_align_fpn_backward(grad, rois, levels, shapes, scales, pooled_height, po
             check(lib.detops_roi_align_fpn_backward_ws_f32(
                 ptr(grad), ptr(rois), ptr(levels), ptrs, Hs, Ws, sc, len(gins), N, C, K, pooled_height,
                 pooled_width, int(sampling_ratio), 1, ptr(ws), nbytes, stream_of(grad)), "roi_align_fpn_backward")
+    return gins
+
+
+def _roi_align_fpn_backward_nhwc(grad, rois, levels, shapes, scales, pooled_height, pooled_width, sampling_ratio):
+    if grad.dtype != torch.float32:
+        raise RuntimeError("roi_align_fpn_backward: expected a float32 gradient, got %s" % grad.dtype)
+    g_nhwc = is_channels_last(grad)
+    if not g_nhwc:
+        grad = grad.contiguous()
+    rois = _f32c("roi_align_fpn_backward", rois)
+    K = rois.size(0)
+    gins = [torch.empty(tuple(s), dtype=torch.float32, device=grad.device, memory_format=torch.channels_last) for s in shapes]
+    N, C = shapes[0][:2]
+    ptrs, Hs, Ws, sc = _nhwc_host_arrays(gins, scales)
+    with _on_device(grad):
+        nbytes = int(lib.detops_roi_align_fpn_backward_nhwc_workspace_bytes(Hs, Ws, len(gins), N, C, K, pooled_height, pooled_width))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=grad.device) if nbytes > 0 else None
+        with _timed(("roi_align_fpn_bwd[K=%d,C=%d,%dx%d]", (K, C, pooled_height, pooled_width)), grad):
+            check(lib.detops_roi_align_fpn_backward_nhwc_f32(
+                ptr(grad), int(g_nhwc), ptr(rois), ptr(levels), ptrs, Hs, Ws, sc, len(gins), N, C, K, pooled_height,
+                pooled_width, int(sampling_ratio), 1, ptr(ws), nbytes, stream_of(grad)), "roi_align_fpn_backward_nhwc")
     return gins
 
 

@@ -57,6 +57,10 @@ SIGNATURES = {
     "detops_mask_loss_workspace_bytes": (c_size_t, [c_int]),
     "detops_mask_loss_f32": (c_int, [_P] * 3 + [c_int] * 3 + [_P] * 3 + [c_size_t, _P]),
     "detops_head_loss_backward_f32": (c_int, [_P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _P]),
+    "detops_roi_align_fpn_forward_nhwc_workspace_bytes": (c_size_t, [c_int]),
+    "detops_roi_align_fpn_forward_nhwc_f32": (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int, _P] + [c_int] * 8 + [c_float] * 3 + [_P, c_size_t, _P]),
+    "detops_roi_align_fpn_backward_nhwc_workspace_bytes": (c_size_t, [_P, _P] + [c_int] * 6),
+    "detops_roi_align_fpn_backward_nhwc_f32": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P, c_size_t, _P]),
     "detops_fpn_topdown_forward": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
     "detops_fpn_topdown_backward": (c_int, [_P, _P] + [c_int] * 6 + [_P]),
     "detops_fpn_topdown_forward_nhwc": (c_int, [_P, _P, _P] + [c_int] * 7 + [_P]),

@@ -25,14 +25,26 @@ class GeneralizedRCNN(nn.Module):
         """Run the backbone + FPN on channels-last (NHWC) activations: MIOpen's implicit-GEMM kernels then read and write
         their native layout (no `batched_transpose_*` launches around them) and the fused FrozenBN / top-down kernels
         follow the tensor's layout.  `heads=False`: the pyramid is handed to the RPN / ROI heads as NCHW (one conversion
-        per level); `heads=True`: the heads take the channels-last pyramid as it is.  Parameters, buffers and the
+        per level).  `heads=True`: the heads take the channels-last pyramid as it is — the RPN head's convolutions run
+        channels-last (its two small outputs are handed to the proposal / loss kernels as NCHW), the poolers read the
+        pyramid in place (csrc/roi_align_nhwc.hip), the box head's pooled tensor stays [K, C, 7, 7] for its FC layers and
+        the mask head (pooler output, convolutions, deconvolution) runs channels-last.  Parameters, buffers and the
         state_dict are untouched (a memory format is a stride permutation, not a shape)."""
         fmt = torch.channels_last if on else torch.contiguous_format
         self.backbone.to(memory_format=fmt)
-        if heads and on:
-            self.rpn.to(memory_format=fmt)
+        heads = bool(on and heads and hasattr(self.rpn, "head") and type(self.rpn).__name__ == "RPNModule")
+        hfmt = torch.channels_last if heads else torch.contiguous_format
+        if type(self.rpn).__name__ == "RPNModule":
+            self.rpn.head.to(memory_format=hfmt)
+        mask = self.roi_heads["mask"] if (self.roi_heads and "mask" in self.roi_heads) else None
+        if mask is not None and hasattr(mask.feature_extractor, "pooler") and hasattr(mask.feature_extractor, "blocks"):
+            box = self.roi_heads["box"] if "box" in self.roi_heads else None
+            if box is None or mask.feature_extractor is not box.feature_extractor:
+                mask.feature_extractor.to(memory_format=hfmt)
+                mask.predictor.to(memory_format=hfmt)
+                mask.feature_extractor.pooler.output_channels_last = heads
         self.channels_last = bool(on)
-        self.channels_last_heads = bool(on and heads)
+        self.channels_last_heads = heads
         return self
 
     def forward(self, images, targets=None):

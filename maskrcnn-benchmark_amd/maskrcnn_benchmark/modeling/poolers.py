@@ -44,9 +44,11 @@ class _ROIAlignFPN(Function):
     """autograd glue of the fused multi-level ROIAlign."""
 
     @staticmethod
-    def forward(ctx, rois, output_size, scales, sampling_ratio, k_min, k_max, *features):
+    def forward(ctx, rois, output_size, scales, sampling_ratio, k_min, k_max, out_channels_last, *features):
+        # a channels-last pyramid is pooled in place by the NHWC kernels (and its gradient maps come back channels-last)
+        ctx.nhwc = all(_C.is_channels_last(f) for f in features) and features[0].dtype == torch.float32
         out, levels = _C.roi_align_fpn_forward(features, rois, scales, output_size[0], output_size[1],
-                                               sampling_ratio, k_min, k_max)
+                                               sampling_ratio, k_min, k_max, out_channels_last=out_channels_last and ctx.nhwc)
         ctx.save_for_backward(rois, levels)
         ctx.cfg = (output_size, scales, sampling_ratio)
         ctx.shapes = [tuple(f.shape) for f in features]
@@ -55,7 +57,7 @@ class _ROIAlignFPN(Function):
         # entry drops from 106 to 92 us, but a second busy hardware queue next to the saturated compute queue costs the
         # STEP +0.5-0.9 ms in fp32 and +4 ms under bf16 autocast.
         ctx.prepared = None
-        if PREPARE_BACKWARD_AT_FORWARD and any(ctx.needs_input_grad[6:]) and rois.is_cuda:
+        if PREPARE_BACKWARD_AT_FORWARD and any(ctx.needs_input_grad[7:]) and rois.is_cuda and not ctx.nhwc:
             ctx.prepared = _C.roi_align_fpn_backward_prepare(rois, levels, ctx.shapes, scales, output_size[0],
                                                              output_size[1], sampling_ratio)
         return out
@@ -66,16 +68,16 @@ class _ROIAlignFPN(Function):
         rois, levels = ctx.saved_tensors
         output_size, scales, sampling_ratio = ctx.cfg
         grads = _C.roi_align_fpn_backward(grad, rois, levels, ctx.shapes, scales, output_size[0],
-                                          output_size[1], sampling_ratio, prepared=ctx.prepared)
+                                          output_size[1], sampling_ratio, prepared=ctx.prepared, channels_last=ctx.nhwc)
         ctx.prepared = None
-        return (None, None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None, None) + tuple(grads)
 
 
-def roi_align_fpn(features, rois, output_size, scales, sampling_ratio, k_min, k_max):
+def roi_align_fpn(features, rois, output_size, scales, sampling_ratio, k_min, k_max, out_channels_last=False):
     """fp32 island (the reference marks ROIAlign.forward `@amp.float_function`, layers/roi_align.py:57)."""
     with torch.autocast(device_type=rois.device.type, enabled=False):
         return _ROIAlignFPN.apply(rois.float(), tuple(output_size), tuple(scales), sampling_ratio, k_min, k_max,
-                                  *[f.float() for f in features])
+                                  bool(out_channels_last), *[f.float() for f in features])
 
 
 class Pooler(nn.Module):
@@ -93,6 +95,9 @@ class Pooler(nn.Module):
         self.k_min = int(round(-torch.log2(torch.tensor(scales[0], dtype=torch.float32)).item()))
         self.k_max = int(round(-torch.log2(torch.tensor(scales[-1], dtype=torch.float32)).item()))
         self.map_levels = LevelMapper(self.k_min, self.k_max)
+        # pooled tensor channels-last when the pyramid is (for a convolutional head running channels-last); the default
+        # keeps [K, C, PH, PW] contiguous (the box head's FC layer flattens it)
+        self.output_channels_last = False
 
     @staticmethod
     def convert_to_roi_format(boxes):
@@ -115,7 +120,7 @@ class Pooler(nn.Module):
         if len(self.poolers) == 1:
             return self.poolers[0](x[0], rois)
         return roi_align_fpn(x, rois, self.output_size, self.scales, self.sampling_ratio,
-                             self.k_min, self.k_max)
+                             self.k_min, self.k_max, out_channels_last=self.output_channels_last)
 
 
 def make_pooler(cfg, head_name):

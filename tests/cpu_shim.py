@@ -30,7 +30,7 @@ def _roi_align_backward(grad, rois, scale, ph, pw, N, C, H, W, sr):
 
 
 def _fpn_forward(inputs, rois, scales, ph, pw, sr, k_min, k_max, canonical_scale=224.0, canonical_level=4.0,
-                 eps=1e-6):
+                 eps=1e-6, out_channels_last=False):
     r = _np(rois.float())
     lv = oracle.fpn_level(r, k_min, k_max, canonical_scale, canonical_level, eps)
     K, C = r.shape[0], inputs[0].shape[1]
@@ -42,7 +42,7 @@ def _fpn_forward(inputs, rois, scales, ph, pw, sr, k_min, k_max, canonical_scale
     return torch.from_numpy(out), torch.from_numpy(lv.astype(np.int32))
 
 
-def _fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr, prepared=None):
+def _fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr, prepared=None, channels_last=False):
     r, g, lv = _np(rois.float()), _np(grad.float()), _np(levels)
     outs = []
     for l, (shp, s) in enumerate(zip(shapes, scales)):
@@ -117,12 +117,13 @@ _PATCHES = {
 def _emu_patches():
     import emu
 
-    def fpn_forward(inputs, rois, scales, ph, pw, sr, k_min, k_max, canonical_scale=224.0, canonical_level=4.0, eps=1e-6):
+    def fpn_forward(inputs, rois, scales, ph, pw, sr, k_min, k_max, canonical_scale=224.0, canonical_level=4.0, eps=1e-6,
+                    out_channels_last=False):
         out, lv = emu.roi_align_fpn_forward([_np(f.float()) for f in inputs], _np(rois.float()),
                                             [float(s) for s in scales], ph, pw, sr, k_min, k_max)
         return torch.from_numpy(out), torch.from_numpy(lv)
 
-    def fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr, prepared=None):
+    def fpn_backward(grad, rois, levels, shapes, scales, ph, pw, sr, prepared=None, channels_last=False):
         outs = emu.roi_align_fpn_backward(_np(grad.float()), _np(rois.float()), _np(levels), [tuple(s) for s in shapes],
                                           [float(s) for s in scales], ph, pw, sr)
         return [torch.from_numpy(o) for o in outs]

@@ -810,6 +810,19 @@ def test_focal_vs_oracle_and_golden(golden_dir):
     _close(b, g["d_logits"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_focal_vs_reference_cuda_formula_in_fp64_up_to_100(golden_dir, tag):
+    """the HIP kernels against the reference's CUDA formula (SigmoidFocalLoss_cuda.cu:29-99) evaluated in float64 over logits
+    up to |x| = 100 (tests/golden/make_golden_focal_formula.py): 1e-4 relative / 1e-5 absolute, forward and backward"""
+    C = _C()
+    g = _load(golden_dir, "focal_cuda_formula_fp64.npz")
+    gamma, alpha = (float(v) for v in g["cfg_" + tag])
+    f = C.sigmoid_focalloss_forward(_t(g["logits"]), _t(g["targets"]), 80, gamma, alpha)
+    _close(f, g["losses_" + tag], rtol=1e-4, atol=1e-5)
+    b = C.sigmoid_focalloss_backward(_t(g["logits"]), _t(g["targets"]), _t(g["d_losses"]), 80, gamma, alpha)
+    _close(b, g["d_logits_" + tag], rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("gamma,alpha,C", [(2.0, 0.25, 80), (1.5, 0.4, 80), (0.0, 0.5, 7), (1.0, 0.25, 3)])
 def test_focal_parameters_and_odd_class_counts(gamma, alpha, C):
     logits, targets = synth.focal_inputs(999, C, seed=7)
@@ -1222,3 +1235,77 @@ def test_deform_conv_fused_mfma_forward_cfg5_shapes(shape, dtype, modulated):
     scale = np.abs(ref).max()
     assert y.dtype == dtype and np.abs(f(y) - ref).max() <= 2e-2 * scale
     assert np.abs(f(y) - f(y0)).max() <= 2e-2 * scale
+
+
+# ------------------------------------------------------------------ ROIAlign over a channels-last pyramid (csrc/roi_align_nhwc.hip)
+def _nhwc_case(C, K, ph, sr, seed, images=2, shapes=None):
+    rng = np.random.RandomState(seed)
+    shapes = shapes or synth.fpn_shapes()[:4]
+    feats = [rng.randn(images, C, h, w).astype(np.float32) for (h, w) in shapes]
+    rois = synth.fpn_rois(seed=seed + 5, per_image=K // images, n_images=images)
+    scales = [1.0 / s for s in synth.FPN_STRIDES[:len(shapes)]]
+    return feats, rois, scales
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,K,ph,sr,out_cl", [(256, 1024, 7, 2, False), (256, 256, 14, 2, True), (256, 256, 14, 2, False),
+                                               (64, 200, 7, 0, False), (6, 50, 5, 3, True), (80, 100, 7, 2, True)])
+def test_roi_align_fpn_forward_channels_last_is_bit_equal_to_the_oracle(C, K, ph, sr, out_cl):
+    """ROIAlign forward over a channels-last pyramid (NHWC kernels): same operation order as the reference CPU kernel with FP
+    contraction off -> bit-equal to the oracle (csrc/cpu/ROIAlign_cpu.cpp:113-219), at the model's size (1024 x 256 x 7 x 7 over
+    the four pyramid levels of the 800 x 1344 input) and for contiguous / channels-last pooled tensors, adaptive sampling,
+    channel counts that are not multiples of 4."""
+    from maskrcnn_benchmark import _C
+    feats, rois, scales = _nhwc_case(C, K, ph, sr, seed=C + ph)
+    tf = [_t(f).contiguous(memory_format=torch.channels_last) for f in feats]
+    out, lv = _C.roi_align_fpn_forward(tf, _t(rois), scales, ph, ph, sr, 2, 5, out_channels_last=out_cl)
+    assert _C.is_channels_last(out) == out_cl
+    lvn = lv.cpu().numpy()
+    assert np.array_equal(lvn, synth.level_map(rois))
+    got = out.contiguous().cpu().numpy()
+    for l, (f, s) in enumerate(zip(feats, scales)):
+        sel = np.nonzero(lvn == l)[0]
+        if sel.size:
+            want = oracle.roi_align_forward(f, rois[sel], s, ph, ph, sr)
+            assert np.array_equal(got[sel], want), "level %d: max diff %g" % (l, np.abs(got[sel] - want).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,K,ph,sr,g_cl", [(256, 1024, 7, 2, False), (256, 256, 14, 2, True), (256, 128, 14, 2, False),
+                                             (64, 200, 7, 0, False), (6, 50, 5, 3, True), (80, 100, 7, 2, False)])
+def test_roi_align_fpn_backward_channels_last_matches_the_oracle_and_is_reproducible(C, K, ph, sr, g_cl):
+    """ROIAlign backward into a channels-last pyramid (pixel-owner NHWC kernel, no atomics): <= 1e-4 relative to the
+    fp64-accumulated oracle (csrc/cuda/ROIAlign_cuda.cu:125-254 restated), every level, from a contiguous and a channels-last
+    pooled gradient; two runs are bit-identical; an `accumulate` into existing maps is not part of the Python surface."""
+    from maskrcnn_benchmark import _C
+    feats, rois, scales = _nhwc_case(C, K, ph, sr, seed=C + ph + 1)
+    rng = np.random.RandomState(K)
+    g = rng.randn(K, C, ph, ph).astype(np.float32)
+    lvn = synth.level_map(rois)
+    tg = _t(g).contiguous(memory_format=torch.channels_last) if g_cl else _t(g)
+    shapes = [tuple(f.shape) for f in feats]
+    a = _C.roi_align_fpn_backward(tg, _t(rois), _t(lvn), shapes, scales, ph, ph, sr, channels_last=True)
+    b = _C.roi_align_fpn_backward(tg, _t(rois), _t(lvn), shapes, scales, ph, ph, sr, channels_last=True)
+    for l, (f, s) in enumerate(zip(feats, scales)):
+        assert a[l].shape == f.shape and (_C.is_channels_last(a[l]) or a[l].is_contiguous())
+        assert torch.equal(a[l], b[l])
+        sel = np.nonzero(lvn == l)[0]
+        want = oracle.roi_align_backward(g[sel], rois[sel], s, ph, ph, *f.shape, sr, acc64=True)
+        got = a[l].contiguous().cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), "level %d" % l
+
+
+@pytest.mark.gpu
+def test_roi_align_channels_last_adjoint_identity_at_model_size():
+    """<fwd(x), g> == <x, bwd(g)> for the NHWC pair at the model's size (size-independent property; fp64 accumulation of the
+    two inner products on the host)"""
+    from maskrcnn_benchmark import _C
+    feats, rois, scales = _nhwc_case(256, 1024, 7, 2, seed=11)
+    rng = np.random.RandomState(2)
+    g = rng.randn(1024, 256, 7, 7).astype(np.float32)
+    tf = [_t(f).contiguous(memory_format=torch.channels_last) for f in feats]
+    out, lv = _C.roi_align_fpn_forward(tf, _t(rois), scales, 7, 7, 2, 2, 5)
+    gin = _C.roi_align_fpn_backward(_t(g), _t(rois), lv, [tuple(f.shape) for f in feats], scales, 7, 7, 2, channels_last=True)
+    lhs = float((out.double() * _t(g).double()).sum())
+    rhs = sum(float((a.double() * b.double()).sum()) for a, b in zip(tf, gin))
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs)), (lhs, rhs)

@@ -130,11 +130,14 @@ def bench_roi_align(C, iters, which=("fwd", "bwd"), fused_only=False, experiment
     return out
 
 
-def bench_roi_sets(C, iters, model_npz=None, only_sets=None, only_heads=None, which=("fwd", "bwd"), images=2, tag=""):
+def bench_roi_sets(C, iters, model_npz=None, only_sets=None, only_heads=None, which=("fwd", "bwd"), images=2, tag="", layout="nchw"):
     """FPN-fused ROIAlign forward / backward on every ROI set of synth.roi_sets(): the SURVEY 8d log-uniform set, the
     trained-like set and the sets the detector itself produced (tools/dump_model_rois.py) - VERDICT r02 item 1a."""
     out = []
     feats = [torch.randn(images, 256, h, w, device="cuda") for (h, w) in synth.fpn_shapes()[:4]]
+    nhwc = layout == "nhwc"    # channels-last pyramid: csrc/roi_align_nhwc.hip (box head: contiguous pooled tensor / gradient,
+    if nhwc:                   # mask head: channels-last pooled tensor / gradient, as in the detector)
+        feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
     scales = [1.0 / s for s in synth.FPN_STRIDES[:4]]
     shapes = [tuple(f.shape) for f in feats]
     feat_bytes = sum(f.numel() * 4 for f in feats)
@@ -164,12 +167,17 @@ def bench_roi_sets(C, iters, model_npz=None, only_sets=None, only_heads=None, wh
             tl = _t(lv)
             alg = 4 * K * 256 * ph * ph + feat_bytes + 20 * K
             g = torch.randn(K, 256, ph, ph, device="cuda")
+            ocl = nhwc and head == "mask"
+            if ocl:
+                g = g.contiguous(memory_format=torch.channels_last)
+            if nhwc:
+                label = label + " | nhwc"
             extra = {"rois_per_level": np.bincount(lv, minlength=4).tolist()}
             if "fwd" in which:
-                us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5), iters)
+                us = dev_time_us(lambda: C.roi_align_fpn_forward(feats, tr, scales, ph, ph, 2, 2, 5, out_channels_last=ocl), iters)
                 out.append(_entry(f"roi_align_fwd fpn-fused {head}-head K={K} {ph}x{ph} [{label}]", us, alg, extra))
             if "bwd" in which:
-                us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2), iters)
+                us = dev_time_us(lambda: C.roi_align_fpn_backward(g, tr, tl, shapes, scales, ph, ph, 2, channels_last=nhwc), iters)
                 out.append(_entry(f"roi_align_bwd fpn-fused {head}-head K={K} {ph}x{ph} [{label}]", us, alg, extra))
     return out
 
@@ -469,6 +477,7 @@ def main():
     ap.add_argument("--heads", default="", help="roi_sets: box,mask (default both)")
     ap.add_argument("--dir", default="", help="roi_sets: fwd,bwd (default both)")
     ap.add_argument("--model-rois", default=None, help="npz of tools/dump_model_rois.py (default: tests/golden/model_rois.npz)")
+    ap.add_argument("--layout", default="nchw", help="roi_sets: nchw | nhwc | both")
     ap.add_argument("--images", type=int, default=2, help="roi_sets: images per batch (4 = the > L3 variant: 365.6 MB of maps)")
     ap.add_argument("--tune", default="", help="library tuning switches for the whole run, key=value,key=value")
     ap.add_argument("--sweep", default="", help="roi_sets: cartesian sweep over tuning switches, 'key=v1|v2,key2=v1|v2'")
@@ -495,9 +504,10 @@ def main():
         for combo in itertools.product(*[vals for _, vals in axes]):
             for (k, _), v in zip(axes, combo):
                 tune(k, v)
-            res += bench_roi_sets(C, args.iters, args.model_rois, set(filter(None, args.sets.split(","))),
-                                  set(filter(None, args.heads.split(","))), tuple(filter(None, args.dir.split(","))) or ("fwd", "bwd"),
-                                  images=args.images, tag=" ".join("%s=%d" % (k, v) for (k, _), v in zip(axes, combo)))
+            for lay in (("nchw", "nhwc") if args.layout == "both" else (args.layout,)):
+                res += bench_roi_sets(C, args.iters, args.model_rois, set(filter(None, args.sets.split(","))),
+                                      set(filter(None, args.heads.split(","))), tuple(filter(None, args.dir.split(","))) or ("fwd", "bwd"),
+                                      images=args.images, tag=" ".join("%s=%d" % (k, v) for (k, _), v in zip(axes, combo)), layout=lay)
         for k, _ in axes:
             tune(k, 0)
     if "roi_align_fwd" in only:
