@@ -17,14 +17,17 @@
 //             [K, C, PH, PW] (the box head's FC layer and every checkpoint keep their layout: the workgroup assembles the
 //             ROI's C x bins block in LDS and writes it as one contiguous 50 KB piece) or channels-last [K, PH, PW, C]
 //             (the mask head's convolutions: direct coalesced stores).
-//   backward  pixel-owner and atomic-free like the NCHW ring kernel, but transposed: a workgroup owns an 8 x 8 pixel tile
-//             x 64 channels, a wave two pixel rows, a LANE ONE CHANNEL with its 16 pixel sums in registers.  Per ROI that
-//             reaches the tile ("hit", ascending ROI index: deterministic) the separable adjoint
+//   backward  pixel-owner and atomic-free like the NCHW ring kernel, but transposed and HIT-PARALLEL: a workgroup owns a
+//             4 x 8 pixel tile x 64 channels; a LANE IS ONE CHANNEL with the tile's 32 pixel sums in registers; each of the
+//             4 waves takes every 4th ROI that reaches the tile ("hit", ascending ROI index) and walks the separable adjoint
 //                 grad_in[y, x, c] += sum_ph AY[y, ph] * ( sum_pw AX[x, pw] * grad_out[r, c, ph, pw] )
-//             is walked with scalar trip counts taken from the ROI's compact adjoint rows (exact zero skipping); the pooled
-//             gradient of the hit is staged [channel][bin] in LDS (NCHW gradient, one contiguous 12.5 KB copy, read back
-//             conflict-free because the bin count is odd) or read as coalesced channel vectors (channels-last gradient).
-//             Every gradient-map element is written exactly once (zero tiles included): no zero-fill pass, no atomics.
+//             for the WHOLE tile with scalar trip counts taken from the ROI's compact adjoint rows (exact zero skipping, the
+//             x pass of a bin row shared by the tile's pixel rows).  No barrier inside the hit loop — a wave stages its own hit
+//             (the [channel][bin] block of an NCHW gradient by LDS-DMA, 12.5 KB contiguous, read back conflict-free because
+//             the bin count is odd; a channels-last gradient is read as coalesced channel vectors) — so a crowded tile's
+//             chain is a quarter as long as its hit list, and the waves of a CU hide each other's staging latency.  The
+//             four partial tiles are added in wave order through LDS (deterministic); every gradient-map element is
+//             written exactly once (zero tiles included): no zero-fill pass, no atomics.
 #include "roi_align_common.h"
 
 namespace {
@@ -32,8 +35,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kNfBlock = 256;     // 4 waves
-constexpr int kNfWaves = kNfBlock / kWave;
+constexpr int kNfBlockNhwc = 256;  // channels-last output (no LDS tile): 4 waves, many workgroups per CU
+constexpr int kNfBlockNchw = 1024; // [K, C, PH, PW] output: the 50 KB LDS tile caps the workgroups per CU — 16 waves each keep the CU's 32 wave slots full (measured 74 / 58 / 50 us at 256 / 512 / 1024 threads: the kernel is latency-bound)
 constexpr int kNfTab = 64;        // axis-table entries per axis kept in LDS (fixed sampling: PH * sr <= 64)
 constexpr int kNfGroupBins = 49;  // bins per workgroup (the 7 x 7 box head in one group)
 
@@ -56,7 +59,7 @@ roi_nhwc_order_kernel(Levels L, const float* __restrict__ rois, const int32_t* _
   roi_order_role(L, rois, levels_in, K, order, keys, static_cast<int>(blockIdx.x));
 }
 
-template <int V, bool kOutNhwc>
+template <int V, bool kOutNhwc, int kNfBlock>
 __global__ void __launch_bounds__(kNfBlock)
 roi_align_fwd_nhwc_kernel(Levels L, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
                           int32_t* __restrict__ levels_out, const int32_t* __restrict__ order, float* __restrict__ out,
@@ -64,6 +67,7 @@ roi_align_fwd_nhwc_kernel(Levels L, const float* __restrict__ rois, const int32_
   DETOPS_DYNAMIC_LDS(float, tile);       // kOutNhwc == false: the workgroup's [channels][bins of the group] output block
   __shared__ Tap tabY[kNfTab];
   __shared__ Tap tabX[kNfTab];
+  constexpr int kNfWaves = kNfBlock / kWave;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const int bins = PH * PW;
   const int per_roi = groups * cchunks;
@@ -155,10 +159,10 @@ roi_align_fwd_nhwc_kernel(Levels L, const float* __restrict__ rois, const int32_
 // ------------------------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kNbT = 8;            // tile: 8 x 8 pixels
+constexpr int kNbTH = 4, kNbTW = 8; // tile: 4 rows x 8 columns of pixels (a lane keeps its 32 sums in registers)
 constexpr int kNbCh = kWave;       // channels per workgroup (a lane each)
-constexpr int kNbBlock = 256;      // 4 waves x 2 pixel rows
-constexpr int kNbRows = 2;         // pixel rows per wave
+constexpr int kNbBlock = 256;      // 4 waves, each walks whole hits
+constexpr int kNbWaves = kNbBlock / kWave;
 constexpr int kNbMaxC = 4;         // fast walk: bins per pixel and axis held in registers (longer ranges: generic walk)
 constexpr int kNbStageBins = 64;   // NCHW gradient: the hit's [64 channels][bins] block is staged in LDS when bins <= this
 constexpr int kNbPrepTiles = 4;    // tiles per list-role workgroup of the pre-pass (a wave each)
@@ -176,7 +180,7 @@ struct NbPlan {
 struct NbWs {
   int4* recs;       // [K][2]: {level, image, fy0, ny}, {fx0, nx, longest y range, longest x range}
   int* counts;      // [num_tiles] hits per tile
-  int* lists;       // [num_tiles][cap] ROI indices, ascending
+  int4* lists;      // [num_tiles][cap] {ROI index, fy0 | ny << 16, fx0 | nx << 16, 0}, ascending ROI index
   float* tabs;      // [K][Hmax * PPH + Wmax * PPW] compact adjoint rows (build_adjoint_rows), then 16 bytes of zeros
 };
 
@@ -194,8 +198,8 @@ bool nb_plan(const Levels& L, int N, int C, int K, int PH, int PW, NbPlan& P, Nb
     if (L.lv[i].W > 32767 || L.lv[i].H > 32767) return false;
     P.Hmax = max(P.Hmax, L.lv[i].H);
     P.Wmax = max(P.Wmax, L.lv[i].W);
-    P.tiles_x[i] = static_cast<int>(ceil_div64(L.lv[i].W, kNbT));
-    P.tiles_y[i] = static_cast<int>(ceil_div64(L.lv[i].H, kNbT));
+    P.tiles_x[i] = static_cast<int>(ceil_div64(L.lv[i].W, kNbTW));
+    P.tiles_y[i] = static_cast<int>(ceil_div64(L.lv[i].H, kNbTH));
     const int64_t n = static_cast<int64_t>(N) * P.tiles_x[i] * P.tiles_y[i];
     P.first_tile[i] = static_cast<int>(tiles);
     P.n_tiles[i] = static_cast<int>(n);
@@ -207,7 +211,7 @@ bool nb_plan(const Levels& L, int N, int C, int K, int PH, int PW, NbPlan& P, Nb
   auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
   size_t o = up(sizeof(int4) * 2 * static_cast<size_t>(K));
   lay.off_counts = o; o = up(o + sizeof(int) * static_cast<size_t>(P.num_tiles));
-  lay.off_lists = o;  o = up(o + sizeof(int) * static_cast<size_t>(P.num_tiles) * P.cap);
+  lay.off_lists = o;  o = up(o + sizeof(int4) * static_cast<size_t>(P.num_tiles) * P.cap);
   lay.off_tabs = o;   o = up(o + sizeof(float) * static_cast<size_t>(K) *
                                  (static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(P.Wmax) * P.PPW) + 16);
   lay.total = o;
@@ -227,7 +231,7 @@ __device__ __forceinline__ NbTile nb_tile(const Levels& L, const NbPlan& P, int 
   int rem = tile - first;
   const int tix = rem % ntx; rem /= ntx;
   NbTile t;
-  t.lvl = lvl; t.b = rem / nty; t.y0 = (rem % nty) * kNbT; t.x0 = tix * kNbT;
+  t.lvl = lvl; t.b = rem / nty; t.y0 = (rem % nty) * kNbTH; t.x0 = tix * kNbTW;
   return t;
 }
 
@@ -269,7 +273,7 @@ roi_bwd_nhwc_prep_kernel(Levels L, NbPlan P, NbWs ws, const float* __restrict__ 
   NbTile t{0, 0, 0, 0};
   if (live) t = nb_tile(L, P, tile);
   int count = 0;
-  int* list = ws.lists + static_cast<size_t>(live ? tile : 0) * P.cap;
+  int4* list = ws.lists + static_cast<size_t>(live ? tile : 0) * P.cap;
   for (int r0 = 0; r0 < K; r0 += kNbPrepRois) {
     const int n = min(kNbPrepRois, K - r0);
     __syncthreads();
@@ -290,14 +294,15 @@ roi_bwd_nhwc_prep_kernel(Levels L, NbPlan P, NbWs ws, const float* __restrict__ 
       for (int i0 = 0; i0 < n; i0 += kWave) {
         const int i = i0 + lane;
         bool hit = false;
+        int4 e = make_int4(0, 0, 0, 0);
         if (i < n) {
-          const int4 e = ext[i];
+          e = ext[i];
           const int fy0 = e.y & 0xffff, eny = e.y >> 16, fx0 = e.z & 0xffff, enx = e.z >> 16;
-          hit = (e.x == (t.lvl | (t.b << 8))) && eny > 0 && enx > 0 && fy0 < t.y0 + kNbT && fy0 + eny > t.y0 &&
-                fx0 < t.x0 + kNbT && fx0 + enx > t.x0;
+          hit = (e.x == (t.lvl | (t.b << 8))) && eny > 0 && enx > 0 && fy0 < t.y0 + kNbTH && fy0 + eny > t.y0 &&
+                fx0 < t.x0 + kNbTW && fx0 + enx > t.x0;
         }
         const unsigned long long m = __ballot(hit);
-        if (hit) list[count + __popcll(m & ((1ull << lane) - 1ull))] = r0 + i;
+        if (hit) list[count + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(r0 + i, e.y, e.z, 0);
         count += __popcll(m);
       }
     }
@@ -305,75 +310,76 @@ roi_bwd_nhwc_prep_kernel(Levels L, NbPlan P, NbWs ws, const float* __restrict__ 
   if (live && lane == 0) ws.counts[tile] = count;
 }
 
-// One hit's walk for a wave: its two pixel rows x 8 columns, a lane per channel.
-//   rows  LDS, [16][PP]: compact adjoint rows of the tile's 8 pixel rows (0..7) and 8 pixel columns (8..15) for this ROI
-//   G     the hit's pooled gradient as seen by this lane: G(bin) -> value
-// kFast: every pixel's bin range on the x axis has at most kNbMaxC entries -> weights and bin indices in registers, the
-// x pass is branch-free; otherwise scalar loops over the exact ranges.
+// One hit's walk by one wave: the whole tile (kNbTH x kNbTW pixels), a lane per channel.
+//   rows  LDS (this wave's), [kNbTH + kNbTW][PP]: compact adjoint rows of the tile's pixel rows, then of its pixel columns
+//   G     the hit's pooled gradient as seen by this lane: G(bin) -> value (any bin index >= 0 is readable)
+// The x pass of bin row ph (u[x] = sum_pw AX[x, pw] * g[ph, pw]) is computed once and used by every pixel row ph reaches.
+// kFast (every column's bin range has at most kNbMaxC entries): BRANCH-FREE — the x weights live in registers (compact rows
+// are zero-padded, so the entries beyond a column's range multiply neighbouring bins by 0), a pixel row outside ph's reach
+// gets the weight 0.  For finite gradients this is exact; a non-finite pooled gradient (a GradScaler overflow step, which
+// is skipped anyway) turns into NaN in the pixels around it instead of staying in the bins' own footprint.
+// Otherwise: scalar loops over the exact ranges.
 template <bool kFast, typename GFn>
-__device__ __forceinline__ void nb_walk(const float* rows, int PP, int PW, int wave, float (&acc)[kNbRows][kNbT], GFn G) {
-  int lo_y[kNbRows], cnt_y[kNbRows];
+__device__ __forceinline__ void nb_walk(const float* rows, int PP, int PW, float (&acc)[kNbTH][kNbTW], GFn G) {
+  int lo_y[kNbTH], cnt_y[kNbTH];
   int ph_lo = 0x7fffffff, ph_hi = -1;
 #pragma unroll
-  for (int j = 0; j < kNbRows; ++j) {
-    const unsigned h = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(__float_as_int(rows[(wave * kNbRows + j) * PP])));
+  for (int j = 0; j < kNbTH; ++j) {
+    const unsigned h = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(__float_as_int(rows[j * PP])));
     lo_y[j] = static_cast<int>(h & 0xffu);
     cnt_y[j] = static_cast<int>(h >> 16);
     if (cnt_y[j] > 0) { ph_lo = min(ph_lo, lo_y[j]); ph_hi = max(ph_hi, lo_y[j] + cnt_y[j] - 1); }
   }
   if (ph_hi < 0) return;
-  int lo_x[kNbT], cnt_x[kNbT];
+  int lo_x[kNbTW], cnt_x[kNbTW];
 #pragma unroll
-  for (int x = 0; x < kNbT; ++x) {
-    const unsigned h = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(__float_as_int(rows[(kNbT + x) * PP])));
-    lo_x[x] = static_cast<int>(h & 0xffu);
+  for (int x = 0; x < kNbTW; ++x) {
+    const unsigned h = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(__float_as_int(rows[(kNbTH + x) * PP])));
     cnt_x[x] = static_cast<int>(h >> 16);
+    lo_x[x] = cnt_x[x] > 0 ? static_cast<int>(h & 0xffu) : 0;
   }
   if (kFast) {
-    float wx[kNbT][kNbMaxC];
+    float wx[kNbTW][kNbMaxC];
 #pragma unroll
-    for (int x = 0; x < kNbT; ++x)
+    for (int x = 0; x < kNbTW; ++x)
 #pragma unroll
-      for (int t = 0; t < kNbMaxC; ++t) wx[x][t] = rows[(kNbT + x) * PP + 1 + t];   // zero beyond the range (compact rows are zero-padded)
+      for (int t = 0; t < kNbMaxC; ++t) wx[x][t] = rows[(kNbTH + x) * PP + 1 + t];
     for (int ph = ph_lo; ph <= ph_hi; ++ph) {
       const int rb = ph * PW;
-      float wy[kNbRows];
-      bool on[kNbRows];
+      float u[kNbTW];
 #pragma unroll
-      for (int j = 0; j < kNbRows; ++j) {
-        on[j] = cnt_y[j] > 0 && ph >= lo_y[j] && ph < lo_y[j] + cnt_y[j];
-        wy[j] = on[j] ? rows[(wave * kNbRows + j) * PP + 1 + (ph - lo_y[j])] : 0.f;
+      for (int x = 0; x < kNbTW; ++x) {
+        const int b0 = rb + lo_x[x];
+        u[x] = wx[x][0] * G(b0);
+#pragma unroll
+        for (int t = 1; t < kNbMaxC; ++t) u[x] += wx[x][t] * G(b0 + t);
       }
 #pragma unroll
-      for (int x = 0; x < kNbT; ++x) {
-        if (cnt_x[x] > 0) {
-          float u = 0.f;
+      for (int j = 0; j < kNbTH; ++j) {
+        const int d = ph - lo_y[j];
+        const bool on = d >= 0 && d < cnt_y[j];
+        const float w = rows[j * PP + 1 + (on ? d : 0)];
+        const float wy = on ? w : 0.f;
 #pragma unroll
-          for (int t = 0; t < kNbMaxC; ++t) u += wx[x][t] * G(rb + lo_x[x] + min(t, cnt_x[x] - 1));   // beyond the range: the last valid bin, weight 0
-#pragma unroll
-          for (int j = 0; j < kNbRows; ++j)
-            if (on[j]) acc[j][x] += wy[j] * u;
-        }
+        for (int x = 0; x < kNbTW; ++x) acc[j][x] += wy * u[x];
       }
     }
   } else {
     for (int ph = ph_lo; ph <= ph_hi; ++ph) {
       const int rb = ph * PW;
-      float wy[kNbRows];
-      bool on[kNbRows];
+      float u[kNbTW];
 #pragma unroll
-      for (int j = 0; j < kNbRows; ++j) {
-        on[j] = cnt_y[j] > 0 && ph >= lo_y[j] && ph < lo_y[j] + cnt_y[j];
-        wy[j] = on[j] ? rows[(wave * kNbRows + j) * PP + 1 + (ph - lo_y[j])] : 0.f;
+      for (int x = 0; x < kNbTW; ++x) {
+        u[x] = 0.f;
+        for (int t = 0; t < cnt_x[x]; ++t) u[x] += rows[(kNbTH + x) * PP + 1 + t] * G(rb + lo_x[x] + t);
       }
 #pragma unroll
-      for (int x = 0; x < kNbT; ++x) {
-        if (cnt_x[x] > 0) {
-          float u = 0.f;
-          for (int t = 0; t < cnt_x[x]; ++t) u += rows[(kNbT + x) * PP + 1 + t] * G(rb + lo_x[x] + t);
+      for (int j = 0; j < kNbTH; ++j) {
+        if (cnt_y[j] > 0 && ph >= lo_y[j] && ph < lo_y[j] + cnt_y[j]) {
+          const float wy = rows[j * PP + 1 + (ph - lo_y[j])];
 #pragma unroll
-          for (int j = 0; j < kNbRows; ++j)
-            if (on[j]) acc[j][x] += wy[j] * u;
+          for (int x = 0; x < kNbTW; ++x)
+            if (cnt_x[x] > 0) acc[j][x] += wy * u[x];
         }
       }
     }
@@ -381,138 +387,141 @@ __device__ __forceinline__ void nb_walk(const float* rows, int PP, int PW, int w
 }
 
 // kGNhwc: grad_out is [K, PH, PW, C] (read as coalesced channel vectors); else [K, C, PH, PW].
-// kStage (NCHW gradient only): the hit's [channels of the chunk][bins] block goes through LDS (double-buffered).
+// kStage (NCHW gradient only): the hit's [channels of the chunk][bins] block goes through this wave's LDS buffer (LDS-DMA).
+// PERSISTENT: the grid is what the chip holds at once; a workgroup takes the (tile, channel chunk) units b, b + grid, ...
+// (tiles are numbered coarsest level first, so every workgroup starts on a crowded tile and ends on empty ones, which
+// cost a count and one row of stores per wave).
 template <bool kGNhwc, bool kStage>
-__global__ void __launch_bounds__(kNbBlock)
-roi_align_bwd_nhwc_kernel(Levels L, NbPlan P, NbWs ws, const float* __restrict__ gout, int C, int PH, int PW) {
+__global__ void __launch_bounds__(kNbBlock, 3)
+roi_align_bwd_nhwc_kernel(Levels L, NbPlan P, NbWs ws, const float* __restrict__ gout, int C, int PH, int PW, int units) {
   DETOPS_DYNAMIC_LDS(float, smem);
-  // smem: rows [2][16][PP] | (kStage) gblk [2][kNbCh * bins (+ pad to 4)]
+  // smem: per wave { rows [kNbTH + kNbTW][PP] | (kStage) gblk [kNbCh * bins, padded to 1 KiB pieces] }; reused for the combine
+  constexpr int kR = kNbTH + kNbTW;
+  static_assert(kNbTH == kNbWaves, "the epilogue hands pixel row w of the tile to wave w");
   const int PP = max(P.PPH, P.PPW);
   const int bins = PH * PW;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int unit = static_cast<int>(blockIdx.x);
-  const int tile = unit / P.cchunks, chunk = unit - tile * P.cchunks;
-  const NbTile t = nb_tile(L, P, tile);
-  float* gin = L.lv[0].gin; int H = L.lv[0].H, W = L.lv[0].W;
-#pragma unroll
-  for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
-    if (i == t.lvl) { gin = L.lv[i].gin; H = L.lv[i].H; W = L.lv[i].W; }
-  const int c0 = chunk * kNbCh;
-  const int cc = min(kNbCh, C - c0);
-  const bool chan = lane < cc;
-  const int count = ws.counts[tile];
-  const int* list = ws.lists + static_cast<size_t>(tile) * P.cap;
   const size_t slot = static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(P.Wmax) * P.PPW;
+  const int rows_f = kR * PP;
+  const int gblk_f = kStage ? ((kNbCh * bins + 255) & ~255) : 0;     // whole 1 KiB DMA pieces
+  const int wave_f = rows_f + gblk_f;
+  float* rw = smem + wave * wave_f;                                   // this wave's rows
+  float* gb = rw + rows_f;                                            // this wave's gradient block
+  bool lds_dirty = false;                                             // the previous unit's combine still owns the LDS
 
-  float acc[kNbRows][kNbT];
+  for (int unit = static_cast<int>(blockIdx.x); unit < units; unit += static_cast<int>(gridDim.x)) {
+    const int tile = unit / P.cchunks, chunk = unit - tile * P.cchunks;
+    const NbTile t = nb_tile(L, P, tile);
+    float* gin = L.lv[0].gin; int H = L.lv[0].H, W = L.lv[0].W;
 #pragma unroll
-  for (int j = 0; j < kNbRows; ++j)
-#pragma unroll
-    for (int x = 0; x < kNbT; ++x) acc[j][x] = 0.f;
-
-  const int rows_f = 16 * PP;                               // floats per rows buffer
-  const int gblk_f = kStage ? ((kNbCh * bins + 3) & ~3) : 0;
-  float* rowsb = smem;                                      // [2][rows_f]
-  float* gblk = smem + 2 * rows_f;                          // [2][gblk_f]
-
-  // Hit i is staged into buffer (i & 1) in two halves so that its global loads overlap the walk of hit i - 1:
-  // fetch(i) issues the loads into registers (one float4 of the 16 compact rows per thread, and with kStage up to
-  // kPreG float4 of the gradient block), commit(i) stores them to LDS after the walk.
-  constexpr int kPreG = kNbCh * kNbStageBins / 4 / kNbBlock;      // 4
-  const int q4 = PP / 4;                                           // float4 pieces per row (16 * q4 <= 256)
-  float4 pre_row = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 pre_g[kPreG];
-  int g_total4 = 0;
-  auto fetch = [&](int i) {
-    const int r = list[i];
-    const int4 ra = ws.recs[2 * static_cast<size_t>(r)], rb = ws.recs[2 * static_cast<size_t>(r) + 1];
-    const int fy0 = ra.z, eny = ra.w, fx0 = rb.x, enx = rb.y;
-    pre_row = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 16 * q4) {
-      const int rr = tid / q4, piece = tid - rr * q4;
-      const float* rbase = ws.tabs + static_cast<size_t>(r) * slot;
-      if (rr < kNbT) {
-        const int yi = t.y0 + rr - fy0;
-        if (yi >= 0 && yi < eny && piece * 4 < P.PPH)
-          pre_row = *reinterpret_cast<const float4*>(rbase + static_cast<size_t>(yi) * P.PPH + piece * 4);
-      } else {
-        const int xi = t.x0 + (rr - kNbT) - fx0;
-        if (xi >= 0 && xi < enx && piece * 4 < P.PPW)
-          pre_row = *reinterpret_cast<const float4*>(rbase + static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(xi) * P.PPW + piece * 4);
+    for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
+      if (i == t.lvl) { gin = L.lv[i].gin; H = L.lv[i].H; W = L.lv[i].W; }
+    const int c0 = chunk * kNbCh;
+    const int cc = min(kNbCh, C - c0);
+    const bool chan = lane < cc;
+    const int count = ws.counts[tile];
+    auto put = [&](int y, int x, float v) {
+      const int xx = t.x0 + x;
+      if (y < H && xx < W && chan) {
+        float* o = gin + ((static_cast<size_t>(t.b) * H + y) * W + xx) * C + c0 + lane;
+        *o = P.accumulate ? (*o + v) : v;
       }
-    }
-    if (kStage) {
-      // [r][c0 ..][bins]: cc * bins contiguous floats; host guarantees (C * bins) % 4 == 0 and c0 * bins % 4 == 0
-      const float4* src = reinterpret_cast<const float4*>(gout + (static_cast<size_t>(r) * C + c0) * bins);
-      g_total4 = cc * bins / 4;
+    };
+    if (count == 0) {
+      // no ROI reaches the tile: zeros, one pixel row per wave (every element is written exactly once)
 #pragma unroll
-      for (int q = 0; q < kPreG; ++q) {
-        const int o = tid + q * kNbBlock;
-        if (o < g_total4) pre_g[q] = src[o];
-      }
+      for (int x = 0; x < kNbTW; ++x) put(t.y0 + wave, x, 0.f);
+      continue;
     }
-  };
-  auto commit = [&](int i) {
-    float* rw = rowsb + (i & 1) * rows_f;
-    if (tid < 16 * q4) *reinterpret_cast<float4*>(rw + (tid / q4) * PP + (tid % q4) * 4) = pre_row;
-    if (kStage) {
-      float4* dst = reinterpret_cast<float4*>(gblk + (i & 1) * gblk_f);
-#pragma unroll
-      for (int q = 0; q < kPreG; ++q) {
-        const int o = tid + q * kNbBlock;
-        if (o < g_total4) dst[o] = pre_g[q];
-      }
-    }
-  };
+    const int4* list = ws.lists + static_cast<size_t>(tile) * P.cap;
+    if (lds_dirty) { __syncthreads(); lds_dirty = false; }
 
-  if (count > 0) {
-    fetch(0);
-    commit(0);
-    __syncthreads();
-    for (int i = 0; i < count; ++i) {
-      if (i + 1 < count) fetch(i + 1);                       // loads in flight across the walk
-      const float* rw = rowsb + (i & 1) * rows_f;
-      const int r = list[i];
+    float acc[kNbTH][kNbTW];
+#pragma unroll
+    for (int j = 0; j < kNbTH; ++j)
+#pragma unroll
+      for (int x = 0; x < kNbTW; ++x) acc[j][x] = 0.f;
+
+    for (int i = wave; i < count; i += kNbWaves) {
+      const int4 e = list[i];
+      const int r = e.x;
+      const int fy0 = e.y & 0xffff, eny = e.y >> 16, fx0 = e.z & 0xffff, enx = e.z >> 16;
+      DETOPS_WAVE_SYNC();           // the previous hit's LDS reads are done before its buffers are overwritten
+      if (kStage) {
+        // [r][c0 ..][bins]: cc * bins contiguous floats (host: (C * bins) % 4 == 0), copied lane-linear by LDS-DMA
+        const float* src = gout + (static_cast<size_t>(r) * C + c0) * bins;
+        const int total4 = cc * bins / 4;
+        for (int o = 0; o < total4; o += kWave)
+          if (o + lane < total4) glds16(src + 4 * (o + lane), gb + 4 * o);
+      }
+      {
+        const int q4 = PP / 4;                                           // float4 pieces per row
+        const float* rbase = ws.tabs + static_cast<size_t>(r) * slot;
+        for (int p = lane; p < kR * q4; p += kWave) {
+          const int rr = p / q4, piece = p - rr * q4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (rr < kNbTH) {
+            const int yi = t.y0 + rr - fy0;
+            if (yi >= 0 && yi < eny && piece * 4 < P.PPH) v = *reinterpret_cast<const float4*>(rbase + static_cast<size_t>(yi) * P.PPH + piece * 4);
+          } else {
+            const int xi = t.x0 + (rr - kNbTH) - fx0;
+            if (xi >= 0 && xi < enx && piece * 4 < P.PPW)
+              v = *reinterpret_cast<const float4*>(rbase + static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(xi) * P.PPW + piece * 4);
+          }
+          *reinterpret_cast<float4*>(rw + rr * PP + piece * 4) = v;
+        }
+      }
+      DETOPS_WAVE_SYNC();           // rows written by some lanes are read by all lanes (the DMA'd block is waited for by the compiler)
       // longest bin range of any of the tile's columns for this ROI: selects the walk
       int cmax = 0;
 #pragma unroll
-      for (int x = 0; x < kNbT; ++x)
-        cmax = max(cmax, static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(__float_as_int(rw[(kNbT + x) * PP]))) >> 16));
+      for (int x = 0; x < kNbTW; ++x)
+        cmax = max(cmax, static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(__float_as_int(rw[(kNbTH + x) * PP]))) >> 16));
       if (kStage) {
-        const float* gb = gblk + (i & 1) * gblk_f + lane * bins;
-        auto G = [&](int bin) { return gb[bin]; };
-        if (cmax <= kNbMaxC) nb_walk<true>(rw, PP, PW, wave, acc, G);
-        else nb_walk<false>(rw, PP, PW, wave, acc, G);
+        const float* gl = gb + lane * bins;          // reads up to kNbMaxC - 1 floats past a row's end stay inside the padded block
+        auto G = [&](int bin) { return gl[bin]; };
+        if (cmax <= kNbMaxC) nb_walk<true>(rw, PP, PW, acc, G);
+        else nb_walk<false>(rw, PP, PW, acc, G);
       } else if (kGNhwc) {
         const float* gp = gout + static_cast<size_t>(r) * bins * C + c0 + (chan ? lane : 0);
-        auto G = [&](int bin) { return gp[static_cast<size_t>(bin) * C]; };
-        if (cmax <= kNbMaxC) nb_walk<true>(rw, PP, PW, wave, acc, G);
-        else nb_walk<false>(rw, PP, PW, wave, acc, G);
+        auto G = [&](int bin) { return gp[static_cast<size_t>(min(bin, bins - 1)) * C]; };
+        if (cmax <= kNbMaxC) nb_walk<true>(rw, PP, PW, acc, G);
+        else nb_walk<false>(rw, PP, PW, acc, G);
       } else {
         const float* gp = gout + (static_cast<size_t>(r) * C + c0 + (chan ? lane : 0)) * bins;
-        auto G = [&](int bin) { return gp[bin]; };
-        if (cmax <= kNbMaxC) nb_walk<true>(rw, PP, PW, wave, acc, G);
-        else nb_walk<false>(rw, PP, PW, wave, acc, G);
+        auto G = [&](int bin) { return gp[min(bin, bins - 1)]; };
+        if (cmax <= kNbMaxC) nb_walk<true>(rw, PP, PW, acc, G);
+        else nb_walk<false>(rw, PP, PW, acc, G);
       }
-      if (i + 1 < count) commit(i + 1);                      // the other buffer: nobody reads it during this iteration
-      __syncthreads();
     }
-  }
-  // every element of the tile is written exactly once (zero tiles included)
-  if (chan) {
+
+    // ---- the result = the waves' partial tiles added in wave order (deterministic); every element stored exactly once
+    const int nparts = min(count, kNbWaves);            // waves that walked at least one hit (workgroup-uniform)
+    if (nparts == 1) {
+      if (wave == 0) {                                   // wave 0's registers are the result
 #pragma unroll
-    for (int j = 0; j < kNbRows; ++j) {
-      const int y = t.y0 + wave * kNbRows + j;
-      if (y < H) {
+        for (int j = 0; j < kNbTH; ++j)
 #pragma unroll
-        for (int x = 0; x < kNbT; ++x) {
-          const int xx = t.x0 + x;
-          if (xx < W) {
-            float* o = gin + ((static_cast<size_t>(t.b) * H + y) * W + xx) * C + c0 + lane;
-            *o = P.accumulate ? (*o + acc[j][x]) : acc[j][x];
-          }
-        }
+          for (int x = 0; x < kNbTW; ++x) put(t.y0 + j, x, acc[j][x]);
       }
+    } else {
+      // part[wave][row][x][channel] through LDS (32 KiB, over the staging buffers); wave w then adds and stores pixel row w
+      float* part = smem;
+      __syncthreads();          // every wave is done with its staging buffers
+      if (wave < nparts) {
+#pragma unroll
+        for (int j = 0; j < kNbTH; ++j)
+#pragma unroll
+          for (int x = 0; x < kNbTW; ++x) part[((wave * kNbTH + j) * kNbTW + x) * kNbCh + lane] = acc[j][x];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int x = 0; x < kNbTW; ++x) {
+        float v = part[((0 * kNbTH + wave) * kNbTW + x) * kNbCh + lane];
+        for (int w2 = 1; w2 < nparts; ++w2) v += part[((w2 * kNbTH + wave) * kNbTW + x) * kNbCh + lane];
+        put(t.y0 + wave, x, v);
+      }
+      lds_dirty = true;
     }
   }
 }
@@ -565,12 +574,19 @@ DETOPS_API int detops_roi_align_fpn_forward_nhwc_f32(
   const int64_t grid = static_cast<int64_t>(K) * groups * cchunks;
   if (grid > 0x7fffffff) return DETOPS_EUNSUPPORTED;
   const size_t lds = output_nhwc ? 0 : sizeof(float) * static_cast<size_t>(kWave) * V * gbins;
-#define NF_LAUNCH(VV, NHWC)                                                                                          \
-  hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<VV, NHWC>), dim3(static_cast<unsigned>(grid)), dim3(kNfBlock), lds, st, L, rois, \
+#define NF_LAUNCH(VV, NHWC, BLK)                                                                                          \
+  hipLaunchKernelGGL((roi_align_fwd_nhwc_kernel<VV, NHWC, BLK>), dim3(static_cast<unsigned>(grid)), dim3(BLK), lds, st, L, rois, \
                      static_cast<const int32_t*>(nullptr), levels_out, static_cast<const int32_t*>(order), output, C, K, PH, PW,  \
                      sampling_ratio, groups, gbins, cchunks)
-  if (V == 4) { if (output_nhwc) NF_LAUNCH(4, true); else NF_LAUNCH(4, false); }
-  else        { if (output_nhwc) NF_LAUNCH(1, true); else NF_LAUNCH(1, false); }
+  const int blk = detops_tuning().roi_fwd_ct;          // A/B switch: threads per workgroup of the [K, C, PH, PW]-output form (0 = default)
+  if (V == 4) {
+    if (output_nhwc) NF_LAUNCH(4, true, kNfBlockNhwc);
+    else if (blk == 256) NF_LAUNCH(4, false, 256);
+    else if (blk == 512) NF_LAUNCH(4, false, 512);
+    else NF_LAUNCH(4, false, kNfBlockNchw);
+  } else {
+    if (output_nhwc) NF_LAUNCH(1, true, kNfBlockNhwc); else NF_LAUNCH(1, false, kNfBlockNchw);
+  }
 #undef NF_LAUNCH
   return launch_status();
 }
@@ -612,7 +628,7 @@ DETOPS_API int detops_roi_align_fpn_backward_nhwc_f32(
   if (workspace_bytes < lay.total) return DETOPS_EINVAL;
   P.accumulate = zero_grad_in ? 0 : 1;
   unsigned char* base = static_cast<unsigned char*>(workspace);
-  NbWs ws{reinterpret_cast<int4*>(base), reinterpret_cast<int*>(base + lay.off_counts), reinterpret_cast<int*>(base + lay.off_lists),
+  NbWs ws{reinterpret_cast<int4*>(base), reinterpret_cast<int*>(base + lay.off_counts), reinterpret_cast<int4*>(base + lay.off_lists),
           reinterpret_cast<float*>(base + lay.off_tabs)};
   const int list_blocks = static_cast<int>(ceil_div64(P.num_tiles, kNbPrepTiles));
   hipLaunchKernelGGL(roi_bwd_nhwc_prep_kernel, dim3(P.rec_blocks + list_blocks), dim3(kBlock), 0, st, L, P, ws, rois, levels, K, PH, PW,
@@ -621,15 +637,23 @@ DETOPS_API int detops_roi_align_fpn_backward_nhwc_f32(
   if (e) return e;
   const int bins = PH * PW;
   const int PP = std::max(P.PPH, P.PPW);
-  // staged through LDS as [channel][bin]: conflict-free reads need an odd row stride, the float4 copy (C * bins) % 4 == 0
+  // staged through LDS as [channel][bin]: conflict-free reads need an odd row stride, the 16-byte DMA pieces (C * bins) % 4 == 0
   const bool stage = !grad_out_nhwc && bins <= kNbStageBins && (bins & 1) && (static_cast<int64_t>(C) * bins) % 4 == 0;
-  const size_t lds = sizeof(float) * (2 * static_cast<size_t>(16) * PP + (stage ? 2 * static_cast<size_t>((kNbCh * bins + 3) & ~3) : 0));
-  const dim3 grid(static_cast<unsigned>(static_cast<int64_t>(P.num_tiles) * P.cchunks));
+  const size_t wave_f = (kNbTH + kNbTW) * static_cast<size_t>(PP) + (stage ? static_cast<size_t>((kNbCh * bins + 255) & ~255) : 0);
+  const size_t lds = sizeof(float) * std::max(kNbWaves * wave_f, static_cast<size_t>(kNbWaves) * kNbTH * kNbTW * kNbCh);
+  const int units = static_cast<int>(static_cast<int64_t>(P.num_tiles) * P.cchunks);
+  // persistent grid: the workgroups the chip holds at once (advisory: any grid size is correct)
+  int resident = -1;
+  if (grad_out_nhwc) resident = detops_resident_workgroups(roi_align_bwd_nhwc_kernel<true, false>, kNbBlock, lds);
+  else if (stage) resident = detops_resident_workgroups(roi_align_bwd_nhwc_kernel<false, true>, kNbBlock, lds);
+  else resident = detops_resident_workgroups(roi_align_bwd_nhwc_kernel<false, false>, kNbBlock, lds);
+  if (resident <= 0) resident = 2 * kNumCU;
+  const dim3 grid(static_cast<unsigned>(std::min(units, resident)));
   if (grad_out_nhwc)
-    hipLaunchKernelGGL((roi_align_bwd_nhwc_kernel<true, false>), grid, dim3(kNbBlock), lds, st, L, P, ws, grad_out, C, PH, PW);
+    hipLaunchKernelGGL((roi_align_bwd_nhwc_kernel<true, false>), grid, dim3(kNbBlock), lds, st, L, P, ws, grad_out, C, PH, PW, units);
   else if (stage)
-    hipLaunchKernelGGL((roi_align_bwd_nhwc_kernel<false, true>), grid, dim3(kNbBlock), lds, st, L, P, ws, grad_out, C, PH, PW);
+    hipLaunchKernelGGL((roi_align_bwd_nhwc_kernel<false, true>), grid, dim3(kNbBlock), lds, st, L, P, ws, grad_out, C, PH, PW, units);
   else
-    hipLaunchKernelGGL((roi_align_bwd_nhwc_kernel<false, false>), grid, dim3(kNbBlock), lds, st, L, P, ws, grad_out, C, PH, PW);
+    hipLaunchKernelGGL((roi_align_bwd_nhwc_kernel<false, false>), grid, dim3(kNbBlock), lds, st, L, P, ws, grad_out, C, PH, PW, units);
   return launch_status();
 }

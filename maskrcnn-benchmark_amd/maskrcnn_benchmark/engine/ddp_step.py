@@ -21,6 +21,7 @@ The update is SGD with momentum exactly as torch.optim.SGD computes it (dampenin
 with the reference's per-parameter hyper-parameters (biases: lr x BIAS_LR_FACTOR, WEIGHT_DECAY_BIAS;
 solver/build.py:7-20), held in the optimizer's param groups so LR schedulers keep working.
 """
+import logging
 import os
 
 import torch
@@ -167,8 +168,8 @@ class BucketedDataParallel(torch.nn.Module):
     that did not fill (a parameter without gradient on this rank: its slice is sent as zeros) are flushed and the
     main stream joins the callbacks.  `module` is the wrapped model (checkpoints strip the prefix as for DDP).
 
-    Communication (`comm`): "direct" — RCCL called through engine/rccl_comm.py on ONE low-priority side stream that
-    also runs the bucket updates (two HIP streams in the step, one event per bucket; the default on the GPU: "auto" tries
+    Communication (`comm`): "direct" — RCCL called through engine/rccl_comm.py on ONE side stream (normal priority by
+    default, DETOPS_DDP_PRIO=low|high|main for A/B runs) that also runs the bucket updates (two HIP streams in the step, one event per bucket; the default on the GPU: "auto" tries
     it, self-tests one all-reduce and falls back); "pg" — torch.distributed's ProcessGroupNCCL (its own stream, a work
     object + future per bucket, the update in the future's callback on a pool stream) and the only path for gloo / CPU
     tensors.  `self.comm_mode` says which one runs.
@@ -225,34 +226,51 @@ class BucketedDataParallel(torch.nn.Module):
             if want in ("direct", "side-nocoll"):
                 raise RuntimeError("comm=%r needs fp32 parameters on one GPU and an RCCL process group" % want)
             return
+        # Phase 1 — everything that can fail on ONE rank alone (library load, symbol resolution, side-stream creation) runs
+        # BEFORE any collective and is folded into one flag; the ranks then agree (MIN) on whether all of them can go on.
+        # A rank that cannot never skips a collective its peers are waiting in.
+        local_err, side, prio, rccl_comm = None, None, 0, None
         try:
             from . import rccl_comm
-            ok = torch.tensor([1.0 if rccl_comm.available() else 0.0], device=dev)
-            if self.world > 1:          # agree BEFORE the collective communicator set-up: nobody waits for a rank that cannot join
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.process_group)
-            if float(ok) < 1.0:
-                raise RuntimeError("librccl.so (or one of its entry points) is not loadable on every rank")
+            if not rccl_comm.available():
+                raise RuntimeError("librccl.so (or one of its entry points) is not loadable")
             prio_want = os.environ.get("DETOPS_DDP_PRIO", "normal")
             if prio_want == "low":
-                self._side, prio = rccl_comm.low_priority_stream(dev)
+                side, prio = rccl_comm.low_priority_stream(dev)
             elif prio_want == "high":
-                self._side, prio = torch.cuda.Stream(dev, priority=-1), -1
+                side, prio = torch.cuda.Stream(dev, priority=-1), -1
             elif prio_want == "main":     # measurement only: no second stream at all
-                self._side, prio = torch.cuda.current_stream(dev), 0
-            else:
-                self._side, prio = torch.cuda.Stream(dev), 0
-            if want != "side-nocoll":
-                self._rccl = rccl_comm.RcclComm(dev, self.process_group)
-                self._rccl.selftest()
-            for b in self.buckets:
-                b.event = torch.cuda.Event()
-            self.comm_mode = "direct" if want != "side-nocoll" else "side-nocoll"
-            self.comm_note = "side stream priority %d" % prio
-        except Exception as e:  # noqa: BLE001 — the run must not depend on the direct path
-            if want == "direct" or want == "side-nocoll":
-                raise
-            self.comm_mode, self._rccl, self._side = "pg", None, None
-            self.comm_note = "direct RCCL unavailable (%s: %s)" % (type(e).__name__, e)
+                side, prio = torch.cuda.current_stream(dev), 0
+            else:                         # the default: a normal-priority side stream (lowest / high measured no better)
+                side, prio = torch.cuda.Stream(dev), 0
+        except Exception as e:  # noqa: BLE001 — local set-up only; reported in comm_note
+            local_err = e
+        ok = torch.tensor([0.0 if local_err is not None else 1.0], device=dev)
+        if self.world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.process_group)
+        if float(ok) < 1.0:
+            if want in ("direct", "side-nocoll"):
+                raise RuntimeError("comm=%r: the direct RCCL path cannot be set up on every rank (%s)" % (
+                    want, "this rank: %s: %s" % (type(local_err).__name__, local_err) if local_err is not None else "another rank failed"))
+            self.comm_note = "direct RCCL unavailable (%s)" % (
+                "%s: %s" % (type(local_err).__name__, local_err) if local_err is not None else "another rank could not set it up")
+        else:
+            # Phase 2 — the collective part: every rank enters it (agreed above).  RuntimeError is what RcclComm raises for a
+            # failed RCCL call or self-test; anything else is a programming error and propagates.
+            try:
+                self._side = side
+                if want != "side-nocoll":
+                    self._rccl = rccl_comm.RcclComm(dev, self.process_group)
+                    self._rccl.selftest()
+                for b in self.buckets:
+                    b.event = torch.cuda.Event()
+                self.comm_mode = "direct" if want != "side-nocoll" else "side-nocoll"
+                self.comm_note = "side stream priority %d" % prio
+            except (RuntimeError, OSError) as e:
+                if want == "direct" or want == "side-nocoll":
+                    raise
+                self._drop_direct()
+                self.comm_note = "direct RCCL unavailable (%s: %s)" % (type(e).__name__, e)
         if self._side is not None and os.environ.get("DETOPS_DDP_NATIVE", "1") != "0":
             self._make_flat_parameters()
             if self._native_update:
@@ -261,8 +279,37 @@ class BucketedDataParallel(torch.nn.Module):
             flag = torch.tensor([1.0 if self.comm_mode == "pg" else 0.0], device=dev)
             dist.all_reduce(flag, group=self.process_group)
             if 0 < float(flag) and self.comm_mode != "pg":
-                self.comm_mode, self._rccl, self._side = "pg", None, None
+                self._drop_direct()
                 self.comm_note = "another rank fell back to ProcessGroupNCCL"
+        logging.getLogger("maskrcnn_benchmark.ddp").info(
+            "BucketedDataParallel: %d bucket(s), world %d, comm_mode=%s (%s)", len(self.buckets), self.world, self.comm_mode, self.comm_note)
+
+    def _drop_direct(self):
+        """leave the direct path: destroy the communicator (if one was created), forget the side stream, fall back to the
+        process group's collectives"""
+        if self._rccl is not None:
+            try:
+                self._rccl.destroy()
+            except Exception:  # noqa: BLE001
+                pass
+        if self._native_update:
+            raise RuntimeError("BucketedDataParallel: cannot leave the direct path after the parameters moved into flat buckets")
+        self.comm_mode, self._rccl, self._side = "pg", None, None
+
+    def close(self):
+        """Release what the wrapper owns outside torch's process group: wait for the side stream, destroy the wrapper's own
+        RCCL communicator and drop the stream.  Call before `dist.destroy_process_group()` (tools/train_net.py, bench.py);
+        idempotent.  The wrapped module stays usable without the wrapper (its parameters keep their values)."""
+        dev = self.buckets[0].flat.device if self.buckets else None
+        if dev is not None and dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        for h in getattr(self, "_hooks", []):
+            h.remove()
+        self._hooks = []
+        if self._rccl is not None:
+            self._rccl.destroy()
+            self._rccl = None
+        self._side = None
 
     @torch.no_grad()
     def _make_flat_parameters(self):
@@ -277,6 +324,9 @@ class BucketedDataParallel(torch.nn.Module):
         moms = set(g["momentum"] for g in opt.param_groups)
         if len(moms) != 1 or 0 in moms or any(g.get("nesterov") or g.get("dampening") for g in opt.param_groups):
             return
+        owned = set(id(q) for g in opt.param_groups for q in g["params"])
+        if any(id(q) not in owned for b in self.buckets for q in b.params):
+            return      # a trained parameter the optimizer does not know: the torch path reports it (KeyError in step_params)
         for b in self.buckets:
             b.flat_p, b.flat_m = torch.zeros_like(b.flat), torch.zeros_like(b.flat)
             for p, o in zip(b.params, b.offsets):
@@ -376,13 +426,20 @@ class BucketedDataParallel(torch.nn.Module):
             if self.overlap_optimizer and self.optimizer.deferred:
                 self.optimizer.last_update_stream = side.cuda_stream
                 if self._native_update:
-                    first = b.params[0]
-                    if first.data_ptr() != b.flat_p.data_ptr() + 4 * b.offsets[0]:
-                        raise RuntimeError("BucketedDataParallel: a parameter was re-allocated after wrapping (model.to(...)?): "
-                                           "its storage is no longer the bucket's")
-                    mb = self.optimizer.state[first].get("momentum_buffer")
-                    if mb is None or mb.data_ptr() != b.flat_m.data_ptr() + 4 * b.offsets[0]:
-                        self._adopt_momentum(b)     # optimizer.load_state_dict() replaced the state tensors
+                    # every parameter (and momentum buffer) of the bucket must still BE its slice of the flat arrays: a
+                    # partial `.data = ...` / load_state_dict(assign=True) / optimizer state load would otherwise leave a
+                    # parameter that the kernel no longer updates (host loop over <= a few hundred pointers per bucket)
+                    base_p, base_m, state = b.flat_p.data_ptr(), b.flat_m.data_ptr(), self.optimizer.state
+                    adopt = False
+                    for q, o in zip(b.params, b.offsets):
+                        if q.data_ptr() != base_p + 4 * o:
+                            raise RuntimeError("BucketedDataParallel: a parameter was re-allocated after wrapping (model.to(...), "
+                                               ".data = ..., load_state_dict(assign=True)?): its storage is no longer the bucket's")
+                        mb = state[q].get("momentum_buffer")
+                        if mb is None or mb.data_ptr() != base_m + 4 * o:
+                            adopt = True
+                    if adopt:
+                        self._adopt_momentum(b)     # optimizer.load_state_dict() replaced (some of) the state tensors
                     gs = self.optimizer.param_groups
                     gw, gb = gs[0], gs[-1]
                     _C.sgd_momentum_flat_(b.flat_p, b.flat, b.flat_m, b.split, gw["lr"], gw["weight_decay"], gb["lr"],

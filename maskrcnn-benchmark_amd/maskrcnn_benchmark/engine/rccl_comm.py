@@ -48,9 +48,9 @@ def available():
     """Can this process call RCCL directly?  (library present, the entry points resolve.)  Checked on every rank BEFORE the
     collective `ncclCommInitRank`, so that a rank that cannot must not leave the others waiting inside it."""
     try:
-        lib = _load()
+        lib = _load()       # raises OSError (no library) or AttributeError (an entry point does not resolve)
         return all(hasattr(lib, n) for n in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy"))
-    except OSError:
+    except Exception:       # noqa: BLE001 — a probe: ANY local failure means "this rank cannot", never an escape past the ranks' agreement
         return False
 
 

@@ -13,7 +13,11 @@ import sys
 def main(path, steps=4, top=40):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "roi_align_fwd" in r["Kernel_Name"] and "7, 7" in r["Kernel_Name"]]
+    # the box head's ROIAlign forward: the NCHW kernel carries its 7 x 7 bins in the name, the channels-last kernel
+    # (roi_align_fwd_nhwc_kernel<V, kOutNhwc = false, ...>) is the box head's when its output is not channels-last
+    def box_fwd(name):
+        return "roi_align_fwd" in name and ("7, 7" in name or ("nhwc_kernel<" in name and ", false" in name))
+    marks = [i for i, r in enumerate(rows) if box_fwd(r["Kernel_Name"])]
     if len(marks) < steps + 1:
         raise SystemExit("not enough steps in the trace (%d markers)" % len(marks))
     a, b = marks[-steps - 1], marks[-1]
