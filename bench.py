@@ -36,6 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "maskrcnn-benchm
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+RANK_SECONDS = []      # timed_steps: every rank's own wall time of the timed region (rank order)
 KERNEL_SAMPLES = 50    # event pairs per hand-written entry point in the kernel-timing post-pass (>= 50 launches)
 
 
@@ -419,8 +420,12 @@ def timed_steps(step, batches, steps, sync, distributed, device, before=None):
     host_elapsed = time.perf_counter() - t0      # everything enqueued; the device may still be running
     sync()
     elapsed = time.perf_counter() - t0
+    RANK_SECONDS[:] = [elapsed]
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)                       # diagnosis: every rank's own clock (min / max in the line)
+        RANK_SECONDS[:] = [float(v.item()) for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, host_elapsed, out
@@ -584,19 +589,34 @@ def main():
     # collective sequence everywhere); rank 0's figures are reported.
     timer = None
     post_steps = 0
+    exposed_ms = None
     if not args.no_kernel_timing:
         calls = call_counter.calls if call_counter else {}
         post_steps = args.kernel_timing_steps
         strides = {name: max(1, (n * post_steps) // KERNEL_SAMPLES) for name, n in calls.items()}
         timer = _C.KernelTimer(every_cap=max(1, post_steps // 10), strides=strides)
         _C.KERNEL_TIMER = timer
+        if hasattr(model, "exposed_wait_events"):
+            model.exposed_wait_events = []       # BucketedDataParallel: event pair around the main stream's join with the side stream
         for i in range(post_steps):
             step(*batches[i % len(batches)])
         sync()
         _C.KERNEL_TIMER = None
+        if getattr(model, "exposed_wait_events", None):
+            ev = model.exposed_wait_events
+            model.exposed_wait_events = None
+            exposed_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
         progress("%d kernel-timing steps done (outside the timed region)" % post_steps)
     gpu_phase_s = time.perf_counter() - gpu_t0
     loss_vals = {k: float(v.detach()) for k, v in losses.items()} if losses else {}
+    # N > 1 diagnosis (VERDICT r05 #4b): every rank's communication path and its exposed all-reduce time, gathered on rank 0
+    ddp_ranks = None
+    if distributed:
+        mine = {"rank": rank, "comm_mode": getattr(model, "comm_mode", None), "comm_note": getattr(model, "comm_note", None),
+                "exposed_allreduce_ms": None if exposed_ms is None else round(exposed_ms, 4)}
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        ddp_ranks = box
 
     if rank == 0:
         images = args.images_per_gpu * world * args.steps
@@ -637,6 +657,13 @@ def main():
             # "pg" = ProcessGroupNCCL (with the reason, when the direct path was tried and refused)
             "ddp_comm": ({"mode": getattr(model, "comm_mode", None), "note": getattr(model, "comm_note", None)}
                          if (distributed or args.force_ddp) else None),
+            # per-rank view of the timed region (N > 1): each rank's own ms per step (the line's clock is the max), the
+            # communication path every rank took, and the main stream's wait for the side stream at the end of backward
+            # (= all-reduce + update time the backward pass did not hide; measured in the post-pass)
+            "rank_ms_per_step": ({"min": round(min(RANK_SECONDS) / args.steps * 1e3, 3), "max": round(max(RANK_SECONDS) / args.steps * 1e3, 3),
+                                  "all": [round(v / args.steps * 1e3, 3) for v in RANK_SECONDS]} if RANK_SECONDS else None),
+            "exposed_allreduce_ms": None if exposed_ms is None else round(exposed_ms, 4),
+            "ddp_ranks": ddp_ranks,
             # host time to ENQUEUE the timed steps (rank 0): close to ms_per_step = the host is the limiter
             "host_enqueue_ms_per_step": round(1000.0 * host_elapsed / args.steps, 3),
         }
@@ -712,10 +739,8 @@ def main():
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if distributed or args.force_ddp:
-        comm = getattr(model, "_rccl", None)
-        if comm is not None:        # the wrapper's own RCCL communicator (engine/rccl_comm.py): released before the process group
-            torch.cuda.synchronize(device)
-            comm.destroy()
+        if hasattr(model, "close"):   # the wrapper's own RCCL communicator + side stream: released before the process group
+            model.close()
         dist.destroy_process_group()
 
 

@@ -187,6 +187,15 @@ int detops_roi_align_fpn_forward_nhwc_f32(const float* const* inputs_host, const
                                           int sampling_ratio, int k_min, int k_max, float canonical_scale,
                                           float canonical_level, float eps, void* workspace, size_t workspace_bytes,
                                           detops_stream_t stream);
+/* The pixel-owner ring backward (csrc/roi_align_bwd.hip) with channels-last gradient maps: same kernels, the store epilogue
+ * writes a thread's channel sums as consecutive floats.  grad_out [K, C, PH, PW]; workspace of
+ * detops_roi_align_backward_workspace_bytes(...) bytes.  DETOPS_EUNSUPPORTED when the ring plan does not serve the shape
+ * (small / under-filled maps, other bin counts): use detops_roi_align_fpn_backward_nhwc_f32 then. */
+int detops_roi_align_fpn_backward_ring_nhwc_f32(const float* grad_out, const float* rois, const int32_t* levels,
+                                                float* const* grad_inputs_host, const int* H_host, const int* W_host,
+                                                const float* scale_host, int num_levels, int N, int C, int K, int PH,
+                                                int PW, int sampling_ratio, int zero_grad_in, void* workspace,
+                                                size_t workspace_bytes, detops_stream_t stream);
 size_t detops_roi_align_fpn_backward_nhwc_workspace_bytes(const int* H_host, const int* W_host, int num_levels, int N,
                                                           int C, int K, int PH, int PW);
 int detops_roi_align_fpn_backward_nhwc_f32(const float* grad_out, int grad_out_nhwc, const float* rois,
@@ -538,6 +547,20 @@ int detops_frozen_bn_act_backward_nhwc(const void* grad_y, const void* y, const 
                                        void* grad_x, void* grad_residual, int dtype, int64_t rows, int C,
                                        int relu, detops_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Bias (+ ReLU) behind a channels-last convolution (csrc/bias_act.hip) — `conv + bias [+ relu]` of the detector's biased
+ * convolutions (reference modeling/backbone/fpn.py:30-40, modeling/rpn/rpn.py:61-76, roi_heads/mask_head): the forward is
+ * detops_frozen_bn_act_forward_nhwc with scale 1; the backward is one pass over the gradient:
+ *   g = relu ? (y > 0 ? grad_y : 0) : grad_y ;  grad_x = g (may alias grad_y when relu = 0) ;  grad_bias[c] = sum_rows g[., c]
+ * x, y, grad_* are [rows = N*H*W, C] fp32 (16-byte aligned); C must satisfy detops_bias_act_supported (a multiple of 4
+ * dividing 1024); deterministic (per-workgroup partial sums added in index order: `workspace` of
+ * detops_bias_act_backward_workspace_bytes(rows, C) bytes), no atomics.
+ * ---------------------------------------------------------------------------------------- */
+int detops_bias_act_supported(int C);
+size_t detops_bias_act_backward_workspace_bytes(int64_t rows, int C);
+int detops_bias_act_backward_nhwc_f32(const float* grad_y, const float* y, float* grad_x, float* grad_bias, int64_t rows,
+                                      int C, int relu, void* workspace, size_t workspace_bytes, detops_stream_t stream);
+
 /* RPN loss in one pass over the head outputs (reference modeling/rpn/loss.py:92-127 with
  * modeling/box_coder.py:27-51 and modeling/rpn/utils.py:9-45): objectness = BCE-with-logits over the sampled
  * anchors, box = smooth-L1(beta) against BoxCoder.encode(matched gt, anchor) over the sampled positives, both
@@ -622,6 +645,10 @@ int detops_pack_f32(const void* const* srcs, const int64_t* counts, const int64_
 int detops_sgd_momentum_flat_f32(float* params, const float* grads, float* momentum_buf, int64_t n, int64_t split,
                                  float lr_weights, float wd_weights, float lr_biases, float wd_biases, float momentum,
                                  detops_stream_t stream);
+/* Measurement tool (not on the training path): `workgroups` workgroups of 1024 threads hold their CUs' wave slots for
+ * `microseconds` on `stream` — a one-GPU stand-in for the CUs a ring all-reduce kernel occupies beside the compute stream at
+ * N > 1 (engine/ddp_step.py: DETOPS_DDP_STANDIN, profiles/r06_ddp_contention.txt). */
+int detops_debug_occupy(int workgroups, int microseconds, detops_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * FPN top-down step (csrc/fpn_topdown.hip) — replaces the pair `F.interpolate(last_inner, mode="nearest")` +

@@ -131,3 +131,34 @@ DETOPS_API int detops_sgd_momentum_flat_f32(float* params, const float* grads, f
                      momentum);
   return launch_status();
 }
+
+// ---- contention stand-in (measurement tool, not part of the training path): `workgroups` workgroups of 1024 threads that
+// each hold a CU's wave slots for `microseconds` (100 MHz wall clock) — what a ring all-reduce kernel of RCCL does to the
+// compute stream's kernels at N > 1 (a fixed number of channels = workgroups resident for the duration of a 25 MB bucket),
+// reproducible on ONE GPU where the 1-rank collective is a no-op.  engine/ddp_step.py launches it on the wrapper's side
+// stream when DETOPS_DDP_STANDIN="workgroups:microseconds" is set (tools/gpu/r06_ddp_contention.sh).
+namespace {
+__global__ void __launch_bounds__(1024)
+occupy_kernel(long long ticks, int* __restrict__ sink) {
+  const long long t0 = detops_wall_clock();
+  int spins = 0;
+  while (detops_wall_clock() - t0 < ticks) {
+#ifndef DETOPS_CPU_EMU
+    __builtin_amdgcn_s_sleep(32);
+#endif
+    if (++spins > (1 << 26)) break;     // bounded whatever the clock does
+#ifdef DETOPS_CPU_EMU
+    break;
+#endif
+  }
+  if (sink && spins < 0) *sink = spins;  // never true: keeps the loop
+}
+}  // namespace
+
+DETOPS_API int detops_debug_occupy(int workgroups, int microseconds, detops_stream_t stream) {
+  if (workgroups < 0 || microseconds < 0 || workgroups > 4096 || microseconds > 100000) return DETOPS_EINVAL;
+  if (workgroups == 0 || microseconds == 0) return 0;
+  hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(1024), 0, as_stream(stream), static_cast<long long>(microseconds) * 100,
+                     static_cast<int*>(nullptr));
+  return launch_status();
+}

@@ -49,6 +49,7 @@ struct RingPlan {
   int seg, extra_cap, slot_cap;        // split policy and the capacities of the extras table / partial-sum slots
   int split_ceil, max_seg;
   int debug;                           // ablation bits (tuning roi_bwd_debug): 1 = skip the walk
+  int nhwc;                            // the gradient maps are channels-last ([N, H, W, C]): only the store epilogue differs
 };
 
 struct RingWs {
@@ -562,7 +563,26 @@ roi_align_bwd_ring_kernel(Levels L, RingPlan P, RingWs ws, const float* __restri
 #pragma unroll
       for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
         if (i == lvl) { gin = L.lv[i].gin; H = L.lv[i].H; W = L.lv[i].W; }
-      if (y0 + yl < H && x0 + xl < W) {
+      if (P.nhwc) {
+        // channels-last maps: the thread's CT channel sums are CT consecutive floats of its pixel's channel vector
+        if (y0 + yl < H && x0 + xl < W) {
+          float* dst = gin + ((static_cast<size_t>(img) * H + (y0 + yl)) * W + (x0 + xl)) * C + c0;
+          if (c0 + CT <= C && !P.accumulate && (C & 3) == 0) {
+#pragma unroll
+            for (int c = 0; c < CT / 4; ++c)
+              *reinterpret_cast<float4*>(dst + 4 * c) = make_float4(acc[2 * c].x, acc[2 * c].y, acc[2 * c + 1].x, acc[2 * c + 1].y);
+          } else {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+              if (c0 + c < C) {
+                float v = (c & 1) ? acc[c / 2].y : acc[c / 2].x;
+                if (P.accumulate) v += dst[c];
+                dst[c] = v;
+              }
+            }
+          }
+        }
+      } else if (y0 + yl < H && x0 + xl < W) {
         const size_t plane = static_cast<size_t>(H) * W;
         float* dst = gin + (static_cast<size_t>(img) * C + c0) * plane + static_cast<size_t>(y0 + yl) * W + (x0 + xl);
         if (c0 + CT <= C && !P.accumulate) {
@@ -1257,11 +1277,12 @@ bool ring_plan(const Levels& L, int N, int C, int K, int PH, int PW, RingPlan& P
 // needs the ROIs and the map shapes, not the gradient), 2 = main kernel only (the workspace holds a phase-1 result)
 int run_backward_ring(const Levels& L, const float* rois, const int32_t* levels_in, const float* gout,
                       int N, int C, int K, int PH, int PW, int sr, int accumulate, void* workspace,
-                      size_t workspace_bytes, bool forced, hipStream_t st, int phase = 0) {
+                      size_t workspace_bytes, bool forced, hipStream_t st, int phase = 0, int nhwc = 0) {
   if (C == 0 || N == 0) return 0;
   if (!workspace || K == 0) return -1;
   RingPlan P; RingLayout lay;
   if (!ring_plan(L, N, C, K, PH, PW, P, lay) || workspace_bytes < lay.total) return -1;
+  P.nhwc = nhwc;
   // underfilled launches (a handful of tiles): the scan kernel's ROI-list split serves them better
   if (!forced && static_cast<int64_t>(P.num_tiles) * P.chunks < 2 * kNumCU) return -1;
   P.accumulate = accumulate;
@@ -1564,4 +1585,27 @@ DETOPS_API int detops_roi_align_fpn_backward_f32(
   return detops_roi_align_fpn_backward_ws_f32(grad_out, rois, levels, grad_inputs_host, H_host, W_host,
                                               scale_host, num_levels, N, C, K, PH, PW, sampling_ratio,
                                               zero_grad_in, nullptr, 0, stream);
+}
+
+// The ring backward with CHANNELS-LAST gradient maps (grad_inputs[l] stored [N, H, W, C]): the same pre-pass, walk and
+// deterministic combine; only the store epilogue differs (a thread's channel sums are consecutive floats of its pixel's
+// channel vector).  grad_out stays [K, C, PH, PW].  Returns DETOPS_EUNSUPPORTED when the ring plan does not serve the shape
+// (the caller then uses detops_roi_align_fpn_backward_nhwc_f32, csrc/roi_align_nhwc.hip).
+DETOPS_API int detops_roi_align_fpn_backward_ring_nhwc_f32(
+    const float* grad_out, const float* rois, const int32_t* levels, float* const* grad_inputs_host, const int* H_host,
+    const int* W_host, const float* scale_host, int num_levels, int N, int C, int K, int PH, int PW, int sampling_ratio,
+    int zero_grad_in, void* workspace, size_t workspace_bytes, detops_stream_t stream) {
+  if (bad_dims(N, C, K, PH, PW) || num_levels < 1 || num_levels > DETOPS_MAX_LEVELS || !grad_inputs_host || !H_host || !W_host ||
+      !scale_host)
+    return DETOPS_EINVAL;
+  if (K <= 0 || C == 0 || N == 0 || !grad_out || !rois || (num_levels > 1 && !levels) || !workspace) return DETOPS_EUNSUPPORTED;
+  Levels L{};
+  L.num = num_levels;
+  for (int i = 0; i < num_levels; ++i) {
+    if (!grad_inputs_host[i] || H_host[i] <= 0 || W_host[i] <= 0) return DETOPS_EINVAL;
+    L.lv[i] = Level{nullptr, grad_inputs_host[i], H_host[i], W_host[i], scale_host[i]};
+  }
+  const int rc = run_backward_ring(L, rois, levels, grad_out, N, C, K, PH, PW, sampling_ratio, zero_grad_in ? 0 : 1, workspace,
+                                   workspace_bytes, false, as_stream(stream), 0, 1);
+  return rc == -1 ? DETOPS_EUNSUPPORTED : rc;
 }

@@ -19,6 +19,7 @@ There is no CPU path: CPU tensors raise "Not implemented on the CPU" (the refere
 for its CUDA-only operators, e.g. csrc/ROIAlign.h:44).
 """
 import ctypes
+import os
 
 import torch
 
@@ -914,18 +915,40 @@ def roi_align_fpn_backward(grad, rois, levels, shapes, scales, pooled_height, po
     return gins
 
 
+NHWC_BACKWARD = os.environ.get("DETOPS_ROIALIGN_NHWC_BWD", "auto")   # auto | ring | native  (A/B switch)
+
+
 def _roi_align_fpn_backward_nhwc(grad, rois, levels, shapes, scales, pooled_height, pooled_width, sampling_ratio):
+    """Channels-last gradient maps.  Two kernels serve this: the pixel-owner ring kernel of the NCHW path with a channels-last
+    store epilogue (csrc/roi_align_bwd.hip: 7 x 7 / 14 x 14 bins on launches that fill the chip — the model's shapes; the
+    pooled gradient is read as [K, C, PH, PW]), and the NHWC-native hit-parallel kernel (csrc/roi_align_nhwc.hip: any shape,
+    contiguous or channels-last pooled gradient).  "auto": the ring kernel where its plan applies (measured 3x faster at the
+    model's shapes, profiles/r06*), the native kernel otherwise."""
     if grad.dtype != torch.float32:
         raise RuntimeError("roi_align_fpn_backward: expected a float32 gradient, got %s" % grad.dtype)
-    g_nhwc = is_channels_last(grad)
-    if not g_nhwc:
-        grad = grad.contiguous()
     rois = _f32c("roi_align_fpn_backward", rois)
     K = rois.size(0)
     gins = [torch.empty(tuple(s), dtype=torch.float32, device=grad.device, memory_format=torch.channels_last) for s in shapes]
     N, C = shapes[0][:2]
     ptrs, Hs, Ws, sc = _nhwc_host_arrays(gins, scales)
     with _on_device(grad):
+        if NHWC_BACKWARD != "native" and K > 0:
+            g = grad.contiguous()          # [K, C, PH, PW] (a channels-last pooled gradient is converted: 51 MB for the mask head)
+            ws, nbytes = _bwd_workspace(grad.device, Hs, Ws, len(gins), N, C, K, pooled_height, pooled_width)
+            if ws is not None:
+                with _timed(("roi_align_fpn_bwd[K=%d,C=%d,%dx%d]", (K, C, pooled_height, pooled_width)), g):
+                    rc = lib.detops_roi_align_fpn_backward_ring_nhwc_f32(
+                        ptr(g), ptr(rois), ptr(levels), ptrs, Hs, Ws, sc, len(gins), N, C, K, pooled_height, pooled_width,
+                        int(sampling_ratio), 1, ptr(ws), nbytes, stream_of(g))
+                if rc == 0:
+                    return gins
+                if rc != -3:      # DETOPS_EUNSUPPORTED: the ring plan does not serve this shape
+                    check(rc, "roi_align_fpn_backward_ring_nhwc")
+            if NHWC_BACKWARD == "ring":
+                raise RuntimeError("roi_align_fpn_backward: the ring plan does not serve this shape (DETOPS_ROIALIGN_NHWC_BWD=ring)")
+        g_nhwc = is_channels_last(grad)
+        if not g_nhwc:
+            grad = grad.contiguous()
         nbytes = int(lib.detops_roi_align_fpn_backward_nhwc_workspace_bytes(Hs, Ws, len(gins), N, C, K, pooled_height, pooled_width))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=grad.device) if nbytes > 0 else None
         with _timed(("roi_align_fpn_bwd[K=%d,C=%d,%dx%d]", (K, C, pooled_height, pooled_width)), grad):
@@ -1096,6 +1119,55 @@ def frozen_bn_act_backward(grad_y, y, scale, relu, need_residual):
                                                     code, N, C, HW, int(bool(relu)), stream_of(grad_y)),
                   "frozen_bn_act_backward")
     return gx, gres
+
+
+_ONES = {}
+
+
+def _ones(C, device):
+    key = (int(C), str(device))
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones((C,), dtype=torch.float32, device=device)
+    return t
+
+
+def bias_act_supported(x, bias):
+    """the fused bias (+ ReLU) path serves fp32 channels-last activations whose channel count divides 1024"""
+    return (bias is not None and on_device(x) and x.dtype == torch.float32 and bias.dtype == torch.float32 and x.dim() == 4
+            and is_channels_last(x) and bool(lib.detops_bias_act_supported(int(x.shape[1]))))
+
+
+class _BiasAct(torch.autograd.Function):
+    """y = [relu](x + bias[c]) on a channels-last activation, one pass each way (csrc/bias_act.hip)"""
+
+    @staticmethod
+    def forward(ctx, x, bias, relu):
+        y = frozen_bn_act_forward(x, _ones(x.shape[1], x.device), bias.contiguous(), None, relu)
+        ctx.relu = relu
+        ctx.save_for_backward(y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        N, C, H, W = gy.shape
+        rows = N * H * W
+        gb = torch.empty((C,), dtype=torch.float32, device=gy.device)
+        gx = torch.empty_like(gy) if ctx.relu else gy
+        nbytes = int(lib.detops_bias_act_backward_workspace_bytes(rows, C))
+        ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=gy.device)
+        with _on_device(gy), _timed(("bias_act_bwd[n=%d,C=%d,relu=%d]", (gy.numel(), C, bool(ctx.relu))), gy, every=4):
+            check(lib.detops_bias_act_backward_nhwc_f32(ptr(gy), ptr(y) if ctx.relu else None, ptr(gx), ptr(gb), rows, C,
+                                                        int(bool(ctx.relu)), ptr(ws), nbytes, stream_of(gy)), "bias_act_backward")
+        return gx, gb, None
+
+
+def bias_act(x, bias, relu=False):
+    """[relu](x + bias[c]) for a channels-last fp32 activation (extension; see bias_act_supported)"""
+    _need_cuda("bias_act", x, bias)
+    return _BiasAct.apply(x, bias, bool(relu))
 
 
 # ------------------------------------------------------------------------------------------ deformable conv

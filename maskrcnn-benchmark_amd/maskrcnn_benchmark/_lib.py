@@ -59,6 +59,7 @@ SIGNATURES = {
     "detops_head_loss_backward_f32": (c_int, [_P, ctypes.c_int64, _P, _P, ctypes.c_int64, _P, _P]),
     "detops_roi_align_fpn_forward_nhwc_workspace_bytes": (c_size_t, [c_int]),
     "detops_roi_align_fpn_forward_nhwc_f32": (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int, _P] + [c_int] * 8 + [c_float] * 3 + [_P, c_size_t, _P]),
+    "detops_roi_align_fpn_backward_ring_nhwc_f32": (c_int, [_P] * 7 + [c_int] * 8 + [_P, c_size_t, _P]),
     "detops_roi_align_fpn_backward_nhwc_workspace_bytes": (c_size_t, [_P, _P] + [c_int] * 6),
     "detops_roi_align_fpn_backward_nhwc_f32": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P] + [c_int] * 8 + [_P, c_size_t, _P]),
     "detops_fpn_topdown_forward": (c_int, [_P, _P, _P] + [c_int] * 6 + [_P]),
@@ -67,6 +68,10 @@ SIGNATURES = {
     "detops_fpn_topdown_backward_nhwc": (c_int, [_P, _P] + [c_int] * 7 + [_P]),
     "detops_pack_max_tensors": (c_int, []),
     "detops_pack_f32": (c_int, [_P, _P, _P, c_int, _P, _P]),
+    "detops_bias_act_supported": (c_int, [c_int]),
+    "detops_bias_act_backward_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int]),
+    "detops_bias_act_backward_nhwc_f32": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_int, c_int, _P, c_size_t, _P]),
+    "detops_debug_occupy": (c_int, [c_int, c_int, _P]),
     "detops_sgd_momentum_flat_f32": (c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64] + [c_float] * 5 + [_P]),
     "detops_rpn_decode_f32": (c_int, [_P] * 5 + [c_int] * 5 + [c_float] * 6 + [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, _P, _P]),
     "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),

@@ -209,6 +209,9 @@ class BucketedDataParallel(torch.nn.Module):
         if cur:
             self.buckets.append(_Bucket(cur, is_bias))
         self._next, self._armed, self._futures = 0, False, []
+        self.exposed_wait_events = None     # a list: _finish_backward appends an event pair around the main stream's join
+        spec = os.environ.get("DETOPS_DDP_STANDIN", "")
+        self._standin = tuple(int(v) for v in spec.split(":")) if spec else None
         self._setup_comm(comm if comm is not None else os.environ.get("DETOPS_DDP_COMM", "auto"))
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(b))
                        for b in self.buckets for p in b.params]
@@ -423,6 +426,10 @@ class BucketedDataParallel(torch.nn.Module):
             side.wait_event(b.event)
             if self._rccl is not None:
                 self._rccl.all_reduce_avg_(b.flat, side)
+            if self._standin is not None:
+                # measurement only (DETOPS_DDP_STANDIN="workgroups:microseconds"): hold CUs on the side stream the way an
+                # N > 1 ring all-reduce kernel would for this bucket — the 1-rank collective above is a no-op copy
+                _C.check(_C.lib.detops_debug_occupy(self._standin[0], self._standin[1], side.cuda_stream), "debug_occupy")
             if self.overlap_optimizer and self.optimizer.deferred:
                 self.optimizer.last_update_stream = side.cuda_stream
                 if self._native_update:
@@ -473,7 +480,17 @@ class BucketedDataParallel(torch.nn.Module):
         for f in self._futures:
             f.wait()                # device: the current stream waits for the callbacks' stream; host does not block
         if self._side is not None and self.buckets:
-            torch.cuda.current_stream(self.buckets[0].flat.device).wait_stream(self._side)   # device-side join
+            main = torch.cuda.current_stream(self.buckets[0].flat.device)
+            if self.exposed_wait_events is not None:
+                # diagnosis (bench.py's post-pass): how long the compute stream stands still here = the part of the bucket
+                # all-reduces + updates the backward pass did NOT hide
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(main)
+                main.wait_stream(self._side)
+                b.record(main)
+                self.exposed_wait_events.append((a, b))
+            else:
+                main.wait_stream(self._side)   # device-side join
         self._reset()
 
 

@@ -22,6 +22,8 @@ def do_train(cfg, model, data_loader, optimizer, scheduler, checkpointer, device
              log_period=20):
     logger = logging.getLogger("maskrcnn_benchmark.trainer")
     logger.info("Start training")
+    if hasattr(model, "comm_mode"):    # BucketedDataParallel: say which communication path runs (a silent fall-back is slower)
+        logger.info("data parallel: comm_mode=%s (%s)", model.comm_mode, model.comm_note)
     meters = MetricLogger(delimiter="  ")
     start_iter = arguments["iteration"]
     max_iter = start_iter + len(data_loader)      # the loader holds the REMAINING iterations (reference: IterationBasedBatchSampler)

@@ -5,6 +5,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from maskrcnn_benchmark import _C
+from maskrcnn_benchmark.layers.misc import conv_bias_act
 
 _FUSED_TOPDOWN = __import__("os").environ.get("DETOPS_FPN_TOPDOWN", "fused") != "torch"   # A/B switch
 
@@ -25,19 +26,19 @@ class FPN(nn.Module):
 
     def forward(self, x):
         """x: C2..C5 (fine -> coarse).  Returns P2..P5 (+ extra levels), fine -> coarse."""
-        last = getattr(self, self.inner_blocks[-1])(x[-1])
-        results = [getattr(self, self.layer_blocks[-1])(last)]
+        last = conv_bias_act(getattr(self, self.inner_blocks[-1]), x[-1])
+        results = [conv_bias_act(getattr(self, self.layer_blocks[-1]), last)]
         for feat, inner, layer in zip(x[:-1][::-1], self.inner_blocks[:-1][::-1], self.layer_blocks[:-1][::-1]):
             if not inner:
                 continue
-            lateral = getattr(self, inner)(feat)
+            lateral = conv_bias_act(getattr(self, inner), feat)
             if _FUSED_TOPDOWN and _C.on_device(lateral) and lateral.dtype == last.dtype and lateral.dtype in _C._lib.DTYPE_CODE:
                 # one streaming pass instead of interpolate + add and their full-size temporary (csrc/fpn_topdown.hip)
                 last = _C.fpn_topdown(lateral, last)
             else:
                 top_down = F.interpolate(last, size=(int(lateral.shape[-2]), int(lateral.shape[-1])), mode="nearest")
                 last = lateral + top_down
-            results.insert(0, getattr(self, layer)(last))
+            results.insert(0, conv_bias_act(getattr(self, layer), last))
         if isinstance(self.top_blocks, LastLevelP6P7):
             results.extend(self.top_blocks(x[-1], results[-1]))
         elif isinstance(self.top_blocks, LastLevelMaxPool):

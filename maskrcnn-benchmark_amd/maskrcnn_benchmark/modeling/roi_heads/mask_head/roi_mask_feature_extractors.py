@@ -2,6 +2,7 @@
 from torch import nn
 from torch.nn import functional as F
 
+from maskrcnn_benchmark.layers.misc import conv_bias_act
 from maskrcnn_benchmark.modeling import registry
 from maskrcnn_benchmark.modeling.make_layers import make_conv3x3
 from maskrcnn_benchmark.modeling.poolers import make_pooler
@@ -32,7 +33,7 @@ class MaskRCNNFPNFeatureExtractor(nn.Module):
     def forward(self, x, proposals):
         x = self.pooler(x, proposals)
         for name in self.blocks:
-            x = F.relu(getattr(self, name)(x))
+            x = conv_bias_act(getattr(self, name), x, relu=True)
         return x
 
 

@@ -3,6 +3,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from maskrcnn_benchmark.layers import Conv2d, ConvTranspose2d
+from maskrcnn_benchmark.layers.misc import conv_bias_act
 from maskrcnn_benchmark.modeling import registry
 
 
@@ -27,7 +28,7 @@ class MaskRCNNC4Predictor(nn.Module):
         _kaiming_out(self)
 
     def forward(self, x):
-        return self.mask_fcn_logits(F.relu(self.conv5_mask(x)))
+        return self.mask_fcn_logits(conv_bias_act(self.conv5_mask, x, relu=True))
 
 
 @registry.ROI_MASK_PREDICTOR.register("MaskRCNNConv1x1Predictor")

@@ -3,6 +3,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from maskrcnn_benchmark.layers.misc import conv_bias_act
+
 from maskrcnn_benchmark.modeling import registry
 from maskrcnn_benchmark.modeling.box_coder import BoxCoder
 
@@ -43,7 +45,7 @@ class RPNHead(nn.Module):
     def forward(self, x):
         logits, bbox_reg = [], []
         for feature in x:
-            t = F.relu(self.conv(feature))
+            t = conv_bias_act(self.conv, feature, relu=True)      # channels-last: conv, then ONE fused bias + ReLU pass
             # the proposal / loss kernels read the A and 4A-channel outputs in NCHW; under a channels-last pyramid these two
             # small tensors are the only ones converted (a no-op for NCHW features)
             logits.append(self.cls_logits(t).contiguous())

@@ -1,5 +1,5 @@
-# Round 6, experiment D: persistent hit-parallel NHWC backward (branch-free walk), 16-wave NHWC forward; shipped find-db.
-O=gpurun_out/r06d; mkdir -p $O; export MIOPEN_LOG_LEVEL=1
+# Round 6, experiment E: ring backward with a channels-last store epilogue, fused bias (+ ReLU) + in-pass bias gradient for channels-last convolutions.
+O=gpurun_out/r06e; mkdir -p $O; export MIOPEN_LOG_LEVEL=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 jl() { grep -E "^\{" "$1" | tail -1 | python -c "
 import json,sys
@@ -15,7 +15,7 @@ P=/tmp/prof_all; rm -rf $P
 timeout 500 rocprofv3 --kernel-trace --output-format csv -d $P -o bench -- python bench.py --steps 6 --warmup 6 --no-cpu-baseline --no-kernel-timing --layout all < /dev/null > $O/prof_all.log 2>&1
 T=$(find $P -name "*kernel_trace.csv" | head -1)
 [ -n "$T" ] && python tools/trace_steps.py "$T" 4 70 > $O/all_step_breakdown.txt 2>&1 && head -50 $O/all_step_breakdown.txt | cut -c1-150
-PM="python tools/opbench.py --only roi_sets --layout nhwc --heads box --dir bwd --iters 5 --sets model-random-init"
+PM="python tools/opbench.py --only roi_sets --layout nhwc --heads box --dir fwd --iters 5 --sets model-random-init"
 for pass in "sq:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
             "sq2:SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   n=${pass%%:*}; c=${pass#*:}; rm -rf /tmp/pmc_$n

@@ -50,6 +50,10 @@ def main():
     logger.info("Using %d GPUs", world)
     logger.info("Running with config:\n%s", cfg.dump())
     model, optimizer, scheduler, _ = build_training(cfg, device, distributed, local_rank)
+    # which communication path the data-parallel wrapper took ("direct" RCCL on its side stream, or the ProcessGroupNCCL
+    # fallback with the reason) and the activation layout — a silent fall-back costs ~1.3 ms per step (profiles/r05b_ddp_paths.txt)
+    logger.info("data parallel: comm_mode=%s (%s); layout=%s", getattr(model, "comm_mode", "single process"),
+                getattr(model, "comm_note", "-"), getattr(getattr(model, "module", model), "layout", "nchw"))
     out_dir = cfg.OUTPUT_DIR if cfg.OUTPUT_DIR != "." else ""
     if out_dir and get_rank() == 0:
         os.makedirs(out_dir, exist_ok=True)      # reference tools/train_net.py:166-168
@@ -64,6 +68,8 @@ def main():
         loader = make_data_loader(cfg, is_train=True, is_distributed=distributed, start_iter=arguments["iteration"],
                                   length=remaining * max(cfg.SOLVER.IMS_PER_BATCH // world, 1))
         do_train(cfg, model, loader, optimizer, scheduler, checkpointer, device, cfg.SOLVER.CHECKPOINT_PERIOD, arguments)
+    if hasattr(model, "close"):       # BucketedDataParallel: its own RCCL communicator and side stream go before the process group
+        model.close()
     if distributed:
         torch.distributed.destroy_process_group()
 
