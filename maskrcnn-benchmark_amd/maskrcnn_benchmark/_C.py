@@ -1133,17 +1133,27 @@ def _ones(C, device):
 
 
 def bias_act_supported(x, bias):
-    """the fused bias (+ ReLU) path serves fp32 channels-last activations whose channel count divides 1024"""
+    """bias_act serves fp32 channels-last activations on the device (any channel count: widths dividing 1024 through the
+    fused kernels of csrc/bias_act.hip, the others — the RPN's 3 / 12 and the mask logits' 81 channels — through an in-place
+    add and a matrix-vector product for the bias gradient)"""
     return (bias is not None and on_device(x) and x.dtype == torch.float32 and bias.dtype == torch.float32 and x.dim() == 4
-            and is_channels_last(x) and bool(lib.detops_bias_act_supported(int(x.shape[1]))))
+            and is_channels_last(x))
 
 
 class _BiasAct(torch.autograd.Function):
-    """y = [relu](x + bias[c]) on a channels-last activation, one pass each way (csrc/bias_act.hip)"""
+    """y = [relu](x + bias[c]) on a channels-last activation (csrc/bias_act.hip).  The point is the BACKWARD: the bias
+    gradient of a channels-last gradient is a column sum over [N*H*W, C]; PyTorch's `sum((0, 2, 3))` runs it through a generic
+    strided reduce kernel at ~0.1 TB/s."""
 
     @staticmethod
     def forward(ctx, x, bias, relu):
-        y = frozen_bn_act_forward(x, _ones(x.shape[1], x.device), bias.contiguous(), None, relu)
+        ctx.fused = bool(lib.detops_bias_act_supported(int(x.shape[1])))
+        if ctx.fused:
+            y = frozen_bn_act_forward(x, _ones(x.shape[1], x.device), bias.contiguous(), None, relu)
+        else:
+            y = x.add_(bias.view(1, -1, 1, 1)) if not x.requires_grad else x + bias.view(1, -1, 1, 1)
+            if relu:
+                y = y.relu_()
         ctx.relu = relu
         ctx.save_for_backward(y if relu else None)
         return y
@@ -1154,6 +1164,11 @@ class _BiasAct(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last)
         N, C, H, W = gy.shape
         rows = N * H * W
+        if not ctx.fused:
+            gx = gy * (y > 0) if ctx.relu else gy
+            g2d = gx.permute(0, 2, 3, 1).reshape(rows, C)          # a view of the channels-last storage
+            gb = torch.mv(g2d.t(), _ones(rows, gy.device))         # column sums as one bandwidth-bound GEMV
+            return gx, gb, None
         gb = torch.empty((C,), dtype=torch.float32, device=gy.device)
         gx = torch.empty_like(gy) if ctx.relu else gy
         nbytes = int(lib.detops_bias_act_backward_workspace_bytes(rows, C))
@@ -1165,7 +1180,8 @@ class _BiasAct(torch.autograd.Function):
 
 
 def bias_act(x, bias, relu=False):
-    """[relu](x + bias[c]) for a channels-last fp32 activation (extension; see bias_act_supported)"""
+    """[relu](x + bias[c]) for a channels-last fp32 activation (extension; see bias_act_supported).  `x` may be overwritten
+    (it is the caller's fresh convolution output)."""
     _need_cuda("bias_act", x, bias)
     return _BiasAct.apply(x, bias, bool(relu))
 

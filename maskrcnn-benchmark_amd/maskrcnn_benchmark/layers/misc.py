@@ -40,13 +40,13 @@ def conv_bias_act(conv, x, relu=False):
     plain = type(conv) in (nn.Conv2d, Conv2d)
     trans = type(conv) in (nn.ConvTranspose2d, ConvTranspose2d)
     if (plain or trans) and conv.bias is not None and x.numel() > 0 and conv.padding_mode == "zeros" and _C.is_channels_last(x) \
-            and x.dtype == torch.float32 and _C.on_device(x) and bool(_C.lib.detops_bias_act_supported(int(conv.weight.shape[1 if trans else 0]) * (conv.groups if trans else 1))):
+            and x.dtype == torch.float32 and _C.on_device(x):
         if plain:
             y = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         else:
             y = torch.nn.functional.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding, conv.output_padding,
                                                      conv.groups, conv.dilation)
-        if _C.is_channels_last(y):
+        if _C.bias_act_supported(y, conv.bias):
             return _C.bias_act(y, conv.bias, relu)
         y = y + conv.bias.view(1, -1, 1, 1)
         return torch.relu(y) if relu else y

@@ -28,7 +28,7 @@ class MaskRCNNC4Predictor(nn.Module):
         _kaiming_out(self)
 
     def forward(self, x):
-        return self.mask_fcn_logits(conv_bias_act(self.conv5_mask, x, relu=True))
+        return conv_bias_act(self.mask_fcn_logits, conv_bias_act(self.conv5_mask, x, relu=True))
 
 
 @registry.ROI_MASK_PREDICTOR.register("MaskRCNNConv1x1Predictor")

@@ -48,8 +48,8 @@ class RPNHead(nn.Module):
             t = conv_bias_act(self.conv, feature, relu=True)      # channels-last: conv, then ONE fused bias + ReLU pass
             # the proposal / loss kernels read the A and 4A-channel outputs in NCHW; under a channels-last pyramid these two
             # small tensors are the only ones converted (a no-op for NCHW features)
-            logits.append(self.cls_logits(t).contiguous())
-            bbox_reg.append(self.bbox_pred(t).contiguous())
+            logits.append(conv_bias_act(self.cls_logits, t).contiguous())
+            bbox_reg.append(conv_bias_act(self.bbox_pred, t).contiguous())
         return logits, bbox_reg
 
 
