@@ -9,6 +9,8 @@
 // y = [relu](x + b), one pass); the backward below is ONE pass that applies the ReLU mask, writes grad_x and accumulates
 // the per-channel column sums in registers (a thread's channel window is loop-invariant), reduced per workgroup through LDS
 // into `partials`; a second small launch adds the workgroups' partials in index order: deterministic, no atomics.
+#include <algorithm>
+
 #include "detops_common.h"
 
 namespace {
@@ -78,6 +80,27 @@ bias_grad_finish_kernel(const float* __restrict__ partials, float* __restrict__ 
   }
 }
 
+// Column sums of a [rows, C] matrix for ANY C <= 256 (the RPN's 3 / 12-channel outputs, the mask logits' 81): a thread is
+// (row lane, channel) with the channel count padded to a power of two, consecutive threads read consecutive addresses;
+// per-workgroup partial sums in row-lane order through LDS, then bias_grad_finish_kernel.
+__global__ void __launch_bounds__(kBaThreads)
+column_sum_kernel(const float* __restrict__ x, float* __restrict__ partials, int C, int Cp, int64_t rows) {
+  __shared__ float red[kBaThreads];
+  const int tid = threadIdx.x;
+  const int c = tid % Cp, rl = tid / Cp, rpb = kBaThreads / Cp;      // rows per workgroup pass
+  float s = 0.f;
+  if (c < C)
+    for (int64_t r = static_cast<int64_t>(blockIdx.x) * rpb + rl; r < rows; r += static_cast<int64_t>(gridDim.x) * rpb)
+      s += x[r * C + c];
+  red[tid] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float t = red[c];
+    for (int q = 1; q < rpb; ++q) t += red[q * Cp + c];
+    partials[static_cast<size_t>(blockIdx.x) * C + c] = t;
+  }
+}
+
 int ba_blocks(int64_t nvec, int C) {
   int64_t blocks = ceil_div64(nvec, static_cast<int64_t>(kBaThreads) * 8);
   if (blocks < 1) blocks = 1;
@@ -116,5 +139,34 @@ DETOPS_API int detops_bias_act_backward_nhwc_f32(const float* grad_y, const floa
   if (e) return e;
   hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(static_cast<unsigned>(ceil_div64(C, kBfCh))), dim3(kBfCh * kBfRows), 0, st, partials,
                      grad_bias, C, blocks);
+  return launch_status();
+}
+
+// out[c] = sum_r x[r, c] for a row-major [rows, C] fp32 matrix, C <= 256 (any value); deterministic.  workspace:
+// detops_column_sum_workspace_bytes(rows, C) bytes.
+DETOPS_API size_t detops_column_sum_workspace_bytes(int64_t rows, int C) {
+  if (rows <= 0 || C <= 0 || C > kBaThreads) return 0;
+  return sizeof(float) * static_cast<size_t>(kBaMaxBlocks) * C;
+}
+
+DETOPS_API int detops_column_sum_f32(const float* x, float* out, int64_t rows, int C, void* workspace, size_t workspace_bytes,
+                                     detops_stream_t stream) {
+  if (rows < 0 || C <= 0) return DETOPS_EINVAL;
+  if (C > kBaThreads) return DETOPS_EUNSUPPORTED;
+  if (!out || (rows > 0 && (!x || !workspace))) return DETOPS_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (rows == 0) { DETOPS_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * C, st)); return 0; }
+  int Cp = 1;
+  while (Cp < C) Cp <<= 1;
+  const int rpb = kBaThreads / Cp;
+  int64_t blocks = ceil_div64(rows, static_cast<int64_t>(rpb) * 16);
+  blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, kBaMaxBlocks));
+  if (workspace_bytes < sizeof(float) * static_cast<size_t>(blocks) * C) return DETOPS_EINVAL;
+  float* partials = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(column_sum_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBaThreads), 0, st, x, partials, C, Cp, rows);
+  int e = launch_status();
+  if (e) return e;
+  hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(static_cast<unsigned>(ceil_div64(C, kBfCh))), dim3(kBfCh * kBfRows), 0, st, partials, out,
+                     C, static_cast<int>(blocks));
   return launch_status();
 }

@@ -1166,9 +1166,7 @@ class _BiasAct(torch.autograd.Function):
         rows = N * H * W
         if not ctx.fused:
             gx = gy * (y > 0) if ctx.relu else gy
-            g2d = gx.permute(0, 2, 3, 1).reshape(rows, C)          # a view of the channels-last storage
-            gb = torch.mv(g2d.t(), _ones(rows, gy.device))         # column sums as one bandwidth-bound GEMV
-            return gx, gb, None
+            return gx, column_sum(gx.permute(0, 2, 3, 1).reshape(rows, C)), None    # (a view of the channels-last storage)
         gb = torch.empty((C,), dtype=torch.float32, device=gy.device)
         gx = torch.empty_like(gy) if ctx.relu else gy
         nbytes = int(lib.detops_bias_act_backward_workspace_bytes(rows, C))
@@ -1177,6 +1175,21 @@ class _BiasAct(torch.autograd.Function):
             check(lib.detops_bias_act_backward_nhwc_f32(ptr(gy), ptr(y) if ctx.relu else None, ptr(gx), ptr(gb), rows, C,
                                                         int(bool(ctx.relu)), ptr(ws), nbytes, stream_of(gy)), "bias_act_backward")
         return gx, gb, None
+
+
+def column_sum(x2d):
+    """[rows, C] row-major fp32 -> [C] column sums (extension, csrc/bias_act.hip; C <= 256), deterministic"""
+    _need_cuda("column_sum", x2d)
+    x2d = _f32c("column_sum", x2d)
+    rows, C = x2d.shape
+    out = torch.empty((C,), dtype=torch.float32, device=x2d.device)
+    if C > 256:
+        return x2d.sum(0)
+    nbytes = int(lib.detops_column_sum_workspace_bytes(rows, C))
+    ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=x2d.device)
+    with _on_device(x2d):
+        check(lib.detops_column_sum_f32(ptr(x2d), ptr(out), rows, C, ptr(ws), nbytes, stream_of(x2d)), "column_sum")
+    return out
 
 
 def bias_act(x, bias, relu=False):

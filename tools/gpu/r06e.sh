@@ -1,5 +1,5 @@
 # Round 6, experiment E: ring backward with a channels-last store epilogue, fused bias (+ ReLU) + in-pass bias gradient for channels-last convolutions.
-O=gpurun_out/r06f; mkdir -p $O; export MIOPEN_LOG_LEVEL=1
+O=gpurun_out/r06g; mkdir -p $O; export MIOPEN_LOG_LEVEL=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 jl() { grep -E "^\{" "$1" | tail -1 | python -c "
 import json,sys
