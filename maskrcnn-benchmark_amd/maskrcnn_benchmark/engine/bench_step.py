@@ -29,8 +29,9 @@ def choose_layout(cfg, device, layout="auto"):
     """-> "nchw" | "backbone" | "all": which part of the detector runs on channels-last (NHWC) activations
     (GeneralizedRCNN.set_channels_last).  "auto" (overridable with DETOPS_LAYOUT): channels-last on the GPU for the fp32
     FPN detectors without deformable convolutions — the configurations it was measured on, with the tuned MIOpen find-db
-    for the NHWC problem keys that ships in-tree (profiles/r06a_*: 37.6 -> 35.8 ms per step for e2e_mask_rcnn_R_50_FPN_1x
-    with the backbone alone); NCHW everywhere else (CPU, half precision, DCN stages: not measured / slower)."""
+    for the NHWC problem keys that ships in-tree (e2e_mask_rcnn_R_50_FPN_1x on one box: NCHW 38.0 ms per step, backbone + FPN
+    channels-last 36.2, the heads as well 33.4: profiles/r06g_*); NCHW everywhere else (CPU, half precision, DCN stages: not
+    measured / slower)."""
     layout = os.environ.get("DETOPS_LAYOUT", layout) if layout == "auto" else layout
     if layout in ("nchw", "backbone", "all"):
         return layout
@@ -41,7 +42,7 @@ def choose_layout(cfg, device, layout="auto"):
     return AUTO_LAYOUT if ok else "nchw"
 
 
-AUTO_LAYOUT = "backbone"
+AUTO_LAYOUT = "all"
 
 
 def build_training(cfg, device, distributed=False, local_rank=0, overlap_optimizer=True, force_ddp=False, bucket_cap_mb=None,

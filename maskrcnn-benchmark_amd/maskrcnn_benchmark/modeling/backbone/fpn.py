@@ -64,5 +64,5 @@ class LastLevelP6P7(nn.Module):
         self.use_P5 = in_channels == out_channels
 
     def forward(self, c5, p5):
-        p6 = self.p6(p5 if self.use_P5 else c5)
-        return [p6, self.p7(F.relu(p6))]
+        p6 = conv_bias_act(self.p6, p5 if self.use_P5 else c5)
+        return [p6, conv_bias_act(self.p7, F.relu(p6))]
