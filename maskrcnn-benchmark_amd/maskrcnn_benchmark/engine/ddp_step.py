@@ -150,10 +150,23 @@ class _Bucket(object):
         if self.split is None:
             self.split = at
         self.flat = torch.zeros(at, dtype=params[0].dtype, device=params[0].device)
-        self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, params)]
+        # a view has its PARAMETER's strides (a channels-last convolution weight stays channels-last inside its slot): the
+        # fused multi-tensor SGD of the process-group path needs parameter, gradient and momentum laid out alike
+        self.views = [self._view(self.flat, o, p) for o, p in zip(self.offsets, params)]
         self.pending = len(params)
         self.event = None       # direct-RCCL path: "this bucket is packed" (recorded on the main stream, reused every step)
         self.flat_p = self.flat_m = None
+
+    @staticmethod
+    def _view(flat, offset, p):
+        piece = flat[offset:offset + p.numel()]
+        if p.is_contiguous() or not p.is_contiguous(memory_format=torch.channels_last):
+            return piece.view(p.shape)
+        return piece.as_strided(p.shape, p.stride())
+
+    def contiguous_views(self):
+        """the native flat-bucket path moves the parameters themselves into row-major slots: the gradient views follow"""
+        self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
 
 
 class BucketedDataParallel(torch.nn.Module):
@@ -332,6 +345,7 @@ class BucketedDataParallel(torch.nn.Module):
             return      # a trained parameter the optimizer does not know: the torch path reports it (KeyError in step_params)
         for b in self.buckets:
             b.flat_p, b.flat_m = torch.zeros_like(b.flat), torch.zeros_like(b.flat)
+            b.contiguous_views()
             for p, o in zip(b.params, b.offsets):
                 pv = b.flat_p[o:o + p.numel()].view(p.shape)
                 pv.copy_(p.data)
