@@ -543,7 +543,8 @@ roi_align_bwd_nhwc_kernel(Levels L, NbPlan P, NbWs ws, const float* __restrict__
 // grid is persistent and units are numbered coarsest level first.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kNgBlock = 256;                 // 4 waves = 4 independent units
-constexpr int kNgPrepBlock = 256;
+constexpr int kNgPrepBlock = 1024;           // pre-pass 1: 16 waves = 16 tiles share one LDS table of ROI extents
+constexpr int kNgRecBlock = 256;             // pre-pass 2: a wave per hit
 
 struct NgPlan {
   NbPlan nb;                 // tiles (kNbTH x kNbTW), channel chunks, level table
@@ -590,21 +591,26 @@ roi_bwd_ng_prep1_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ r
   __shared__ int4 ext[kNbPrepRois];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   if (static_cast<int>(blockIdx.x) >= list_blocks) {
-    // ---- transpose role: ROI r's [C][bins] block, 64 channels at a time through the same LDS array
-    const int r = static_cast<int>(blockIdx.x) - list_blocks;
+    // ---- transpose role: one (ROI, 64-channel chunk) per workgroup: [64][bins] contiguous in, [bins][64-channel piece] out
+    const int u = static_cast<int>(blockIdx.x) - list_blocks;
+    const int r = u / P.nb.cchunks, c0 = (u - r * P.nb.cchunks) * kNbCh;
     const int bins = PH * PW;
-    float* t = reinterpret_cast<float*>(ext);                    // 16 KiB: 64 channels x <= 64 bins ... chunked below
-    const int chunk_c = (kNbPrepRois * 4) / bins;                 // channels per pass (4096 floats of LDS)
-    const float* src = gout + static_cast<size_t>(r) * C * bins;
-    float* dst = ws.gT + static_cast<size_t>(r) * bins * C;
-    for (int c0 = 0; c0 < C; c0 += chunk_c) {
-      const int cn = min(chunk_c, C - c0);
+    const int cn = min(kNbCh, C - c0);
+    float* t = reinterpret_cast<float*>(ext);                    // 16 KiB >= 64 channels x 49 bins; larger bin counts in passes
+    const float* src = gout + (static_cast<size_t>(r) * C + c0) * bins;
+    float* dst = ws.gT + static_cast<size_t>(r) * bins * C + c0;
+    const int bpass = (kNbPrepRois * 4) / kNbCh;                  // bins per pass (64 at 16 KiB)
+    for (int b0 = 0; b0 < bins; b0 += bpass) {
+      const int bn = min(bpass, bins - b0);
       __syncthreads();
-      for (int o = tid; o < cn * bins; o += kNgPrepBlock) t[o] = src[static_cast<size_t>(c0) * bins + o];   // linear, coalesced
+      for (int o = tid; o < cn * bn; o += kNgPrepBlock) {         // element (c, b) = (o / bn, o % bn): runs of bn floats per channel
+        const int c = o / bn, b = o - c * bn;
+        t[c * (bn | 1) + b] = src[static_cast<size_t>(c) * bins + b0 + b];
+      }
       __syncthreads();
-      for (int o = tid; o < cn * bins; o += kNgPrepBlock) {       // out index: bin-major, channel fastest
-        const int b = o / cn, c = o - b * cn;
-        dst[static_cast<size_t>(b) * C + c0 + c] = t[c * bins + b];
+      for (int o = tid; o < bn * kNbCh; o += kNgPrepBlock) {      // out: bin-major, channel fastest (256-byte pieces)
+        const int b = o >> 6, c = o & (kNbCh - 1);
+        if (c < cn) dst[static_cast<size_t>(b0 + b) * C + c] = t[c * (bn | 1) + b];
       }
     }
     return;
@@ -613,14 +619,15 @@ roi_bwd_ng_prep1_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ r
   const bool live = tile < P.nb.num_tiles;
   NbTile t{0, 0, 0, 0};
   if (live) t = nb_tile(L, P.nb, tile);
-  // pass A: count; pass B: write (the ROI extents are recomputed per pass: K <= a few thousand)
+  // pass A: count; pass B: write (the ROI extents stay in LDS between the passes when K fits the table)
   int count = 0, base = 0;
   for (int pass = 0; pass < 2; ++pass) {
     int seen = 0;
     for (int r0 = 0; r0 < K; r0 += kNbPrepRois) {
       const int n = min(kNbPrepRois, K - r0);
-      __syncthreads();
-      for (int i = tid; i < n; i += kNgPrepBlock) {
+      const bool fill = pass == 0 || K > kNbPrepRois;
+      if (fill) __syncthreads();
+      for (int i = tid; fill && i < n; i += kNgPrepBlock) {
         const float* roi = rois + static_cast<size_t>(r0 + i) * 5;
         int lvl = 0;
         if (L.num > 1) lvl = levels_in ? levels_in[r0 + i] : fpn_level(roi, L);
@@ -632,7 +639,7 @@ roi_bwd_ng_prep1_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ r
         const bool ok = e.ny > 0 && e.nx > 0;
         ext[i] = make_int4(lvl | (e.b << 8), ok ? (e.fy0 | (e.ny << 16)) : 0, ok ? (e.fx0 | (e.nx << 16)) : 0, 0);
       }
-      __syncthreads();
+      if (fill) __syncthreads();
       if (live) {
         for (int i0 = 0; i0 < n; i0 += kWave) {
           const int i = i0 + lane;
@@ -672,12 +679,12 @@ roi_bwd_ng_prep1_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ r
 //   record = { ROI, ph_lo | nph << 8, pw_lo | npw << 8, 0 }  AY[PH][4]  AX[PWMAX][8]      (window-relative, zero-padded)
 // Weights by the exact reference tap arithmetic, summed per bin in sample order like build_adjoint_rows:
 //   A[pixel][bin] = (1 / grid) * sum_i ([tap.lo == pixel] * tap.h + [tap.hi == pixel] * tap.l).
-__global__ void __launch_bounds__(kNgPrepBlock)
+__global__ void __launch_bounds__(kNgRecBlock)
 roi_bwd_ng_prep2_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
                         int PH, int PW, int sr) {
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const int total = min(ws.ctrl[0], P.hit_cap);
-  for (int h = static_cast<int>(blockIdx.x) * (kNgPrepBlock / kWave) + wave; h < total; h += static_cast<int>(gridDim.x) * (kNgPrepBlock / kWave)) {
+  for (int h = static_cast<int>(blockIdx.x) * (kNgRecBlock / kWave) + wave; h < total; h += static_cast<int>(gridDim.x) * (kNgRecBlock / kWave)) {
     const int2 hr = ws.hits[h];
     const NbTile t = nb_tile(L, P.nb, hr.x);
     const int r = hr.y;
@@ -737,12 +744,18 @@ roi_bwd_ng_prep2_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ r
 template <int PWMAX>
 __global__ void __launch_bounds__(kNgBlock)
 roi_align_bwd_ng_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ gT, int C, int PH, int PW, int units) {
+  // per wave: the current hit's record as a broadcast table (every lane reads the same address: one LDS access per read)
+  constexpr int kRecMax = 4 + 14 * 4 + 14 * 8;            // 172 floats
+  __shared__ __attribute__((aligned(16))) float rtab[kNgBlock / kWave][((kRecMax + 63) / 64) * 64];
   // the wave index is wave-uniform, but the compiler only knows that if it comes out of a scalar register: everything derived
-  // from it (unit, tile, record address) then lives in SGPRs and the record is read by SCALAR loads
+  // from it (unit, tile, record address) then lives in SGPRs
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(threadIdx.x / kWave)));
   const int bins = PH * PW;
   const int nw = static_cast<int>(gridDim.x) * (kNgBlock / kWave);
+  const int rec_f = P.rec_f;
+  const int nrl = (rec_f + kWave - 1) / kWave;              // record loads per lane (2 for 7 x 7, 3 for 14 x 14)
+  float* rt = rtab[wave];
   for (int unit = static_cast<int>(blockIdx.x) * (kNgBlock / kWave) + wave; unit < units; unit += nw) {
     const int tile = unit / P.nb.cchunks, chunk = unit - tile * P.nb.cchunks;
     const NbTile t = nb_tile(L, P.nb, tile);
@@ -754,36 +767,69 @@ roi_align_bwd_ng_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ g
     const bool chan = c0 + lane < C;
     const int cl = chan ? c0 + lane : c0;
     const int2 head = ws.heads[tile];
+    const int first = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(head.x)));
+    const int count = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(head.y)));
     float acc[kNbTH][kNbTW];
 #pragma unroll
     for (int y = 0; y < kNbTH; ++y)
 #pragma unroll
       for (int x = 0; x < kNbTW; ++x) acc[y][x] = 0.f;
-    for (int i = 0; i < head.y; ++i) {
-      const float* __restrict__ rec = ws.recs + static_cast<size_t>(head.x + i) * P.rec_f;
-      const int4 hd = *reinterpret_cast<const int4*>(rec);
-      const int r = hd.x, ph_lo = hd.y & 0xff, nph = hd.y >> 8, pw_lo = hd.z & 0xff, npw = hd.z >> 8;
-      const float* __restrict__ ay = rec + 4;
-      const float* __restrict__ ax = rec + 4 + PH * 4;
-      const float* gp = gT + (static_cast<size_t>(r) * bins + pw_lo) * C + cl;
-      for (int q = 0; q < nph; ++q) {
-        const float* grow = gp + static_cast<size_t>(ph_lo + q) * PW * C;
-        float gv[PWMAX];
+    // the record of hit i is fetched (lane-cooperatively: one coalesced load per 64 floats) while hit i - 1 is walked
+    float pre[3] = {0.f, 0.f, 0.f};
+    auto fetch = [&](int i) {
+      const float* rec = ws.recs + static_cast<size_t>(first + i) * rec_f;
 #pragma unroll
-        for (int j = 0; j < PWMAX; ++j) gv[j] = (j < npw) ? grow[static_cast<size_t>(j) * C] : 0.f;
+      for (int q = 0; q < 3; ++q)
+        if (q < nrl && q * kWave + lane < rec_f) pre[q] = rec[q * kWave + lane];
+    };
+    if (count > 0) fetch(0);
+    for (int i = 0; i < count; ++i) {
+      DETOPS_WAVE_SYNC();                    // the previous hit's table reads are done
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (q < nrl) rt[q * kWave + lane] = pre[q];
+      DETOPS_WAVE_SYNC();
+      if (i + 1 < count) fetch(i + 1);
+      const int r = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(__float_as_int(rt[0]))));
+      const int hy = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(__float_as_int(rt[1]))));
+      const int hx = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(__float_as_int(rt[2]))));
+      const int ph_lo = hy & 0xff, nph = hy >> 8, pw_lo = hx & 0xff, npw = hx >> 8;
+      if (nph <= 0 || npw <= 0) continue;
+      const float* ay = rt + 4;
+      const float* ax = rt + 4 + PH * 4;
+      float wxr[PWMAX][kNbTW];               // AX of the hit in registers (uniform values): reused by every bin row
+#pragma unroll
+      for (int j = 0; j < PWMAX; ++j) {
+        const float4 a = *reinterpret_cast<const float4*>(ax + j * 8), b = *reinterpret_cast<const float4*>(ax + j * 8 + 4);
+        wxr[j][0] = a.x; wxr[j][1] = a.y; wxr[j][2] = a.z; wxr[j][3] = a.w;
+        wxr[j][4] = b.x; wxr[j][5] = b.y; wxr[j][6] = b.z; wxr[j][7] = b.w;
+      }
+      const float* gp = gT + (static_cast<size_t>(r) * bins + static_cast<size_t>(ph_lo) * PW + pw_lo) * C + cl;
+      const size_t rowstep = static_cast<size_t>(PW) * C;
+      // bins beyond the window are read as the window's last bin (in bounds) and meet a zero weight
+      float gv[PWMAX], gn[PWMAX];
+#pragma unroll
+      for (int j = 0; j < PWMAX; ++j) gv[j] = gp[static_cast<size_t>(min(j, npw - 1)) * C];
+      for (int q = 0; q < nph; ++q) {
+        if (q + 1 < nph) {
+          const float* grow = gp + static_cast<size_t>(q + 1) * rowstep;
+#pragma unroll
+          for (int j = 0; j < PWMAX; ++j) gn[j] = grow[static_cast<size_t>(min(j, npw - 1)) * C];
+        }
         float u[kNbTW];
 #pragma unroll
-        for (int x = 0; x < kNbTW; ++x) u[x] = ax[x] * gv[0];
+        for (int x = 0; x < kNbTW; ++x) u[x] = wxr[0][x] * gv[0];
 #pragma unroll
         for (int j = 1; j < PWMAX; ++j)
 #pragma unroll
-          for (int x = 0; x < kNbTW; ++x) u[x] += ax[j * 8 + x] * gv[j];
+          for (int x = 0; x < kNbTW; ++x) u[x] += wxr[j][x] * gv[j];
+        const float4 wy = *reinterpret_cast<const float4*>(ay + q * 4);
 #pragma unroll
-        for (int y = 0; y < kNbTH; ++y) {
-          const float wy = ay[q * 4 + y];
-#pragma unroll
-          for (int x = 0; x < kNbTW; ++x) acc[y][x] += wy * u[x];
+        for (int x = 0; x < kNbTW; ++x) {
+          acc[0][x] += wy.x * u[x]; acc[1][x] += wy.y * u[x]; acc[2][x] += wy.z * u[x]; acc[3][x] += wy.w * u[x];
         }
+#pragma unroll
+        for (int j = 0; j < PWMAX; ++j) gv[j] = gn[j];
       }
     }
     if (chan) {
@@ -816,11 +862,11 @@ int run_backward_ng(const Levels& L, const float* gout, int grad_out_nhwc, const
           reinterpret_cast<float*>(base + lay.off_recs), reinterpret_cast<float*>(base + lay.off_gT)};
   DETOPS_HIP_TRY(hipMemsetAsync(base, 0, 256, st));
   const int list_blocks = static_cast<int>(ceil_div64(P.nb.num_tiles, kNgPrepBlock / kWave));
-  hipLaunchKernelGGL(roi_bwd_ng_prep1_kernel, dim3(list_blocks + (grad_out_nhwc ? 0 : K)), dim3(kNgPrepBlock), 0, st, L, P, ws, rois, levels,
-                     gout, K, C, PH, PW, sr, list_blocks);
+  hipLaunchKernelGGL(roi_bwd_ng_prep1_kernel, dim3(list_blocks + (grad_out_nhwc ? 0 : K * P.nb.cchunks)), dim3(kNgPrepBlock), 0, st, L, P, ws,
+                     rois, levels, gout, K, C, PH, PW, sr, list_blocks);
   int e = launch_status();
   if (e) return e;
-  hipLaunchKernelGGL(roi_bwd_ng_prep2_kernel, dim3(4 * kNumCU), dim3(kNgPrepBlock), 0, st, L, P, ws, rois, levels, PH, PW, sr);
+  hipLaunchKernelGGL(roi_bwd_ng_prep2_kernel, dim3(8 * kNumCU), dim3(kNgRecBlock), 0, st, L, P, ws, rois, levels, PH, PW, sr);
   e = launch_status();
   if (e) return e;
   const int units = static_cast<int>(static_cast<int64_t>(P.nb.num_tiles) * P.nb.cchunks);
