@@ -544,7 +544,6 @@ roi_align_bwd_nhwc_kernel(Levels L, NbPlan P, NbWs ws, const float* __restrict__
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kNgBlock = 256;                 // 4 waves = 4 independent units
 constexpr int kNgPrepBlock = 1024;           // pre-pass 1: 16 waves = 16 tiles share one LDS table of ROI extents
-constexpr int kNgRecBlock = 256;             // pre-pass 2: a wave per hit
 
 struct NgPlan {
   NbPlan nb;                 // tiles (kNbTH x kNbTW), channel chunks, level table
@@ -581,9 +580,66 @@ bool ng_plan(const Levels& L, int N, int C, int K, int PH, int PW, bool need_gT,
   return true;
 }
 
-// Pre-pass 1, two roles by block index:
-//   list role      — a wave per tile: ordered ballot compaction of the ROIs that reach the tile; one atomic per tile hands out
-//                    its record range (the ranges' ORDER in the workspace is arbitrary, their contents are not)
+// One wave builds the record of one (tile, ROI) hit.
+//   record = { ROI, ph_lo | nph << 8, pw_lo | npw << 8, 0 }  AY[PH][4]  AX[PWMAX][8]      (window-relative, zero-padded)
+// Weights by the exact reference tap arithmetic, summed per bin in sample order like build_adjoint_rows:
+//   A[pixel][bin] = (1 / grid) * sum_i ([tap.lo == pixel] * tap.h + [tap.hi == pixel] * tap.l).
+__device__ __forceinline__ void ng_build_record(const Levels& L, const NgPlan& P, const NbTile& t, const float* __restrict__ rois, int r,
+                                                int PH, int PW, int sr, float* __restrict__ rec, int lane) {
+  const float* roi = rois + static_cast<size_t>(r) * 5;
+  int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
+#pragma unroll
+  for (int q = 1; q < DETOPS_MAX_LEVELS; ++q)
+    if (q == t.lvl) { H = L.lv[q].H; W = L.lv[q].W; scale = L.lv[q].scale; }
+  const RoiGeom g = roi_geometry(roi, scale, PH, PW, sr);
+  // which bins reach the tile, per axis: lanes [0, PH) the y axis, [32, 32 + PW) the x axis (PH, PW <= 14)
+  const bool isy = lane < 32;
+  const int b = lane & 31;
+  const int nb = isy ? PH : PW, grid = isy ? g.gh : g.gw, size = isy ? H : W;
+  const int p0 = isy ? t.y0 : t.x0, pn = isy ? kNbTH : kNbTW;
+  const float start = isy ? g.start_h : g.start_w, bin = isy ? g.bin_h : g.bin_w;
+  bool reach = false;
+  if (b < nb) {
+    for (int i = 0; i < grid; ++i) {
+      const Tap tp = axis_entry(start, bin, b, i, grid, size, 1);
+      if (tp.l != 0.f || tp.h != 0.f)
+        reach = reach || (tp.lo >= p0 && tp.lo < p0 + pn) || (tp.hi >= p0 && tp.hi < p0 + pn);
+    }
+  }
+  const unsigned long long m = __ballot(reach);
+  const unsigned my = static_cast<unsigned>(m & 0xffffffffull), mx = static_cast<unsigned>(m >> 32);
+  const int ph_lo = my ? __builtin_ctz(my) : 0, nph = my ? (32 - __builtin_clz(my)) - ph_lo : 0;
+  const int pw_lo = mx ? __builtin_ctz(mx) : 0, npw = mx ? (32 - __builtin_clz(mx)) - pw_lo : 0;
+  if (lane == 0)
+    *reinterpret_cast<int4*>(rec) = make_int4(r, ph_lo | (nph << 8), pw_lo | (npw << 8), 0);
+  // dense weights: element e < PH * 4 -> AY[i = e / 4][y = e % 4]; then AX[j][x] (8 per row)
+  const int ny_el = PH * 4, nx_el = P.PWMAX * 8;
+  for (int e = lane; e < ny_el + nx_el; e += kWave) {
+    const bool ey = e < ny_el;
+    const int ee = ey ? e : e - ny_el;
+    const int j = ey ? (ee >> 2) : (ee >> 3), px = ey ? (ee & 3) : (ee & 7);
+    const int bb = (ey ? ph_lo : pw_lo) + j;                        // absolute bin
+    const int nwin = ey ? nph : npw, nbins = ey ? PH : PW;
+    const int gr = ey ? g.gh : g.gw, sz = ey ? H : W;
+    const float st = ey ? g.start_h : g.start_w, bn = ey ? g.bin_h : g.bin_w;
+    const int pix = (ey ? t.y0 : t.x0) + px;
+    float w = 0.f;
+    if (j < nwin && bb < nbins && pix < sz) {
+      const float inv = 1.f / static_cast<float>(gr);
+      for (int i = 0; i < gr; ++i) {
+        const Tap tp = axis_entry(st, bn, bb, i, gr, sz, 1);
+        if (tp.lo == pix) w += tp.h * inv;
+        if (tp.hi == pix) w += tp.l * inv;
+      }
+    }
+    rec[4 + e] = w;
+  }
+}
+
+// Pre-pass, two roles by block index:
+//   list role      — a wave per tile: ballot pass over the ROIs that reach the tile (count), one atomic per tile hands out its
+//                    record range (the ranges' ORDER in the workspace is arbitrary, their contents are not), second pass:
+//                    the hits' records in ROI order (ng_build_record)
 //   transpose role — (NCHW pooled gradient) a workgroup per ROI: [C][bins] -> [bins][C] through LDS
 __global__ void __launch_bounds__(kNgPrepBlock)
 roi_bwd_ng_prep1_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
@@ -650,12 +706,21 @@ roi_bwd_ng_prep1_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ r
             hit = (e.x == (t.lvl | (t.b << 8))) && eny > 0 && enx > 0 && fy0 < t.y0 + kNbTH && fy0 + eny > t.y0 &&
                   fx0 < t.x0 + kNbTW && fx0 + enx > t.x0;
           }
-          const unsigned long long m = __ballot(hit);
-          if (pass == 1 && hit) {
-            const int slot = base + seen + __popcll(m & ((1ull << lane) - 1ull));
-            if (slot < P.hit_cap) ws.hits[slot] = make_int2(tile, r0 + i);
+          unsigned long long m = __ballot(hit);
+          if (pass == 1) {
+            // the records of this round's hits, in ROI order (the whole wave builds one record at a time)
+            int k = 0;
+            while (m) {
+              const int bpos = __builtin_ctzll(m);
+              m &= m - 1;
+              const int slot = seen + k;
+              if (slot < count) ng_build_record(L, P, t, rois, r0 + i0 + bpos, PH, PW, sr, ws.recs + static_cast<size_t>(base + slot) * P.rec_f, lane);
+              ++k;
+            }
+            seen += k;
+          } else {
+            seen += __popcll(m);
           }
-          seen += __popcll(m);
         }
       }
     }
@@ -671,72 +736,6 @@ roi_bwd_ng_prep1_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ r
         }
         if (lane == 0) ws.heads[tile] = make_int2(base, count);
       }
-    }
-  }
-}
-
-// Pre-pass 2: a wave per hit builds its record.
-//   record = { ROI, ph_lo | nph << 8, pw_lo | npw << 8, 0 }  AY[PH][4]  AX[PWMAX][8]      (window-relative, zero-padded)
-// Weights by the exact reference tap arithmetic, summed per bin in sample order like build_adjoint_rows:
-//   A[pixel][bin] = (1 / grid) * sum_i ([tap.lo == pixel] * tap.h + [tap.hi == pixel] * tap.l).
-__global__ void __launch_bounds__(kNgRecBlock)
-roi_bwd_ng_prep2_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
-                        int PH, int PW, int sr) {
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  const int total = min(ws.ctrl[0], P.hit_cap);
-  for (int h = static_cast<int>(blockIdx.x) * (kNgRecBlock / kWave) + wave; h < total; h += static_cast<int>(gridDim.x) * (kNgRecBlock / kWave)) {
-    const int2 hr = ws.hits[h];
-    const NbTile t = nb_tile(L, P.nb, hr.x);
-    const int r = hr.y;
-    const float* roi = rois + static_cast<size_t>(r) * 5;
-    int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
-#pragma unroll
-    for (int q = 1; q < DETOPS_MAX_LEVELS; ++q)
-      if (q == t.lvl) { H = L.lv[q].H; W = L.lv[q].W; scale = L.lv[q].scale; }
-    const RoiGeom g = roi_geometry(roi, scale, PH, PW, sr);
-    float* rec = ws.recs + static_cast<size_t>(h) * P.rec_f;
-    // which bins reach the tile, per axis: lanes [0, PH) the y axis, [32, 32 + PW) the x axis (PH, PW <= 14)
-    const bool isy = lane < 32;
-    const int b = lane & 31;
-    const int nb = isy ? PH : PW, grid = isy ? g.gh : g.gw, size = isy ? H : W;
-    const int p0 = isy ? t.y0 : t.x0, pn = isy ? kNbTH : kNbTW;
-    const float start = isy ? g.start_h : g.start_w, bin = isy ? g.bin_h : g.bin_w;
-    bool reach = false;
-    if (b < nb) {
-      for (int i = 0; i < grid; ++i) {
-        const Tap tp = axis_entry(start, bin, b, i, grid, size, 1);
-        if (tp.l != 0.f || tp.h != 0.f)
-          reach = reach || (tp.lo >= p0 && tp.lo < p0 + pn) || (tp.hi >= p0 && tp.hi < p0 + pn);
-      }
-    }
-    const unsigned long long m = __ballot(reach);
-    const unsigned my = static_cast<unsigned>(m & 0xffffffffull), mx = static_cast<unsigned>(m >> 32);
-    const int ph_lo = my ? __builtin_ctz(my) : 0, nph = my ? (32 - __builtin_clz(my)) - ph_lo : 0;
-    const int pw_lo = mx ? __builtin_ctz(mx) : 0, npw = mx ? (32 - __builtin_clz(mx)) - pw_lo : 0;
-    if (lane == 0)
-      *reinterpret_cast<int4*>(rec) = make_int4(r, ph_lo | (nph << 8), pw_lo | (npw << 8), 0);
-    // dense weights: element e < PH * 4 -> AY[i = e / 4][y = e % 4]; then AX[j][x] (8 per row)
-    const int ny_el = PH * 4, nx_el = P.PWMAX * 8;
-    for (int e = lane; e < ny_el + nx_el; e += kWave) {
-      const bool ey = e < ny_el;
-      const int ee = ey ? e : e - ny_el;
-      const int per = ey ? 4 : 8;
-      const int j = ee / per, px = ee - j * per;
-      const int bb = (ey ? ph_lo : pw_lo) + j;                        // absolute bin
-      const int nwin = ey ? nph : npw, nbins = ey ? PH : PW;
-      const int gr = ey ? g.gh : g.gw, sz = ey ? H : W;
-      const float st = ey ? g.start_h : g.start_w, bn = ey ? g.bin_h : g.bin_w;
-      const int pix = (ey ? t.y0 : t.x0) + px;
-      float w = 0.f;
-      if (j < nwin && bb < nbins && pix < sz) {
-        const float inv = 1.f / static_cast<float>(gr);
-        for (int i = 0; i < gr; ++i) {
-          const Tap tp = axis_entry(st, bn, bb, i, gr, sz, 1);
-          if (tp.lo == pix) w += tp.h * inv;
-          if (tp.hi == pix) w += tp.l * inv;
-        }
-      }
-      rec[4 + e] = w;
     }
   }
 }
@@ -774,7 +773,10 @@ roi_align_bwd_ng_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ g
     for (int y = 0; y < kNbTH; ++y)
 #pragma unroll
       for (int x = 0; x < kNbTW; ++x) acc[y][x] = 0.f;
-    // the record of hit i is fetched (lane-cooperatively: one coalesced load per 64 floats) while hit i - 1 is walked
+    // Software pipeline over the unit's hits (a chain in ROI order): the RECORD of hit i + 1 is fetched (lane-cooperatively,
+    // one coalesced load per 64 floats) while hit i is walked, and the FIRST bin row of hit i + 1's pooled gradient is
+    // requested during hit i's last bin row (its header is read out of the fetched registers) — so that no memory round trip
+    // sits between two hits of a crowded tile's chain.
     float pre[3] = {0.f, 0.f, 0.f};
     auto fetch = [&](int i) {
       const float* rec = ws.recs + static_cast<size_t>(first + i) * rec_f;
@@ -782,19 +784,33 @@ roi_align_bwd_ng_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ g
       for (int q = 0; q < 3; ++q)
         if (q < nrl && q * kWave + lane < rec_f) pre[q] = rec[q * kWave + lane];
     };
-    if (count > 0) fetch(0);
+    const size_t rowstep = static_cast<size_t>(PW) * C;
+    float gv[PWMAX], gn[PWMAX];
+    auto row_of = [&](int r, int ph, int pw_lo, int npw, float (&dst)[PWMAX]) {      // bins beyond the window: its last bin (in bounds), weight 0
+      const float* grow = gT + (static_cast<size_t>(r) * bins + static_cast<size_t>(ph) * PW + pw_lo) * C + cl;
+#pragma unroll
+      for (int j = 0; j < PWMAX; ++j) dst[j] = grow[static_cast<size_t>(min(j, npw - 1)) * C];
+    };
+    auto header = [&](int& r, int& ph_lo, int& nph, int& pw_lo, int& npw) {          // of the record in `pre` (lanes 0..2 of its first load)
+      const unsigned w0 = static_cast<unsigned>(__float_as_int(pre[0]));
+      r = static_cast<int>(__builtin_amdgcn_readlane(w0, 0));
+      const int hy = static_cast<int>(__builtin_amdgcn_readlane(w0, 1)), hx = static_cast<int>(__builtin_amdgcn_readlane(w0, 2));
+      ph_lo = hy & 0xff; nph = hy >> 8; pw_lo = hx & 0xff; npw = hx >> 8;
+    };
+    int r = 0, ph_lo = 0, nph = 0, pw_lo = 0, npw = 0;
+    if (count > 0) {
+      fetch(0);
+      header(r, ph_lo, nph, pw_lo, npw);
+      if (nph > 0 && npw > 0) row_of(r, ph_lo, pw_lo, npw, gv);
+    }
     for (int i = 0; i < count; ++i) {
       DETOPS_WAVE_SYNC();                    // the previous hit's table reads are done
 #pragma unroll
       for (int q = 0; q < 3; ++q)
         if (q < nrl) rt[q * kWave + lane] = pre[q];
       DETOPS_WAVE_SYNC();
-      if (i + 1 < count) fetch(i + 1);
-      const int r = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(__float_as_int(rt[0]))));
-      const int hy = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(__float_as_int(rt[1]))));
-      const int hx = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(__float_as_int(rt[2]))));
-      const int ph_lo = hy & 0xff, nph = hy >> 8, pw_lo = hx & 0xff, npw = hx >> 8;
-      if (nph <= 0 || npw <= 0) continue;
+      const bool more = i + 1 < count;
+      if (more) fetch(i + 1);
       const float* ay = rt + 4;
       const float* ax = rt + 4 + PH * 4;
       float wxr[PWMAX][kNbTW];               // AX of the hit in registers (uniform values): reused by every bin row
@@ -804,33 +820,34 @@ roi_align_bwd_ng_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ g
         wxr[j][0] = a.x; wxr[j][1] = a.y; wxr[j][2] = a.z; wxr[j][3] = a.w;
         wxr[j][4] = b.x; wxr[j][5] = b.y; wxr[j][6] = b.z; wxr[j][7] = b.w;
       }
-      const float* gp = gT + (static_cast<size_t>(r) * bins + static_cast<size_t>(ph_lo) * PW + pw_lo) * C + cl;
-      const size_t rowstep = static_cast<size_t>(PW) * C;
-      // bins beyond the window are read as the window's last bin (in bounds) and meet a zero weight
-      float gv[PWMAX], gn[PWMAX];
-#pragma unroll
-      for (int j = 0; j < PWMAX; ++j) gv[j] = gp[static_cast<size_t>(min(j, npw - 1)) * C];
-      for (int q = 0; q < nph; ++q) {
-        if (q + 1 < nph) {
-          const float* grow = gp + static_cast<size_t>(q + 1) * rowstep;
-#pragma unroll
-          for (int j = 0; j < PWMAX; ++j) gn[j] = grow[static_cast<size_t>(min(j, npw - 1)) * C];
+      const bool live = nph > 0 && npw > 0;
+      const int rows = live ? nph : 1;       // a hit without a window (cannot happen for a listed ROI) still advances the pipeline
+      int r2 = 0, ph2 = 0, nph2 = 0, pw2 = 0, npw2 = 0;
+      for (int q = 0; q < rows; ++q) {
+        if (q + 1 < rows) {
+          row_of(r, ph_lo + q + 1, pw_lo, npw, gn);
+        } else if (more) {
+          header(r2, ph2, nph2, pw2, npw2);                      // waits for the record load issued at the top of this hit
+          if (nph2 > 0 && npw2 > 0) row_of(r2, ph2, pw2, npw2, gn);
         }
-        float u[kNbTW];
+        if (live) {
+          float u[kNbTW];
 #pragma unroll
-        for (int x = 0; x < kNbTW; ++x) u[x] = wxr[0][x] * gv[0];
+          for (int x = 0; x < kNbTW; ++x) u[x] = wxr[0][x] * gv[0];
 #pragma unroll
-        for (int j = 1; j < PWMAX; ++j)
+          for (int j = 1; j < PWMAX; ++j)
 #pragma unroll
-          for (int x = 0; x < kNbTW; ++x) u[x] += wxr[j][x] * gv[j];
-        const float4 wy = *reinterpret_cast<const float4*>(ay + q * 4);
+            for (int x = 0; x < kNbTW; ++x) u[x] += wxr[j][x] * gv[j];
+          const float4 wy = *reinterpret_cast<const float4*>(ay + q * 4);
 #pragma unroll
-        for (int x = 0; x < kNbTW; ++x) {
-          acc[0][x] += wy.x * u[x]; acc[1][x] += wy.y * u[x]; acc[2][x] += wy.z * u[x]; acc[3][x] += wy.w * u[x];
+          for (int x = 0; x < kNbTW; ++x) {
+            acc[0][x] += wy.x * u[x]; acc[1][x] += wy.y * u[x]; acc[2][x] += wy.z * u[x]; acc[3][x] += wy.w * u[x];
+          }
         }
 #pragma unroll
         for (int j = 0; j < PWMAX; ++j) gv[j] = gn[j];
       }
+      r = r2; ph_lo = ph2; nph = nph2; pw_lo = pw2; npw = npw2;
     }
     if (chan) {
 #pragma unroll
@@ -865,9 +882,6 @@ int run_backward_ng(const Levels& L, const float* gout, int grad_out_nhwc, const
   hipLaunchKernelGGL(roi_bwd_ng_prep1_kernel, dim3(list_blocks + (grad_out_nhwc ? 0 : K * P.nb.cchunks)), dim3(kNgPrepBlock), 0, st, L, P, ws,
                      rois, levels, gout, K, C, PH, PW, sr, list_blocks);
   int e = launch_status();
-  if (e) return e;
-  hipLaunchKernelGGL(roi_bwd_ng_prep2_kernel, dim3(8 * kNumCU), dim3(kNgRecBlock), 0, st, L, P, ws, rois, levels, PH, PW, sr);
-  e = launch_status();
   if (e) return e;
   const int units = static_cast<int>(static_cast<int64_t>(P.nb.num_tiles) * P.nb.cchunks);
   const float* gT = grad_out_nhwc ? gout : ws.gT;
