@@ -784,7 +784,6 @@ roi_align_bwd_ng_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ g
       for (int q = 0; q < 3; ++q)
         if (q < nrl && q * kWave + lane < rec_f) pre[q] = rec[q * kWave + lane];
     };
-    const size_t rowstep = static_cast<size_t>(PW) * C;
     float gv[PWMAX], gn[PWMAX];
     auto row_of = [&](int r, int ph, int pw_lo, int npw, float (&dst)[PWMAX]) {      // bins beyond the window: its last bin (in bounds), weight 0
       const float* grow = gT + (static_cast<size_t>(r) * bins + static_cast<size_t>(ph) * PW + pw_lo) * C + cl;

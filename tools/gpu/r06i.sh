@@ -1,5 +1,5 @@
 # Round 6, experiment I: record-form ("gather") NHWC backward vs the ring kernel with a channels-last store.
-O=gpurun_out/r06k; mkdir -p $O
+O=gpurun_out/r06l; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 DETOPS_ROIALIGN_NHWC_BWD=native timeout 900 python -m pytest tests/test_ops_gpu.py -q -x -k "channels_last" -p no:cacheprovider < /dev/null > $O/pytest_native.log 2>&1; tail -2 $O/pytest_native.log
 for mode in native ring; do
