@@ -401,7 +401,9 @@ roi_align_bwd_nhwc_kernel(Levels L, NbPlan P, NbWs ws, const float* __restrict__
   const int PP = max(P.PPH, P.PPW);
   const int bins = PH * PW;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
-  const int wave = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(tid / kWave)));   // in an SGPR: what derives from it is scalar
+  // the wave index is wave-uniform, but the compiler only knows that when it comes out of a scalar register: everything
+  // derived from it (hit index, list entry, row addresses) then lives in SGPRs (162 -> 134 VGPRs)
+  const int wave = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(tid / kWave)));
   const size_t slot = static_cast<size_t>(P.Hmax) * P.PPH + static_cast<size_t>(P.Wmax) * P.PPW;
   const int rows_f = kR * PP;
   const int gblk_f = kStage ? ((kNbCh * bins + 255) & ~255) : 0;     // whole 1 KiB DMA pieces
@@ -527,372 +529,6 @@ roi_align_bwd_nhwc_kernel(Levels L, NbPlan P, NbWs ws, const float* __restrict__
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// backward, record form ("gather"): the fast path for 7 x 7 and 14 x 14 bins.
-//
-// What the hit-parallel kernel above spends its time on is not the adjoint's arithmetic (~5 FMAs per pixel, channel and
-// ROI) but FINDING the operands per hit: row staging, head decoding, dependent LDS round trips, a gradient block staged per
-// wave (PMC: ~800 VALU + ~750 SALU wave-instructions per wave and hit against ~300 of arithmetic).  Here every (tile, ROI)
-// hit gets a small dense RECORD from the pre-pass — the bin window the tile can see {ph_lo, nph, pw_lo, npw} and the
-// zero-padded dense weights AY[nph][4 pixel rows], AX[npw][8 pixel columns] — and the pooled gradient is read
-// CHANNELS-LAST ([K, bins, C]: an NCHW gradient is transposed once by the pre-pass), so that a hit is
-//     per bin row:  npw coalesced 256-byte loads (one per bin, a lane per channel), u[x] = sum_pw AX[pw][x] * g[pw],
-//                   acc[y][x] += AY[ph][y] * u[x]
-// with every weight a scalar-cache load at an address known in advance, no LDS, no barrier, no staging.  A WAVE owns a
-// (tile, 64-channel chunk) unit and walks ALL of its hits in ROI order (deterministic; no partial sums to combine); the
-// grid is persistent and units are numbered coarsest level first.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int kNgBlock = 256;                 // 4 waves = 4 independent units
-constexpr int kNgPrepBlock = 1024;           // pre-pass 1: 16 waves = 16 tiles share one LDS table of ROI extents
-
-struct NgPlan {
-  NbPlan nb;                 // tiles (kNbTH x kNbTW), channel chunks, level table
-  int PWMAX;                 // 7 | 14: the record's AX rows are PWMAX wide
-  int rec_f;                 // floats per record = 4 + PH * 4 + PWMAX * 8
-  int hit_cap;               // records the workspace holds
-};
-
-struct NgWs {
-  int* ctrl;                 // [0] records handed out (zeroed per call), [1] overflow flag
-  int2* heads;               // [num_tiles] {first record, count}
-  int2* hits;                // [hit_cap] {tile, ROI}
-  float* recs;               // [hit_cap][rec_f]
-  float* gT;                 // [K][bins][C] (only for an NCHW pooled gradient)
-};
-
-struct NgLayout { size_t off_heads, off_hits, off_recs, off_gT, total; };
-
-bool ng_plan(const Levels& L, int N, int C, int K, int PH, int PW, bool need_gT, NgPlan& P, NgLayout& lay) {
-  NbLayout nl;
-  if (!nb_plan(L, N, C, K, PH, PW, P.nb, nl)) return false;
-  if (!((PH == 7 && PW == 7) || (PH == 14 && PW == 14)) || C % 4 != 0) return false;
-  P.PWMAX = PW;
-  P.rec_f = 4 + PH * 4 + P.PWMAX * 8;
-  const int64_t cap = std::min<int64_t>(static_cast<int64_t>(K) * 48 + P.nb.num_tiles, 1 << 21);
-  P.hit_cap = static_cast<int>(cap);
-  auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-  size_t o = 256;
-  lay.off_heads = o; o = up(o + sizeof(int2) * static_cast<size_t>(P.nb.num_tiles));
-  lay.off_hits = o;  o = up(o + sizeof(int2) * static_cast<size_t>(P.hit_cap));
-  lay.off_recs = o;  o = up(o + sizeof(float) * static_cast<size_t>(P.hit_cap) * P.rec_f);
-  lay.off_gT = o;    if (need_gT) o = up(o + sizeof(float) * static_cast<size_t>(K) * PH * PW * C);
-  lay.total = o;
-  return true;
-}
-
-// One wave builds the record of one (tile, ROI) hit.
-//   record = { ROI, ph_lo | nph << 8, pw_lo | npw << 8, 0 }  AY[PH][4]  AX[PWMAX][8]      (window-relative, zero-padded)
-// Weights by the exact reference tap arithmetic, summed per bin in sample order like build_adjoint_rows:
-//   A[pixel][bin] = (1 / grid) * sum_i ([tap.lo == pixel] * tap.h + [tap.hi == pixel] * tap.l).
-__device__ __forceinline__ void ng_build_record(const Levels& L, const NgPlan& P, const NbTile& t, const float* __restrict__ rois, int r,
-                                                int PH, int PW, int sr, float* __restrict__ rec, int lane) {
-  const float* roi = rois + static_cast<size_t>(r) * 5;
-  int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
-#pragma unroll
-  for (int q = 1; q < DETOPS_MAX_LEVELS; ++q)
-    if (q == t.lvl) { H = L.lv[q].H; W = L.lv[q].W; scale = L.lv[q].scale; }
-  const RoiGeom g = roi_geometry(roi, scale, PH, PW, sr);
-  // which bins reach the tile, per axis: lanes [0, PH) the y axis, [32, 32 + PW) the x axis (PH, PW <= 14)
-  const bool isy = lane < 32;
-  const int b = lane & 31;
-  const int nb = isy ? PH : PW, grid = isy ? g.gh : g.gw, size = isy ? H : W;
-  const int p0 = isy ? t.y0 : t.x0, pn = isy ? kNbTH : kNbTW;
-  const float start = isy ? g.start_h : g.start_w, bin = isy ? g.bin_h : g.bin_w;
-  bool reach = false;
-  if (b < nb) {
-    for (int i = 0; i < grid; ++i) {
-      const Tap tp = axis_entry(start, bin, b, i, grid, size, 1);
-      if (tp.l != 0.f || tp.h != 0.f)
-        reach = reach || (tp.lo >= p0 && tp.lo < p0 + pn) || (tp.hi >= p0 && tp.hi < p0 + pn);
-    }
-  }
-  const unsigned long long m = __ballot(reach);
-  const unsigned my = static_cast<unsigned>(m & 0xffffffffull), mx = static_cast<unsigned>(m >> 32);
-  const int ph_lo = my ? __builtin_ctz(my) : 0, nph = my ? (32 - __builtin_clz(my)) - ph_lo : 0;
-  const int pw_lo = mx ? __builtin_ctz(mx) : 0, npw = mx ? (32 - __builtin_clz(mx)) - pw_lo : 0;
-  if (lane == 0)
-    *reinterpret_cast<int4*>(rec) = make_int4(r, ph_lo | (nph << 8), pw_lo | (npw << 8), 0);
-  // dense weights: element e < PH * 4 -> AY[i = e / 4][y = e % 4]; then AX[j][x] (8 per row)
-  const int ny_el = PH * 4, nx_el = P.PWMAX * 8;
-  for (int e = lane; e < ny_el + nx_el; e += kWave) {
-    const bool ey = e < ny_el;
-    const int ee = ey ? e : e - ny_el;
-    const int j = ey ? (ee >> 2) : (ee >> 3), px = ey ? (ee & 3) : (ee & 7);
-    const int bb = (ey ? ph_lo : pw_lo) + j;                        // absolute bin
-    const int nwin = ey ? nph : npw, nbins = ey ? PH : PW;
-    const int gr = ey ? g.gh : g.gw, sz = ey ? H : W;
-    const float st = ey ? g.start_h : g.start_w, bn = ey ? g.bin_h : g.bin_w;
-    const int pix = (ey ? t.y0 : t.x0) + px;
-    float w = 0.f;
-    if (j < nwin && bb < nbins && pix < sz) {
-      const float inv = 1.f / static_cast<float>(gr);
-      for (int i = 0; i < gr; ++i) {
-        const Tap tp = axis_entry(st, bn, bb, i, gr, sz, 1);
-        if (tp.lo == pix) w += tp.h * inv;
-        if (tp.hi == pix) w += tp.l * inv;
-      }
-    }
-    rec[4 + e] = w;
-  }
-}
-
-// Pre-pass, two roles by block index:
-//   list role      — a wave per tile: ballot pass over the ROIs that reach the tile (count), one atomic per tile hands out its
-//                    record range (the ranges' ORDER in the workspace is arbitrary, their contents are not), second pass:
-//                    the hits' records in ROI order (ng_build_record)
-//   transpose role — (NCHW pooled gradient) a workgroup per ROI: [C][bins] -> [bins][C] through LDS
-__global__ void __launch_bounds__(kNgPrepBlock)
-roi_bwd_ng_prep1_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ rois, const int32_t* __restrict__ levels_in,
-                        const float* __restrict__ gout, int K, int C, int PH, int PW, int sr, int list_blocks) {
-  __shared__ int4 ext[kNbPrepRois];
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  if (static_cast<int>(blockIdx.x) >= list_blocks) {
-    // ---- transpose role: one (ROI, 64-channel chunk) per workgroup: [64][bins] contiguous in, [bins][64-channel piece] out
-    const int u = static_cast<int>(blockIdx.x) - list_blocks;
-    const int r = u / P.nb.cchunks, c0 = (u - r * P.nb.cchunks) * kNbCh;
-    const int bins = PH * PW;
-    const int cn = min(kNbCh, C - c0);
-    float* t = reinterpret_cast<float*>(ext);                    // 16 KiB >= 64 channels x 49 bins; larger bin counts in passes
-    const float* src = gout + (static_cast<size_t>(r) * C + c0) * bins;
-    float* dst = ws.gT + static_cast<size_t>(r) * bins * C + c0;
-    const int bpass = (kNbPrepRois * 4) / kNbCh;                  // bins per pass (64 at 16 KiB)
-    for (int b0 = 0; b0 < bins; b0 += bpass) {
-      const int bn = min(bpass, bins - b0);
-      __syncthreads();
-      for (int o = tid; o < cn * bn; o += kNgPrepBlock) {         // element (c, b) = (o / bn, o % bn): runs of bn floats per channel
-        const int c = o / bn, b = o - c * bn;
-        t[c * (bn | 1) + b] = src[static_cast<size_t>(c) * bins + b0 + b];
-      }
-      __syncthreads();
-      for (int o = tid; o < bn * kNbCh; o += kNgPrepBlock) {      // out: bin-major, channel fastest (256-byte pieces)
-        const int b = o >> 6, c = o & (kNbCh - 1);
-        if (c < cn) dst[static_cast<size_t>(b0 + b) * C + c] = t[c * (bn | 1) + b];
-      }
-    }
-    return;
-  }
-  const int tile = static_cast<int>(blockIdx.x) * (kNgPrepBlock / kWave) + wave;
-  const bool live = tile < P.nb.num_tiles;
-  NbTile t{0, 0, 0, 0};
-  if (live) t = nb_tile(L, P.nb, tile);
-  // pass A: count; pass B: write (the ROI extents stay in LDS between the passes when K fits the table)
-  int count = 0, base = 0;
-  for (int pass = 0; pass < 2; ++pass) {
-    int seen = 0;
-    for (int r0 = 0; r0 < K; r0 += kNbPrepRois) {
-      const int n = min(kNbPrepRois, K - r0);
-      const bool fill = pass == 0 || K > kNbPrepRois;
-      if (fill) __syncthreads();
-      for (int i = tid; fill && i < n; i += kNgPrepBlock) {
-        const float* roi = rois + static_cast<size_t>(r0 + i) * 5;
-        int lvl = 0;
-        if (L.num > 1) lvl = levels_in ? levels_in[r0 + i] : fpn_level(roi, L);
-        int H = L.lv[0].H, W = L.lv[0].W; float scale = L.lv[0].scale;
-#pragma unroll
-        for (int q = 1; q < DETOPS_MAX_LEVELS; ++q)
-          if (q == lvl) { H = L.lv[q].H; W = L.lv[q].W; scale = L.lv[q].scale; }
-        const RoiExtent e = roi_extent(roi, scale, H, W, PH, PW, sr);
-        const bool ok = e.ny > 0 && e.nx > 0;
-        ext[i] = make_int4(lvl | (e.b << 8), ok ? (e.fy0 | (e.ny << 16)) : 0, ok ? (e.fx0 | (e.nx << 16)) : 0, 0);
-      }
-      if (fill) __syncthreads();
-      if (live) {
-        for (int i0 = 0; i0 < n; i0 += kWave) {
-          const int i = i0 + lane;
-          bool hit = false;
-          if (i < n) {
-            const int4 e = ext[i];
-            const int fy0 = e.y & 0xffff, eny = e.y >> 16, fx0 = e.z & 0xffff, enx = e.z >> 16;
-            hit = (e.x == (t.lvl | (t.b << 8))) && eny > 0 && enx > 0 && fy0 < t.y0 + kNbTH && fy0 + eny > t.y0 &&
-                  fx0 < t.x0 + kNbTW && fx0 + enx > t.x0;
-          }
-          unsigned long long m = __ballot(hit);
-          if (pass == 1) {
-            // the records of this round's hits, in ROI order (the whole wave builds one record at a time)
-            int k = 0;
-            while (m) {
-              const int bpos = __builtin_ctzll(m);
-              m &= m - 1;
-              const int slot = seen + k;
-              if (slot < count) ng_build_record(L, P, t, rois, r0 + i0 + bpos, PH, PW, sr, ws.recs + static_cast<size_t>(base + slot) * P.rec_f, lane);
-              ++k;
-            }
-            seen += k;
-          } else {
-            seen += __popcll(m);
-          }
-        }
-      }
-    }
-    if (pass == 0) {
-      count = seen;
-      if (live) {
-        int b = 0;
-        if (lane == 0 && count > 0) b = detops_fetch_add_relaxed(ws.ctrl, count);
-        base = __shfl(b, 0);
-        if (base + count > P.hit_cap) {                 // out of record space: the caller falls back (flag checked on the device by the main kernel)
-          if (lane == 0) ws.ctrl[1] = 1;
-          count = max(0, min(count, P.hit_cap - base));
-        }
-        if (lane == 0) ws.heads[tile] = make_int2(base, count);
-      }
-    }
-  }
-}
-
-template <int PWMAX>
-__global__ void __launch_bounds__(kNgBlock)
-roi_align_bwd_ng_kernel(Levels L, NgPlan P, NgWs ws, const float* __restrict__ gT, int C, int PH, int PW, int units) {
-  // per wave: the current hit's record as a broadcast table (every lane reads the same address: one LDS access per read)
-  constexpr int kRecMax = 4 + 14 * 4 + 14 * 8;            // 172 floats
-  __shared__ __attribute__((aligned(16))) float rtab[kNgBlock / kWave][((kRecMax + 63) / 64) * 64];
-  // the wave index is wave-uniform, but the compiler only knows that if it comes out of a scalar register: everything derived
-  // from it (unit, tile, record address) then lives in SGPRs
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(threadIdx.x / kWave)));
-  const int bins = PH * PW;
-  const int nw = static_cast<int>(gridDim.x) * (kNgBlock / kWave);
-  const int rec_f = P.rec_f;
-  const int nrl = (rec_f + kWave - 1) / kWave;              // record loads per lane (2 for 7 x 7, 3 for 14 x 14)
-  float* rt = rtab[wave];
-  for (int unit = static_cast<int>(blockIdx.x) * (kNgBlock / kWave) + wave; unit < units; unit += nw) {
-    const int tile = unit / P.nb.cchunks, chunk = unit - tile * P.nb.cchunks;
-    const NbTile t = nb_tile(L, P.nb, tile);
-    float* gin = L.lv[0].gin; int H = L.lv[0].H, W = L.lv[0].W;
-#pragma unroll
-    for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
-      if (i == t.lvl) { gin = L.lv[i].gin; H = L.lv[i].H; W = L.lv[i].W; }
-    const int c0 = chunk * kNbCh;
-    const bool chan = c0 + lane < C;
-    const int cl = chan ? c0 + lane : c0;
-    const int2 head = ws.heads[tile];
-    const int first = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(head.x)));
-    const int count = static_cast<int>(__builtin_amdgcn_readfirstlane(static_cast<unsigned>(head.y)));
-    float acc[kNbTH][kNbTW];
-#pragma unroll
-    for (int y = 0; y < kNbTH; ++y)
-#pragma unroll
-      for (int x = 0; x < kNbTW; ++x) acc[y][x] = 0.f;
-    // Software pipeline over the unit's hits (a chain in ROI order): the RECORD of hit i + 1 is fetched (lane-cooperatively,
-    // one coalesced load per 64 floats) while hit i is walked, and the FIRST bin row of hit i + 1's pooled gradient is
-    // requested during hit i's last bin row (its header is read out of the fetched registers) — so that no memory round trip
-    // sits between two hits of a crowded tile's chain.
-    float pre[3] = {0.f, 0.f, 0.f};
-    auto fetch = [&](int i) {
-      const float* rec = ws.recs + static_cast<size_t>(first + i) * rec_f;
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        if (q < nrl && q * kWave + lane < rec_f) pre[q] = rec[q * kWave + lane];
-    };
-    float gv[PWMAX], gn[PWMAX];
-    auto row_of = [&](int r, int ph, int pw_lo, int npw, float (&dst)[PWMAX]) {      // bins beyond the window: its last bin (in bounds), weight 0
-      const float* grow = gT + (static_cast<size_t>(r) * bins + static_cast<size_t>(ph) * PW + pw_lo) * C + cl;
-#pragma unroll
-      for (int j = 0; j < PWMAX; ++j) dst[j] = grow[static_cast<size_t>(min(j, npw - 1)) * C];
-    };
-    auto header = [&](int& r, int& ph_lo, int& nph, int& pw_lo, int& npw) {          // of the record in `pre` (lanes 0..2 of its first load)
-      const unsigned w0 = static_cast<unsigned>(__float_as_int(pre[0]));
-      r = static_cast<int>(__builtin_amdgcn_readlane(w0, 0));
-      const int hy = static_cast<int>(__builtin_amdgcn_readlane(w0, 1)), hx = static_cast<int>(__builtin_amdgcn_readlane(w0, 2));
-      ph_lo = hy & 0xff; nph = hy >> 8; pw_lo = hx & 0xff; npw = hx >> 8;
-    };
-    int r = 0, ph_lo = 0, nph = 0, pw_lo = 0, npw = 0;
-    if (count > 0) {
-      fetch(0);
-      header(r, ph_lo, nph, pw_lo, npw);
-      if (nph > 0 && npw > 0) row_of(r, ph_lo, pw_lo, npw, gv);
-    }
-    for (int i = 0; i < count; ++i) {
-      DETOPS_WAVE_SYNC();                    // the previous hit's table reads are done
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        if (q < nrl) rt[q * kWave + lane] = pre[q];
-      DETOPS_WAVE_SYNC();
-      const bool more = i + 1 < count;
-      if (more) fetch(i + 1);
-      const float* ay = rt + 4;
-      const float* ax = rt + 4 + PH * 4;
-      float wxr[PWMAX][kNbTW];               // AX of the hit in registers (uniform values): reused by every bin row
-#pragma unroll
-      for (int j = 0; j < PWMAX; ++j) {
-        const float4 a = *reinterpret_cast<const float4*>(ax + j * 8), b = *reinterpret_cast<const float4*>(ax + j * 8 + 4);
-        wxr[j][0] = a.x; wxr[j][1] = a.y; wxr[j][2] = a.z; wxr[j][3] = a.w;
-        wxr[j][4] = b.x; wxr[j][5] = b.y; wxr[j][6] = b.z; wxr[j][7] = b.w;
-      }
-      const bool live = nph > 0 && npw > 0;
-      const int rows = live ? nph : 1;       // a hit without a window (cannot happen for a listed ROI) still advances the pipeline
-      int r2 = 0, ph2 = 0, nph2 = 0, pw2 = 0, npw2 = 0;
-      for (int q = 0; q < rows; ++q) {
-        if (q + 1 < rows) {
-          row_of(r, ph_lo + q + 1, pw_lo, npw, gn);
-        } else if (more) {
-          header(r2, ph2, nph2, pw2, npw2);                      // waits for the record load issued at the top of this hit
-          if (nph2 > 0 && npw2 > 0) row_of(r2, ph2, pw2, npw2, gn);
-        }
-        if (live) {
-          float u[kNbTW];
-#pragma unroll
-          for (int x = 0; x < kNbTW; ++x) u[x] = wxr[0][x] * gv[0];
-#pragma unroll
-          for (int j = 1; j < PWMAX; ++j)
-#pragma unroll
-            for (int x = 0; x < kNbTW; ++x) u[x] += wxr[j][x] * gv[j];
-          const float4 wy = *reinterpret_cast<const float4*>(ay + q * 4);
-#pragma unroll
-          for (int x = 0; x < kNbTW; ++x) {
-            acc[0][x] += wy.x * u[x]; acc[1][x] += wy.y * u[x]; acc[2][x] += wy.z * u[x]; acc[3][x] += wy.w * u[x];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < PWMAX; ++j) gv[j] = gn[j];
-      }
-      r = r2; ph_lo = ph2; nph = nph2; pw_lo = pw2; npw = npw2;
-    }
-    if (chan) {
-#pragma unroll
-      for (int y = 0; y < kNbTH; ++y) {
-        const int yy = t.y0 + y;
-        if (yy < H) {
-#pragma unroll
-          for (int x = 0; x < kNbTW; ++x) {
-            const int xx = t.x0 + x;
-            if (xx < W) {
-              float* o = gin + ((static_cast<size_t>(t.b) * H + yy) * W + xx) * C + cl;
-              *o = P.nb.accumulate ? (*o + acc[y][x]) : acc[y][x];
-            }
-          }
-        }
-      }
-    }
-  }
-}
-
-// -1: the shape is outside the record form's plan (or the workspace is too small): use the hit-parallel kernel
-int run_backward_ng(const Levels& L, const float* gout, int grad_out_nhwc, const float* rois, const int32_t* levels, int N, int C,
-                    int K, int PH, int PW, int sr, int accumulate, void* workspace, size_t workspace_bytes, hipStream_t st) {
-  NgPlan P; NgLayout lay;
-  if (!ng_plan(L, N, C, K, PH, PW, !grad_out_nhwc, P, lay) || !workspace || workspace_bytes < lay.total) return -1;
-  P.nb.accumulate = accumulate;
-  unsigned char* base = static_cast<unsigned char*>(workspace);
-  NgWs ws{reinterpret_cast<int*>(base), reinterpret_cast<int2*>(base + lay.off_heads), reinterpret_cast<int2*>(base + lay.off_hits),
-          reinterpret_cast<float*>(base + lay.off_recs), reinterpret_cast<float*>(base + lay.off_gT)};
-  DETOPS_HIP_TRY(hipMemsetAsync(base, 0, 256, st));
-  const int list_blocks = static_cast<int>(ceil_div64(P.nb.num_tiles, kNgPrepBlock / kWave));
-  hipLaunchKernelGGL(roi_bwd_ng_prep1_kernel, dim3(list_blocks + (grad_out_nhwc ? 0 : K * P.nb.cchunks)), dim3(kNgPrepBlock), 0, st, L, P, ws,
-                     rois, levels, gout, K, C, PH, PW, sr, list_blocks);
-  int e = launch_status();
-  if (e) return e;
-  const int units = static_cast<int>(static_cast<int64_t>(P.nb.num_tiles) * P.nb.cchunks);
-  const float* gT = grad_out_nhwc ? gout : ws.gT;
-  int resident = PW == 7 ? detops_resident_workgroups(roi_align_bwd_ng_kernel<7>, kNgBlock, 0)
-                         : detops_resident_workgroups(roi_align_bwd_ng_kernel<14>, kNgBlock, 0);
-  if (resident <= 0) resident = 4 * kNumCU;
-  const dim3 grid(static_cast<unsigned>(std::min<int64_t>(ceil_div64(units, kNgBlock / kWave), resident)));
-  if (PW == 7) hipLaunchKernelGGL((roi_align_bwd_ng_kernel<7>), grid, dim3(kNgBlock), 0, st, L, P, ws, gT, C, PH, PW, units);
-  else hipLaunchKernelGGL((roi_align_bwd_ng_kernel<14>), grid, dim3(kNgBlock), 0, st, L, P, ws, gT, C, PH, PW, units);
-  return launch_status();
-}
-
 int nhwc_levels(Levels& L, const float* const* in_host, float* const* gin_host, const int* H_host, const int* W_host,
                 const float* scale_host, int num_levels) {
   if (num_levels < 1 || num_levels > DETOPS_MAX_LEVELS || !H_host || !W_host || !scale_host) return DETOPS_EINVAL;
@@ -970,10 +606,7 @@ DETOPS_API size_t detops_roi_align_fpn_backward_nhwc_workspace_bytes(const int* 
     L.lv[i] = Level{nullptr, nullptr, H_host[i], W_host[i], 1.f};
   }
   NbPlan P; NbLayout lay;
-  size_t need = nb_plan(L, N, C, K, PH, PW, P, lay) ? lay.total : 0;
-  NgPlan GP; NgLayout gl;
-  if (need && ng_plan(L, N, C, K, PH, PW, true, GP, gl)) need = std::max(need, gl.total);
-  return need;
+  return nb_plan(L, N, C, K, PH, PW, P, lay) ? lay.total : 0;
 }
 
 DETOPS_API int detops_roi_align_fpn_backward_nhwc_f32(
@@ -993,11 +626,6 @@ DETOPS_API int detops_roi_align_fpn_backward_nhwc_f32(
     return 0;
   }
   if (!grad_out || !rois || (num_levels > 1 && !levels) || !workspace) return DETOPS_EINVAL;
-  if (detops_tuning().roi_bwd_impl != 5) {      // 5: force the hit-parallel kernel (A/B, tests)
-    const int rc2 = run_backward_ng(L, grad_out, grad_out_nhwc, rois, levels, N, C, K, PH, PW, sampling_ratio, zero_grad_in ? 0 : 1,
-                                    workspace, workspace_bytes, st);
-    if (rc2 != -1) return rc2;
-  }
   NbPlan P; NbLayout lay;
   if (!nb_plan(L, N, C, K, PH, PW, P, lay)) return DETOPS_EUNSUPPORTED;
   if (workspace_bytes < lay.total) return DETOPS_EINVAL;
