@@ -663,6 +663,9 @@ def main():
             "rank_ms_per_step": ({"min": round(min(RANK_SECONDS) / args.steps * 1e3, 3), "max": round(max(RANK_SECONDS) / args.steps * 1e3, 3),
                                   "all": [round(v / args.steps * 1e3, 3) for v in RANK_SECONDS]} if RANK_SECONDS else None),
             "exposed_allreduce_ms": None if exposed_ms is None else round(exposed_ms, 4),
+            # NMS segments the single-launch kernel gave up on and the repair launch redid since the start of the process
+            # (results are complete either way; non-zero = the scan's waits timed out beside other work on the CUs)
+            "nms_repaired_segments": _C.nms_repaired_segments(device),
             "ddp_ranks": ddp_ranks,
             # host time to ENQUEUE the timed steps (rank 0): close to ms_per_step = the host is the limiter
             "host_enqueue_ms_per_step": round(1000.0 * host_elapsed / args.steps, 3),
