@@ -179,14 +179,30 @@ def rocprof_kernel_us(entry_name):
         return None
     bins = re.search(r",(\d+)x(\d+)\]", entry_name)
     bn = re.match(r"frozen_bn_(fwd|bwd)\[n=\d+,nc=(\d+),e=\d+,res=(\d)", entry_name)
+    fam = entry_name.split("[")[0]
+
+    def matches(line):
+        if "mean=" not in line:
+            return False
+        if bn:   # frozen_bn_{fwd,bwd}[_nhwc]_kernel<T, V, relu, residual>
+            want = "frozen_bn_%s_" % bn.group(1)
+            flag = ", %s>" % ("true" if bn.group(3) == "1" else "false")
+            if want not in line or flag not in line:
+                return False
+            if "nhwc_kernel" in line:
+                return True      # (the channels-last form's grid does not encode the plane count: the first entry of that flavour)
+            return ("grid=%d " % (int(bn.group(2)) * 256)) in line
+        if fam == "roi_align_fpn_fwd" and "roi_align_fwd_nhwc_kernel<" in line and bins:
+            # channels-last pyramid: <V, kOutNhwc, threads>: the box head's 7 x 7 call returns [K, C, PH, PW] (kOutNhwc = false),
+            # the mask head's 14 x 14 call a channels-last tensor
+            return (", false," in line) == (bins.group(1) == "7")
+        if key in line:
+            return (not bins or "roi_align" not in key or ("<%s, %s" % bins.groups()) in line)
+        return False
+
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*kernel_times*.txt")), reverse=True):
         for line in open(path):
-            if bn:   # frozen_bn_{fwd,bwd}_kernel<T, V, relu, residual> launched on (N*C) x chunks workgroups of 256 threads
-                want = "frozen_bn_%s_kernel<" % bn.group(1)
-                flag = ", %s>" % ("true" if bn.group(3) == "1" else "false")
-                if want not in line or flag not in line or ("grid=%d " % (int(bn.group(2)) * 256)) not in line:
-                    continue
-            if key in line and "mean=" in line and (not bins or "roi_align" not in key or ("<%s, %s" % bins.groups()) in line):
+            if matches(line):
                 m = re.search(r"mean=\s*([0-9.]+) us", line)
                 if m:
                     return {"us": float(m.group(1)), "source": os.path.relpath(path, ROOT)}

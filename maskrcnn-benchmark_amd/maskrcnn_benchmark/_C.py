@@ -1349,9 +1349,16 @@ def _nhwc_ok(input, weight, group, dg, geom=None):
     return True
 
 
+def _dcn_in(x):
+    """a channels-last tensor stays as it is (the channels-last pipeline reads it in place); anything else is made contiguous"""
+    return x if is_channels_last(x) else x.contiguous()
+
+
 def _to_nhwc(x):
-    """[B, C, H, W] -> [B, H*W, C] (contiguous)."""
+    """[B, C, H, W] -> [B, H*W, C] (contiguous).  A channels-last tensor IS that layout: a view, no launch."""
     B, C, H, W = x.shape
+    if is_channels_last(x):
+        return x.permute(0, 2, 3, 1).reshape(B, H * W, C)
     x = x.contiguous()
     out = torch.empty((B, H * W, C), dtype=x.dtype, device=x.device)
     if out.numel():
@@ -1406,8 +1413,12 @@ def _nhwc_forward(input, weight, offset, mask, bias, out, geom):
     Cout = weight.size(0)
     xT = _to_nhwc(input)
     colT = _im2col_nhwc(xT, offset, mask, B, C, H, W, geom)
-    torch.bmm(_w_tap_major(weight).unsqueeze(0).expand(B, -1, -1), colT.view(B, -1, colT.size(1)).transpose(1, 2),
-              out=out.view(B, Cout, -1))
+    if is_channels_last(out):
+        # channels-last output: ONE GEMM over the whole batch straight into the output's storage ([B*Ho*Wo, Cout])
+        torch.mm(colT, _w_tap_major(weight).t(), out=out.permute(0, 2, 3, 1).reshape(-1, Cout))
+    else:
+        torch.bmm(_w_tap_major(weight).unsqueeze(0).expand(B, -1, -1), colT.view(B, -1, colT.size(1)).transpose(1, 2),
+                  out=out.view(B, Cout, -1))
     if bias is not None:
         out += bias.to(out.dtype).view(1, -1, 1, 1)
     return xT, colT
@@ -1459,7 +1470,8 @@ def deform_conv_backward_all(input, offset, mask, weight, grad_output, kH, kW, p
     geom = (kH, kW, padH, padW, dH, dW, dilH, dilW, deformable_group)
     if not _nhwc_ok(input, weight, group, deformable_group, geom):
         return None
-    input, offset, weight, grad_output = input.contiguous(), offset.contiguous(), weight.contiguous(), grad_output.contiguous()
+    cl_in = is_channels_last(input)
+    input, offset, weight, grad_output = _dcn_in(input), offset.contiguous(), weight.contiguous(), _dcn_in(grad_output)
     if mask is not None:
         mask = mask.contiguous()
     B, C, H, W = input.shape
@@ -1476,7 +1488,10 @@ def deform_conv_backward_all(input, offset, mask, weight, grad_output, kH, kW, p
         del colsG
         S_T = _transposed_sample(gT, offset, mask, B, C, H, W, Cout, geom)     # [B*H*W, K*Cout]
         W2T = weight.permute(1, 2, 3, 0).reshape(C, -1)          # [C, K*Cout]
-        grad_input = torch.bmm(W2T.unsqueeze(0).expand(B, -1, -1), S_T.view(B, H * W, -1).transpose(1, 2)).view(B, C, H, W)
+        if cl_in:     # the input was channels-last: so is its gradient ([B*H*W, C] from one GEMM, viewed as [B, C, H, W])
+            grad_input = torch.mm(S_T, W2T.t()).view(B, H, W, C).permute(0, 3, 1, 2)
+        else:
+            grad_input = torch.bmm(W2T.unsqueeze(0).expand(B, -1, -1), S_T.view(B, H * W, -1).transpose(1, 2)).view(B, C, H, W)
     if need_weight:
         if colT is None:
             colT = _im2col_nhwc(xT, offset, mask, B, C, H, W, geom)  # [B*Ho*Wo, K*C]
@@ -1503,7 +1518,7 @@ def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW
     `keep` (extension): a list that receives what deform_conv_backward_all(saved=...) can reuse, when the
     channels-last pipeline served the call."""
     _dcn_check("deform_conv_forward", input, weight, offset, output)
-    input, offset, weight = input.contiguous(), offset.contiguous(), weight.contiguous()
+    input, offset, weight = _dcn_in(input), offset.contiguous(), weight.contiguous()
     Ho, Wo = _shape_check(input, offset, None, weight, kH, kW, dH, dW, padH, padW, dilationH,
                           dilationW, group, deformable_group)
     B, C = input.shape[:2]
@@ -1511,14 +1526,16 @@ def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW
     if B % im2col_step != 0:
         raise RuntimeError("im2col step must divide batchsize")
     out = output.view(B, Cout, Ho, Wo)
-    if out.is_contiguous() and _fused_dcn_forward(input, weight, offset, None, None, out, kH, kW, padH, padW, dH, dW,
-                                                  dilationH, dilationW, group, deformable_group):
+    cl = is_channels_last(input)
+    if not cl and out.is_contiguous() and _fused_dcn_forward(input, weight, offset, None, None, out, kH, kW, padH, padW, dH, dW,
+                                                             dilationH, dilationW, group, deformable_group):
         return 1
-    if out.is_contiguous() and _nhwc_ok(input, weight, group, deformable_group):
+    if (out.is_contiguous() or is_channels_last(out)) and _nhwc_ok(input, weight, group, deformable_group):
         kept = _nhwc_forward(input, weight, offset, None, None, out, (kH, kW, padH, padW, dH, dW, dilationH, dilationW, deformable_group))
         if keep is not None:
             keep.append(kept)
         return 1
+    input = input.contiguous()
     for b0 in range(0, B, im2col_step):
         sl = slice(b0, b0 + im2col_step)
         col = deformable_im2col(input[sl], offset[sl], None, kH, kW, padH, padW, dH, dW, dilationH,
@@ -1597,7 +1614,8 @@ def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, outpu
     The reference loops per image; one im2col + one GEMM per group over the whole batch gives the
     same sums."""
     _dcn_check("modulated_deform_conv_forward", input, weight, offset, mask, output)
-    if not input.is_contiguous():
+    cl = is_channels_last(input)
+    if not input.is_contiguous() and not cl:
         raise RuntimeError("input tensor has to be contiguous")
     if not weight.is_contiguous():
         raise RuntimeError("weight tensor has to be contiguous")
@@ -1611,16 +1629,17 @@ def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, outpu
     Ho, Wo = _out_hw(H, W, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w)
     offset, mask = offset.contiguous(), mask.contiguous()
     out = output.view(B, Cout, Ho, Wo)
-    if out.is_contiguous() and _fused_dcn_forward(input, weight, offset, mask, bias.to(input.dtype).contiguous() if with_bias else None,
-                                                  out, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w,
-                                                  dilation_h, dilation_w, group, deformable_group):
+    if not cl and out.is_contiguous() and _fused_dcn_forward(input, weight, offset, mask, bias.to(input.dtype).contiguous() if with_bias else None,
+                                                             out, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w,
+                                                             dilation_h, dilation_w, group, deformable_group):
         return
-    if out.is_contiguous() and _nhwc_ok(input, weight, group, deformable_group):
+    if (out.is_contiguous() or is_channels_last(out)) and _nhwc_ok(input, weight, group, deformable_group):
         kept = _nhwc_forward(input, weight, offset, mask, bias if with_bias else None, out,
                              (kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w, deformable_group))
         if keep is not None:
             keep.append(kept)
         return
+    input = input.contiguous()
     col = deformable_im2col(input, offset, mask, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w,
                             dilation_h, dilation_w, deformable_group)
     buf = torch.empty((Cout, B * Ho * Wo), dtype=input.dtype, device=input.device)

@@ -181,8 +181,8 @@ class BucketedDataParallel(torch.nn.Module):
     that did not fill (a parameter without gradient on this rank: its slice is sent as zeros) are flushed and the
     main stream joins the callbacks.  `module` is the wrapped model (checkpoints strip the prefix as for DDP).
 
-    Communication (`comm`): "direct" — RCCL called through engine/rccl_comm.py on ONE side stream (normal priority by
-    default, DETOPS_DDP_PRIO=low|high|main for A/B runs) that also runs the bucket updates (two HIP streams in the step, one event per bucket; the default on the GPU: "auto" tries
+    Communication (`comm`): "direct" — RCCL called through engine/rccl_comm.py on ONE side stream (HIGH priority by
+    default: its own hardware queue; DETOPS_DDP_PRIO=low|normal|main for A/B runs) that also runs the bucket updates (two HIP streams in the step, one event per bucket; the default on the GPU: "auto" tries
     it, self-tests one all-reduce and falls back); "pg" — torch.distributed's ProcessGroupNCCL (its own stream, a work
     object + future per bucket, the update in the future's callback on a pool stream) and the only path for gloo / CPU
     tensors.  `self.comm_mode` says which one runs.
@@ -250,14 +250,17 @@ class BucketedDataParallel(torch.nn.Module):
             from . import rccl_comm
             if not rccl_comm.available():
                 raise RuntimeError("librccl.so (or one of its entry points) is not loadable")
-            prio_want = os.environ.get("DETOPS_DDP_PRIO", "normal")
+            # "high" by default (round 6, profiles/r06_ddp_contention.txt): with GPU_MAX_HW_QUEUES=2 a NORMAL-priority stream
+            # shares the compute stream's hardware queue — whatever runs on it serialises with the step (measured with a
+            # contention stand-in: +8 x its duration); an explicit priority gets its own queue and overlaps
+            prio_want = os.environ.get("DETOPS_DDP_PRIO", "high")
             if prio_want == "low":
                 side, prio = rccl_comm.low_priority_stream(dev)
             elif prio_want == "high":
                 side, prio = torch.cuda.Stream(dev, priority=-1), -1
             elif prio_want == "main":     # measurement only: no second stream at all
                 side, prio = torch.cuda.current_stream(dev), 0
-            else:                         # the default: a normal-priority side stream (lowest / high measured no better)
+            else:                         # "normal": shares a hardware queue with the compute stream unless GPU_MAX_HW_QUEUES >= 8
                 side, prio = torch.cuda.Stream(dev), 0
         except Exception as e:  # noqa: BLE001 — local set-up only; reported in comm_note
             local_err = e

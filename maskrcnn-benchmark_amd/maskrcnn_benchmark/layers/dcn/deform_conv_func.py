@@ -27,8 +27,10 @@ class DeformConvFunction(Function):
         ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
         offset, weight = _same_dtype(input, offset, weight)
         ctx.save_for_backward(input, offset, weight)
-        output = input.new_empty(DeformConvFunction._output_size(input, weight, ctx.padding,
-                                                                  ctx.dilation, ctx.stride))
+        # a channels-last input gets a channels-last output (the pipeline is channel-fastest inside: no layout launches)
+        output = torch.empty(DeformConvFunction._output_size(input, weight, ctx.padding, ctx.dilation, ctx.stride),
+                             dtype=input.dtype, device=input.device,
+                             memory_format=torch.channels_last if _C.is_channels_last(input) else torch.contiguous_format)
         ctx.bufs_ = [input.new_empty(0), input.new_empty(0)]  # columns, ones (API compatibility)
         if not _C.on_device(input):
             raise NotImplementedError
@@ -106,10 +108,11 @@ class ModulatedDeformConvFunction(Function):
         offset, mask, weight, bias = _same_dtype(input, offset, mask, weight, bias)
         if needs_grad:
             ctx.save_for_backward(input, offset, mask, weight, bias)
-        output = input.new_empty(ModulatedDeformConvFunction._infer_shape(ctx, input, weight))
+        output = torch.empty(ModulatedDeformConvFunction._infer_shape(ctx, input, weight), dtype=input.dtype, device=input.device,
+                             memory_format=torch.channels_last if _C.is_channels_last(input) else torch.contiguous_format)
         ctx._bufs = [input.new_empty(0), input.new_empty(0)]
         keep = [] if needs_grad else None
-        _C.modulated_deform_conv_forward(input.contiguous(), weight, bias, ctx._bufs[0], offset, mask,
+        _C.modulated_deform_conv_forward(input if _C.is_channels_last(input) else input.contiguous(), weight, bias, ctx._bufs[0], offset, mask,
                                          output, ctx._bufs[1], weight.shape[2], weight.shape[3],
                                          ctx.stride, ctx.stride, ctx.padding, ctx.padding,
                                          ctx.dilation, ctx.dilation, ctx.groups,

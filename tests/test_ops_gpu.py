@@ -743,6 +743,37 @@ def test_nms_single_launch_beside_rccl_all_reduces_and_bucket_updates():
     assert _C().nms_repaired_segments() == 0
 
 
+@pytest.mark.parametrize("prio", ["high", "low"])
+def test_nms_single_launch_beside_a_contention_stand_in(prio):
+    """VERDICT r05 #4d: the single-launch NMS (inter-workgroup waits, bounded + repaired) while workgroups on a second,
+    explicit-priority stream HOLD compute units the way an N > 1 ring all-reduce kernel does (detops_debug_occupy: 64
+    workgroups of 1024 threads for 1 ms, back to back): results bit-exact.  A repaired segment would still be correct — the
+    count is reported, and expected to be 0 (profiles/r06_ddp_contention.txt: 0 in every setting)."""
+    from maskrcnn_benchmark import _C as C
+    from maskrcnn_benchmark.engine import rccl_comm
+    segs = synth.rpn_nms_segments()
+    boxes = np.concatenate([b for b, _ in segs])
+    scores = np.concatenate([s for _, s in segs])
+    offs = np.cumsum([0] + [len(s) for _, s in segs]).astype(np.int32)
+    tb, ts, to = _t(boxes), _t(scores), _t(offs)
+    refs = [oracle.nms(b, sc, 0.7) for b, sc in segs]
+    side = rccl_comm.low_priority_stream(DEV)[0] if prio == "low" else torch.cuda.Stream(DEV, priority=-1)
+    C.nms_repaired_segments(reset=True)
+    outs = []
+    for rep in range(6):
+        for _ in range(4):
+            C.check(C.lib.detops_debug_occupy(64, 1000, side.cuda_stream), "debug_occupy")
+        for _ in range(3):
+            outs.append(C.nms_batched(tb, ts, to, 2000, 0.7))
+    torch.cuda.synchronize()
+    for keep, num in outs:
+        keep, num = keep.cpu().numpy(), num.cpu().numpy()
+        for i, ref in enumerate(refs):
+            assert num[i] == len(ref), (i, num[i])
+            np.testing.assert_array_equal(keep[offs[i]:offs[i] + num[i]], ref)
+    assert C.nms_repaired_segments() == 0
+
+
 def test_nms_threshold_boundary_is_exact():
     """Pairs whose IoU is EXACTLY the threshold, one ulp above and one ulp below it, and degenerate unions (negative
     "areas", huge coordinates) must come out as the reference's `inter / union >= thr` (nms_cpu.cpp:59-60) does: the
@@ -1309,3 +1340,40 @@ def test_roi_align_channels_last_adjoint_identity_at_model_size():
     lhs = float((out.double() * _t(g).double()).sum())
     rhs = sum(float((a.double() * b.double()).sum()) for a, b in zip(tf, gin))
     assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs)), (lhs, rhs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_roi_align_backward_non_finite_gradient_stays_in_the_rois_tiles(layout):
+    """A non-finite pooled gradient (a GradScaler overflow step) of ONE bin: the branch-free walks multiply neighbouring rows by
+    stored zero weights, so 0 * Inf = NaN may appear around the bin's own footprint — but only inside the 8 x 32 pixel tiles
+    the ROI reaches (documented in DESIGN.md section 3.2); every other gradient element, every other level and image stay
+    finite and equal to the run without the Inf."""
+    from maskrcnn_benchmark import _C
+    feats, rois, scales = _nhwc_case(64, 512, 7, 2, seed=77)
+    rng = np.random.RandomState(5)
+    g = rng.randn(512, 64, 7, 7).astype(np.float32)
+    lvn = synth.level_map(rois)
+    k = int(np.nonzero(lvn == 1)[0][0])          # a ROI on the stride-8 level
+    g2 = g.copy()
+    g2[k, 3, 2, 4] = np.inf
+    shapes = [tuple(f.shape) for f in feats]
+    cl = layout == "nhwc"
+    a = _C.roi_align_fpn_backward(_t(g), _t(rois), _t(lvn), shapes, scales, 7, 7, 2, channels_last=cl)
+    b = _C.roi_align_fpn_backward(_t(g2), _t(rois), _t(lvn), shapes, scales, 7, 7, 2, channels_last=cl)
+    img = int(rois[k, 0])
+    x1, y1, x2, y2 = (rois[k, 1:] * scales[1])
+    H, W = shapes[1][2:]
+    ty0, ty1 = max(int(np.floor(y1)) - 1, 0) // 8 * 8, min((int(np.ceil(y2)) + 1) // 8 * 8 + 8, H)
+    tx0, tx1 = max(int(np.floor(x1)) - 1, 0) // 32 * 32, min((int(np.ceil(x2)) + 1) // 32 * 32 + 32, W)
+    for l in range(len(feats)):
+        ga, gb = a[l].contiguous().cpu().numpy(), b[l].contiguous().cpu().numpy()
+        bad = ~np.isfinite(gb)
+        if l != 1:
+            assert not bad.any() and np.array_equal(ga, gb)
+            continue
+        assert bad.any()
+        allowed = np.zeros_like(bad)
+        allowed[img, :, ty0:ty1, tx0:tx1] = True
+        assert not (bad & ~allowed).any(), "non-finite values outside the ROI's tiles"
+        assert np.array_equal(ga[~allowed], gb[~allowed])
