@@ -1617,6 +1617,8 @@ def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, outpu
     cl = is_channels_last(input)
     if not input.is_contiguous() and not cl:
         raise RuntimeError("input tensor has to be contiguous")
+    if is_channels_last(weight):          # a model switched to channels-last carries its 4-d parameters that way
+        weight = weight.contiguous()
     if not weight.is_contiguous():
         raise RuntimeError("weight tensor has to be contiguous")
     B, C, H, W = input.shape

@@ -27,21 +27,26 @@ def load_cfg(config_file, opts=()):
 
 def choose_layout(cfg, device, layout="auto"):
     """-> "nchw" | "backbone" | "all": which part of the detector runs on channels-last (NHWC) activations
-    (GeneralizedRCNN.set_channels_last).  "auto" (overridable with DETOPS_LAYOUT): channels-last on the GPU for the fp32
-    FPN detectors without deformable convolutions — the configurations it was measured on, with the tuned MIOpen find-db
+    (GeneralizedRCNN.set_channels_last).  "auto" (overridable with DETOPS_LAYOUT): channels-last on the GPU for the FPN
+    detectors in every precision — the configurations it was measured on (fp32, bf16 autocast: 97.6 -> 128.6 img/s, R-101 +
+    DCN under fp16: 54.2 -> 64.3 img/s, profiles/r06p_half_precision_layouts.txt), with the tuned MIOpen find-db
     for the NHWC problem keys that ships in-tree (e2e_mask_rcnn_R_50_FPN_1x on one box: NCHW 38.0 ms per step, backbone + FPN
-    channels-last 36.2, the heads as well 33.4: profiles/r06g_*); NCHW everywhere else (CPU, half precision, DCN stages: not
-    measured / slower)."""
+    channels-last 36.2, the heads as well 33.4: profiles/r06g_*); NCHW on the CPU and for non-FPN bodies (not measured)."""
     layout = os.environ.get("DETOPS_LAYOUT", layout) if layout == "auto" else layout
     if layout in ("nchw", "backbone", "all"):
         return layout
     if layout != "auto":
         raise ValueError("layout must be auto | nchw | backbone | all, got %r" % (layout,))
-    ok = (torch.device(device).type == "cuda" and cfg.DTYPE == "float32" and "FPN" in cfg.MODEL.BACKBONE.CONV_BODY
-          and not any(cfg.MODEL.RESNETS.STAGE_WITH_DCN) and cfg.MODEL.META_ARCHITECTURE == "GeneralizedRCNN")
-    return AUTO_LAYOUT if ok else "nchw"
+    ok = (torch.device(device).type == "cuda" and "FPN" in cfg.MODEL.BACKBONE.CONV_BODY
+          and cfg.MODEL.META_ARCHITECTURE == "GeneralizedRCNN")
+    if not ok:
+        return "nchw"
+    # deformable stages: the DCN layers read / write channels-last tensors in place (layers/dcn); measured for R-101 + DCN
+    # under fp16 (profiles/r06p_*, r06q_*)
+    return AUTO_LAYOUT_DCN if any(cfg.MODEL.RESNETS.STAGE_WITH_DCN) else AUTO_LAYOUT
 
 
+AUTO_LAYOUT_DCN = "backbone"
 AUTO_LAYOUT = "all"
 
 

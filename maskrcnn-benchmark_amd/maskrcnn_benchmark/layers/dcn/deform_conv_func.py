@@ -26,6 +26,7 @@ class DeformConvFunction(Function):
         ctx.stride, ctx.padding, ctx.dilation = _pair(stride), _pair(padding), _pair(dilation)
         ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
         offset, weight = _same_dtype(input, offset, weight)
+        weight = weight.contiguous()      # (a model switched to channels-last carries its 4-d parameters that way)
         ctx.save_for_backward(input, offset, weight)
         # a channels-last input gets a channels-last output (the pipeline is channel-fastest inside: no layout launches)
         output = torch.empty(DeformConvFunction._output_size(input, weight, ctx.padding, ctx.dilation, ctx.stride),
@@ -70,8 +71,8 @@ class DeformConvFunction(Function):
         if fused is not None:
             return (fused[0], fused[1], fused[3], None, None, None, None, None, None)
         if need_in:
-            grad_input = torch.zeros_like(input)
-            grad_offset = torch.zeros_like(offset)
+            grad_input = torch.zeros_like(input, memory_format=torch.contiguous_format)
+            grad_offset = torch.zeros_like(offset, memory_format=torch.contiguous_format)
             _C.deform_conv_backward_input(input, offset, grad_output, grad_input, grad_offset, weight,
                                           ctx.bufs_[0], *geom, step)
         if ctx.needs_input_grad[2]:
@@ -106,6 +107,7 @@ class ModulatedDeformConvFunction(Function):
         # decided on the ORIGINAL arguments: a .to(dtype) copy made under no-grad reports requires_grad=False
         needs_grad = weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad
         offset, mask, weight, bias = _same_dtype(input, offset, mask, weight, bias)
+        weight = weight.contiguous()      # (a model switched to channels-last carries its 4-d parameters that way)
         if needs_grad:
             ctx.save_for_backward(input, offset, mask, weight, bias)
         output = torch.empty(ModulatedDeformConvFunction._infer_shape(ctx, input, weight), dtype=input.dtype, device=input.device,
@@ -134,9 +136,9 @@ class ModulatedDeformConvFunction(Function):
         ctx.kept_ = None
         if fused is not None:
             return fused + (None, None, None, None, None)
-        grad_input = torch.zeros_like(input)
-        grad_offset = torch.zeros_like(offset)
-        grad_mask = torch.zeros_like(mask)
+        grad_input = torch.zeros_like(input, memory_format=torch.contiguous_format)
+        grad_offset = torch.zeros_like(offset, memory_format=torch.contiguous_format)
+        grad_mask = torch.zeros_like(mask, memory_format=torch.contiguous_format)
         grad_weight = torch.zeros_like(weight)
         grad_bias = torch.zeros_like(bias)
         _C.modulated_deform_conv_backward(input.contiguous(), weight, bias, ctx._bufs[0], offset, mask,

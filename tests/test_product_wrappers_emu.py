@@ -105,6 +105,46 @@ def test_roi_align_modules_over_the_pyramid_equal_the_oracle():
         assert np.abs(tf[l].grad.numpy() - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize("modulated", [False, True])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 2e-2)])
+def test_deform_conv_modules_on_channels_last_tensors_equal_the_nchw_run(modulated, dtype, tol):
+    """DeformConv / ModulatedDeformConv on a channels-last input (and channels-last parameters, as `model.to(memory_format=
+    torch.channels_last)` leaves them): the channels-last pipeline reads the input in place, writes a channels-last output
+    with one GEMM and returns a channels-last input gradient — same values as the NCHW call (the GEMMs' summation order
+    differs: 1e-5 fp32, 2e-2 half)."""
+    from maskrcnn_benchmark import _C
+    from maskrcnn_benchmark.layers import DeformConv, ModulatedDeformConv
+    torch.manual_seed(3)
+    B, C, H, W, Cout, k = 2, 32, 11, 13, 32, 3
+    x = torch.randn(B, C, H, W).to(dtype)
+    off = (torch.randn(B, 2 * k * k, H, W) * 1.5).to(dtype)
+    msk = torch.rand(B, k * k, H, W).to(dtype)
+    layer = (ModulatedDeformConv(C, Cout, k, 1, 1, bias=True) if modulated else DeformConv(C, Cout, k, 1, 1)).to(dtype)
+    g = torch.randn(B, Cout, H, W).to(dtype)
+    cl = torch.channels_last
+
+    def run(fmt):
+        layer.to(memory_format=fmt)
+        for p in layer.parameters():
+            p.grad = None
+        xi = x.clone(memory_format=fmt).requires_grad_()
+        oi = off.clone(memory_format=fmt).requires_grad_()
+        args = (xi, oi) + ((msk.clone(memory_format=fmt).requires_grad_(),) if modulated else ())
+        y = layer(*args)
+        y.backward(g.clone(memory_format=fmt))
+        return y, xi.grad, oi.grad, [p.grad.clone() for p in layer.parameters()]
+
+    y0, gx0, go0, gp0 = run(torch.contiguous_format)
+    y1, gx1, go1, gp1 = run(cl)
+    assert _C.is_channels_last(y1) and _C.is_channels_last(gx1)
+    scale = float(y0.float().abs().max())
+    assert torch.allclose(y1.float(), y0.float(), rtol=tol, atol=tol * scale)
+    assert torch.allclose(gx1.float(), gx0.float(), rtol=tol, atol=tol * float(gx0.float().abs().max()))
+    assert torch.allclose(go1.float(), go0.float(), rtol=tol, atol=tol * float(go0.float().abs().max()))
+    for a, b in zip(gp1, gp0):
+        assert torch.allclose(a.float(), b.float(), rtol=tol, atol=tol * float(b.float().abs().max()) + 1e-6)
+
+
 def test_nms_wrappers_equal_the_oracle_bit_exactly():
     from maskrcnn_benchmark import _C
     b, s = synth.nms_boxes(700, seed=5)
