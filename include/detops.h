@@ -672,6 +672,36 @@ int detops_fpn_topdown_forward_nhwc(const void* lateral, const void* top, void* 
 int detops_fpn_topdown_backward_nhwc(const void* grad_out, void* grad_top, int dtype, int N, int C, int H, int W, int h, int w,
                                      detops_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Double precision (csrc/f64_ops.hip, csrc/cpu_branch.hip) — the reference dispatches these operators over
+ * AT_DISPATCH_FLOATING_TYPES, i.e. float AND double (csrc/cuda/ROIAlign_cuda.cu:283,329, ROIPool_cuda.cu:137,185,
+ * SigmoidFocalLoss_cuda.cu:129,173, csrc/cpu/ROIAlign_cpu.cpp:242, csrc/cpu/nms_cpu.cpp:71).  Same argument meaning as the
+ * _f32 entry points; plain one-thread-per-element kernels with the reference's arithmetic in double (API completeness: no
+ * configuration of the training path computes in double).  detops_nms_sorted_f64 takes boxes already sorted by descending
+ * score and returns a byte per sorted box (1 = kept); the two *_cpu_f64 entry points are host code for CPU tensors.
+ * ---------------------------------------------------------------------------------------- */
+int detops_roi_align_forward_f64(const double* input, const double* rois, double* output, int N, int C, int H, int W, int K,
+                                 int PH, int PW, float spatial_scale, int sampling_ratio, detops_stream_t stream);
+int detops_roi_align_backward_f64(const double* grad_out, const double* rois, double* grad_in, int N, int C, int H, int W,
+                                  int K, int PH, int PW, float spatial_scale, int sampling_ratio, int zero_grad_in,
+                                  detops_stream_t stream);
+int detops_roi_pool_forward_f64(const double* input, const double* rois, double* output, int32_t* argmax, int N, int C, int H,
+                                int W, int K, int PH, int PW, float spatial_scale, detops_stream_t stream);
+int detops_roi_pool_backward_f64(const double* grad_out, const double* rois, const int32_t* argmax, double* grad_in, int N,
+                                 int C, int H, int W, int K, int PH, int PW, int zero_grad_in, detops_stream_t stream);
+int detops_sigmoid_focal_loss_forward_f64(const double* logits, const int32_t* targets, double* losses, int num_rows,
+                                          int num_classes, float gamma, float alpha, detops_stream_t stream);
+int detops_sigmoid_focal_loss_backward_f64(const double* logits, const int32_t* targets, const double* d_losses,
+                                           double* d_logits, int num_rows, int num_classes, float gamma, float alpha,
+                                           detops_stream_t stream);
+size_t detops_nms_sorted_f64_workspace_bytes(int n);
+int detops_nms_sorted_f64(const double* sorted_boxes, int n, float iou_threshold, unsigned char* keep_sorted, void* workspace,
+                          size_t workspace_bytes, detops_stream_t stream);
+int detops_roi_align_forward_cpu_f64(const double* input, const double* rois, double* output, int N, int C, int H, int W,
+                                     int K, int PH, int PW, float spatial_scale, int sampling_ratio);
+int detops_nms_cpu_f64(const double* boxes, const double* scores, int n, float iou_threshold, int64_t* keep,
+                       int32_t* num_keep);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

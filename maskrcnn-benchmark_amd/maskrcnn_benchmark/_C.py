@@ -139,12 +139,126 @@ def _timed(name, t, every=1):
 _ESIZE = {torch.float32: 4, torch.float16: 2, torch.bfloat16: 2}
 
 
+# ------------------------------------------------------------------------------------------ double precision
+# The reference dispatches its operators over float AND double (AT_DISPATCH_FLOATING_TYPES).  float64 tensors take the plain
+# kernels of csrc/f64_ops.hip (device) / csrc/cpu_branch.hip (CPU tensors: nms, roi_align_forward); everything tuned in this
+# library is fp32.
+def _f64(t):
+    return t is not None and t.dtype == torch.float64
+
+
+def _f64c(name, *ts):
+    for t in ts:
+        if t.dtype != torch.float64:
+            raise RuntimeError("%s: all floating-point tensors must be float64 (got %s)" % (name, t.dtype))
+    return [t.contiguous() for t in ts]
+
+
+def _nms_f64(dets, scores, threshold):
+    dets, scores = _f64c("nms", dets, scores)
+    n = dets.size(0)
+    if dets.dim() != 2 or dets.size(1) != 4 or scores.numel() != n:
+        raise RuntimeError("nms: expected dets [n,4] and scores [n]")
+    if not on_device(dets):
+        keep = torch.empty((n,), dtype=torch.long)
+        num = torch.zeros((1,), dtype=torch.int32)
+        check(lib.detops_nms_cpu_f64(ptr(dets), ptr(scores), n, float(threshold), ptr(keep), ptr(num)), "nms(cpu, f64)")
+        return keep[: int(num.item())]
+    _need_cuda("nms", dets, scores)
+    order = torch.sort(scores, descending=True, stable=True).indices       # ties: ascending index, like the CPU path
+    sorted_boxes = dets[order].contiguous()
+    kept = torch.empty((n,), dtype=torch.uint8, device=dets.device)
+    nbytes = int(lib.detops_nms_sorted_f64_workspace_bytes(n))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dets.device)
+    with _on_device(dets):
+        check(lib.detops_nms_sorted_f64(ptr(sorted_boxes), n, float(threshold), ptr(kept), ptr(ws), nbytes, stream_of(dets)), "nms(f64)")
+    return torch.sort(order[kept.bool()]).values       # ascending original indices = nonzero(suppressed == 0)
+
+
+def _roi_align_forward_f64(input, rois, spatial_scale, ph, pw, sr):
+    input, rois = _f64c("roi_align_forward", input, rois)
+    N, C, H, W = input.shape
+    K = rois.size(0)
+    out = torch.empty((K, C, ph, pw), dtype=torch.float64, device=input.device)
+    if out.numel() == 0:
+        return out
+    if not on_device(input):
+        check(lib.detops_roi_align_forward_cpu_f64(ptr(input), ptr(rois), ptr(out), N, C, H, W, K, ph, pw, float(spatial_scale), int(sr)),
+              "roi_align_forward(cpu, f64)")
+        return out
+    _need_cuda("roi_align_forward", input, rois)
+    with _on_device(input):
+        check(lib.detops_roi_align_forward_f64(ptr(input), ptr(rois), ptr(out), N, C, H, W, K, ph, pw, float(spatial_scale), int(sr),
+                                               stream_of(input)), "roi_align_forward(f64)")
+    return out
+
+
+def _roi_align_backward_f64(grad, rois, spatial_scale, ph, pw, N, C, H, W, sr):
+    _need_cuda("roi_align_backward", grad, rois)
+    grad, rois = _f64c("roi_align_backward", grad, rois)
+    gin = torch.empty((N, C, H, W), dtype=torch.float64, device=grad.device)
+    with _on_device(grad):
+        check(lib.detops_roi_align_backward_f64(ptr(grad), ptr(rois), ptr(gin), N, C, H, W, rois.size(0), ph, pw, float(spatial_scale),
+                                                int(sr), 1, stream_of(grad)), "roi_align_backward(f64)")
+    return gin
+
+
+def _roi_pool_forward_f64(input, rois, spatial_scale, ph, pw):
+    _need_cuda("roi_pool_forward", input, rois)
+    input, rois = _f64c("roi_pool_forward", input, rois)
+    N, C, H, W = input.shape
+    K = rois.size(0)
+    out = torch.empty((K, C, ph, pw), dtype=torch.float64, device=input.device)
+    argmax = torch.zeros((K, C, ph, pw), dtype=torch.int32, device=input.device)
+    if out.numel():
+        with _on_device(input):
+            check(lib.detops_roi_pool_forward_f64(ptr(input), ptr(rois), ptr(out), ptr(argmax), N, C, H, W, K, ph, pw, float(spatial_scale),
+                                                  stream_of(input)), "roi_pool_forward(f64)")
+    return out, argmax
+
+
+def _roi_pool_backward_f64(grad, rois, argmax, ph, pw, N, C, H, W):
+    _need_cuda("roi_pool_backward", grad, rois, argmax)
+    grad, rois = _f64c("roi_pool_backward", grad, rois)
+    argmax = argmax.contiguous()
+    gin = torch.empty((N, C, H, W), dtype=torch.float64, device=grad.device)
+    with _on_device(grad):
+        check(lib.detops_roi_pool_backward_f64(ptr(grad), ptr(rois), ptr(argmax), ptr(gin), N, C, H, W, rois.size(0), ph, pw, 1,
+                                               stream_of(grad)), "roi_pool_backward(f64)")
+    return gin
+
+
+def _focal_f64(logits, targets, d_losses, num_classes, gamma, alpha):
+    _need_cuda("sigmoid_focalloss", logits, targets)
+    (logits,) = _f64c("sigmoid_focalloss", logits)
+    if logits.dim() != 2:
+        raise RuntimeError("logits should be NxClass")
+    if targets.dim() != 1:
+        raise RuntimeError("targets should be Nx1")
+    R, Cc = logits.shape
+    if Cc != num_classes or targets.numel() != R:
+        raise RuntimeError("sigmoid_focalloss: inconsistent shapes")
+    t32 = targets.to(torch.int32).contiguous()
+    out = torch.empty_like(logits)
+    with _on_device(logits):
+        if d_losses is None:
+            check(lib.detops_sigmoid_focal_loss_forward_f64(ptr(logits), ptr(t32), ptr(out), R, Cc, float(gamma), float(alpha),
+                                                            stream_of(logits)), "sigmoid_focalloss_forward(f64)")
+        else:
+            (d_losses,) = _f64c("sigmoid_focalloss_backward", d_losses)
+            check(lib.detops_sigmoid_focal_loss_backward_f64(ptr(logits), ptr(t32), ptr(d_losses), ptr(out), R, Cc, float(gamma),
+                                                             float(alpha), stream_of(logits)), "sigmoid_focalloss_backward(f64)")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ NMS
 def nms(dets, scores, threshold):
     """reference csrc/nms.h:10-28: dets [n,4] xyxy, scores [n] -> int64 kept indices, ascending.
     CPU semantics (IoU >= threshold suppresses; csrc/cpu/nms_cpu.cpp:60)."""
     if dets.numel() == 0:  # nms.h:17-18 returns an empty CPU long tensor
         return torch.empty((0,), dtype=torch.long, device="cpu")
+    if _f64(dets):
+        return _nms_f64(dets, scores, threshold)
     on_cpu = not on_device(dets) and not on_device(scores)
     if not on_cpu:
         _need_cuda("nms", dets, scores)
@@ -701,6 +815,8 @@ def rpn_decode(box_regression, topk_idx, topk_scores, anchors, image_hw, weights
 # ------------------------------------------------------------------------------------------ ROIAlign
 def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
     """reference csrc/ROIAlign.h:11-25 -> [K,C,PH,PW]."""
+    if _f64(input):
+        return _roi_align_forward_f64(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio)
     if not on_device(input) and not on_device(rois):
         return _roi_align_forward_cpu(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio)
     _need_cuda("roi_align_forward", input, rois)
@@ -748,6 +864,9 @@ def _fwd_workspace(device, K, ph, pw, sr):
 def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
                        height, width, sampling_ratio):
     """reference csrc/ROIAlign.h:27-45 -> zero-initialised [bs,ch,h,w] with the scattered grads."""
+    if _f64(grad):
+        return _roi_align_backward_f64(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels, height, width,
+                                       sampling_ratio)
     _need_cuda("roi_align_backward", grad, rois)
     grad = _f32c("roi_align_backward", grad)
     rois = _f32c("roi_align_backward", rois)
@@ -961,6 +1080,8 @@ def _roi_align_fpn_backward_nhwc(grad, rois, levels, shapes, scales, pooled_heig
 # ------------------------------------------------------------------------------------------ ROIPool
 def roi_pool_forward(input, rois, spatial_scale, pooled_height, pooled_width):
     """reference csrc/ROIPool.h:11-24 -> (output, argmax int32)."""
+    if _f64(input):
+        return _roi_pool_forward_f64(input, rois, spatial_scale, pooled_height, pooled_width)
     _need_cuda("roi_pool_forward", input, rois)
     input = _f32c("roi_pool_forward", input)
     rois = _f32c("roi_pool_forward", rois)
@@ -981,6 +1102,8 @@ def roi_pool_forward(input, rois, spatial_scale, pooled_height, pooled_width):
 def roi_pool_backward(grad, input, rois, argmax, spatial_scale, pooled_height, pooled_width,
                       batch_size, channels, height, width):
     """reference csrc/ROIPool.h:26-45 (`input` is unused there too)."""
+    if _f64(grad):
+        return _roi_pool_backward_f64(grad, rois, argmax, pooled_height, pooled_width, batch_size, channels, height, width)
     _need_cuda("roi_pool_backward", grad, rois, argmax)
     grad = _f32c("roi_pool_backward", grad)
     rois = _f32c("roi_pool_backward", rois)
@@ -1010,6 +1133,8 @@ def _focal_args(name, logits, targets, num_classes):
 
 def sigmoid_focalloss_forward(logits, targets, num_classes, gamma, alpha):
     """reference csrc/SigmoidFocalLoss.h:10-24 -> losses [R,C]."""
+    if _f64(logits):
+        return _focal_f64(logits, targets, None, num_classes, gamma, alpha)
     logits, targets = _focal_args("sigmoid_focalloss_forward", logits, targets, num_classes)
     losses = torch.empty_like(logits)
     with _on_device(logits):
@@ -1022,6 +1147,8 @@ def sigmoid_focalloss_forward(logits, targets, num_classes, gamma, alpha):
 
 def sigmoid_focalloss_backward(logits, targets, d_losses, num_classes, gamma, alpha):
     """reference csrc/SigmoidFocalLoss.h:26-41 -> d_logits [R,C]."""
+    if _f64(logits):
+        return _focal_f64(logits, targets, d_losses, num_classes, gamma, alpha)
     logits, targets = _focal_args("sigmoid_focalloss_backward", logits, targets, num_classes)
     _need_cuda("sigmoid_focalloss_backward", d_losses)
     d_losses = _f32c("sigmoid_focalloss_backward", d_losses)

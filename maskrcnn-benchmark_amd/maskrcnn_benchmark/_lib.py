@@ -73,6 +73,16 @@ SIGNATURES = {
     "detops_bias_act_backward_nhwc_f32": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_int, c_int, _P, c_size_t, _P]),
     "detops_column_sum_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int]),
     "detops_column_sum_f32": (c_int, [_P, _P, ctypes.c_int64, c_int, _P, c_size_t, _P]),
+    "detops_roi_align_forward_f64": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, _P]),
+    "detops_roi_align_backward_f64": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, c_int, _P]),
+    "detops_roi_pool_forward_f64": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),
+    "detops_roi_pool_backward_f64": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_P]),
+    "detops_sigmoid_focal_loss_forward_f64": (c_int, [_P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_sigmoid_focal_loss_backward_f64": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_float, _P]),
+    "detops_nms_sorted_f64_workspace_bytes": (c_size_t, [c_int]),
+    "detops_nms_sorted_f64": (c_int, [_P, c_int, c_float, _P, _P, c_size_t, _P]),
+    "detops_roi_align_forward_cpu_f64": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int]),
+    "detops_nms_cpu_f64": (c_int, [_P, _P, c_int, c_float, _P, _P]),
     "detops_debug_occupy": (c_int, [c_int, c_int, _P]),
     "detops_sgd_momentum_flat_f32": (c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64] + [c_float] * 5 + [_P]),
     "detops_rpn_decode_f32": (c_int, [_P] * 5 + [c_int] * 5 + [c_float] * 6 + [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, _P, _P]),

@@ -46,7 +46,7 @@ def choose_layout(cfg, device, layout="auto"):
     return AUTO_LAYOUT_DCN if any(cfg.MODEL.RESNETS.STAGE_WITH_DCN) else AUTO_LAYOUT
 
 
-AUTO_LAYOUT_DCN = "backbone"
+AUTO_LAYOUT_DCN = "all"
 AUTO_LAYOUT = "all"
 
 

@@ -32,9 +32,11 @@ class GeneralizedRCNN(nn.Module):
         state_dict are untouched (a memory format is a stride permutation, not a shape)."""
         fmt = torch.channels_last if on else torch.contiguous_format
         self.backbone.to(memory_format=fmt)
-        heads = bool(on and heads and hasattr(self.rpn, "head") and type(self.rpn).__name__ == "RPNModule")
+        heads = bool(on and heads and hasattr(self.rpn, "head") and type(self.rpn).__name__ in ("RPNModule", "RetinaNetModule"))
         hfmt = torch.channels_last if heads else torch.contiguous_format
-        if type(self.rpn).__name__ == "RPNModule":
+        if type(self.rpn).__name__ in ("RPNModule", "RetinaNetModule"):
+            # (RetinaNet: the two towers and the class / box convolutions; their channels-last outputs ARE the (N, H, W, A, C)
+            #  order the loss and the post-processor flatten them to — modeling/rpn/utils.py::permute_and_flatten)
             self.rpn.head.to(memory_format=hfmt)
         mask = self.roi_heads["mask"] if (self.roi_heads and "mask" in self.roi_heads) else None
         if mask is not None and hasattr(mask.feature_extractor, "pooler") and hasattr(mask.feature_extractor, "blocks"):

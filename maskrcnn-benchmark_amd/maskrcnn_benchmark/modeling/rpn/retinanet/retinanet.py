@@ -4,6 +4,7 @@ import math
 import torch
 from torch import nn
 
+from maskrcnn_benchmark.layers.misc import conv_bias_act
 from maskrcnn_benchmark.modeling.box_coder import BoxCoder
 
 from ..anchor_generator import make_anchor_generator_retinanet
@@ -35,9 +36,24 @@ class RetinaNetHead(nn.Module):
                     nn.init.constant_(m.bias, 0)
         nn.init.constant_(self.cls_logits.bias, -math.log((1 - R.PRIOR_PROB) / R.PRIOR_PROB))
 
+    @staticmethod
+    def _tower(tower, f):
+        # (conv, ReLU) pairs: on a channels-last activation each pair is the convolution without its bias + ONE fused
+        # bias + ReLU pass, with the bias gradient reduced inside its backward (layers/misc.py::conv_bias_act)
+        mods = list(tower)
+        i = 0
+        while i < len(mods):
+            if isinstance(mods[i], nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                f = conv_bias_act(mods[i], f, relu=True)
+                i += 2
+            else:
+                f = mods[i](f)
+                i += 1
+        return f
+
     def forward(self, x):
-        return ([self.cls_logits(self.cls_tower(f)) for f in x],
-                [self.bbox_pred(self.bbox_tower(f)) for f in x])
+        return ([conv_bias_act(self.cls_logits, self._tower(self.cls_tower, f)) for f in x],
+                [conv_bias_act(self.bbox_pred, self._tower(self.bbox_tower, f)) for f in x])
 
 
 class RetinaNetModule(nn.Module):

@@ -6,6 +6,9 @@ from ..utils import cat
 
 
 def permute_and_flatten(layer, N, A, C, H, W):
+    if layer.dim() == 4 and not layer.is_contiguous() and layer.is_contiguous(memory_format=torch.channels_last):
+        # a channels-last head output IS [N, H, W, A*C] in memory: the reference's (N, H, W, A, C) order is a view of it
+        return layer.permute(0, 2, 3, 1).reshape(N, -1, C)
     return layer.view(N, -1, C, H, W).permute(0, 3, 4, 1, 2).reshape(N, -1, C)
 
 
@@ -25,5 +28,3 @@ def concat_box_prediction_layers(box_cls, box_regression, keep_batch=False):
         return box_cls, box_regression
     return box_cls.reshape(-1, C), box_regression.reshape(-1, 4)
 
-
-del torch

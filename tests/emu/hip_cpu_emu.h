@@ -319,6 +319,7 @@ static inline unsigned long long atomicOr(unsigned long long* p, unsigned long l
 
 // fibers never run concurrently: plain read-modify-write is atomic here
 static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
+static inline double atomicAdd(double* p, double v) { const double o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
 static inline int atomicMin(int* p, int v) { const int o = *p; *p = std::min(o, v); return o; }
 static inline int atomicMax(int* p, int v) { const int o = *p; *p = std::max(o, v); return o; }

@@ -86,3 +86,23 @@ def test_cpu_roi_align_forward_edges_and_layer(C):
     assert np.array_equal(y.numpy(), oracle.roi_align_forward(x.numpy(), rois, 1.0, 4, 6, 2))
     b, s = synth.nms_boxes(50, seed=1)
     np.testing.assert_array_equal(nms(torch.from_numpy(b), torch.from_numpy(s), 0.5).numpy(), oracle.nms(b, s, 0.5))
+
+
+def test_cpu_branch_float64_is_bit_equal_to_the_compiled_reference(C):
+    """double tensors (the reference dispatches float and double: csrc/cpu/ROIAlign_cpu.cpp:242, csrc/cpu/nms_cpu.cpp:71): the
+    CPU branch's f64 instantiation against the reference's own kernels compiled in place (oracle/_ref), bit for bit; needs
+    /root/reference (build container)."""
+    ref = oracle.ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    inp, rois, scale = synth.cfg1_roi_align(seed=4, K=60, C=7)
+    x, r = torch.from_numpy(inp).double(), torch.from_numpy(rois).double()
+    x = x + torch.randn_like(x) * 1e-9          # values that are NOT float32-representable
+    for ph, pw, sr in [(7, 7, 2), (3, 5, 0), (14, 14, 2)]:
+        a = C.roi_align_forward(x, r, scale, ph, pw, sr)
+        b = ref.roi_align_forward(x, r, scale, ph, pw, sr)
+        assert a.dtype == torch.float64 and torch.equal(a, b), (ph, pw, sr)
+    bx, sc = synth.nms_boxes(800, seed=2)
+    tb, ts = torch.from_numpy(bx).double() + 1e-7, torch.from_numpy(sc).double()
+    for thr in (0.3, 0.7):
+        assert torch.equal(C.nms(tb, ts, thr), ref.nms(tb, ts, thr))

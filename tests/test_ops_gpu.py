@@ -1377,3 +1377,40 @@ def test_roi_align_backward_non_finite_gradient_stays_in_the_rois_tiles(layout):
         allowed[img, :, ty0:ty1, tx0:tx1] = True
         assert not (bad & ~allowed).any(), "non-finite values outside the ROI's tiles"
         assert np.array_equal(ga[~allowed], gb[~allowed])
+
+
+@pytest.mark.gpu
+def test_float64_operators_on_the_device():
+    """float64 tensors through the reference-named `_C` operators (AT_DISPATCH_FLOATING_TYPES of the reference: float AND double):
+    csrc/f64_ops.hip on the device — ROIAlign forward / backward against a float64 torch formulation (1e-12 / 1e-10), ROIPool and
+    focal loss against the fp32 oracle on fp32-representable inputs, NMS the same kept set as the oracle."""
+    from maskrcnn_benchmark import _C
+    from torch_refs import roi_align_torch
+    inp, rois, scale = synth.cfg1_roi_align(seed=12, K=200, C=16)
+    x64, r64 = _t(inp).double(), _t(rois).double()
+    out = _C.roi_align_forward(x64, r64, scale, 7, 7, 2)
+    assert out.dtype == torch.float64 and out.is_cuda
+    xg = x64.clone().requires_grad_()
+    ref = roi_align_torch(xg, r64, scale, 7, 7, 2)
+    assert torch.allclose(out, ref.detach(), rtol=1e-12, atol=1e-12)
+    assert np.abs(out.cpu().numpy() - oracle.roi_align_forward(inp, rois, scale, 7, 7, 2)).max() <= 1e-5
+    g = torch.randn(out.shape, dtype=torch.float64, device=DEV)
+    ref.backward(g)
+    gin = _C.roi_align_backward(g, r64, scale, 7, 7, *inp.shape, 2)
+    assert torch.allclose(gin, xg.grad, rtol=1e-9, atol=1e-11)
+    o32, a32 = oracle.roi_pool_forward(inp, rois, scale, 5, 4)
+    o64, a64 = _C.roi_pool_forward(x64, r64, scale, 5, 4)
+    assert np.array_equal(o64.cpu().numpy().astype(np.float32), o32) and np.array_equal(a64.cpu().numpy(), a32)
+    gp = torch.randn(o64.shape, dtype=torch.float64, device=DEV)
+    gi = _C.roi_pool_backward(gp, x64, r64, a64, scale, 5, 4, *inp.shape)
+    want = oracle.roi_pool_backward(gp.cpu().numpy().astype(np.float32), rois, a32, *inp.shape)
+    assert np.abs(gi.cpu().numpy() - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    logits, targets = synth.focal_inputs(3000, 80)
+    f = _C.sigmoid_focalloss_forward(_t(logits).double(), _t(targets), 80, 2.0, 0.25)
+    np.testing.assert_allclose(f.cpu().numpy(), oracle.sigmoid_focal_loss_forward(logits, targets, 2.0, 0.25), rtol=1e-4, atol=1e-6)
+    d = np.random.RandomState(3).rand(*logits.shape).astype(np.float32)
+    b = _C.sigmoid_focalloss_backward(_t(logits).double(), _t(targets), _t(d).double(), 80, 2.0, 0.25)
+    np.testing.assert_allclose(b.cpu().numpy(), oracle.sigmoid_focal_loss_backward(logits, targets, d, 2.0, 0.25), rtol=1e-4, atol=1e-6)
+    bx, sc = synth.nms_boxes(3000, seed=9)
+    keep = _C.nms(_t(bx).double(), _t(sc).double(), 0.6)
+    assert keep.dtype == torch.int64 and np.array_equal(keep.cpu().numpy(), oracle.nms(bx, sc, 0.6))

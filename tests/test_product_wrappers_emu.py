@@ -339,8 +339,9 @@ def test_detector_trains_and_detects_through_the_product_wrappers(config):
             assert d.has_field("mask") and d.get_field("mask").shape[0] == len(d)
 
 
+@pytest.mark.parametrize("config", ["e2e_mask_rcnn_R_50_FPN_1x.yaml", "retinanet/retinanet_R-50-FPN_1x.yaml"])
 @pytest.mark.parametrize("heads", [False, True])
-def test_detector_on_a_channels_last_pyramid_equals_the_nchw_run(heads):
+def test_detector_on_a_channels_last_pyramid_equals_the_nchw_run(heads, config):
     """GeneralizedRCNN.set_channels_last: backbone + FPN on NHWC activations (the fused FrozenBN / top-down kernels follow
     the layout), the pyramid handed over as NCHW (heads=False) or as it is (heads=True).  A memory format changes no value:
     losses and parameter gradients of one training forward / backward equal the NCHW run's (CPU convolutions may pick another
@@ -348,7 +349,7 @@ def test_detector_on_a_channels_last_pyramid_equals_the_nchw_run(heads):
     from maskrcnn_benchmark.data.synthetic import BatchCollator, SyntheticCOCODataset
     from maskrcnn_benchmark.engine.bench_step import load_cfg
     from maskrcnn_benchmark.modeling.detector import build_detection_model
-    cfg = load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml",
+    cfg = load_cfg(config,
                    ["MODEL.DEVICE", "cpu", "MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 100, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 150,
                     "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 512, "MODEL.RPN.BATCH_SIZE_PER_IMAGE", 100000,
                     "MODEL.RESNETS.RES2_OUT_CHANNELS", 16,
@@ -356,7 +357,7 @@ def test_detector_on_a_channels_last_pyramid_equals_the_nchw_run(heads):
                     "MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM", 32, "MODEL.ROI_MASK_HEAD.CONV_LAYERS", (16, 16)])
     torch.manual_seed(0)
     model = build_detection_model(cfg).train()
-    ds = SyntheticCOCODataset(length=2, height=96, width=128, with_masks=True, min_objects=2, max_objects=4)
+    ds = SyntheticCOCODataset(length=2, height=96, width=128, with_masks=cfg.MODEL.MASK_ON, min_objects=2, max_objects=4)
     images, targets, _ = BatchCollator(32)([ds[0], ds[1]])
 
     def run():
@@ -440,3 +441,44 @@ def test_deformable_detector_trains_through_the_product_wrappers():
     sum(losses.values()).backward()
     trainable = [p for p in model.parameters() if p.requires_grad]
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in trainable) and len(trainable) > 90
+
+
+def test_float64_operators_equal_the_float32_oracle_and_the_reference_semantics():
+    """The reference dispatches ROIAlign / ROIPool / SigmoidFocalLoss / nms over float AND double (AT_DISPATCH_FLOATING_TYPES:
+    ROIAlign_cuda.cu:283,329, ROIPool_cuda.cu:137,185, SigmoidFocalLoss_cuda.cu:129,173, nms_cpu.cpp:71).  float64 tensors take
+    csrc/f64_ops.hip: same results as the fp32 operators on the same (fp32-representable) inputs to fp32 rounding, NMS keeps
+    exactly the same boxes, and ROIAlign forward / backward agree with a float64 torch formulation to 1e-12."""
+    from maskrcnn_benchmark import _C
+    from torch_refs import roi_align_torch
+    inp, rois, scale = synth.cfg1_roi_align(seed=12, K=40, C=6)
+    x64, r64 = _t(inp).double(), _t(rois).double()
+    out = _C.roi_align_forward(x64, r64, scale, 7, 7, 2)
+    assert out.dtype == torch.float64
+    xg = x64.clone().requires_grad_()
+    ref = roi_align_torch(xg, r64, scale, 7, 7, 2)
+    assert torch.allclose(out, ref.detach(), rtol=1e-12, atol=1e-12)
+    assert np.abs(out.numpy() - oracle.roi_align_forward(inp, rois, scale, 7, 7, 2)).max() <= 1e-5
+    g = torch.randn(out.shape, dtype=torch.float64)
+    ref.backward(g)
+    gin = _C.roi_align_backward(g, r64, scale, 7, 7, *inp.shape, 2)
+    assert gin.dtype == torch.float64 and torch.allclose(gin, xg.grad, rtol=1e-10, atol=1e-12)
+    # ROIPool
+    o32, a32 = oracle.roi_pool_forward(inp, rois, scale, 5, 4)
+    o64, a64 = _C.roi_pool_forward(x64, r64, scale, 5, 4)
+    assert np.array_equal(o64.numpy().astype(np.float32), o32) and np.array_equal(a64.numpy(), a32)
+    gp = torch.randn(o64.shape, dtype=torch.float64)
+    gi = _C.roi_pool_backward(gp, x64, r64, a64, scale, 5, 4, *inp.shape)
+    want = oracle.roi_pool_backward(gp.numpy().astype(np.float32), rois, a32, *inp.shape)
+    assert np.abs(gi.numpy() - want).max() <= 1e-4
+    # focal loss
+    logits, targets = synth.focal_inputs(300, 20)
+    f = _C.sigmoid_focalloss_forward(_t(logits).double(), _t(targets), 20, 2.0, 0.25)
+    assert f.dtype == torch.float64
+    np.testing.assert_allclose(f.numpy(), oracle.sigmoid_focal_loss_forward(logits, targets, 2.0, 0.25), rtol=1e-4, atol=1e-6)
+    d = np.random.RandomState(3).rand(*logits.shape).astype(np.float32)
+    b = _C.sigmoid_focalloss_backward(_t(logits).double(), _t(targets), _t(d).double(), 20, 2.0, 0.25)
+    np.testing.assert_allclose(b.numpy(), oracle.sigmoid_focal_loss_backward(logits, targets, d, 2.0, 0.25), rtol=1e-4, atol=1e-6)
+    # NMS: the same kept set as the fp32 oracle on fp32-representable boxes
+    bx, sc = synth.nms_boxes(500, seed=9)
+    keep = _C.nms(_t(bx).double(), _t(sc).double(), 0.6)
+    assert keep.dtype == torch.int64 and np.array_equal(keep.numpy(), oracle.nms(bx, sc, 0.6))
