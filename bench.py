@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--no-miopen-search", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--export-miopen-db", default=None, metavar="DIR",
                     help="write MIOpen's find-db + kernel cache of this run to DIR (see setup_miopen_db)")
+    ap.add_argument("--eval", action="store_true",
+                    help="time the INFERENCE forward instead of the training step (eval mode, no_grad, test-size images, the "
+                         "PostProcessors included): a context line next to the reference's s/im column (MODEL_ZOO.md:26), "
+                         "not the headline metric")
     ap.add_argument("--stub-step", action="store_true",
                     help="test hook: CPU tensors, gloo, a stub step — exercises the launch / world-size / timed-region / "
                          "JSON logic without a GPU; the line is marked as a stub, not a measurement")
@@ -490,6 +494,72 @@ def stub_main(args):
         dist.destroy_process_group()
 
 
+def eval_main(args, cfg, device, layout, miopen_db, hw_queues, progress):
+    """`--eval`: the detector's inference forward (reference engine/inference.py:18-41 compute_on_dataset's `model(images)`,
+    timed like its Timer: per-image seconds over the loop), eval mode under no_grad, synthetic test-size images resident on
+    the device, the test-time RPN selection and the box / mask (or RetinaNet) PostProcessors inside the timed region.  N = 1.
+    With random-init weights every class score is ~1/81 < the yaml's SCORE_THRESH (0.05), so the box PostProcessor's
+    per-class NMS sees no candidates; pass `MODEL.ROI_HEADS.SCORE_THRESH 0.0` (`MODEL.RETINANET.INFERENCE_TH 0.0`) for the
+    opposite extreme (every candidate of every class enters the segmented NMS).  Both are in DESIGN.md §6."""
+    import torch
+    from maskrcnn_benchmark import _C
+    from maskrcnn_benchmark.engine.bench_step import choose_layout, make_device_batches
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("bench.py --eval: N = 1 only (inference shards by image; no collective to measure)")
+    model = build_detection_model(cfg).to(device).eval()
+    layout = choose_layout(cfg, device, layout)
+    if layout != "nchw":
+        model.set_channels_last(True, heads=layout == "all")
+    batches = make_device_batches(cfg, device, images_per_gpu=args.images_per_gpu, num_batches=2, seed=0,
+                                  height=cfg.INPUT.MIN_SIZE_TEST, width=cfg.INPUT.MAX_SIZE_TEST)
+    H, W = batches[0][0].tensors.shape[-2:]
+    amp = {"float32": None, "bfloat16": torch.bfloat16, "float16": torch.float16}[cfg.DTYPE]
+
+    def step(images, _targets=None):
+        with torch.no_grad():
+            if amp is None:
+                return model(images)
+            with torch.autocast(device_type="cuda", dtype=amp):
+                return model(images)
+
+    det = None
+    for i in range(args.warmup):
+        det = step(*batches[i % len(batches)])
+        torch.cuda.synchronize(device)
+        progress("warm-up forward %d done" % (i + 1))
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        det = step(*batches[i % len(batches)])
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    images = args.images_per_gpu * args.steps
+    counts = [len(d) for d in det]
+    finite = all(bool(torch.isfinite(d.bbox).all()) and bool(torch.isfinite(d.get_field("scores")).all()) for d in det)
+    thresh = cfg.MODEL.RETINANET.INFERENCE_TH if cfg.MODEL.RETINANET_ON else cfg.MODEL.ROI_HEADS.SCORE_THRESH
+    line = {
+        "metric": "inference images/sec %s" % os.path.splitext(os.path.basename(args.config))[0],
+        "value": round(images / elapsed, 3), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "s_per_image": round(elapsed / images, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"float32": "f32", "bfloat16": "bf16", "float16": "f16"}[cfg.DTYPE], "data": "synthetic",
+        "config": {"workload": "%s: inference forward + post-processing, %d img/GPU of synthetic %dx%d (padded %dx%d), "
+                               "random-init weights" % (os.path.basename(args.config), args.images_per_gpu,
+                                                        cfg.INPUT.MAX_SIZE_TEST, cfg.INPUT.MIN_SIZE_TEST, H, W),
+                   "global_batch": args.images_per_gpu, "parallelism": "dp1", "score_thresh": thresh},
+        "detections_per_image": counts, "detections_finite": finite,
+        # context only: the reference's published inference time for e2e_mask_rcnn_R_50_FPN_1x (MODEL_ZOO.md:26, 8 x V100,
+        # fp32, trained weights) — other hardware and other score statistics, so vs_baseline stays null
+        "reference_published_s_per_image": 0.12966 if "mask_rcnn_R_50_FPN" in args.config else None,
+        "max_mem_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+        "miopen": {"search": bool(torch.backends.cudnn.benchmark), "db": miopen_db}, "layout": layout,
+        "hip": {"GPU_MAX_HW_QUEUES": hw_queues, "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
+        "nms_repaired_segments": _C.nms_repaired_segments(device),
+    }
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
     hw_queues = pin_hip_queues()
@@ -548,6 +618,8 @@ def main():
             print("[bench %6.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
     layout = "all" if args.channels_last_heads else ("backbone" if args.channels_last else args.layout)
+    if args.eval:
+        return eval_main(args, cfg, device, layout, miopen_db, hw_queues, progress)
     model, optimizer, scheduler, step = build_training(cfg, device, distributed, local_rank,
                                                        force_ddp=args.force_ddp and not distributed,
                                                        bucket_cap_mb=args.bucket_mb, layout=layout)

@@ -560,11 +560,16 @@ int detops_bias_act_supported(int C);
 size_t detops_bias_act_backward_workspace_bytes(int64_t rows, int C);
 int detops_bias_act_backward_nhwc_f32(const float* grad_y, const float* y, float* grad_x, float* grad_bias, int64_t rows,
                                       int C, int relu, void* workspace, size_t workspace_bytes, detops_stream_t stream);
+/* the same with fp32 / fp16 / bf16 storage (dtype code; grad_bias and the partial sums stay fp32): the autocast configurations */
+int detops_bias_act_backward_nhwc(const void* grad_y, const void* y, void* grad_x, float* grad_bias, int dtype, int64_t rows,
+                                  int C, int relu, void* workspace, size_t workspace_bytes, detops_stream_t stream);
 /* out[c] = sum_r x[r, c] of a row-major [rows, C] fp32 matrix, any C <= 256 (bias gradients of the channel counts the fused
  * pass does not serve: the RPN's 3 / 12, the mask logits' 81); deterministic; workspace of detops_column_sum_workspace_bytes. */
 size_t detops_column_sum_workspace_bytes(int64_t rows, int C);
 int detops_column_sum_f32(const float* x, float* out, int64_t rows, int C, void* workspace, size_t workspace_bytes,
                           detops_stream_t stream);
+int detops_column_sum(const void* x, float* out, int dtype, int64_t rows, int C, void* workspace, size_t workspace_bytes,
+                      detops_stream_t stream);
 
 /* RPN loss in one pass over the head outputs (reference modeling/rpn/loss.py:92-127 with
  * modeling/box_coder.py:27-51 and modeling/rpn/utils.py:9-45): objectness = BCE-with-logits over the sampled

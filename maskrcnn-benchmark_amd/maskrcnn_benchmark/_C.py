@@ -1263,7 +1263,7 @@ def bias_act_supported(x, bias):
     """bias_act serves fp32 channels-last activations on the device (any channel count: widths dividing 1024 through the
     fused kernels of csrc/bias_act.hip, the others — the RPN's 3 / 12 and the mask logits' 81 channels — through an in-place
     add and a matrix-vector product for the bias gradient)"""
-    return (bias is not None and on_device(x) and x.dtype == torch.float32 and bias.dtype == torch.float32 and x.dim() == 4
+    return (bias is not None and on_device(x) and x.dtype in _lib.DTYPE_CODE and bias.dtype == torch.float32 and x.dim() == 4
             and is_channels_last(x))
 
 
@@ -1278,7 +1278,8 @@ class _BiasAct(torch.autograd.Function):
         if ctx.fused:
             y = frozen_bn_act_forward(x, _ones(x.shape[1], x.device), bias.contiguous(), None, relu)
         else:
-            y = x.add_(bias.view(1, -1, 1, 1)) if not x.requires_grad else x + bias.view(1, -1, 1, 1)
+            bb = bias.to(x.dtype).view(1, -1, 1, 1)
+            y = x.add_(bb) if not x.requires_grad else x + bb
             if relu:
                 y = y.relu_()
         ctx.relu = relu
@@ -1299,23 +1300,25 @@ class _BiasAct(torch.autograd.Function):
         nbytes = int(lib.detops_bias_act_backward_workspace_bytes(rows, C))
         ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=gy.device)
         with _on_device(gy), _timed(("bias_act_bwd[n=%d,C=%d,relu=%d]", (gy.numel(), C, bool(ctx.relu))), gy, every=4):
-            check(lib.detops_bias_act_backward_nhwc_f32(ptr(gy), ptr(y) if ctx.relu else None, ptr(gx), ptr(gb), rows, C,
-                                                        int(bool(ctx.relu)), ptr(ws), nbytes, stream_of(gy)), "bias_act_backward")
+            check(lib.detops_bias_act_backward_nhwc(ptr(gy), ptr(y) if ctx.relu else None, ptr(gx), ptr(gb), _lib.DTYPE_CODE[gy.dtype],
+                                                    rows, C, int(bool(ctx.relu)), ptr(ws), nbytes, stream_of(gy)), "bias_act_backward")
         return gx, gb, None
 
 
 def column_sum(x2d):
-    """[rows, C] row-major fp32 -> [C] column sums (extension, csrc/bias_act.hip; C <= 256), deterministic"""
+    """[rows, C] row-major fp32 / fp16 / bf16 -> fp32 [C] column sums (extension, csrc/bias_act.hip; C <= 256), deterministic"""
     _need_cuda("column_sum", x2d)
-    x2d = _f32c("column_sum", x2d)
+    if x2d.dtype not in _lib.DTYPE_CODE:
+        raise RuntimeError("column_sum: unsupported dtype %s" % x2d.dtype)
+    x2d = x2d.contiguous()
     rows, C = x2d.shape
     out = torch.empty((C,), dtype=torch.float32, device=x2d.device)
     if C > 256:
-        return x2d.sum(0)
+        return x2d.float().sum(0)
     nbytes = int(lib.detops_column_sum_workspace_bytes(rows, C))
     ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=x2d.device)
     with _on_device(x2d):
-        check(lib.detops_column_sum_f32(ptr(x2d), ptr(out), rows, C, ptr(ws), nbytes, stream_of(x2d)), "column_sum")
+        check(lib.detops_column_sum(ptr(x2d), ptr(out), _lib.DTYPE_CODE[x2d.dtype], rows, C, ptr(ws), nbytes, stream_of(x2d)), "column_sum")
     return out
 
 

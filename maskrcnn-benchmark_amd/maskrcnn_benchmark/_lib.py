@@ -71,6 +71,8 @@ SIGNATURES = {
     "detops_bias_act_supported": (c_int, [c_int]),
     "detops_bias_act_backward_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int]),
     "detops_bias_act_backward_nhwc_f32": (c_int, [_P, _P, _P, _P, ctypes.c_int64, c_int, c_int, _P, c_size_t, _P]),
+    "detops_bias_act_backward_nhwc": (c_int, [_P, _P, _P, _P, c_int, ctypes.c_int64, c_int, c_int, _P, c_size_t, _P]),
+    "detops_column_sum": (c_int, [_P, _P, c_int, ctypes.c_int64, c_int, _P, c_size_t, _P]),
     "detops_column_sum_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int]),
     "detops_column_sum_f32": (c_int, [_P, _P, ctypes.c_int64, c_int, _P, c_size_t, _P]),
     "detops_roi_align_forward_f64": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int, _P]),

@@ -6,6 +6,7 @@ zero-element batch.  The shape arithmetic is kept (an empty ROI batch still has 
 correctly shaped, differentiable empty tensor), everything else defers to torch.nn.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -29,18 +30,26 @@ def _conv_out(size, pad, dil, k, stride):
     return (size + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
 
 
+# A/B switch: "0" keeps half-precision (autocast) convolutions on the module call (bias inside the convolution)
+BIAS_ACT_HALF = os.environ.get("DETOPS_BIAS_ACT_HALF", "1") != "0"
+
+
+def _half_compute(x):
+    return x.dtype != torch.float32 or torch.is_autocast_enabled()
+
+
 def conv_bias_act(conv, x, relu=False):
-    """`conv(x)` (+ ReLU) for a convolution / transposed-convolution MODULE.  On a channels-last fp32 activation on the
-    device the bias leaves the convolution call: the convolution runs without it and ONE fused pass adds it (and applies the
-    ReLU); the backward's bias gradient is a column sum inside that pass' mirror (csrc/bias_act.hip) instead of PyTorch's
+    """`conv(x)` (+ ReLU) for a convolution / transposed-convolution MODULE.  On a channels-last activation (fp32, or fp16 /
+    bf16 under autocast) on the device the bias leaves the convolution call: the convolution runs without it and ONE fused
+    pass adds it (and applies the ReLU); the backward's bias gradient is a column sum inside that pass' mirror (csrc/bias_act.hip) instead of PyTorch's
     strided `sum((0, 2, 3))`, which its generic reduce kernel serves at ~0.1 TB/s on channels-last gradients (2.3 ms of
     the fp32 step, profiles/r06d_*).  Same values as the module call (x + b is one rounding either way).  Everything else
-    (NCHW, half precision, CPU, norm-wrapped blocks, widths the kernel does not serve) takes the module call."""
+    (NCHW, CPU, norm-wrapped blocks, widths the kernel does not serve) takes the module call."""
     from maskrcnn_benchmark import _C
     plain = type(conv) in (nn.Conv2d, Conv2d)
     trans = type(conv) in (nn.ConvTranspose2d, ConvTranspose2d)
     if (plain or trans) and conv.bias is not None and x.numel() > 0 and conv.padding_mode == "zeros" and _C.is_channels_last(x) \
-            and x.dtype == torch.float32 and _C.on_device(x):
+            and x.dtype in _C._lib.DTYPE_CODE and _C.on_device(x) and (BIAS_ACT_HALF or not _half_compute(x)):
         if plain:
             y = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         else:
@@ -48,7 +57,7 @@ def conv_bias_act(conv, x, relu=False):
                                                      conv.groups, conv.dilation)
         if _C.bias_act_supported(y, conv.bias):
             return _C.bias_act(y, conv.bias, relu)
-        y = y + conv.bias.view(1, -1, 1, 1)
+        y = y + conv.bias.to(y.dtype).view(1, -1, 1, 1)
         return torch.relu(y) if relu else y
     y = conv(x)
     return torch.relu(y) if relu else y

@@ -1414,3 +1414,39 @@ def test_float64_operators_on_the_device():
     bx, sc = synth.nms_boxes(3000, seed=9)
     keep = _C.nms(_t(bx).double(), _t(sc).double(), 0.6)
     assert keep.dtype == torch.int64 and np.array_equal(keep.cpu().numpy(), oracle.nms(bx, sc, 0.6))
+
+
+# ------------------------------------------------------------------ bias (+ ReLU) behind a channels-last convolution (csrc/bias_act.hip)
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C,H,W", [(256, 200, 336), (256, 25, 42), (64, 9, 3), (12, 50, 84), (81, 28, 28), (3, 100, 168)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_bias_act_channels_last_forward_backward_and_bias_gradient(dtype, tol, C, H, W, relu):
+    """y = [relu](x + b) on a channels-last activation and its one-pass backward: grad_x is an exact select, the bias gradient
+    is the fp32 column sum of the masked gradient (reference: the `+ bias` of the FPN / RPN / mask-head convolutions,
+    modeling/backbone/fpn.py:30-40, rpn.py:61-76), at the sizes of the model's P2 lateral, a coarse level, the RPN's 3/12-channel
+    outputs and the mask logits (column_sum path); two runs give the same bits."""
+    from maskrcnn_benchmark import _C
+    g = torch.Generator(device="cpu").manual_seed(C + H)
+    x = torch.randn(2, C, H, W, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, C, H, W, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(C, generator=g).to(DEV).requires_grad_()
+    assert _C.bias_act_supported(x, b)
+
+    def run():
+        xi = x.clone(memory_format=torch.channels_last).requires_grad_()
+        b.grad = None
+        y = _C.bias_act(xi, b, relu)
+        y.backward(gy)
+        return y.detach(), xi.grad, b.grad.clone()
+
+    y, gx, gb = run()
+    assert _C.is_channels_last(y) and y.dtype == dtype and gb.dtype == torch.float32
+    ref = x.float() + b.detach().view(1, -1, 1, 1)
+    ref = ref.relu() if relu else ref
+    assert (y.float() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    want_gx = gy.float() * (y.float() > 0).float() if relu else gy.float()
+    assert torch.equal(gx.float(), want_gx)
+    want_gb = want_gx.double().sum((0, 2, 3))
+    assert (gb.double() - want_gb).abs().max() <= 1e-5 * max(1.0, float(want_gx.abs().double().sum((0, 2, 3)).max()))
+    y2, gx2, gb2 = run()
+    assert torch.equal(y2, y) and torch.equal(gx2, gx) and torch.equal(gb2, gb)

@@ -241,6 +241,51 @@ def test_frozen_bn_channels_last_is_bit_equal_to_the_nchw_kernels(dtype, C, H, W
         assert torch.equal(gr1, gr0)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C,H,W", [(256, 5, 7), (64, 9, 3), (8, 6, 6), (12, 5, 7), (81, 4, 4), (3, 7, 5)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv_bias_act_on_channels_last_equals_conv_with_bias(dtype, tol, C, H, W, relu):
+    """layers.misc.conv_bias_act (csrc/bias_act.hip): the convolution without its bias + the fused bias(+ReLU) pass whose
+    backward also produces the bias gradient (fp32, deterministic column sums); widths that take the fused kernel (C | 1024,
+    C % 4 == 0) and those that take column_sum (12, 81, 3); fp32 and the two autocast storage types"""
+    from maskrcnn_benchmark import _C
+    from maskrcnn_benchmark.layers.misc import conv_bias_act
+    rng = np.random.RandomState(C * 3 + H)
+    conv = torch.nn.Conv2d(4, C, 1)
+    with torch.no_grad():
+        conv.bias.copy_(_t(rng.randn(C).astype(np.float32)))
+    x = _t(rng.randn(2, 4, H, W).astype(np.float32))
+    gy = _t(rng.randn(2, C, H, W).astype(np.float32)).to(dtype)
+    # the convolution itself runs in fp32 on the host and is cast: only the bias pass is under test
+    pre = torch.nn.functional.conv2d(x, conv.weight).detach().to(dtype).contiguous(memory_format=torch.channels_last)
+    xi = pre.clone(memory_format=torch.channels_last).requires_grad_()
+    assert _C.bias_act_supported(xi, conv.bias)
+    y = _C.bias_act(xi, conv.bias, relu)
+    assert _C.is_channels_last(y) and y.dtype == dtype
+    y.backward(gy.contiguous(memory_format=torch.channels_last))
+    ref = pre.float() + conv.bias.detach().view(1, -1, 1, 1)
+    ref = ref.relu() if relu else ref
+    assert torch.allclose(y.float(), ref, rtol=tol, atol=tol)
+    mask = (y.float() > 0).float() if relu else torch.ones_like(ref)
+    g = gy.float() * mask
+    assert torch.equal(xi.grad.float(), g)                                   # a select: exact in every storage type
+    assert conv.bias.grad.dtype == torch.float32
+    want = g.double().sum((0, 2, 3))
+    assert torch.allclose(conv.bias.grad.double(), want, rtol=1e-5, atol=1e-4)   # fp32 sums of the stored values
+    # deterministic: the same call again gives the same bits
+    first = conv.bias.grad.clone()
+    conv.bias.grad = None
+    xi2 = pre.clone(memory_format=torch.channels_last).requires_grad_()
+    _C.bias_act(xi2, conv.bias, relu).backward(gy.contiguous(memory_format=torch.channels_last))
+    assert torch.equal(conv.bias.grad, first)
+    # the module-level entry takes the same route (fp32 only on the host: F.conv2d has no half kernels here)
+    if dtype == torch.float32:
+        conv.bias.grad = None
+        xc = x.clone(memory_format=torch.channels_last)
+        out = conv_bias_act(conv, xc, relu=relu)
+        assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+
+
 def test_fpn_module_uses_the_fused_topdown_step_and_equals_the_composition(monkeypatch):
     from maskrcnn_benchmark import _C
     from maskrcnn_benchmark.modeling.backbone import fpn as fpn_mod
