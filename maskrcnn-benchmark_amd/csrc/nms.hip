@@ -72,9 +72,25 @@ struct Work {
 // stage with j <= 64 stay inside the 128-key chunk the SAME wave handled in the previous stage (pair t covers keys
 // 2*(t - t%j) + t%j and + j; 64 consecutive t's = keys [2*t0, 2*t0 + 128)), so those stages need no workgroup
 // barrier: 56 of the 66 stages at n = 2048.
+// Workgroup-wide AND of a per-thread predicate (two barriers; the flag is a workgroup-shared word).
+__device__ __forceinline__ bool block_all(bool ok) {
+  __shared__ int s_all;
+  if (threadIdx.x == 0) s_all = 1;
+  __syncthreads();
+  if (!ok) s_all = 0;            // every writer stores the same value
+  __syncthreads();
+  return s_all != 0;
+}
+
+// ALREADY SORTED?  The detector's callers hand over top-k output (modeling/rpn/inference.py: `topk(sorted=True)`, then the
+// fused decode keeps that order): scores descend and equal scores sit in position order, which is exactly ascending keys.
+// The keys are unique, so the sorted sequence is unique: skipping the network on such input changes nothing in the result
+// and takes the 15-25 us of the 66-stage network off the head of every segment's critical path.  `nms_no_presorted` (tuning)
+// switches the test off for A/B runs.
 template <bool WT>   // WT: the sorted rows are consumed by other workgroups of the same launch (write-through stores)
 __device__ __forceinline__ void sort_and_gather(u64* keys, const float* __restrict__ boxes,
-                                                const float* __restrict__ scores, SegView sv, int npad, const Work& w, int s) {
+                                                const float* __restrict__ scores, SegView sv, int npad, const Work& w, int s,
+                                                bool check_sorted = true) {
   const int n = sv.n;
   // smallest power of two >= n (uniform), bounded by npad (the host-side capacity)
   int np = 2;
@@ -83,7 +99,12 @@ __device__ __forceinline__ void sort_and_gather(u64* keys, const float* __restri
   for (int i = threadIdx.x; i < np; i += blockDim.x)
     keys[i] = (i < n) ? make_key(scores[sv.begin + i], static_cast<unsigned>(i)) : ~0ull;
   __syncthreads();
-  for (int k = 2; k <= np; k <<= 1) {
+  bool sorted = check_sorted;
+  if (sorted) {
+    for (int i = threadIdx.x; i + 1 < np; i += blockDim.x) sorted = sorted && keys[i] <= keys[i + 1];
+    sorted = block_all(sorted);
+  }
+  for (int k = 2; k <= np && !sorted; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = threadIdx.x; t < (np >> 1); t += blockDim.x) {
         // t-th compare-exchange pair of this stage: i has bit j clear, partner = i | j
@@ -133,7 +154,8 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src_lane) {
 
 template <bool WT>
 __device__ __forceinline__ void sort_and_gather_reg(u64* xch, const float* __restrict__ boxes,
-                                                    const float* __restrict__ scores, SegView sv, const Work& w, int s) {
+                                                    const float* __restrict__ scores, SegView sv, const Work& w, int s,
+                                                    bool check_sorted = true) {
   const int n = sv.n, tid = threadIdx.x, lane = tid & (kWave - 1);
   const int np = 4 * static_cast<int>(blockDim.x);
   u64 key[4];
@@ -142,7 +164,17 @@ __device__ __forceinline__ void sort_and_gather_reg(u64* xch, const float* __res
     const int e = 4 * tid + r;
     key[r] = e < n ? make_key(scores[sv.begin + e], static_cast<unsigned>(e)) : ~0ull;
   }
-  for (int k = 2; k <= np; k <<= 1) {
+  bool sorted = check_sorted;
+  if (sorted) {
+    // thread t's four keys ascend and its last one does not exceed thread t + 1's first (lane 63: through LDS)
+    const int wave = tid / kWave, nw = static_cast<int>(blockDim.x) / kWave;
+    if (lane == 0) xch[wave] = key[0];
+    u64 next0 = shfl_u64(key[0], (lane + 1) & (kWave - 1));
+    __syncthreads();
+    if (lane == kWave - 1) next0 = wave + 1 < nw ? xch[wave + 1] : ~0ull;
+    sorted = block_all(key[0] <= key[1] && key[1] <= key[2] && key[2] <= key[3] && key[3] <= next0);   // (its barriers also release xch)
+  }
+  for (int k = 2; k <= np && !sorted; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       if (j < 4) {                                  // partner in this thread: slots (0,1),(2,3) for j = 1, (0,2),(1,3) for j = 2
         auto cx = [&](u64& a, u64& b, int r) {      // compare-exchange of slots r < r ^ j (constant register indices)
@@ -585,16 +617,17 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const int T = S * G;                                            // G tile workgroups per segment
   int bid = blockIdx.x;                                           // role index: sorts, tiles, scans
-  if (scan_first && bid >= S) bid = bid < 2 * S ? bid + T : bid - S;
+  const bool check_sorted = !(scan_first & 2);                    // bit 1: tuning nms_no_presorted (A/B)
+  if ((scan_first & 1) && bid >= S) bid = bid < 2 * S ? bid + T : bid - S;
   if (bid < S) {                                                  // ---- sort
     const int s = bid;
     if (tid < kWave) store_u32_wt(&ctrl[s].done[tid], 0u);
     if (tid == kWave) store_u32_wt(&ctrl[s].error, 0u);
     const SegView sv = seg_view(seg_offsets, n_single, s);
     if (sv.n <= 4 * kScanThreads)     // every call of the detector (n <= 2048): keys in registers
-      sort_and_gather_reg<true>(reinterpret_cast<u64*>(smem_raw), boxes, scores, sv, w, s);
+      sort_and_gather_reg<true>(reinterpret_cast<u64*>(smem_raw), boxes, scores, sv, w, s, check_sorted);
     else
-      sort_and_gather<true>(reinterpret_cast<u64*>(smem_raw), boxes, scores, sv, npad, w, s);
+      sort_and_gather<true>(reinterpret_cast<u64*>(smem_raw), boxes, scores, sv, npad, w, s, check_sorted);
     DETOPS_VMCNT_WAIT(0);            // this wave's write-through stores (sorted rows, the zeroed counters) are in memory
     __syncthreads();
     if (tid == 0) flag_store_relaxed(&ctrl[s].token, publish_token);   // everything it guards is already in memory (== token, except under the fault-injection switch)
@@ -779,7 +812,7 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
                        seg_offsets, max_n, npad, thr, w, reinterpret_cast<FusedCtrl*>(base_ptr + l.off_ctrl), token,
                        detops_tuning().nms_fault == 1 ? (token ^ 2ull) : token,   // fault injection (tests): the token never shows up
                        detops_tuning().nms_spin_budget > 0 ? detops_tuning().nms_spin_budget : kSpinBudget, S, G,
-                       scan_first, keep, num_keep, keep_mask);
+                       scan_first | (detops_tuning().nms_no_presorted ? 2 : 0), keep, num_keep, keep_mask);
     if (detops_tuning().nms_no_repair != 1)    // failed segments (num_keep = -1) are redone, each by one workgroup alone
       hipLaunchKernelGGL(nms_repair_kernel, dim3(S), dim3(kScanThreads), npad * sizeof(u64) + 2 * kWave * sizeof(u64) + 64,
                          st, boxes, scores, seg_offsets, max_n, npad, thr, w, keep, num_keep, keep_mask, status);

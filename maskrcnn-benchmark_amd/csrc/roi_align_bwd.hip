@@ -563,8 +563,34 @@ roi_align_bwd_ring_kernel(Levels L, RingPlan P, RingWs ws, const float* __restri
 #pragma unroll
       for (int i = 1; i < DETOPS_MAX_LEVELS; ++i)
         if (i == lvl) { gin = L.lv[i].gin; H = L.lv[i].H; W = L.lv[i].W; }
-      if (P.nhwc) {
-        // channels-last maps: the thread's CT channel sums are CT consecutive floats of its pixel's channel vector
+      if (P.nhwc && c0 + CT <= C && !P.accumulate && (C & 3) == 0 && !(P.debug & 256)) {
+        // channels-last maps: the thread's CT channel sums are CT consecutive floats of its pixel's channel vector.  Stored
+        // straight from the accumulators, one instruction would touch 64 lines with 16 bytes each; instead the wave's
+        // two pixel rows go through its LDS patch one after the other and leave as whole CT * 4-byte pieces: CG
+        // consecutive lanes per pixel, 64 / CG pixels per store instruction (CT = 32: eight full 128-byte lines).
+        constexpr int PITCH = CT + 4;                                  // floats per pixel row of the patch: 16-byte aligned, bank quads rotate
+        static_assert(4 * 32 * PITCH <= NR * G::SLOT_FLOATS + G::STRIP_FLOATS, "the transposition patch lives in the ring");
+        float* patch = lds + wave * (32 * PITCH);
+        const int q = lane % CG, pp = lane / CG;
+        constexpr int PPI = kWave / CG;                               // pixels per store instruction
+        for (int h = 0; h < 2; ++h) {
+          __syncthreads();                                             // the last walk / the previous row's reads are over everywhere
+          if ((lane >> 5) == h) {
+#pragma unroll
+            for (int c = 0; c < CG; ++c)
+              *reinterpret_cast<float4*>(patch + xl * PITCH + 4 * c) = make_float4(acc[2 * c].x, acc[2 * c].y, acc[2 * c + 1].x, acc[2 * c + 1].y);
+          }
+          __syncthreads();
+          const int yy = y0 + 2 * wave + h;
+          float* row = gin + ((static_cast<size_t>(img) * H + yy) * W + x0) * C + c0 + 4 * q;
+#pragma unroll
+          for (int i = 0; i < 32 / PPI; ++i) {
+            const int px = i * PPI + pp;
+            const float4 v = *reinterpret_cast<const float4*>(patch + px * PITCH + 4 * q);
+            if (yy < H && x0 + px < W) *reinterpret_cast<float4*>(row + static_cast<size_t>(px) * C) = v;
+          }
+        }
+      } else if (P.nhwc) {
         if (y0 + yl < H && x0 + xl < W) {
           float* dst = gin + ((static_cast<size_t>(img) * H + (y0 + yl)) * W + (x0 + xl)) * C + c0;
           if (c0 + CT <= C && !P.accumulate && (C & 3) == 0) {

@@ -273,6 +273,47 @@ def test_emu_nms_single_launch_and_three_launch_paths(fused):
         assert np.array_equal(emu.nms(b, sc, 0.6), oracle.nms(b, sc, 0.6))
 
 
+@pytest.mark.parametrize("no_presorted", [0, 1])
+def test_emu_nms_input_already_in_score_order_skips_the_sort_network(no_presorted):
+    """The detector hands the segmented NMS top-k output (scores descending, ties in position order): the sort workgroups
+    detect ascending keys and skip the bitonic network (csrc/nms.hip, block_all).  Same results as the full network
+    (`nms_no_presorted=1`) and as the oracle for: sorted segments of every sort form (register keys <= 2048, LDS keys <= 4096),
+    sorted with runs of equal scores, one inversion at the very end / across a wave boundary / across a thread boundary
+    (must NOT be taken for sorted), a descending run followed by padding, an unsorted segment beside sorted ones."""
+    emu.tuning_set("nms_no_presorted", no_presorted)
+
+    def sorted_case(n, seed, ties=False):
+        b, sc = synth.nms_boxes(n, seed=seed)
+        order = np.argsort(-sc, kind="stable")
+        b, sc = b[order], sc[order]
+        if ties:
+            sc[10:40] = sc[10]
+            sc[n // 2:n // 2 + 70] = sc[n // 2]
+        return np.ascontiguousarray(b), np.ascontiguousarray(sc)
+
+    def swapped(n, seed, i):
+        b, sc = sorted_case(n, seed)
+        sc[[i, i + 1]] = sc[[i + 1, i]]
+        return b, sc
+
+    segs = [sorted_case(2000, 1), sorted_case(819, 2, ties=True), swapped(2000, 3, 1998), swapped(1500, 4, 255), swapped(1500, 5, 3),
+            sorted_case(4096, 6), swapped(3000, 7, 2998), synth.nms_boxes(700, seed=8), sorted_case(1, 9), sorted_case(65, 10, ties=False)]
+    boxes = np.concatenate([x for x, _ in segs])
+    scores = np.concatenate([y for _, y in segs])
+    offs = np.cumsum([0] + [len(y) for _, y in segs]).astype(np.int32)
+    keep, num = emu.nms_batched(boxes, scores, offs, 4096, 0.7)
+    km, _ = emu.nms_batched(boxes, scores, offs, 4096, 0.7, mask=True)
+    for i, (x, y) in enumerate(segs):
+        ref = oracle.nms(x, y, 0.7)
+        assert num[i] == len(ref), i
+        assert np.array_equal(keep[offs[i]:offs[i] + num[i]], ref), i
+        want = np.zeros(len(y), np.uint8)
+        want[ref] = 1
+        assert np.array_equal(km[offs[i]:offs[i + 1]], want), i
+    for (x, y) in (segs[0], segs[2], segs[5]):            # the single-segment entry point
+        assert np.array_equal(emu.nms(x, y, 0.5), oracle.nms(x, y, 0.5))
+
+
 def test_emu_nms_failed_segments_are_redone_by_the_repair_launch():
     """VERDICT r04 "missing" #4: the single launch's failure marker must not turn into "this segment proposes nothing".
     Fault injection (the sort workgroups publish a wrong token, test-sized polling budget -> every consumer wait gives

@@ -1450,3 +1450,46 @@ def test_bias_act_channels_last_forward_backward_and_bias_gradient(dtype, tol, C
     assert (gb.double() - want_gb).abs().max() <= 1e-5 * max(1.0, float(want_gx.abs().double().sum((0, 2, 3)).max()))
     y2, gx2, gb2 = run()
     assert torch.equal(y2, y) and torch.equal(gx2, gx) and torch.equal(gb2, gb)
+
+
+@pytest.mark.parametrize("no_presorted", [0, 1])
+def test_nms_input_already_in_score_order_skips_the_sort_network(no_presorted):
+    """the detector's NMS input is top-k output (scores descending, ties in position order): the fused launch's sort
+    workgroups detect ascending keys and skip the network.  Bit-exact against the oracle (reference csrc/cpu/nms_cpu.cpp:37-63)
+    with the detection on and off: the model's 10 RPN segments in score order, runs of equal scores, single inversions at the
+    end / across a wave / a thread boundary, LDS-sorted sizes (<= 4096), an unsorted segment among sorted ones; three rounds
+    on the allocator's dirty workspace."""
+    from maskrcnn_benchmark import _lib
+    _lib.tuning_set("nms_no_presorted", no_presorted)
+    try:
+        def in_order(b, sc, ties=False, swap=None):
+            o = np.argsort(-sc, kind="stable")
+            b, sc = np.ascontiguousarray(b[o]), np.ascontiguousarray(sc[o])
+            if ties and len(sc) > 200:
+                sc[10:40] = sc[10]
+                sc[len(sc) // 2:len(sc) // 2 + 70] = sc[len(sc) // 2]
+            if swap is not None:
+                sc[[swap, swap + 1]] = sc[[swap + 1, swap]]
+            return b, sc
+        segs = [in_order(b, s, ties=(i % 3 == 1)) for i, (b, s) in enumerate(synth.rpn_nms_segments())]
+        segs += [in_order(*synth.nms_boxes(2000, seed=3), swap=1998), in_order(*synth.nms_boxes(1500, seed=4), swap=255),
+                 in_order(*synth.nms_boxes(1500, seed=5), swap=3), in_order(*synth.nms_boxes(4096, seed=6)),
+                 in_order(*synth.nms_boxes(3000, seed=7), swap=2998), synth.nms_boxes(700, seed=8), in_order(*synth.nms_boxes(1, seed=9))]
+        boxes = np.concatenate([b for b, _ in segs])
+        scores = np.concatenate([s for _, s in segs])
+        offs = np.cumsum([0] + [len(s) for _, s in segs]).astype(np.int32)
+        tb, ts, to = _t(boxes), _t(scores), _t(offs)
+        refs = [oracle.nms(b, s, 0.7) for b, s in segs]
+        for rep in range(3):
+            keep, num = _C().nms_batched(tb, ts, to, 4096, 0.7)
+            km, _ = _C().nms_batched_mask(tb, ts, to, 4096, 0.7)
+            keep, num, km = keep.cpu().numpy(), num.cpu().numpy(), km.cpu().numpy()
+            for i, ref in enumerate(refs):
+                assert num[i] == len(ref), (rep, i)
+                np.testing.assert_array_equal(keep[offs[i]:offs[i] + num[i]], ref)
+                want = np.zeros(offs[i + 1] - offs[i], np.uint8)
+                want[ref] = 1
+                np.testing.assert_array_equal(km[offs[i]:offs[i + 1]].astype(np.uint8), want)
+        assert _C().nms_repaired_segments(torch.device(DEV, 0) if isinstance(DEV, str) else DEV) >= 0
+    finally:
+        _lib.tuning_set("nms_no_presorted", 0)

@@ -269,6 +269,17 @@ def bench_nms(C, iters):
         out.append(_entry("nms batched 10 RPN segments, %s (no sync)" % label, us, 20 * tot,
                           {"pairs_per_us": round(pairs / us, 1)}))
     tune("nms_fused", 0)
+    # the detector's calls: every segment is top-k output, i.e. already in score order (modeling/rpn/inference.py) — the sort
+    # workgroups detect that and skip the network (`nms_no_presorted=1`: always sort)
+    so = [np.argsort(-s, kind="stable") for _, s in segs]
+    boxes_s = _t(np.concatenate([b[o] for (b, _), o in zip(segs, so)]))
+    scores_s = _t(np.concatenate([s[o] for (_, s), o in zip(segs, so)]))
+    for off, label in ((0, "in score order"), (1, "in score order, network forced")):
+        tune("nms_no_presorted", off)
+        us = dev_time_us(lambda: C.nms_batched(boxes_s, scores_s, offs, 2000, 0.7), iters)
+        out.append(_entry("nms batched 10 RPN segments %s, one launch (no sync)" % label, us, 20 * tot,
+                          {"pairs_per_us": round(pairs / us, 1)}))
+    tune("nms_no_presorted", 0)
     return out
 
 
