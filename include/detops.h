@@ -659,6 +659,9 @@ int detops_sgd_momentum_flat_f32(float* params, const float* grads, float* momen
  * `microseconds` on `stream` — a one-GPU stand-in for the CUs a ring all-reduce kernel occupies beside the compute stream at
  * N > 1 (engine/ddp_step.py: DETOPS_DDP_STANDIN, profiles/r06_ddp_contention.txt). */
 int detops_debug_occupy(int workgroups, int microseconds, detops_stream_t stream);
+/* diagnosis: wall-clock timeline (10 ns ticks) of segment 0 in the last single-launch NMS that ran with tuning nms_debug & 4
+ * (csrc/nms.hip g_nms_timeline); host_out: n <= 6464 words.  Synchronises the device. */
+int detops_debug_nms_timeline(int64_t* host_out, int n);
 
 /* ------------------------------------------------------------------------------------------
  * FPN top-down step (csrc/fpn_topdown.hip) — replaces the pair `F.interpolate(last_inner, mode="nearest")` +

@@ -221,6 +221,7 @@ struct DetopsTuning {
   int nms_fused;           // 0 / 1 single launch for n <= 4096 | 2 three launches (sort, mask, scan) | 3 single launch, scans dispatched last
   int nms_fault;           // tests: 1 = the fused launch's sort workgroups publish a wrong token (every consumer wait times out)
   int nms_spin_budget;     // polls before a wait of the fused launch gives up (0 = default: seconds)
+  int nms_debug;           // diagnosis only: 1 = the fused launch's tile waves skip the IoU loop (timing ablation: results are WRONG), 4 = record the wall-clock timeline of segment 0 (detops_debug_nms_timeline)
   int nms_no_presorted;    // A/B: 1 = the fused launch's sorts always run the network (0 = default: input that is already in score order skips it)
   int nms_no_repair;       // tests / A-B: 1 = do not launch nms_repair_kernel behind the fused launch (failed segments stay at num_keep = -1)
   int roi_fwd_impl;        // 0 auto | 1 generic gather kernel

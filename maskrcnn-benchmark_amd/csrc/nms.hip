@@ -40,6 +40,13 @@ constexpr int kScanMaxN = 65536;    // removed-words / bitset capacity of the sc
 constexpr int kScanThreads = 512;
 constexpr int kMaxWords = kScanMaxN / 64;  // 1024 column blocks
 
+// Diagnostic timeline of ONE fused launch (tuning nms_debug & 4; tools/gpu/nms_probe.py): 10 ns wall-clock ticks of segment 0's
+// workgroups.  [0] first sort start, [1] token published, [2] scan start, [3] token seen by the scan, [4] chain end, [5] kernel end of
+// the scan workgroup; [128 + 3 t ..] = tile t start / go / counted.
+constexpr int kNmsTimelineWords = 128 + 3 * 2112;
+__device__ long long g_nms_timeline[kNmsTimelineWords];
+#define NMS_TL(cond, idx) do { if ((scan_first & 16) && (cond)) g_nms_timeline[(idx)] = detops_wall_clock(); } while (0)
+
 __device__ __forceinline__ u64 make_key(float score, unsigned idx) {
   if (score == 0.f) score = 0.f;  // -0.0 and +0.0 compare equal on the CPU path
   unsigned b = __float_as_uint(score);
@@ -278,7 +285,7 @@ __device__ __forceinline__ float lane_bcast(float v, int c) {
   return __int_as_float(static_cast<int>(__builtin_amdgcn_readlane(static_cast<unsigned>(__float_as_int(v)), c)));
 }
 
-template <bool WT>   // WT: the word is published to another workgroup of the same launch (write-through store)
+template <bool WT, int TRIP = kWave>   // WT: the word is published to another workgroup of the same launch (write-through store); TRIP = 0: timing ablation
 __device__ __forceinline__ void mask_tile(const float4* __restrict__ sb, const float* __restrict__ sa, u64* __restrict__ mask,
                                           int n, int nb, int rb, int cb, float thr) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -309,7 +316,7 @@ __device__ __forceinline__ void mask_tile(const float4* __restrict__ sb, const f
   // bit (max / min / fp add commute, `iarea + carea - inter` sees the same two addends), so the bits below the
   // diagonal are "rows j < lane that suppress lane" — the transposed view the scan's fixed-point resolve needs.
 #pragma unroll 8
-  for (int c = 0; c < kWave; ++c) {
+  for (int c = 0; c < TRIP; ++c) {
 #pragma clang fp contract(off)
     const float bx = lane_bcast(cbx.x, c), by = lane_bcast(cbx.y, c), bz = lane_bcast(cbx.z, c), bw = lane_bcast(cbx.w, c);
     const float ca = lane_bcast(car, c);
@@ -621,6 +628,7 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
   if ((scan_first & 1) && bid >= S) bid = bid < 2 * S ? bid + T : bid - S;
   if (bid < S) {                                                  // ---- sort
     const int s = bid;
+    NMS_TL(s == 0 && tid == 0, 0);
     if (tid < kWave) store_u32_wt(&ctrl[s].done[tid], 0u);
     if (tid == kWave) store_u32_wt(&ctrl[s].error, 0u);
     const SegView sv = seg_view(seg_offsets, n_single, s);
@@ -630,6 +638,7 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
       sort_and_gather<true>(reinterpret_cast<u64*>(smem_raw), boxes, scores, sv, npad, w, s, check_sorted);
     DETOPS_VMCNT_WAIT(0);            // this wave's write-through stores (sorted rows, the zeroed counters) are in memory
     __syncthreads();
+    NMS_TL(s == 0 && tid == 0, 1);
     if (tid == 0) flag_store_relaxed(&ctrl[s].token, publish_token);   // everything it guards is already in memory (== token, except under the fault-injection switch)
     return;
   }
@@ -647,6 +656,8 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
     while (t >= nb - rb) { t -= nb - rb; ++rb; }                  // row lengths nb, nb - 1, ..., 1
     const int cb = rb + t;
     int* s_ok = reinterpret_cast<int*>(smem_raw);
+    const int tl_tile = chunk * kFusedWaves + wave;
+    NMS_TL(s == 0 && lane == 0 && tl_tile < 2112, 128 + 3 * tl_tile);
     if (wave == 0) {
       int budget = spin_budget;
       bool seen = true;
@@ -662,10 +673,16 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
       if (tid == 0) flag_add(&ctrl[s].error, 1);
       return;
     }
-    mask_tile<true>(w.boxes + static_cast<size_t>(s) * w.stride, w.areas + static_cast<size_t>(s) * w.stride,
-                    w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, nb, rb, cb, thr);
+    NMS_TL(s == 0 && lane == 0 && tl_tile < 2112, 129 + 3 * tl_tile);
+    if (scan_first & 4)              // timing ablation (tuning nms_debug = 1): everything but the IoU arithmetic — wrong results
+      mask_tile<true, 0>(w.boxes + static_cast<size_t>(s) * w.stride, w.areas + static_cast<size_t>(s) * w.stride,
+                         w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, nb, rb, cb, thr);
+    else
+      mask_tile<true>(w.boxes + static_cast<size_t>(s) * w.stride, w.areas + static_cast<size_t>(s) * w.stride,
+                      w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, nb, rb, cb, thr);
     DETOPS_VMCNT_WAIT(0);            // the 64 write-through stores of this wave have reached memory
     if (lane == 0) flag_add(&ctrl[s].done[rb], 1);
+    NMS_TL(s == 0 && lane == 0 && tl_tile < 2112, 130 + 3 * tl_tile);
     return;
   }
   const int s = bid - S - T;                                      // ---- scan
@@ -676,6 +693,8 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
   int* wsum = reinterpret_cast<int*>(flags + kWave);
   int* s_fail = wsum + kScanThreads / kWave;
   if (tid < kWave) flags[tid] = 0;
+  NMS_TL(s == 0 && tid == 0, 2);
+  const u64* seg_mask = w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax;
   if (wave == 0) {
     int budget = spin_budget;
     bool ok = true;
@@ -683,22 +702,29 @@ nms_fused_kernel(const float* __restrict__ boxes, const float* __restrict__ scor
       if (!spin_again(budget)) { ok = false; break; }
     }
     DETOPS_ACQUIRE_AGENT();
-    if (ok && nb > 0)
-      ok = scan_chain_any<WIDE>(w.mask + static_cast<size_t>(s) * w.mrows * w.nbmax, n, nb, ctrl[s].done, keptw, spin_budget);
+    NMS_TL(s == 0 && lane == 0, 3);
+    if (ok && nb > 0) ok = scan_chain_any<WIDE>(seg_mask, n, nb, ctrl[s].done, keptw, spin_budget);
+    if (lane == 0) s_fail[0] = ok ? 0 : 1;
+  }
+  __syncthreads();
+  NMS_TL(s == 0 && tid == 0, 4);
+  if (wave == 0) {
+    bool ok = s_fail[0] == 0;
     if (ok && flag_peek(&ctrl[s].error) != 0) ok = false;
     // a wait ran out of its budget (a producer workgroup was starved for seconds — another process or stream holding
     // the CUs): publish NOTHING for this segment and say so (num_keep[s] = -1, all-zero keep mask) instead of a keep
     // set built from rows that were never written
     if (!ok) keptw[lane] = 0ull;
+    DETOPS_WAVE_SYNC();          // every lane of this wave has read s_fail / the token
     if (lane == 0) s_fail[0] = ok ? 0 : 1;
     // every tile of the segment is counted in, so nobody reads the token any more: clear it.  A captured graph
     // replays this launch with the SAME token value — the cleared word is what makes the replay wait again.
-    DETOPS_WAVE_SYNC();          // every lane of this wave has read the token
     if (lane == 0) flag_store_relaxed(&ctrl[s].token, 0ull);
   }
   __syncthreads();
   compact_keep(keptw, flags, wsum, w.order + static_cast<size_t>(s) * w.stride, sv, s, keep, num_keep, keep_mask);
   if (tid == 0 && s_fail[0]) num_keep[s] = -1;     // (same thread that wrote the count in compact_keep)
+  NMS_TL(s == 0 && tid == 0, 5);
 }
 
 // ---------------------------------------------------------------------------- repair of failed segments
@@ -812,7 +838,7 @@ int run_nms(const float* boxes, const float* scores, const int32_t* seg_offsets,
                        seg_offsets, max_n, npad, thr, w, reinterpret_cast<FusedCtrl*>(base_ptr + l.off_ctrl), token,
                        detops_tuning().nms_fault == 1 ? (token ^ 2ull) : token,   // fault injection (tests): the token never shows up
                        detops_tuning().nms_spin_budget > 0 ? detops_tuning().nms_spin_budget : kSpinBudget, S, G,
-                       scan_first | (detops_tuning().nms_no_presorted ? 2 : 0), keep, num_keep, keep_mask);
+                       scan_first | (detops_tuning().nms_no_presorted ? 2 : 0) | ((detops_tuning().nms_debug & 1) ? 4 : 0) | ((detops_tuning().nms_debug & 4) ? 16 : 0), keep, num_keep, keep_mask);
     if (detops_tuning().nms_no_repair != 1)    // failed segments (num_keep = -1) are redone, each by one workgroup alone
       hipLaunchKernelGGL(nms_repair_kernel, dim3(S), dim3(kScanThreads), npad * sizeof(u64) + 2 * kWave * sizeof(u64) + 64,
                          st, boxes, scores, seg_offsets, max_n, npad, thr, w, keep, num_keep, keep_mask, status);
@@ -926,4 +952,16 @@ DETOPS_API int detops_nms_batched_status_f32(const float* boxes, const float* sc
   if (max_n > kScanMaxN) return DETOPS_EUNSUPPORTED;
   return run_nms(boxes, scores, seg_offsets, num_segments, max_n, threshold, keep, num_keep, keep_mask, workspace,
                  workspace_bytes, st, status);
+}
+
+// diagnosis: the timeline words of the last fused launch that ran with tuning nms_debug & 4 (see g_nms_timeline)
+DETOPS_API int detops_debug_nms_timeline(int64_t* host_out, int n) {
+  if (!host_out || n < 0 || n > kNmsTimelineWords) return DETOPS_EINVAL;
+#ifdef DETOPS_CPU_EMU
+  for (int i = 0; i < n; ++i) host_out[i] = g_nms_timeline[i];
+#else
+  DETOPS_HIP_TRY(hipDeviceSynchronize());
+  DETOPS_HIP_TRY(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nms_timeline), sizeof(long long) * static_cast<size_t>(n)));
+#endif
+  return 0;
 }

@@ -21,7 +21,7 @@ const Key kKeys[] = {
     {"nms_fault", &DetopsTuning::nms_fault},             {"nms_spin_budget", &DetopsTuning::nms_spin_budget},
     {"roi_bwd_split", &DetopsTuning::roi_bwd_split},     {"roi_bwd_maxseg", &DetopsTuning::roi_bwd_maxseg},
     {"roi_bwd_extras", &DetopsTuning::roi_bwd_extras},   {"nms_no_repair", &DetopsTuning::nms_no_repair},
-    {"nms_no_presorted", &DetopsTuning::nms_no_presorted},
+    {"nms_no_presorted", &DetopsTuning::nms_no_presorted}, {"nms_debug", &DetopsTuning::nms_debug},
 };
 
 bool set_key(DetopsTuning& t, const char* key, size_t len, int value) {

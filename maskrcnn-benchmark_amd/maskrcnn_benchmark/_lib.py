@@ -86,6 +86,7 @@ SIGNATURES = {
     "detops_roi_align_forward_cpu_f64": (c_int, [_P, _P, _P] + [c_int] * 7 + [c_float, c_int]),
     "detops_nms_cpu_f64": (c_int, [_P, _P, c_int, c_float, _P, _P]),
     "detops_debug_occupy": (c_int, [c_int, c_int, _P]),
+    "detops_debug_nms_timeline": (c_int, [_P, c_int]),
     "detops_sgd_momentum_flat_f32": (c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int64] + [c_float] * 5 + [_P]),
     "detops_rpn_decode_f32": (c_int, [_P] * 5 + [c_int] * 5 + [c_float] * 6 + [_P, ctypes.c_int64, _P, ctypes.c_int64, _P, _P, _P, _P]),
     "detops_roi_pool_forward_f32": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [c_float, _P]),

@@ -314,6 +314,7 @@ static inline unsigned emu_readfirstlane(unsigned v) {
 #define __builtin_amdgcn_readlane(v, l) emu_readlane(v, l)
 #define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
 
 static inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o | v; return o; }
 
