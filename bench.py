@@ -140,6 +140,10 @@ def algorithmic_bytes(name, feat_bytes):
     if m:
         n, e, res, relu = (int(g) for g in m.groups())
         return e * n * (2 + res + relu)
+    m = re.match(r"bias_act_bwd\[n=(\d+),C=\d+,e=(\d+),relu=(\d)\]", name)
+    if m:      # gradient read (+ the saved output for the ReLU mask), masked gradient written when there is a ReLU; C sums out
+        n, e, relu = (int(g) for g in m.groups())
+        return e * n * (1 + 2 * relu)
     m = re.match(r"dcn_(im2col|col2im|col2im_coord|im2col_nhwc)\[B=(\d+),C=(\d+),(\d+)x(\d+),k=(\d+),e=(\d+),m=(\d)\]", name)
     if m:
         B, C, H, W, k, e, msk = (int(g) for g in m.groups()[1:])
@@ -175,7 +179,7 @@ def rocprof_kernel_us(entry_name):
     key = {"roi_align_fpn_bwd": "roi_align_bwd_ring_kernel", "roi_align_fpn_fwd": "roi_align_fwd_dma_kernel",
            "focal_fwd_sum": "focal_kernel", "focal_bwd_scalar": "focal_kernel", "frozen_bn_fwd": "frozen_bn",
            "nms_batched": "nms_fused_kernel",
-           "frozen_bn_bwd": "frozen_bn", "dcn_col2im": "col2im", "dcn_im2col": "im2col_kernel",
+           "frozen_bn_bwd": "frozen_bn", "bias_act_bwd": "bias_act_bwd_nhwc_kernel", "dcn_col2im": "col2im", "dcn_im2col": "im2col_kernel",
            "dcn_col2im_coord": "col2im_coord", "dcn_fused_fwd": "dcn_fused_fwd", "dcn_to_nhwc": "nchw_to_nhwc",
            "dcn_im2col_nhwc": "im2col_nhwc_kernel", "dcn_coord_nhwc": "coord_nhwc_kernel",
            "dcn_transposed_sample": "sampleT_gather_kernel"}.get(entry_name.split("[")[0])

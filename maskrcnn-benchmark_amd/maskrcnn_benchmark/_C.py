@@ -1299,7 +1299,7 @@ class _BiasAct(torch.autograd.Function):
         gx = torch.empty_like(gy) if ctx.relu else gy
         nbytes = int(lib.detops_bias_act_backward_workspace_bytes(rows, C))
         ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=gy.device)
-        with _on_device(gy), _timed(("bias_act_bwd[n=%d,C=%d,relu=%d]", (gy.numel(), C, bool(ctx.relu))), gy, every=4):
+        with _on_device(gy), _timed(("bias_act_bwd[n=%d,C=%d,e=%d,relu=%d]", (gy.numel(), C, _ESIZE[gy.dtype], bool(ctx.relu))), gy, every=4):
             check(lib.detops_bias_act_backward_nhwc(ptr(gy), ptr(y) if ctx.relu else None, ptr(gx), ptr(gb), _lib.DTYPE_CODE[gy.dtype],
                                                     rows, C, int(bool(ctx.relu)), ptr(ws), nbytes, stream_of(gy)), "bias_act_backward")
         return gx, gb, None

@@ -25,19 +25,19 @@ if has trace; then
   T=$(find $P -name "*kernel_trace.csv" | head -1)
   if [ -n "$T" ]; then
     python tools/trace_steps.py "$T" 4 60 > $O/bench_f32_step_breakdown.txt 2>&1
-    python tools/kernel_times.py $P "" 2>/dev/null | grep -E "roi_align|nms_|frozen_bn|focal|match_|sampler|mask_targets|rpn_loss|dcn|col2im|im2col" > $O/bench_kernel_times.txt
+    python tools/kernel_times.py $P "" 2>/dev/null | grep -E "roi_align|roi_nhwc|roi_bwd_prep|nms_|frozen_bn|topdown|bias_act|bias_grad|column_sum|focal|match_|sampler|mask_targets|rpn_loss|rpn_decode|dcn|col2im|im2col|sampleT|coord_nhwc|nchw_to_nhwc" > $O/bench_kernel_times.txt
     head -3 $O/bench_f32_step_breakdown.txt; head -12 $O/bench_kernel_times.txt | cut -c1-150
   fi; el trace
 fi
 if has opbench; then
-  timeout 600 python tools/opbench.py --iters 50 --json $O/opbench.json < /dev/null > $O/opbench.log 2>&1; grep -E "roi_align_(fwd|bwd) (fpn|cfg1)|nms batched|frozen_bn|focal|match_boxes|sample_labels|dcn_block|roi_pool|psroi" $O/opbench.log | cut -c1-150 | head -60; el opbench
+  timeout 900 python tools/opbench.py --iters 50 --layout both --json $O/opbench.json < /dev/null > $O/opbench.log 2>&1; grep -E "roi_align_(fwd|bwd) (fpn|cfg1)|nms batched|frozen_bn|focal|match_boxes|sample_labels|dcn_block|roi_pool|psroi" $O/opbench.log | cut -c1-170 | head -70; el opbench
   # the > L3 variant (4 img/GPU: 365.6 MB of maps against the 256 MiB Infinity Cache)
   timeout 300 python tools/opbench.py --only roi_sets --sets model-random-init --images 4 --iters 30 < /dev/null > $O/roi_align_l3_variant.log 2>&1; grep roi_align $O/roi_align_l3_variant.log | cut -c1-150; el l3-variant
   timeout 200 python tools/gpu/cfg1_bwd.py 0 50 < /dev/null > $O/cfg1_bwd.log 2>&1; grep cfg1 $O/cfg1_bwd.log; el cfg1
   timeout 200 python tools/gpu/ring_timeline.py model-random-init < /dev/null > $O/ring_timeline.txt 2>&1; head -8 $O/ring_timeline.txt; el timeline
 fi
 if has pmc; then
-  PM="python tools/opbench.py --only roi_sets --heads box --dir bwd --iters 5 --sets model-random-init"
+  PM="python tools/opbench.py --only roi_sets --heads box --dir bwd --iters 5 --sets model-random-init --layout nhwc"
   for pass in "sq:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
               "sq2:SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
               "tcc:TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "fw:FETCH_SIZE" "ww:WRITE_SIZE"; do
@@ -46,17 +46,24 @@ if has pmc; then
   done
   python tools/pmc_diag.py /tmp/pmc_sq /tmp/pmc_sq2 /tmp/pmc_tcc /tmp/pmc_fw /tmp/pmc_ww > $O/roi_align_bwd_ring_pmc.txt 2>&1; grep -v "roi_order" $O/roi_align_bwd_ring_pmc.txt | head -40; el pmc-ring
   for d in fwd; do
-    PF="python tools/opbench.py --only roi_sets --heads box --dir $d --iters 5 --sets model-random-init"
+    PF="python tools/opbench.py --only roi_sets --heads box --dir $d --iters 5 --sets model-random-init --layout nhwc"
     for pass in "sq:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
                 "sq2:SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
                 "tcc:TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "fw:FETCH_SIZE" "ww:WRITE_SIZE"; do
       n=${pass%%:*}; c=${pass#*:}; rm -rf /tmp/pmcf_$n
       timeout 150 rocprofv3 --pmc $c --output-format csv -d /tmp/pmcf_$n -o x -- $PF < /dev/null > $O/pmcf_$n.log 2>&1
     done
-    python tools/pmc_diag.py /tmp/pmcf_sq /tmp/pmcf_sq2 /tmp/pmcf_tcc /tmp/pmcf_fw /tmp/pmcf_ww > $O/roi_align_fwd_pmc.txt 2>&1; grep -A28 "roi_align_fwd_dma" $O/roi_align_fwd_pmc.txt | head -32; el pmc-fwd
+    python tools/pmc_diag.py /tmp/pmcf_sq /tmp/pmcf_sq2 /tmp/pmcf_tcc /tmp/pmcf_fw /tmp/pmcf_ww > $O/roi_align_fwd_pmc.txt 2>&1; grep -A28 "roi_align_fwd_nhwc" $O/roi_align_fwd_pmc.txt | head -32; el pmc-fwd
   done
-  # (the ROIAlign launches' calibrated traffic table is tools/gpu/r05j_fetch_calib.sh -> profiles/r05j_traffic.*; this pass
-  #  keeps the FrozenBN / NMS / deformable-conv rows)
+  # HBM traffic of the ROIAlign launches over the channels-last pyramid (the layout the step runs; both heads, both directions):
+  # separate FETCH_SIZE / WRITE_SIZE passes -> traffic_roi_nhwc.json (bench.py looks the newest profiles/*traffic*.json up)
+  TRR="python tools/opbench.py --only roi_sets --sets model-random-init --layout nhwc --iters 5"
+  rm -rf /tmp/trr_f /tmp/trr_w
+  timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/trr_f -o x -- $TRR < /dev/null > $O/traffic_roi_fetch.log 2>&1
+  timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/trr_w -o x -- $TRR < /dev/null > $O/traffic_roi_write.log 2>&1
+  python tools/pmc_traffic.py /tmp/trr_f /tmp/trr_w $O/traffic_roi_nhwc.json 2>&1 | cut -c1-150 > $O/traffic_roi_nhwc.txt; cat $O/traffic_roi_nhwc.txt | head; el pmc-roi-traffic
+  # (the NCHW launches' calibrated table is tools/gpu/r05j_fetch_calib.sh -> profiles/r05j_traffic.*; the pass below keeps the
+  #  FrozenBN / NMS / deformable-conv rows)
   TR="python tools/opbench.py --only frozen_bn,nms,dcn_block --iters 5"
   rm -rf /tmp/tr_f /tmp/tr_w
   timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/tr_f -o x -- $TR < /dev/null > $O/traffic_fetch.log 2>&1
@@ -75,5 +82,13 @@ if has extra; then
   DETOPS_DDP_COMM=pg timeout 300 $B --force-ddp < /dev/null > $O/bench_forceddp_pg.log 2>&1; jline $O/bench_forceddp_pg.log > $O/bench_forceddp_pg.json; brief $O/bench_forceddp_pg.log force-ddp-pg; el force-ddp-pg
   timeout 300 $B --config e2e_faster_rcnn_R_50_FPN_1x.yaml < /dev/null > $O/bench_faster.log 2>&1; jline $O/bench_faster.log > $O/bench_faster.json; brief $O/bench_faster.log faster; el faster
   timeout 300 $B --config retinanet/retinanet_R-50-FPN_1x.yaml < /dev/null > $O/bench_retinanet.log 2>&1; jline $O/bench_retinanet.log > $O/bench_retinanet.json; brief $O/bench_retinanet.log retinanet; el retinanet
+  E="python bench.py --eval --steps 40 --warmup 8"
+  timeout 300 $E < /dev/null > $O/bench_eval_f32.log 2>&1; jline $O/bench_eval_f32.log > $O/bench_eval_f32.json
+  timeout 300 $E --dtype bfloat16 < /dev/null > $O/bench_eval_bf16.log 2>&1; jline $O/bench_eval_bf16.log > $O/bench_eval_bf16.json
+  timeout 300 $E --config retinanet/retinanet_R-50-FPN_1x.yaml MODEL.RETINANET.INFERENCE_TH 0.0 < /dev/null > $O/bench_eval_retinanet.log 2>&1; jline $O/bench_eval_retinanet.log > $O/bench_eval_retinanet.json
+  for f in eval_f32 eval_bf16 eval_retinanet; do python -c "
+import json,sys
+d=json.load(open('$O/bench_$f.json')); print('$f', d['value'], 'img/s', d['s_per_image'], 's/im detections', d['detections_per_image'], d['detections_finite'])" 2>/dev/null; done; el eval
+  timeout 200 python tools/gpu/nms_probe.py < /dev/null > $O/nms_probe.txt 2>&1; tail -8 $O/nms_probe.txt | cut -c1-200; el nms-probe
 fi
 du -sh gpurun_out | tail -1

@@ -53,6 +53,15 @@ def tag_fused_launches(res):
     for (d, ph, _), (_, k) in best.items():
         K = 1024 if ph == "7" else 256
         res[k]["tag"] = "roi_align_fpn_%s[K=%d,C=256,%sx%s]" % (d, K, ph, ph)
+    # forward over a channels-last pyramid (csrc/roi_align_nhwc.hip): <V, kOutNhwc, threads> — the box head's 7 x 7 call returns
+    # [K, C, PH, PW] (kOutNhwc = false), the mask head's 14 x 14 call a channels-last tensor; largest grid of each flavour
+    nh = {}
+    for k in res:
+        m = re.match(r"roi_align_fwd_nhwc_kernel<\d+, (true|false), \d+>\|grid=(\d+)", k)
+        if m and (m.group(1) not in nh or int(m.group(2)) > nh[m.group(1)][0]):
+            nh[m.group(1)] = (int(m.group(2)), k)
+    for flavour, (_, k) in nh.items():
+        res[k]["tag"] = "roi_align_fpn_fwd[K=1024,C=256,7x7]" if flavour == "false" else "roi_align_fpn_fwd[K=256,C=256,14x14]"
     # opbench --only frozen_bn runs the res2-sized activation [2, 256, 200, 336] fp32 (n = 34,406,400; N*C = 512): the
     # residual forward is the largest FrozenBN member of a training step (bench.py names it the same way)
     for k in res:
