@@ -144,7 +144,7 @@ def algorithmic_bytes(name, feat_bytes):
     if m:      # gradient read (+ the saved output for the ReLU mask), masked gradient written when there is a ReLU; C sums out
         n, e, relu = (int(g) for g in m.groups())
         return e * n * (1 + 2 * relu)
-    m = re.match(r"dcn_(im2col|col2im|col2im_coord|im2col_nhwc)\[B=(\d+),C=(\d+),(\d+)x(\d+),k=(\d+),e=(\d+),m=(\d)\]", name)
+    m = re.match(r"dcn_(im2col|col2im|col2im_coord|im2col_nhwc|col2im_nhwc)\[B=(\d+),C=(\d+),(\d+)x(\d+),k=(\d+),e=(\d+),m=(\d)\]", name)
     if m:
         B, C, H, W, k, e, msk = (int(g) for g in m.groups()[1:])
         pix = B * H * W        # 3x3 / stride 1 / pad 1 in every model config: Ho x Wo = H x W
@@ -182,7 +182,7 @@ def rocprof_kernel_us(entry_name):
            "frozen_bn_bwd": "frozen_bn", "bias_act_bwd": "bias_act_bwd_nhwc_kernel", "dcn_col2im": "col2im", "dcn_im2col": "im2col_kernel",
            "dcn_col2im_coord": "col2im_coord", "dcn_fused_fwd": "dcn_fused_fwd", "dcn_to_nhwc": "nchw_to_nhwc",
            "dcn_im2col_nhwc": "im2col_nhwc_kernel", "dcn_coord_nhwc": "coord_nhwc_kernel",
-           "dcn_transposed_sample": "sampleT_gather_kernel"}.get(entry_name.split("[")[0])
+           "dcn_transposed_sample": "sampleT_gather_kernel", "dcn_col2im_nhwc": "col2im_nhwc_gather_kernel"}.get(entry_name.split("[")[0])
     if key is None:
         return None
     bins = re.search(r",(\d+)x(\d+)\]", entry_name)

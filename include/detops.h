@@ -636,6 +636,13 @@ int detops_deformable_transposed_sample(const void* gT, const void* offset, cons
                               int H, int W, int Cout, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
                               int dil_h, int dil_w, int deformable_group, void* workspace, size_t workspace_bytes,
                               detops_stream_t stream);
+/* grad_in_T [B, H*W, C] = col2im of the channel-fastest column gradient colsG_T [B*Ho*Wo, kh*kw, C] as a gather over the same
+ * inverted index (reference col2im: csrc/cuda/deform_conv_kernel_cuda.cu:353-413, an atomic scatter): no S_T, no second GEMM.
+ * workspace: detops_deformable_transposed_sample_workspace_bytes(...). */
+int detops_deformable_col2im_nhwc(const void* colsG_T, const void* offset, const void* mask, void* grad_in_T, int dtype, int B,
+                                  int C, int H, int W, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                                  int dil_h, int dil_w, int deformable_group, void* workspace, size_t workspace_bytes,
+                                  detops_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * The data-parallel step's bucket kernels (csrc/optim.hip) — replace, per gradient bucket of engine/ddp_step.py, the

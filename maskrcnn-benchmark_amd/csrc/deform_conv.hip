@@ -1654,6 +1654,82 @@ sampleT_overflow_kernel(const T* __restrict__ gT, const int32_t* __restrict__ ov
   }
 }
 
+// grad_in_T[p, c] = sum over taps and over the sampling points (q, tap) whose bilinear footprint contains pixel p of
+// weight * colsG_T[q, tap, c]: the reference's col2im (csrc/cuda/deform_conv_kernel_cuda.cu:353-413) as a GATHER over the same
+// inverted index, on the channel-fastest column gradient that the offset gradients need anyway.  Against the transposed
+// sampling above it reads the same number of channel vectors per pixel, writes C instead of kh*kw*Cout values per pixel and
+// needs no second conv-sized GEMM behind it (round 6).
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+col2im_nhwc_gather_kernel(const T* __restrict__ colsG, const int32_t* __restrict__ counter, const EllEntry* __restrict__ ent,
+                          T* __restrict__ ginT, Geom g, int sub, int nv, int64_t npix) {
+  constexpr int V = VecT<T>::N;
+  constexpr int kMaxNv = 4;                       // C / V <= 256 lanes-vectors, sub = min(C / V, 64)
+  const int ls = threadIdx.x % sub;
+  const int64_t gp = static_cast<int64_t>(blockIdx.x) * (kBlock / sub) + threadIdx.x / sub;   // b * H * W + pixel
+  if (gp >= npix) return;
+  const int HW = g.H * g.W, HWo = g.Ho * g.Wo, K = g.kh * g.kw, C = g.C;
+  const int b = static_cast<int>(gp / HW), p = static_cast<int>(gp - static_cast<int64_t>(b) * HW);
+  float acc[kMaxNv][V];
+#pragma unroll
+  for (int k = 0; k < kMaxNv; ++k)
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[k][e] = 0.f;
+  for (int tap = 0; tap < K; ++tap) {
+    const size_t col = (static_cast<size_t>(b) * K + tap) * HW + p;             // counter: [img][tap][pixel]
+    const int n = min(counter[col], kEllCap);
+    const float4* rec = reinterpret_cast<const float4*>(ent + col * kEllCap);
+    int32_t qi[kEllCap];
+    float wi[kEllCap];
+#pragma unroll
+    for (int j = 0; j < kEllCap; j += 2) {
+      const float4 r = rec[j / 2];
+      qi[j] = (j < n ? __float_as_int(r.x) : tap * (g.B * HWo)) - tap * (g.B * HWo);   // column index -> b * Ho * Wo + pix
+      wi[j] = j < n ? r.y : 0.f;
+      qi[j + 1] = (j + 1 < n ? __float_as_int(r.z) : tap * (g.B * HWo)) - tap * (g.B * HWo);
+      wi[j + 1] = j + 1 < n ? r.w : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < kEllCap; ++j) {
+      if (j < n) {                                 // uniform over the pixel's lane group
+        const T* src = colsG + (static_cast<size_t>(qi[j]) * K + tap) * C;
+#pragma unroll
+        for (int k = 0; k < kMaxNv; ++k) {
+          if (k < nv) {
+            float v[V];
+            vec_load(src + (k * sub + ls) * V, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[k][e] = fmaf(wi[j], v[e], acc[k][e]);
+          }
+        }
+      }
+    }
+  }
+  T* dst = ginT + static_cast<size_t>(gp) * C;
+#pragma unroll
+  for (int k = 0; k < kMaxNv; ++k)
+    if (k < nv) vec_store(dst + (k * sub + ls) * V, acc[k]);
+}
+
+// contributions beyond kEllCap per (pixel, tap): added with packed atomics after the gather (rare)
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+col2im_nhwc_overflow_kernel(const T* __restrict__ colsG, const int32_t* __restrict__ ovf_count, const EllOverflow* __restrict__ ovf,
+                            int ovf_cap, T* __restrict__ ginT, Geom g) {
+  const int n = min(*ovf_count, ovf_cap);
+  const int HWo = g.Ho * g.Wo, K = g.kh * g.kw, C = g.C;
+  const int half_c = C / 2;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < static_cast<int64_t>(n) * half_c;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int e = static_cast<int>(i / half_c);
+    const int c = 2 * static_cast<int>(i - static_cast<int64_t>(e) * half_c);
+    const EllOverflow o = ovf[e];                 // li = b * H * W + pixel (dg == 1), colidx = tap * B * HWo + q
+    const int tap = o.colidx / (g.B * HWo), q = o.colidx - tap * (g.B * HWo);
+    const T* src = colsG + (static_cast<size_t>(q) * K + tap) * C + c;
+    atomic_add2_t(ginT + static_cast<size_t>(o.li) * C + c, o.w * ld(src), o.w * ld(src + 1));
+  }
+}
+
 template <typename T>
 int nchw_to_nhwc_t(const void* in, void* out, int B, int C, int HW, hipStream_t st_) {
   if (static_cast<int64_t>(B) * ((HW + 63) / 64) * ((C + 31) / 32) > 0x7fffffff) return DETOPS_EUNSUPPORTED;
@@ -1711,6 +1787,32 @@ int sampleT_t(const void* gT, const void* offset, const void* mask, void* S_T, c
   hipLaunchKernelGGL(sampleT_overflow_kernel<T>, dim3(kNumCU), dim3(kBlock), 0, st_, static_cast<const T*>(gT),
                      static_cast<const int32_t*>(ovf_count), static_cast<const EllOverflow*>(ovf), P.ovf_cap,
                      static_cast<T*>(S_T), g, Cout);
+  return launch_status();
+}
+
+template <typename T>
+int col2im_nhwc_t(const void* colsG, const void* offset, const void* mask, void* ginT, const Geom& g, const EllPlan& P, void* ws,
+                  hipStream_t st_) {
+  NhwcMap m;
+  if (g.dg != 1 || !nhwc_map(g.C, VecT<T>::N, m) || m.nv > 4) return DETOPS_EUNSUPPORTED;
+  const int64_t npix = static_cast<int64_t>(g.B) * g.H * g.W;
+  if (npix == 0) return 0;
+  if (P.npoints_per_dg == 0) {
+    DETOPS_HIP_TRY(hipMemsetAsync(ginT, 0, sizeof(T) * static_cast<size_t>(npix) * g.C, st_));
+    return 0;
+  }
+  char* w = static_cast<char*>(ws);
+  int32_t* count = reinterpret_cast<int32_t*>(w + P.off_count);
+  int32_t* ovf_count = reinterpret_cast<int32_t*>(w + P.off_ovf_count);
+  EllEntry* ent = reinterpret_cast<EllEntry*>(w + P.off_ent);
+  EllOverflow* ovf = reinterpret_cast<EllOverflow*>(w + P.off_ovf);
+  { const int rc = ell_build<T>(offset, mask, g, P, count, ovf_count, ent, ovf, P.off_ent - P.off_count, st_); if (rc) return rc; }
+  hipLaunchKernelGGL(col2im_nhwc_gather_kernel<T>, dim3(static_cast<unsigned>(ceil_div64(npix, m.ppb))), dim3(kBlock), 0, st_,
+                     static_cast<const T*>(colsG), static_cast<const int32_t*>(count), static_cast<const EllEntry*>(ent),
+                     static_cast<T*>(ginT), g, m.sub, m.nv, npix);
+  hipLaunchKernelGGL(col2im_nhwc_overflow_kernel<T>, dim3(kNumCU), dim3(kBlock), 0, st_, static_cast<const T*>(colsG),
+                     static_cast<const int32_t*>(ovf_count), static_cast<const EllOverflow*>(ovf), P.ovf_cap,
+                     static_cast<T*>(ginT), g);
   return launch_status();
 }
 
@@ -1925,6 +2027,24 @@ DETOPS_API int detops_deformable_transposed_sample(const void* gT, const void* o
   if (g.dg != 1 || !ell_plan(g, P)) return DETOPS_EUNSUPPORTED;
   if (!workspace || workspace_bytes < P.total) return DETOPS_EWORKSPACE;
 #define CALL(T) sampleT_t<T>(gT, offset, mask, S_T, g, Cout, P, workspace, as_stream(stream))
+  DETOPS_DTYPE_SWITCH(dtype, CALL)
+#undef CALL
+}
+
+// grad_in_T [B, H*W, C] (the channels-last input gradient) from the channel-fastest column gradient colsG_T [B*Ho*Wo, kh*kw, C]:
+// the reference's col2im as a gather (see col2im_nhwc_gather_kernel).  workspace: detops_deformable_transposed_sample_workspace_bytes.
+DETOPS_API int detops_deformable_col2im_nhwc(const void* colsG_T, const void* offset, const void* mask, void* grad_in_T, int dtype,
+                                             int B, int C, int H, int W, int kh, int kw, int pad_h, int pad_w, int stride_h,
+                                             int stride_w, int dil_h, int dil_w, int deformable_group, void* workspace,
+                                             size_t workspace_bytes, detops_stream_t stream) {
+  Geom g;
+  if (int rc = make_geom(g, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, deformable_group)) return rc;
+  if (B == 0) return 0;
+  if (!colsG_T || !offset || !grad_in_T) return DETOPS_EINVAL;
+  EllPlan P;
+  if (g.dg != 1 || !ell_plan(g, P)) return DETOPS_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < P.total) return DETOPS_EWORKSPACE;
+#define CALL(T) col2im_nhwc_t<T>(colsG_T, offset, mask, grad_in_T, g, P, workspace, as_stream(stream))
   DETOPS_DTYPE_SWITCH(dtype, CALL)
 #undef CALL
 }

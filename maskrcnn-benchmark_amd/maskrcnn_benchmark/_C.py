@@ -1530,6 +1530,27 @@ def _transposed_sample(gT, offset, mask, B, C, H, W, Cout, geom):
     return S_T
 
 
+DCN_INPUT_GRAD = os.environ.get("DETOPS_DCN_INPUT_GRAD", "col2im")   # col2im | transposed  (A/B switch)
+
+
+def _col2im_nhwc(colsG, offset, mask, B, C, H, W, geom):
+    """grad_in_T [B, H*W, C] from the channel-fastest column gradient [B*Ho*Wo, kh*kw*C]: col2im as a gather over the inverted
+    index (csrc/deform_conv.hip col2im_nhwc_gather_kernel); None when the shape is outside the kernel's plan."""
+    kH = geom[0]
+    nbytes = int(lib.detops_deformable_transposed_sample_workspace_bytes(B, C, H, W, *geom))
+    if nbytes == 0 or C // (8 if _ESIZE[colsG.dtype] == 2 else 4) > 256:
+        return None
+    ginT = torch.empty((B, H * W, C), dtype=colsG.dtype, device=colsG.device)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=colsG.device)
+    with _on_device(colsG), _timed(("dcn_col2im_nhwc[B=%d,C=%d,%dx%d,k=%d,e=%d,m=%d]", (B, C, H, W, kH, _ESIZE[colsG.dtype], mask is not None)), colsG, every=8):
+        rc = lib.detops_deformable_col2im_nhwc(ptr(colsG), ptr(offset), ptr(mask), ptr(ginT), _lib.DTYPE_CODE[colsG.dtype],
+                                               B, C, H, W, *geom, ptr(ws), nbytes, stream_of(colsG))
+    if rc == -3:
+        return None
+    check(rc, "deformable_col2im_nhwc")
+    return ginT
+
+
 def _w_tap_major(weight):
     """[Cout, C, kh, kw] -> W2 [Cout, kh*kw*C] (tap-major, channel-fastest: the column order of colT)"""
     Cout = weight.size(0)
@@ -1615,13 +1636,25 @@ def deform_conv_backward_all(input, offset, mask, weight, grad_output, kH, kW, p
         grad_offset = torch.empty_like(offset)                   # written in full by the coordinate kernel
         grad_mask = torch.empty_like(mask) if mask is not None else None
         _coord_nhwc(colsG, xT, offset, mask, grad_offset, grad_mask, B, C, H, W, geom)
+        # input gradient: col2im of the column gradient as a gather (no S_T, no second conv-sized GEMM); the transposed
+        # sampling of the output gradient + GEMM of rounds 3-5 stays as the A/B form and for shapes outside the gather's plan
+        ginT = _col2im_nhwc(colsG, offset, mask, B, C, H, W, geom) if DCN_INPUT_GRAD == "col2im" else None
         del colsG
-        S_T = _transposed_sample(gT, offset, mask, B, C, H, W, Cout, geom)     # [B*H*W, K*Cout]
-        W2T = weight.permute(1, 2, 3, 0).reshape(C, -1)          # [C, K*Cout]
-        if cl_in:     # the input was channels-last: so is its gradient ([B*H*W, C] from one GEMM, viewed as [B, C, H, W])
-            grad_input = torch.mm(S_T, W2T.t()).view(B, H, W, C).permute(0, 3, 1, 2)
+        if ginT is not None:
+            if cl_in:  # the input was channels-last: so is its gradient ([B, H*W, C] viewed as [B, C, H, W])
+                grad_input = ginT.view(B, H, W, C).permute(0, 3, 1, 2)
+            else:      # [B, H*W, C] -> [B, C, H*W]: the same tile transpose with the roles of C and H*W swapped
+                grad_input = torch.empty((B, C, H, W), dtype=ginT.dtype, device=ginT.device)
+                with _on_device(ginT):
+                    check(lib.detops_nchw_to_nhwc(ptr(ginT), ptr(grad_input), _lib.DTYPE_CODE[ginT.dtype], B, H * W, C,
+                                                  stream_of(ginT)), "nhwc_to_nchw")
         else:
-            grad_input = torch.bmm(W2T.unsqueeze(0).expand(B, -1, -1), S_T.view(B, H * W, -1).transpose(1, 2)).view(B, C, H, W)
+            S_T = _transposed_sample(gT, offset, mask, B, C, H, W, Cout, geom)     # [B*H*W, K*Cout]
+            W2T = weight.permute(1, 2, 3, 0).reshape(C, -1)          # [C, K*Cout]
+            if cl_in:     # the input was channels-last: so is its gradient ([B*H*W, C] from one GEMM, viewed as [B, C, H, W])
+                grad_input = torch.mm(S_T, W2T.t()).view(B, H, W, C).permute(0, 3, 1, 2)
+            else:
+                grad_input = torch.bmm(W2T.unsqueeze(0).expand(B, -1, -1), S_T.view(B, H * W, -1).transpose(1, 2)).view(B, C, H, W)
     if need_weight:
         if colT is None:
             colT = _im2col_nhwc(xT, offset, mask, B, C, H, W, geom)  # [B*Ho*Wo, K*C]

@@ -125,6 +125,7 @@ SIGNATURES = {
     "detops_deformable_coord_nhwc": (c_int, [_P] * 6 + [c_int] * 14 + [_P]),
     "detops_deformable_transposed_sample_workspace_bytes": (c_size_t, [c_int] * 13),
     "detops_deformable_transposed_sample": (c_int, [_P, _P, _P, _P] + [c_int] * 15 + [_P, c_size_t, _P]),
+    "detops_deformable_col2im_nhwc": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P, c_size_t, _P]),
     "detops_deformable_col2im_coord": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 14 + [_P]),
     "detops_deform_psroi_pool_forward_f32": (
         c_int, [_P] * 5 + [c_int] * 7 + [c_float] + [c_int] * 5 + [c_float, _P]),

@@ -82,6 +82,7 @@ SIGNATURES = {
     "detops_deformable_coord_nhwc": (c_int, [_P] * 6 + [c_int] * 14 + [_P]),
     "detops_deformable_transposed_sample_workspace_bytes": (ctypes.c_size_t, [c_int] * 13),
     "detops_deformable_transposed_sample": (c_int, [_P, _P, _P, _P] + [c_int] * 15 + [_P, ctypes.c_size_t, _P]),
+    "detops_deformable_col2im_nhwc": (c_int, [_P, _P, _P, _P] + [c_int] * 14 + [_P, ctypes.c_size_t, _P]),
     "detops_deformable_col2im_coord": (c_int, [_P, _P, _P, _P, _P, _P] + [c_int] * 14 + [_P]),
 }
 
@@ -432,7 +433,7 @@ def nchw_to_nhwc(x):
     return out
 
 
-def deformable_nhwc(im, offset, mask, weight, grad_out, kh, kw, pad, stride, dil):
+def deformable_nhwc(im, offset, mask, weight, grad_out, kh, kw, pad, stride, dil, input_grad="col2im"):
     """The channels-last pipeline with numpy standing in for the library GEMMs (what _C.py does with torch.mm):
     -> (out, grad_input, grad_offset, grad_mask, grad_weight), everything in the reference's layouts."""
     im = np.ascontiguousarray(im)
@@ -472,6 +473,12 @@ def deformable_nhwc(im, offset, mask, weight, grad_out, kh, kw, pad, stride, dil
     W2T = weight.transpose(1, 2, 3, 0).reshape(C, K * Cout).astype(f)
     gin = np.einsum("ck,bpk->bcp", W2T, S_T.astype(f).reshape(B, H * W, K * Cout)).reshape(B, C, H, W)
     gw = (g2.T @ colT.astype(f)).reshape(Cout, kh, kw, C).transpose(0, 3, 1, 2)
+    if input_grad == "col2im":      # round 6: the input gradient as a col2im GATHER of the column gradient (what _C.py runs by default)
+        ws = np.full((nbytes,), 0xCD, np.uint8)
+        ginT = np.full((B, H * W, C), np.nan, dt)
+        rc = lib().detops_deformable_col2im_nhwc(_p(colsG), _p(offset), mp, _p(ginT), _DT[dt], *g, _p(ws), nbytes, None)
+        assert rc == 0, rc
+        gin = ginT.astype(f).transpose(0, 2, 1).reshape(B, C, H, W)
     return out, gin, goff, gmask, gw
 
 

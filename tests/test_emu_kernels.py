@@ -702,6 +702,29 @@ def test_emu_deformable_index_tile_owner_build(case):
         assert np.array_equal(out, emu.deformable_col2im(gcol, off, mask, *shape, mode="ell", **geo))
 
 
+def test_emu_deformable_channels_last_input_gradient_with_overflowing_pixels():
+    """every sampling point of every tap lands on the same four pixels: 64 contributions per (pixel, tap) against the 8 slots
+    of the inverted index — the rest goes through the overflow list (packed atomics behind the gather); both forms of the
+    input gradient (col2im gather of the column gradient / transposed sampling + GEMM) against the oracle"""
+    rng = np.random.RandomState(5)
+    B, C, H, W, Cout, k = 1, 64, 8, 8, 64, 3
+    x = rng.randn(B, C, H, W).astype(np.float32)
+    wgt = (rng.randn(Cout, C, k, k) * 0.1).astype(np.float32)
+    off = np.zeros((B, 2 * k * k, H, W), np.float32)
+    for i in range(k):
+        for j in range(k):
+            hh, ww = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+            off[0, 2 * (i * k + j)] = 3.3 - (hh - 1 + i)          # sampling row  = ho - pad + i + off_h = 3.3
+            off[0, 2 * (i * k + j) + 1] = 4.6 - (ww - 1 + j)      # sampling col  = 4.6
+    mask = rng.uniform(0.2, 1.0, (B, k * k, H, W)).astype(np.float32)
+    go = rng.randn(B, Cout, H, W).astype(np.float32)
+    rin = oracle.deform_conv_backward(x, off, mask, wgt, go, False, (1, 1), (1, 1), (1, 1), 1, 1)[0]
+    assert np.count_nonzero(np.abs(rin).sum(1)) == 4
+    for form in ("col2im", "transposed"):
+        gin = emu.deformable_nhwc(x, off, mask, wgt, go, k, k, (1, 1), (1, 1), (1, 1), input_grad=form)[1]
+        np.testing.assert_allclose(gin, rin, rtol=1e-4, atol=2e-4 * np.abs(rin).max(), err_msg=form)
+
+
 # ================================================================================ deformable conv, channels-last pipeline
 @pytest.mark.parametrize("geom", [dict(B=2, C=64, H=9, W=11, Cout=128, k=3, pad=1, stride=1, dil=1),
                                   dict(B=1, C=128, H=12, W=10, Cout=64, k=3, pad=2, stride=2, dil=2),
@@ -726,7 +749,9 @@ def test_emu_deformable_channels_last_pipeline_vs_oracle(geom, modulated):
     np.testing.assert_allclose(out, ref_out, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(ref_out).max()))
     rin, roff, rmask, rw, _ = oracle.deform_conv_backward(x, off, mask, wgt, go, False, pad, stride, dil, 1, 1)
     tol = lambda r: dict(rtol=1e-4, atol=2e-4 * max(1.0, np.abs(r).max()))  # noqa: E731
-    np.testing.assert_allclose(gin, rin, **tol(rin))
+    np.testing.assert_allclose(gin, rin, **tol(rin))            # col2im gather of the column gradient (round 6, the default)
+    gin_t = emu.deformable_nhwc(x, off, mask, wgt, go, g["k"], g["k"], pad, stride, dil, input_grad="transposed")[1]
+    np.testing.assert_allclose(gin_t, rin, **tol(rin))          # transposed sampling of the output gradient + GEMM (rounds 3-5)
     np.testing.assert_allclose(goff, roff, **tol(roff))
     np.testing.assert_allclose(gw, rw, **tol(rw))
     if modulated:
