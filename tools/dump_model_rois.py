@@ -37,9 +37,9 @@ def main():
     captured = {}
     orig = _C.roi_align_fpn_backward
 
-    def spy(grad, rois, levels, shapes, scales, ph, pw, sr):
+    def spy(grad, rois, levels, shapes, scales, ph, pw, sr, **kw):
         captured["box" if ph == 7 else "mask"] = (rois.detach().clone(), levels.detach().clone())
-        return orig(grad, rois, levels, shapes, scales, ph, pw, sr)
+        return orig(grad, rois, levels, shapes, scales, ph, pw, sr, **kw)
 
     _C.roi_align_fpn_backward = spy
     for i in range(args.steps):
