@@ -26,10 +26,11 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kMaxSamples = 2048;  // P*P*S*S entries of the LDS sample table (7*7*4*4 = 784), 32 KiB
 constexpr int kMaxPart = 1024;     // part_size^2 * 2 offset-gradient cells reduced in LDS
+constexpr int kWin = 4;            // backward: side of a thread's private LDS window of input-gradient pixels
 
 struct Sample {
   int off;        // y0 * W + x0, or -1 for a skipped sample
-  int dxy;        // (x1 - x0) | ((y1 - y0) << 1): ceil == floor on integer coordinates
+  int dxy;        // (x1 - x0) | ((y1 - y0) << 1) | (x0 << 2): ceil == floor on integer coordinates
   float dist_x, dist_y;
 };
 
@@ -97,7 +98,7 @@ __device__ __forceinline__ Sample make_sample(const Lattice& g, int ih, int iw, 
   const int x0 = static_cast<int>(floorf(w)), x1 = static_cast<int>(ceilf(w));
   const int y0 = static_cast<int>(floorf(h)), y1 = static_cast<int>(ceilf(h));
   s.off = y0 * W + x0;
-  s.dxy = (x1 - x0) | ((y1 - y0) << 1);
+  s.dxy = (x1 - x0) | ((y1 - y0) << 1) | (x0 << 2);
   s.dist_x = w - x0;
   s.dist_y = h - y0;
   return s;
@@ -153,7 +154,7 @@ psroi_fwd_kernel(const float* __restrict__ data, const float* __restrict__ rois,
     for (int s = 0; s < SS; ++s) {
       const Sample sp = kTable ? s_tab[bin * SS + s] : make_sample(g, s / S, s - (s / S) * S, H, W);
       if (sp.off < 0) continue;
-      const int dx = sp.dxy & 1, dyW = (sp.dxy >> 1) * W;
+      const int dx = sp.dxy & 1, dyW = ((sp.dxy >> 1) & 1) * W;
       const float v11 = d[sp.off], v12 = d[sp.off + dyW], v21 = d[sp.off + dx], v22 = d[sp.off + dyW + dx];
       const float ax = 1 - sp.dist_x, ay = 1 - sp.dist_y;
       const float val = ax * ay * v11 + ax * sp.dist_y * v12 + sp.dist_x * ay * v21 + sp.dist_x * sp.dist_y * v22;
@@ -178,6 +179,11 @@ psroi_bwd_kernel(const float* __restrict__ top_diff, const float* __restrict__ d
   __shared__ int s_part[kTable ? 1024 : 1];
   __shared__ float s_tgrad[kMaxPart];
   __shared__ float s_roi_wh[2];
+  // A bin's S x S samples land on a few pixels of ONE channel plane (window = bin size + 1): the reference adds 4 S^2 values
+  // with global atomics (deform_psroi_pooling_cuda.cu:236-243).  Here a thread first collects them in its private kWin x kWin
+  // LDS window anchored at its first sample's pixel and adds each touched pixel once (round 6; samples outside the window —
+  // bins larger than 3 pixels — keep the direct adds).
+  __shared__ float s_win[kWin * kWin][kBlock];
   const int n = blockIdx.x / num_classes;
   const int class_id = blockIdx.x - n * num_classes;
   const float* roi = rois + static_cast<size_t>(n) * 5;
@@ -229,17 +235,31 @@ psroi_bwd_kernel(const float* __restrict__ top_diff, const float* __restrict__ d
     }
     const size_t base = img + static_cast<size_t>(ctop * group_size * group_size + pl) * plane;
     float tx = 0.f, ty = 0.f;
+#pragma unroll
+    for (int cell = 0; cell < kWin * kWin; ++cell) s_win[cell][threadIdx.x] = 0.f;
+    int win_x = -1, win_row = 0;                      // anchor: column and row offset (y * W) of the first valid sample
     for (int s = 0; s < SS; ++s) {
       const Sample sp = kTable ? s_tab[bin * SS + s] : make_sample(g, s / S, s - (s / S) * S, H, W);
       if (sp.off < 0) continue;
-      const int dx = sp.dxy & 1, dyW = (sp.dxy >> 1) * W;
+      const int dx = sp.dxy & 1, dy = (sp.dxy >> 1) & 1, dyW = dy * W;
+      const int x0 = sp.dxy >> 2;
       const float ax = 1 - sp.dist_x, ay = 1 - sp.dist_y;
       const float q00 = ax * ay, q01 = ax * sp.dist_y, q10 = sp.dist_x * ay, q11 = sp.dist_x * sp.dist_y;
-      float* dd = data_diff + base + sp.off;
-      atomicAdd(dd, q00 * diff_val);
-      atomicAdd(dd + dyW, q01 * diff_val);
-      atomicAdd(dd + dx, q10 * diff_val);
-      atomicAdd(dd + dyW + dx, q11 * diff_val);
+      if (win_x < 0) { win_x = x0; win_row = sp.off - x0; }
+      const int rx = x0 - win_x, rr = sp.off - x0 - win_row;          // rr = (y0 - anchor row) * W
+      const int ry = (rr >= W) + (rr >= 2 * W) + (rr >= 3 * W);
+      if (rx >= 0 && rx + dx < kWin && rr >= 0 && rr < 4 * W && ry + dy < kWin) {
+        s_win[ry * kWin + rx][threadIdx.x] += q00 * diff_val;
+        s_win[(ry + dy) * kWin + rx][threadIdx.x] += q01 * diff_val;
+        s_win[ry * kWin + rx + dx][threadIdx.x] += q10 * diff_val;
+        s_win[(ry + dy) * kWin + rx + dx][threadIdx.x] += q11 * diff_val;
+      } else {
+        float* dd = data_diff + base + sp.off;
+        atomicAdd(dd, q00 * diff_val);
+        atomicAdd(dd + dyW, q01 * diff_val);
+        atomicAdd(dd + dx, q10 * diff_val);
+        atomicAdd(dd + dyW + dx, q11 * diff_val);
+      }
       if (no_trans) continue;
       const float* u = data + base + sp.off;
       const float U00 = u[0], U01 = u[dyW], U10 = u[dx], U11 = u[dyW + dx];
@@ -249,6 +269,14 @@ psroi_bwd_kernel(const float* __restrict__ top_diff, const float* __restrict__ d
       diff_y *= roi_h;
       tx += diff_x;
       ty += diff_y;
+    }
+    if (win_x >= 0) {
+      float* wd = data_diff + base + win_row + win_x;
+#pragma unroll
+      for (int cell = 0; cell < kWin * kWin; ++cell) {
+        const float v = s_win[cell][threadIdx.x];
+        if (v != 0.f) atomicAdd(wd + (cell / kWin) * W + (cell % kWin), v);
+      }
     }
     if (!no_trans) {
       if (lds_tgrad) {
