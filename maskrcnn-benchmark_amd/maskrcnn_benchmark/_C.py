@@ -1351,7 +1351,7 @@ def _shape_check(input, offset, grad_output, weight, kH, kW, dH, dW, padH, padW,
     """reference csrc/cuda/deform_conv_cuda.cu:67-156 (same conditions, RuntimeError)."""
     if weight.dim() != 4:
         raise RuntimeError("4D weight tensor (nOutputPlane,nInputPlane,kH,kW) expected, but got: %d" % weight.dim())
-    if not weight.is_contiguous():
+    if not weight.is_contiguous() and not is_channels_last(weight):
         raise RuntimeError("weight tensor has to be contiguous")
     if kW <= 0 or kH <= 0:
         raise RuntimeError("kernel size should be greater than zero, but got kH: %d kW: %d" % (kH, kW))
@@ -1622,7 +1622,8 @@ def deform_conv_backward_all(input, offset, mask, weight, grad_output, kH, kW, p
     if not _nhwc_ok(input, weight, group, deformable_group, geom):
         return None
     cl_in = is_channels_last(input)
-    input, offset, weight, grad_output = _dcn_in(input), offset.contiguous(), weight.contiguous(), _dcn_in(grad_output)
+    cl_w = is_channels_last(weight)          # channels-last parameter: its tap-major matrix is a view, and so is its gradient
+    input, offset, weight, grad_output = _dcn_in(input), offset.contiguous(), _dcn_in(weight), _dcn_in(grad_output)
     if mask is not None:
         mask = mask.contiguous()
     B, C, H, W = input.shape
@@ -1658,7 +1659,9 @@ def deform_conv_backward_all(input, offset, mask, weight, grad_output, kH, kW, p
     if need_weight:
         if colT is None:
             colT = _im2col_nhwc(xT, offset, mask, B, C, H, W, geom)  # [B*Ho*Wo, K*C]
-        grad_weight = torch.mm(g2.t(), colT).view(Cout, kH, kW, C).permute(0, 3, 1, 2).contiguous()
+        grad_weight = torch.mm(g2.t(), colT).view(Cout, kH, kW, C).permute(0, 3, 1, 2)   # [Cout, C, kH, kW], channels-last strides
+        if not cl_w:
+            grad_weight = grad_weight.contiguous()
     if need_bias:
         grad_bias = g2.sum(0)
     return grad_input, grad_offset, grad_mask, grad_weight, grad_bias
@@ -1681,7 +1684,9 @@ def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW
     `keep` (extension): a list that receives what deform_conv_backward_all(saved=...) can reuse, when the
     channels-last pipeline served the call."""
     _dcn_check("deform_conv_forward", input, weight, offset, output)
-    input, offset, weight = _dcn_in(input), offset.contiguous(), weight.contiguous()
+    # (a channels-last weight — a model switched to channels-last carries its 4-d parameters that way — IS the tap-major matrix
+    #  the channels-last pipeline multiplies with: _w_tap_major is a view of it, no copy launch)
+    input, offset, weight = _dcn_in(input), offset.contiguous(), _dcn_in(weight)
     Ho, Wo = _shape_check(input, offset, None, weight, kH, kW, dH, dW, padH, padW, dilationH,
                           dilationW, group, deformable_group)
     B, C = input.shape[:2]
@@ -1690,7 +1695,7 @@ def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW
         raise RuntimeError("im2col step must divide batchsize")
     out = output.view(B, Cout, Ho, Wo)
     cl = is_channels_last(input)
-    if not cl and out.is_contiguous() and _fused_dcn_forward(input, weight, offset, None, None, out, kH, kW, padH, padW, dH, dW,
+    if not cl and out.is_contiguous() and _fused_dcn_forward(input, weight.contiguous(), offset, None, None, out, kH, kW, padH, padW, dH, dW,
                                                              dilationH, dilationW, group, deformable_group):
         return 1
     if (out.is_contiguous() or is_channels_last(out)) and _nhwc_ok(input, weight, group, deformable_group):
@@ -1698,6 +1703,7 @@ def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW
         if keep is not None:
             keep.append(kept)
         return 1
+    weight = weight.contiguous()
     input = input.contiguous()
     for b0 in range(0, B, im2col_step):
         sl = slice(b0, b0 + im2col_step)
@@ -1780,10 +1786,8 @@ def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, outpu
     cl = is_channels_last(input)
     if not input.is_contiguous() and not cl:
         raise RuntimeError("input tensor has to be contiguous")
-    if is_channels_last(weight):          # a model switched to channels-last carries its 4-d parameters that way
-        weight = weight.contiguous()
-    if not weight.is_contiguous():
-        raise RuntimeError("weight tensor has to be contiguous")
+    if not weight.is_contiguous() and not is_channels_last(weight):
+        raise RuntimeError("weight tensor has to be contiguous")   # (or channels-last: a model switched to channels-last carries its 4-d parameters that way)
     B, C, H, W = input.shape
     Cout, Cker, kh_, kw_ = weight.shape
     if kh_ != kernel_h or kw_ != kernel_w:
@@ -1794,7 +1798,7 @@ def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, outpu
     Ho, Wo = _out_hw(H, W, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w, dilation_h, dilation_w)
     offset, mask = offset.contiguous(), mask.contiguous()
     out = output.view(B, Cout, Ho, Wo)
-    if not cl and out.is_contiguous() and _fused_dcn_forward(input, weight, offset, mask, bias.to(input.dtype).contiguous() if with_bias else None,
+    if not cl and out.is_contiguous() and _fused_dcn_forward(input, weight.contiguous(), offset, mask, bias.to(input.dtype).contiguous() if with_bias else None,
                                                              out, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w,
                                                              dilation_h, dilation_w, group, deformable_group):
         return
@@ -1804,7 +1808,7 @@ def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, outpu
         if keep is not None:
             keep.append(kept)
         return
-    input = input.contiguous()
+    input, weight = input.contiguous(), weight.contiguous()
     col = deformable_im2col(input, offset, mask, kernel_h, kernel_w, pad_h, pad_w, stride_h, stride_w,
                             dilation_h, dilation_w, deformable_group)
     buf = torch.empty((Cout, B * Ho * Wo), dtype=input.dtype, device=input.device)

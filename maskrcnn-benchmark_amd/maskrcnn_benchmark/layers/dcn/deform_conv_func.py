@@ -26,7 +26,7 @@ class DeformConvFunction(Function):
         ctx.stride, ctx.padding, ctx.dilation = _pair(stride), _pair(padding), _pair(dilation)
         ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
         offset, weight = _same_dtype(input, offset, weight)
-        weight = weight.contiguous()      # (a model switched to channels-last carries its 4-d parameters that way)
+        weight = _C._dcn_in(weight)       # contiguous, or channels-last as a model switched to channels-last carries its 4-d parameters
         ctx.save_for_backward(input, offset, weight)
         # a channels-last input gets a channels-last output (the pipeline is channel-fastest inside: no layout launches)
         output = torch.empty(DeformConvFunction._output_size(input, weight, ctx.padding, ctx.dilation, ctx.stride),
@@ -76,7 +76,7 @@ class DeformConvFunction(Function):
             _C.deform_conv_backward_input(input, offset, grad_output, grad_input, grad_offset, weight,
                                           ctx.bufs_[0], *geom, step)
         if ctx.needs_input_grad[2]:
-            grad_weight = torch.zeros_like(weight)
+            grad_weight = torch.zeros_like(weight, memory_format=torch.contiguous_format)
             _C.deform_conv_backward_parameters(input, offset, grad_output, grad_weight, ctx.bufs_[0],
                                                ctx.bufs_[1], *geom, 1, step)
         return (grad_input, grad_offset, grad_weight, None, None, None, None, None, None)
@@ -107,7 +107,7 @@ class ModulatedDeformConvFunction(Function):
         # decided on the ORIGINAL arguments: a .to(dtype) copy made under no-grad reports requires_grad=False
         needs_grad = weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad
         offset, mask, weight, bias = _same_dtype(input, offset, mask, weight, bias)
-        weight = weight.contiguous()      # (a model switched to channels-last carries its 4-d parameters that way)
+        weight = _C._dcn_in(weight)       # contiguous, or channels-last as a model switched to channels-last carries its 4-d parameters
         if needs_grad:
             ctx.save_for_backward(input, offset, mask, weight, bias)
         output = torch.empty(ModulatedDeformConvFunction._infer_shape(ctx, input, weight), dtype=input.dtype, device=input.device,
@@ -139,9 +139,9 @@ class ModulatedDeformConvFunction(Function):
         grad_input = torch.zeros_like(input, memory_format=torch.contiguous_format)
         grad_offset = torch.zeros_like(offset, memory_format=torch.contiguous_format)
         grad_mask = torch.zeros_like(mask, memory_format=torch.contiguous_format)
-        grad_weight = torch.zeros_like(weight)
+        grad_weight = torch.zeros_like(weight, memory_format=torch.contiguous_format)
         grad_bias = torch.zeros_like(bias)
-        _C.modulated_deform_conv_backward(input.contiguous(), weight, bias, ctx._bufs[0], offset, mask,
+        _C.modulated_deform_conv_backward(input.contiguous(), weight.contiguous(), bias, ctx._bufs[0], offset, mask,
                                           ctx._bufs[1], grad_input, grad_weight, grad_bias,
                                           grad_offset, grad_mask, grad_output, weight.shape[2],
                                           weight.shape[3], ctx.stride, ctx.stride, ctx.padding,
