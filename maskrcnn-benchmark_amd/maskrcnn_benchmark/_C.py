@@ -1588,10 +1588,14 @@ def _nhwc_backward(input, weight, offset, mask, grad_output, grad_input, grad_of
         W2 = _w_tap_major(weight)                                # [Cout, K*C]
         colsG = torch.mm(g2, W2)                                 # column gradient, channel-fastest: [B*Ho*Wo, K*C]
         _coord_nhwc(colsG, xT, offset, mask, grad_offset, grad_mask, B, C, H, W, geom)
+        ginT = _col2im_nhwc(colsG, offset, mask, B, C, H, W, geom) if DCN_INPUT_GRAD == "col2im" else None
         del colsG
-        S_T = _transposed_sample(gT, offset, mask, B, C, H, W, Cout, geom)     # [B*H*W, K*Cout]
-        W2T = weight.permute(1, 2, 3, 0).reshape(C, -1)          # [C, K*Cout]
-        grad_input.view(B, C, -1).baddbmm_(W2T.unsqueeze(0).expand(B, -1, -1), S_T.view(B, H * W, -1).transpose(1, 2))
+        if ginT is not None:       # [B, H*W, C]: accumulated into the caller's (reference semantics) NCHW gradient
+            grad_input.view(B, C, -1).add_(ginT.transpose(1, 2))
+        else:
+            S_T = _transposed_sample(gT, offset, mask, B, C, H, W, Cout, geom)     # [B*H*W, K*Cout]
+            W2T = weight.permute(1, 2, 3, 0).reshape(C, -1)          # [C, K*Cout]
+            grad_input.view(B, C, -1).baddbmm_(W2T.unsqueeze(0).expand(B, -1, -1), S_T.view(B, H * W, -1).transpose(1, 2))
     if grad_weight is not None:
         colT = _im2col_nhwc(xT, offset, mask, B, C, H, W, geom)  # [B*Ho*Wo, K*C]
         gw2 = torch.mm(g2.t(), colT)                             # [Cout, K*C]
