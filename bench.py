@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--no-miopen-search", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--export-miopen-db", default=None, metavar="DIR",
                     help="write MIOpen's find-db + kernel cache of this run to DIR (see setup_miopen_db)")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="N = 1: replay the training iteration from a HIP graph (engine/graph_step.py: one capture per input "
+                         "signature, learning rate / sampler seeds / loss scale on the device).  Pays where the step is "
+                         "host-bound (R-101 + DCN under fp16); reported as \"hip_graph\": true in the line")
     ap.add_argument("--eval", action="store_true",
                     help="time the INFERENCE forward instead of the training step (eval mode, no_grad, test-size images, the "
                          "PostProcessors included): a context line next to the reference's s/im column (MODEL_ZOO.md:26), "
@@ -391,6 +395,13 @@ def cpu_baseline_extras(ref, budget_s=6.0):
 HW_QUEUES_DEFAULT = "2"
 
 
+def graph_env(argv):
+    """--hip-graph: ROCm's graph capture of kernel-argument packets must be off BEFORE the HIP runtime starts (the replay of a
+    captured training step faults otherwise: profiles/r04a_hip_graph_flags.txt)"""
+    if "--hip-graph" in argv:
+        os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+
 def pin_hip_queues():
     """GPU_MAX_HW_QUEUES: HIP maps streams onto this many hardware queues.  The data-parallel step has exactly two busy
     streams (compute, RCCL); measured at one rank through the full wrapper (profiles/r03n_data_parallel_overhead.txt):
@@ -566,6 +577,7 @@ def eval_main(args, cfg, device, layout, miopen_db, hw_queues, progress):
 
 def main():
     args = parse()
+    graph_env(sys.argv)
     hw_queues = pin_hip_queues()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         import subprocess
@@ -628,6 +640,12 @@ def main():
                                                        force_ddp=args.force_ddp and not distributed,
                                                        bucket_cap_mb=args.bucket_mb, layout=layout)
     layout = getattr(getattr(model, "module", model), "layout", layout)
+    eager_step = step
+    if args.hip_graph:
+        if distributed or args.force_ddp:
+            raise SystemExit("bench.py --hip-graph: single process only (the data-parallel wrapper is not captured)")
+        from maskrcnn_benchmark.engine.graph_step import GraphedTrainStep
+        step = GraphedTrainStep(eager_step, warmup=3, max_graphs=4)
     batches = make_device_batches(cfg, device, images_per_gpu=args.images_per_gpu, num_batches=2, seed=rank)
     feat_bytes = 0
     H, W = batches[0][0].tensors.shape[-2:]
@@ -690,8 +708,9 @@ def main():
         _C.KERNEL_TIMER = timer
         if hasattr(model, "exposed_wait_events"):
             model.exposed_wait_events = []       # BucketedDataParallel: event pair around the main stream's join with the side stream
+        timed_step = step.run_eager if args.hip_graph else step     # (Python-level timers see nothing of a graph replay)
         for i in range(post_steps):
-            step(*batches[i % len(batches)])
+            timed_step(*batches[i % len(batches)])
         sync()
         _C.KERNEL_TIMER = None
         if getattr(model, "exposed_wait_events", None):
@@ -738,6 +757,8 @@ def main():
             "miopen": {"search": bool(torch.backends.cudnn.benchmark), "db": miopen_db},
             # which activations are channels-last (NHWC): "nchw" none | "backbone" ResNet + FPN | "all" the heads as well
             "layout": layout,
+            # True: the timed steps were replays of captured HIP graphs (engine/graph_step.py); the kernel timers' post-pass ran eagerly
+            "hip_graph": ({"replays": step.replays, "graphs": len(step._graphs), "eager_steps": step.eager_steps} if args.hip_graph else False),
             "hip": {"GPU_MAX_HW_QUEUES": hw_queues, "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},
             "kernel_timers": ("post-pass of %d steps outside the timed region, %s" % (post_steps, "all ranks" if distributed else "rank 0"))
                              if timer is not None else "off",

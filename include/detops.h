@@ -461,6 +461,13 @@ int detops_sample_labels(const void* labels, int label_dtype, int N, int n, int 
                          int64_t* sampled_idx, uint8_t* sampled_valid, void* workspace,
                          size_t workspace_bytes, detops_stream_t stream);
 
+/* the same with a device word mixed into the seed when the kernels run (NULL: exactly detops_sample_labels): for launches captured
+ * into a HIP graph, whose arguments are frozen at capture */
+int detops_sample_labels_dseed(const void* labels, int label_dtype, int N, int n, int batch_size_per_image,
+                               int max_positives, uint64_t seed, const uint64_t* seed_dev, uint8_t* pos_mask,
+                               uint8_t* neg_mask, int64_t* sampled_idx, uint8_t* sampled_valid, void* workspace,
+                               size_t workspace_bytes, detops_stream_t stream);
+
 int detops_mask_targets(const void* masks, int mask_dtype, const int64_t* mask_index, const float* boxes,
                         int G, int H, int W, int P, int M, float* out, detops_stream_t stream);
 

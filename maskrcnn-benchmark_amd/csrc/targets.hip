@@ -196,7 +196,8 @@ struct SamplerPlan {
   int n, B, max_pos, cap;   // cap = survivor capacity per (row, class)
   int count_blocks;         // grid.x of the count kernel (= partial sums per row and class)
   unsigned long long seed;
-};
+  const unsigned long long* seed_dev;   // optional device word mixed into the seed at run time (a captured HIP graph replays its
+};                                      // launch arguments: the word is what changes from one replay to the next)
 
 // key threshold of a class: survivors ~ Binomial(cand, f) with mean mu = quota + 8 sqrt(quota) + 32, i.e. more
 // than 8 standard deviations above the quota (P[fewer than quota] < 1e-14) and far below cap = 16 x B; all
@@ -220,6 +221,7 @@ sampler_filter_kernel(const T* __restrict__ labels, SamplerPlan P, const int32_t
   const int k_pos = min(n_pos, P.max_pos);
   const int k_neg = min(min(n_neg, P.B), P.B - k_pos);
   const unsigned thr_pos = class_threshold(n_pos, k_pos), thr_neg = class_threshold(n_neg, k_neg);
+  const unsigned long long seed = P.seed_dev ? (P.seed ^ (*P.seed_dev * 0x9E3779B97F4A7C15ull)) : P.seed;
   const int lane = threadIdx.x & (kWave - 1);
   const int span = gridDim.x * kBlock;
   for (int i0 = blockIdx.x * kBlock; i0 < P.n; i0 += span) {   // uniform trip count: the ballots need every lane
@@ -229,7 +231,7 @@ sampler_filter_kernel(const T* __restrict__ labels, SamplerPlan P, const int32_t
       pos_mask[static_cast<size_t>(row) * P.n + i] = 0;   // kernel — the next launch — sets the chosen ones
       neg_mask[static_cast<size_t>(row) * P.n + i] = 0;
     }
-    const unsigned key = sample_key(P.seed, row, i);
+    const unsigned key = sample_key(seed, row, i);
     const unsigned thr = c == 1 ? thr_pos : thr_neg;
     const bool keep = c >= 0 && thr != 0u && key <= thr;
 #pragma unroll
@@ -374,8 +376,8 @@ SamplerLayout sampler_layout(int N, int B) {
 }
 
 template <typename T>
-int run_sampler(const void* labels, int N, int n, int B, int max_pos, unsigned long long seed, uint8_t* pos_mask,
-                uint8_t* neg_mask, int64_t* idx, uint8_t* idx_valid, void* ws, hipStream_t st) {
+int run_sampler(const void* labels, int N, int n, int B, int max_pos, unsigned long long seed, const unsigned long long* seed_dev,
+                uint8_t* pos_mask, uint8_t* neg_mask, int64_t* idx, uint8_t* idx_valid, void* ws, hipStream_t st) {
   const SamplerLayout l = sampler_layout(N, B);
   unsigned char* base = static_cast<unsigned char*>(ws);
   int32_t* counts = reinterpret_cast<int32_t*>(base + l.off_counts);
@@ -384,7 +386,7 @@ int run_sampler(const void* labels, int N, int n, int B, int max_pos, unsigned l
   // three launches, nothing to clear: the count kernel writes per-block partial sums and zeroes the survivor counters,
   // masks and lists are written in full by the filter / finish kernels
   const int bx = std::max(1, static_cast<int>(std::min<int64_t>(ceil_div64(n, kBlock), kSamplerBlocks)));
-  const SamplerPlan P{n, B, max_pos, l.cap, bx, seed};
+  const SamplerPlan P{n, B, max_pos, l.cap, bx, seed, seed_dev};
   const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(N));
   const T* lab = static_cast<const T*>(labels);
   hipLaunchKernelGGL(sampler_count_kernel<T>, grid, dim3(kBlock), 0, st, lab, n, counts, nsurv);
@@ -728,26 +730,37 @@ DETOPS_API size_t detops_sample_labels_workspace_bytes(int N, int batch_size_per
   return sampler_layout(N, batch_size_per_image).total;
 }
 
-DETOPS_API int detops_sample_labels(const void* labels, int label_dtype, int N, int n, int batch_size_per_image,
-                                    int max_positives, uint64_t seed, uint8_t* pos_mask, uint8_t* neg_mask,
-                                    int64_t* sampled_idx, uint8_t* sampled_valid, void* workspace,
-                                    size_t workspace_bytes, detops_stream_t stream) {
+// seed_dev (optional): a device word mixed into `seed` when the kernels RUN — for callers that capture the launch into a HIP
+// graph (engine/graph_step.py): the replayed launch arguments are frozen, the word is not.
+DETOPS_API int detops_sample_labels_dseed(const void* labels, int label_dtype, int N, int n, int batch_size_per_image,
+                                          int max_positives, uint64_t seed, const uint64_t* seed_dev, uint8_t* pos_mask,
+                                          uint8_t* neg_mask, int64_t* sampled_idx, uint8_t* sampled_valid, void* workspace,
+                                          size_t workspace_bytes, detops_stream_t stream) {
   if (N < 0 || n < 0 || batch_size_per_image <= 0 || max_positives < 0) return DETOPS_EINVAL;
   if (N == 0 || n == 0) return 0;
   if (!labels || !pos_mask || !neg_mask || (sampled_idx != nullptr) != (sampled_valid != nullptr)) return DETOPS_EINVAL;
   if (batch_size_per_image > 512) return DETOPS_EUNSUPPORTED;   // survivor sort: 16 x quota 64-bit keys in <= 64 KiB of LDS
   if (!workspace || workspace_bytes < detops_sample_labels_workspace_bytes(N, batch_size_per_image)) return DETOPS_EWORKSPACE;
   hipStream_t st = as_stream(stream);
+  const unsigned long long* sd = reinterpret_cast<const unsigned long long*>(seed_dev);
   switch (label_dtype) {
     case DETOPS_LABEL_F32:
-      return run_sampler<float>(labels, N, n, batch_size_per_image, max_positives, seed, pos_mask, neg_mask, sampled_idx,
+      return run_sampler<float>(labels, N, n, batch_size_per_image, max_positives, seed, sd, pos_mask, neg_mask, sampled_idx,
                                 sampled_valid, workspace, st);
     case DETOPS_LABEL_I64:
-      return run_sampler<int64_t>(labels, N, n, batch_size_per_image, max_positives, seed, pos_mask, neg_mask,
+      return run_sampler<int64_t>(labels, N, n, batch_size_per_image, max_positives, seed, sd, pos_mask, neg_mask,
                                   sampled_idx, sampled_valid, workspace, st);
     default:
       return DETOPS_EUNSUPPORTED;
   }
+}
+
+DETOPS_API int detops_sample_labels(const void* labels, int label_dtype, int N, int n, int batch_size_per_image,
+                                    int max_positives, uint64_t seed, uint8_t* pos_mask, uint8_t* neg_mask,
+                                    int64_t* sampled_idx, uint8_t* sampled_valid, void* workspace,
+                                    size_t workspace_bytes, detops_stream_t stream) {
+  return detops_sample_labels_dseed(labels, label_dtype, N, n, batch_size_per_image, max_positives, seed, nullptr, pos_mask,
+                                    neg_mask, sampled_idx, sampled_valid, workspace, workspace_bytes, stream);
 }
 
 DETOPS_API int detops_mask_targets(const void* masks, int mask_dtype, const int64_t* mask_index, const float* boxes,

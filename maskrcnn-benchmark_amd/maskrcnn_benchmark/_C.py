@@ -652,6 +652,11 @@ def _next_sampler_seed(device):
     return (base * 0x9E3779B97F4A7C15 + off * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
 
+# Set by engine/graph_step.py while a training step is captured into / replayed from a HIP graph: an int64 [1] device tensor that
+# the captured step increments; the samplers mix it into their (frozen-at-capture) seed when they RUN.
+GRAPH_SEED = None
+
+
 def sample_labels(labels, batch_size_per_image, max_positives, with_list=False, seed=None):
     """BalancedPositiveNegativeSampler on device (extension; reference
     modeling/balanced_positive_negative_sampler.py:19-68): labels [N,n] float32 or int64 ->
@@ -673,9 +678,9 @@ def sample_labels(labels, batch_size_per_image, max_positives, with_list=False, 
         nbytes = int(lib.detops_sample_labels_workspace_bytes(N, B))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=labels.device)
         with _on_device(labels), _timed(("sample_labels[N=%d,n=%d,B=%d]", (N, n, B)), labels):
-            check(lib.detops_sample_labels(ptr(labels), 0 if labels.dtype == torch.float32 else 1, N, n, B,
-                                           int(max_positives), ctypes.c_uint64(seed), ptr(pos), ptr(neg), ptr(idx),
-                                           ptr(val), ptr(ws), nbytes, stream_of(labels)), "sample_labels")
+            check(lib.detops_sample_labels_dseed(ptr(labels), 0 if labels.dtype == torch.float32 else 1, N, n, B,
+                                                 int(max_positives), ctypes.c_uint64(seed), ptr(GRAPH_SEED), ptr(pos), ptr(neg),
+                                                 ptr(idx), ptr(val), ptr(ws), nbytes, stream_of(labels)), "sample_labels")
     elif with_list:
         idx.zero_()
         val.zero_()

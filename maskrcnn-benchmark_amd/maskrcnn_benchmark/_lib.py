@@ -49,6 +49,7 @@ SIGNATURES = {
     "detops_match_boxes_f32": (c_int, [_P, _P, _P] + [c_int] * 4 + [c_float, c_float, c_int, _P, _P, c_size_t, _P]),
     "detops_sample_labels_workspace_bytes": (c_size_t, [c_int, c_int]),
     "detops_sample_labels": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "detops_sample_labels_dseed": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "detops_mask_targets": (c_int, [_P, c_int, _P, _P] + [c_int] * 5 + [_P, _P]),
     "detops_match_labels": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "detops_roi_head_targets_f32": (c_int, [_P] * 8 + [c_int] * 4 + [c_float] * 4 + [_P] * 6),

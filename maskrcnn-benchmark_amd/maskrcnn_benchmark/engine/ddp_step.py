@@ -43,6 +43,9 @@ class OverlappedSGD(torch.optim.Optimizer):
             for p in g["params"]:
                 self._group_of[p] = gi
         self.deferred = False  # True while BucketedDataParallel applies the updates during backward
+        # group index -> fp32 [1] device tensor holding that group's learning rate: set by engine/graph_step.py, whose
+        # captured step must not freeze the scheduler's value of the capture step into the kernel arguments
+        self.lr_tensors = None
         # torch.amp.GradScaler.step() then hands `grad_scale` / `found_inf` over as attributes and does NOT read
         # found_inf back to the host: the fused kernel unscales and skips on the device (no sync in the fp16 step)
         # (only the fused path takes grad_scale / found_inf: momentum != 0 in every group, fp32 parameters on the GPU)
@@ -82,6 +85,8 @@ class OverlappedSGD(torch.optim.Optimizer):
                     if st.get("momentum_buffer") is None:   # absent, or None in a torch.optim.SGD checkpoint saved before its first step
                         st["momentum_buffer"] = torch.zeros_like(gr, dtype=p.dtype)
                     bufs.append(st["momentum_buffer"])
+                if self.lr_tensors is not None:
+                    lr = self.lr_tensors[gi]
                 torch._fused_sgd_(ps, grads, bufs, weight_decay=wd, momentum=mom, lr=lr, dampening=0.0, nesterov=False,
                                   maximize=False, is_first_step=False, grad_scale=grad_scale, found_inf=found_inf)
                 continue

@@ -2,6 +2,7 @@
 reference's logging cadence (every 20 iterations) and loss reduction across ranks for the log."""
 import datetime
 import logging
+import os
 import time
 
 import torch
@@ -29,6 +30,16 @@ def do_train(cfg, model, data_loader, optimizer, scheduler, checkpointer, device
     max_iter = start_iter + len(data_loader)      # the loader holds the REMAINING iterations (reference: IterationBasedBatchSampler)
     model.train()
     step = TrainStep(model, optimizer, scheduler, dtype=cfg.DTYPE, device_type=torch.device(device).type)
+    if os.environ.get("DETOPS_HIP_GRAPH", "0") == "1":
+        # opt-in: replay the iteration from HIP graphs (engine/graph_step.py: one graph per input signature, at most
+        # DETOPS_HIP_GRAPH_MAX of them, anything else runs eagerly) — for fixed-shape input pipelines on a host-bound step;
+        # needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the process starts
+        if hasattr(model, "comm_mode") or torch.device(device).type != "cuda":
+            logger.warning("DETOPS_HIP_GRAPH=1 ignored: single-process GPU training only")
+        else:
+            from .graph_step import GraphedTrainStep
+            step = GraphedTrainStep(step, max_graphs=int(os.environ.get("DETOPS_HIP_GRAPH_MAX", "4")))
+            logger.info("training iteration replayed from HIP graphs (up to %d input signatures)", step.max_graphs)
     start_training_time = time.time()
     end = time.time()
     for iteration, (images, targets, _) in enumerate(data_loader, start_iter):

@@ -1,6 +1,10 @@
 import os
 import sys
 
+# HIP-graph replay of a captured training step (engine/graph_step.py) needs this BEFORE the HIP runtime starts
+# (profiles/r04a_hip_graph_flags.txt); harmless for everything else
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

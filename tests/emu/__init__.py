@@ -36,6 +36,8 @@ SIGNATURES = {
     "detops_sample_labels_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "detops_sample_labels": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, _P, _P, _P, _P, _P,
                                      ctypes.c_size_t, _P]),
+    "detops_sample_labels_dseed": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint64, _P, _P, _P, _P, _P, _P,
+                                     ctypes.c_size_t, _P]),
     "detops_mask_targets": (c_int, [_P, c_int, _P, _P] + [c_int] * 5 + [_P, _P]),
     "detops_match_labels": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "detops_roi_head_targets_f32": (c_int, [_P] * 8 + [c_int] * 4 + [c_float] * 4 + [_P] * 6),
@@ -99,7 +101,7 @@ def lib():
 
 
 TUNING_KEYS = ("roi_bwd_impl", "roi_bwd_seg", "nms_fault", "nms_spin_budget", "roi_bwd_ring", "roi_bwd_ct", "roi_bwd_split", "roi_bwd_maxseg", "roi_bwd_extras", "roi_bwd_groups", "roi_bwd_scan_ct", "roi_bwd_debug", "roi_fwd_impl", "roi_fwd_records", "roi_fwd_ct",
-               "roi_fwd_order", "roi_fwd_order_mink", "dcn_col2im", "dcn_fused", "dcn_gather_xcd", "dcn_nhwc", "dcn_ell_build", "nms_fused")
+               "roi_fwd_order", "roi_fwd_order_mink", "dcn_col2im", "dcn_fused", "dcn_gather_xcd", "dcn_nhwc", "dcn_ell_build", "nms_fused", "nms_no_repair", "nms_no_presorted", "nms_debug")
 
 
 def tuning_set(key, value):
@@ -232,7 +234,8 @@ def match_boxes(gt, valid, boxes, high, low, allow_lq):
     return out
 
 
-def sample_labels(labels, B, max_pos, seed, with_list=True):
+def sample_labels(labels, B, max_pos, seed, with_list=True, seed_dev=None):
+    """seed_dev: optional 64-bit word the kernels mix into the seed when they run (detops_sample_labels_dseed)"""
     labels = np.ascontiguousarray(labels)
     code = {np.dtype(np.float32): 0, np.dtype(np.int64): 1}[labels.dtype]
     N, n = labels.shape
@@ -242,8 +245,13 @@ def sample_labels(labels, B, max_pos, seed, with_list=True):
     val = np.full((N, B), 7, np.uint8)
     nbytes = lib().detops_sample_labels_workspace_bytes(N, B)
     ws = np.full((nbytes,), 0xAB, np.uint8)
-    rc = lib().detops_sample_labels(_p(labels), code, N, n, B, max_pos, seed, _p(pos), _p(neg),
-                                    _p(idx) if with_list else None, _p(val) if with_list else None, _p(ws), nbytes, None)
+    if seed_dev is None:
+        rc = lib().detops_sample_labels(_p(labels), code, N, n, B, max_pos, seed, _p(pos), _p(neg),
+                                        _p(idx) if with_list else None, _p(val) if with_list else None, _p(ws), nbytes, None)
+    else:
+        word = np.array([seed_dev], dtype=np.uint64)
+        rc = lib().detops_sample_labels_dseed(_p(labels), code, N, n, B, max_pos, seed, _p(word), _p(pos), _p(neg),
+                                              _p(idx) if with_list else None, _p(val) if with_list else None, _p(ws), nbytes, None)
     assert rc == 0, rc
     return pos.astype(bool), neg.astype(bool), idx, val.astype(bool)
 

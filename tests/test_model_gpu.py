@@ -506,3 +506,80 @@ def test_eval_forward_on_the_device_returns_finite_detections(config):
         assert (d.bbox[:, 0::2] <= W - 1 + 1e-3).all() and (d.bbox[:, 1::2] <= H - 1 + 1e-3).all() and (d.bbox >= 0).all()
         if cfg.MODEL.MASK_ON:
             assert d.get_field("mask").shape[0] == len(d)
+
+
+# ------------------------------------------------------------------ the training iteration replayed from a HIP graph
+def _graph_env_ready():
+    import os
+    return os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+
+
+@pytest.mark.skipif(not _graph_env_ready(), reason="HIP graph replay of a training step needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 "
+                                                   "before the HIP runtime starts (tests/conftest.py sets it)")
+def test_graphed_train_step_equals_the_eager_step_where_nothing_is_random():
+    """engine/graph_step.py on RetinaNet (no sampler: the iteration is a deterministic function of weights and inputs): the
+    losses of five iterations replayed from a HIP graph equal the eager TrainStep's from the same initial weights — through the
+    scheduler's warm-up, i.e. with a learning rate that changes every iteration (it lives in a device tensor, not in the
+    captured launch arguments) — to the run-to-run noise of MIOpen's atomic weight-gradient kernels."""
+    from maskrcnn_benchmark.engine.bench_step import build_training, load_cfg, make_device_batches
+    from maskrcnn_benchmark.engine.graph_step import GraphedTrainStep
+    cfg = load_cfg("retinanet/retinanet_R-50-FPN_1x.yaml", ["SOLVER.BASE_LR", 0.002, "SOLVER.WARMUP_ITERS", 50])
+    (images, targets), = make_device_batches(cfg, _dev(), images_per_gpu=1, num_batches=1, height=192, width=256)
+
+    def run(graphed, n=8):
+        torch.manual_seed(0)
+        model, opt, sched, step = build_training(cfg, _dev())
+        g = GraphedTrainStep(step, warmup=3) if graphed else None
+        out = []
+        for i in range(n):
+            ld = (g if graphed else step)(images, targets)
+            out.append({k: float(v.detach()) for k, v in ld.items()})
+        torch.cuda.synchronize()
+        return out, g, opt, sched
+
+    eager, _, _, _ = run(False)
+    graphed, g, opt, sched = run(True)
+    assert g.replays == 8 - 0 and g.eager_steps == 3 and len(g._graphs) == 1
+    # the graphed run did 3 eager warm-up iterations before its first replay: replay i corresponds to eager iteration i + 3
+    for i in range(5):
+        for k in eager[i + 3]:
+            a, b = eager[i + 3][k], graphed[i][k]
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (i, k, a, b)
+    # the device-side learning rate follows the scheduler
+    want = [float(grp["lr"]) for grp in opt.param_groups]
+    assert want[0] != cfg.SOLVER.BASE_LR                        # still warming up: it really changed every iteration
+    for gi, v in enumerate(want):
+        # the tensor holds the value pushed before the LAST replay; one scheduler step has happened since
+        assert abs(float(opt.lr_tensors[gi]) - v) <= abs(v) * 0.2 + 1e-12
+
+
+@pytest.mark.skipif(not _graph_env_ready(), reason="needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the HIP runtime starts")
+def test_graphed_train_step_mask_rcnn_signatures_seeds_and_fallback():
+    """Mask R-CNN through GraphedTrainStep: one graph per input signature (two batches with different ground-truth counts), a
+    third signature beyond `max_graphs` runs eagerly; every iteration — replayed or not — draws a new sampler stream (the device
+    seed word is incremented by the captured step itself); losses stay finite and the weights move."""
+    from maskrcnn_benchmark.engine.bench_step import build_training, load_cfg, make_device_batches
+    from maskrcnn_benchmark.engine.graph_step import GraphedTrainStep
+    cfg = load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml",
+                   ["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 300, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 300,
+                    "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 64])
+    batches = make_device_batches(cfg, _dev(), images_per_gpu=1, num_batches=3, height=192, width=256)
+    counts = [len(t[0]) for _, t in batches]
+    assert len(set(counts)) == 3, counts                         # three signatures
+    torch.manual_seed(0)
+    model, opt, sched, step = build_training(cfg, _dev())
+    g = GraphedTrainStep(step, warmup=2, max_graphs=2)
+    before = [p.detach().clone() for p in model.parameters() if p.requires_grad][:4]
+    seen = []
+    for i in range(9):
+        ld = g(*batches[i % 3])
+        vals = {k: float(v.detach()) for k, v in ld.items()}
+        assert all(v == v and abs(v) != float("inf") for v in vals.values()), (i, vals)
+        seen.append(int(g.seed))
+    torch.cuda.synchronize()
+    assert len(g._graphs) == 2 and g.replays == 6 and g.eager_steps == 2 + 3      # warm-up + the third signature's iterations
+    assert seen == sorted(set(seen)) and len(seen) == 9                            # a new seed every iteration
+    after = [p.detach() for p in model.parameters() if p.requires_grad][:4]
+    assert any(not torch.equal(a, b) for a, b in zip(before, after))
+    from maskrcnn_benchmark import _C
+    assert _C.nms_repaired_segments(_dev()) == 0
