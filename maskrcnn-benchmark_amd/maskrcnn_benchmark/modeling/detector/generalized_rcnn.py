@@ -6,6 +6,8 @@ from torch import nn
 
 from maskrcnn_benchmark.structures.image_list import to_image_list
 
+from maskrcnn_benchmark.layers.half_weights import HalfWeights
+
 from ..backbone import build_backbone
 from ..roi_heads.roi_heads import build_roi_heads
 from ..rpn.loss import begin_step
@@ -20,6 +22,9 @@ class GeneralizedRCNN(nn.Module):
         self.roi_heads = build_roi_heads(cfg, self.backbone.out_channels)
         self.channels_last = False          # see set_channels_last
         self.channels_last_heads = False
+        # mixed precision: every weight's half copy from one multi-tensor launch per forward instead of one cast per layer
+        # (layers/half_weights.py); a plain attribute, not a sub-module: state_dict / parameters() do not see it
+        object.__setattr__(self, "half_weights", HalfWeights(self))
 
     def set_channels_last(self, on=True, heads=False):
         """Run the backbone + FPN on channels-last (NHWC) activations: MIOpen's implicit-GEMM kernels then read and write
@@ -53,9 +58,12 @@ class GeneralizedRCNN(nn.Module):
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")
         begin_step()   # the padded-target batch is shared by the callers of ONE forward, never across forwards
+        half = self.half_weights
         try:
             images = to_image_list(images)
             x = images.tensors
+            if half.usable(x):
+                half.install(torch.get_autocast_dtype(x.device.type))
             if self.channels_last:
                 x = x.contiguous(memory_format=torch.channels_last)
             features = self.backbone(x)
@@ -67,6 +75,7 @@ class GeneralizedRCNN(nn.Module):
             else:  # RPN-only models (RetinaNet) have no ROI heads
                 x, result, detector_losses = features, proposals, {}
         finally:
+            half.remove()  # the modules' `weight` attributes resolve to the fp32 parameters again
             begin_step()   # ... and never beyond it: nothing of this batch stays referenced after the forward (or its exception)
         if self.training:
             losses = {}

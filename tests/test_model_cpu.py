@@ -602,3 +602,55 @@ def test_frozen_bn_folded_cache_follows_every_replacement_path():
     bn.load_state_dict({k: v * 3 for k, v in bn.state_dict().items()}); check()
     bn.running_mean.data.copy_(torch.full((4,), 7.0))             # invisible to any key ...
     bn.invalidate(); check()                                      # ... hence invalidate()
+
+
+def test_half_weights_single_cast_equals_autocast_per_layer_casts(monkeypatch):
+    """layers/half_weights.py: under autocast every weight's half copy comes from ONE multi-tensor cast through one autograd
+    node (and the half gradients go back to the fp32 masters the same way) — the same losses and the same fp32 gradients as
+    autocast's per-layer casts; the modules' `weight` attribute is the fp32 parameter again after the forward (also when the
+    forward raises), parameters / state_dict never see the copies, the data-parallel wrapper switches the mechanism off."""
+    from maskrcnn_benchmark.data.synthetic import BatchCollator, SyntheticCOCODataset
+    from maskrcnn_benchmark.engine.bench_step import load_cfg
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    cfg = load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml",
+                   ["MODEL.DEVICE", "cpu", "MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 100, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 150,
+                    "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 32, "MODEL.RESNETS.RES2_OUT_CHANNELS", 16,
+                    "MODEL.RESNETS.WIDTH_PER_GROUP", 4, "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 16,
+                    "MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM", 32, "MODEL.ROI_MASK_HEAD.CONV_LAYERS", (16, 16)])
+    ds = SyntheticCOCODataset(length=2, height=96, width=128, with_masks=True, min_objects=2, max_objects=4)
+    images, targets, _ = BatchCollator(32)([ds[0], ds[1]])
+
+    def run(enabled):
+        torch.manual_seed(0)
+        model = build_detection_model(cfg).train()
+        model.half_weights.enabled = enabled
+        keys = list(model.state_dict().keys())
+        with cpu_shim.install():
+            torch.manual_seed(1)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                losses = model(images, list(targets))
+            total = sum(v.float() for v in losses.values())
+            total.backward()
+        assert list(model.state_dict().keys()) == keys
+        for m in model.modules():
+            assert "weight" not in m.__dict__
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        return {k: float(v.detach()) for k, v in losses.items()}, grads, model
+
+    la, ga, ma = run(False)
+    lb, gb, mb = run(True)
+    assert mb.half_weights.entries and len(mb.half_weights.entries) > 40 and ma.half_weights.entries is None
+    assert la.keys() == lb.keys() and ga.keys() == gb.keys()
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(la[k])), (k, la[k], lb[k])
+    for n in ga:
+        assert gb[n].dtype == torch.float32 and gb[n].shape == ga[n].shape
+        assert torch.allclose(ga[n], gb[n], rtol=1e-5, atol=1e-7), n
+    # fp32 forward: not used; a forward that raises still restores the attributes
+    with pytest.raises(ValueError):
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            mb(images, None)
+    assert all("weight" not in m.__dict__ for m in mb.modules())
+    with cpu_shim.install():
+        mb(images, list(targets))
+    assert not mb.half_weights.installed
