@@ -5,7 +5,9 @@
 // Pooler hard-codes ROIAlign, modeling/poolers.py:66); it is part of the exported operator API, so
 // it gets the same workgroup-per-(ROI, channel chunk) layout as ROIAlign — the integer bin windows
 // (hstart/hend, wstart/wend) are computed once per workgroup into LDS instead of once per output
-// element per channel — but no further tuning.
+// element per channel.  Backward (round 6): a gradient plane that fits the LDS is OWNED by one workgroup
+// (roi_pool_bwd_owner_kernel: the plane of one (image, channel) is summed in LDS and written once, coalesced — no
+// zero-fill pass, no global atomics); larger planes keep the reference's scatter with global atomics.
 #include <float.h>
 
 #include "detops_common.h"
@@ -104,6 +106,52 @@ roi_pool_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ ro
   }
 }
 
+// One workgroup per (channel, image): the H x W gradient plane lives in LDS.  The ROIs of the image are found in rounds of
+// kBlock (their batch index is column 0 of the ROI row), then the lanes walk (ROI of the round, bin) pairs — consecutive lanes
+// read consecutive bins of one (ROI, channel) block — and add into the plane with LDS atomics (several bins, and several ROIs,
+// may share an argmax pixel; the order of those additions is the hardware's, as in the reference's atomicAdd).  The plane is
+// written once (or added to what grad_in holds when the caller accumulates).
+__global__ void __launch_bounds__(kBlock)
+roi_pool_bwd_owner_kernel(const float* __restrict__ gout, const float* __restrict__ rois,
+                          const int32_t* __restrict__ argmax, float* __restrict__ gin, int C, int plane, int K,
+                          int bins, int accumulate) {
+  DETOPS_DYNAMIC_LDS(float, map);            // [plane] floats
+  __shared__ int s_list[kBlock];
+  __shared__ int s_cnt;
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < plane; i += kBlock) map[i] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += kBlock) {
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();                         // (also: the zero-fill / the previous round's additions are done)
+    const int k = k0 + tid;
+    if (k < K && static_cast<int>(rois[static_cast<size_t>(k) * 5]) == b) s_list[atomicAdd(&s_cnt, 1)] = k;
+    __syncthreads();
+    const int total = s_cnt * bins;
+    constexpr int U = 4;                     // independent (argmax, gradient) loads in flight per lane
+    for (int e0 = tid; e0 < total; e0 += U * kBlock) {
+      int a[U];
+      float g[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = min(e0 + u * kBlock, total - 1);
+        const int j = e / bins, bin = e - j * bins;
+        const size_t idx = (static_cast<size_t>(s_list[j]) * C + c) * bins + bin;
+        a[u] = (e0 + u * kBlock < total) ? argmax[idx] : -1;
+        g[u] = gout[idx];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (a[u] >= 0 && a[u] < plane) atomicAdd(&map[a[u]], g[u]);   // a < 0: empty bin (ROIPool_cuda.cu:100)
+    }
+    __syncthreads();                         // every lane has read the round's count and list before the next round resets them
+  }
+  float* dst = gin + (static_cast<size_t>(b) * C + c) * plane;
+  for (int i = tid; i < plane; i += kBlock) dst[i] = accumulate ? dst[i] + map[i] : map[i];
+}
+
+constexpr size_t kOwnerMaxLds = 144 * 1024;  // one plane per workgroup; 160 KB per CU
+
 }  // namespace
 
 DETOPS_API int detops_roi_pool_forward_f32(const float* input, const float* rois, float* output,
@@ -131,8 +179,20 @@ DETOPS_API int detops_roi_pool_backward_f32(const float* grad_out, const float* 
   hipStream_t st = as_stream(stream);
   const size_t bytes = sizeof(float) * static_cast<size_t>(N) * C * H * W;
   if (bytes && !grad_in) return DETOPS_EINVAL;
-  if (zero_grad_in && bytes) DETOPS_HIP_TRY(hipMemsetAsync(grad_in, 0, bytes, st));
   const int64_t total = static_cast<int64_t>(K) * C * PH * PW;
+  const size_t plane_bytes = sizeof(float) * static_cast<size_t>(H) * W;
+  // the owner form: the plane fits the LDS and there are enough (image, channel) planes to fill the chip
+  // (tuning roi_bwd_impl — tests, A/B: 3 forces the atomic scatter, 1 the owner form wherever the plane fits)
+  const int impl = detops_tuning().roi_bwd_impl;
+  const bool owner = total > 0 && bytes > 0 && plane_bytes <= kOwnerMaxLds && N <= 65535 && impl != 3 &&
+                     static_cast<int64_t>(PH) * PW <= (1 << 20) && (static_cast<int64_t>(N) * C >= kNumCU || impl == 1);
+  if (owner) {
+    if (!grad_out || !rois || !argmax) return DETOPS_EINVAL;
+    hipLaunchKernelGGL(roi_pool_bwd_owner_kernel, dim3(static_cast<unsigned>(C), static_cast<unsigned>(N)), dim3(kBlock),
+                       plane_bytes, st, grad_out, rois, argmax, grad_in, C, H * W, K, PH * PW, zero_grad_in ? 0 : 1);
+    return launch_status();
+  }
+  if (zero_grad_in && bytes) DETOPS_HIP_TRY(hipMemsetAsync(grad_in, 0, bytes, st));
   if (total == 0 || bytes == 0) return 0;
   if (!grad_out || !rois || !argmax) return DETOPS_EINVAL;
   const int blocks = static_cast<int>(std::min<int64_t>(ceil_div64(total, kBlock), kNumCU * 8));

@@ -647,6 +647,29 @@ def psroi_forward(data, rois, trans, no_trans, scale, output_dim, group_size, po
     return out, cnt
 
 
+def roi_pool_forward(data, rois, scale, PH, PW):
+    data, rois = _f32(data), _f32(rois)
+    N, C, H, W = data.shape
+    K = rois.shape[0]
+    out = np.full((K, C, PH, PW), np.nan, np.float32)
+    amax = np.full((K, C, PH, PW), -7, np.int32)
+    rc = lib().detops_roi_pool_forward_f32(_p(data), _p(rois), _p(out), _p(amax), N, C, H, W, K, PH, PW, scale, None)
+    assert rc == 0, rc
+    return out, amax
+
+
+def roi_pool_backward(grad, rois, argmax, N, C, H, W, into=None):
+    """into: accumulate onto this array (zero_grad_in = 0) instead of starting from zeros"""
+    grad, rois = _f32(grad), _f32(rois)
+    argmax = np.ascontiguousarray(argmax, dtype=np.int32)
+    K, _, PH, PW = grad.shape
+    gin = np.full((N, C, H, W), np.nan, np.float32) if into is None else np.ascontiguousarray(into, dtype=np.float32).copy()
+    rc = lib().detops_roi_pool_backward_f32(_p(grad), _p(rois), _p(argmax), _p(gin), N, C, H, W, K, PH, PW,
+                                            1 if into is None else 0, None)
+    assert rc == 0, rc
+    return gin
+
+
 def psroi_backward(grad, data, rois, trans, cnt, no_trans, scale, output_dim, group_size, pooled, part, spp, trans_std):
     grad, data, rois, cnt = _f32(grad), _f32(data), _f32(rois), _f32(cnt)
     trans = None if trans is None else _f32(trans)

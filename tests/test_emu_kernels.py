@@ -449,6 +449,36 @@ def test_emu_frozen_bn(shape, relu, res):
         np.testing.assert_allclose(gr, g, rtol=0, atol=0)
 
 
+# ================================================================================ ROIPool
+@pytest.mark.parametrize("impl", [1, 3])
+def test_emu_roi_pool_backward_owner_and_scatter_forms(impl):
+    """csrc/roi_pool.hip: the plane-owner backward (one workgroup sums the (image, channel) plane in LDS and writes it once;
+    tuning roi_bwd_impl = 1 forces it for this small launch) and the atomic scatter (= 3) against the oracle — 300 ROIs over
+    three images (two rounds of the owner kernel's ROI search, an image with no ROI at all), empty bins, overlapping windows
+    that share an argmax pixel, and accumulation onto an existing gradient"""
+    rng = np.random.RandomState(21)
+    N, C, H, W, K = 3, 5, 19, 27, 300
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    wh = rng.uniform(4, 300, (K, 2))
+    xy = rng.uniform(-20, [W * 16 - 8, H * 16 - 8], (K, 2))
+    rois = np.concatenate([rng.randint(0, 2, (K, 1)), xy, xy + wh], 1).astype(np.float32)      # image 2 has no ROI
+    ref, ramax = oracle.roi_pool_forward(x, rois, 1.0 / 16, 7, 7)
+    out, amax = emu.roi_pool_forward(x, rois, 1.0 / 16, 7, 7)
+    assert np.array_equal(out, ref) and np.array_equal(amax, ramax) and (ramax == -1).any()
+    g = rng.randn(*ref.shape).astype(np.float32)
+    want = oracle.roi_pool_backward(g, rois, ramax, N, C, H, W)
+    emu.tuning_set("roi_bwd_impl", impl)
+    try:
+        got = emu.roi_pool_backward(g, rois, amax, N, C, H, W)
+        base = rng.randn(N, C, H, W).astype(np.float32)
+        acc = emu.roi_pool_backward(g, rois, amax, N, C, H, W, into=base)
+    finally:
+        emu.tuning_set("roi_bwd_impl", 0)
+    tol = 1e-5 * max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() <= tol and not got[2].any()
+    assert np.abs(acc - (want + base)).max() <= 2 * tol
+
+
 # ================================================================================ deformable PS-ROI pooling
 @pytest.mark.parametrize("no_trans,ncls,D,G,P,part,S,std", [
     (True, 1, 8, 3, 3, 3, 4, 0.0), (False, 1, 8, 3, 7, 7, 4, 0.1), (False, 4, 8, 2, 7, 4, 2, 0.1)])

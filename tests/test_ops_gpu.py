@@ -407,6 +407,17 @@ def test_roi_pool_forward_backward():
     out, amax = C.roi_pool_forward(_t(feats), _t(r), 1 / 16, 7, 7)
     ref, ramax = oracle.roi_pool_forward(feats, r, 1 / 16, 7, 7)
     assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(amax.cpu().numpy(), ramax)
+    # ... and its backward, where the plane-owner kernel runs (2 x 256 planes of 50 x 84 in LDS); the scatter form beside it
+    g = np.random.RandomState(8).randn(*ref.shape).astype(np.float32)
+    want = oracle.roi_pool_backward(g, r, ramax, *feats.shape)
+    gin = C.roi_pool_backward(_t(g), _t(feats), _t(r), amax, 1 / 16, 7, 7, *feats.shape)
+    _close(gin, want, rtol=1e-4, atol=1e-4)
+    _tune("roi_bwd_impl", 3)
+    try:
+        gin3 = C.roi_pool_backward(_t(g), _t(feats), _t(r), amax, 1 / 16, 7, 7, *feats.shape)
+    finally:
+        _tune("roi_bwd_impl", 0)
+    _close(gin3, want, rtol=1e-4, atol=1e-4)
     from maskrcnn_benchmark.layers import ROIPool
 
     assert repr(ROIPool((7, 7), 0.25)) == "ROIPool(output_size=(7, 7), spatial_scale=0.25)"
