@@ -32,6 +32,21 @@ def test_emu_roi_align_forward_bit_exact(ph, pw, sr):
     assert np.array_equal(out, oracle.roi_align_forward(inp, rois, scale, ph, pw, sr))
 
 
+@pytest.mark.parametrize("ph,pw,sr", [(7, 7, 2), (14, 14, 2), (7, 7, 1), (3, 5, 2), (16, 16, 2)])
+def test_emu_roi_align_forward_small_maps_of_two_images_bit_exact(ph, pw, sr):
+    """one small map per image, the ROIs of two images interleaved, a ragged last channel chunk (40 channels), edge ROIs
+    (outside the map, degenerate, slivers): bit-equal to the oracle.  (Round 6 built a kernel that keeps the planes of a small
+    map in LDS for this shape — BASELINE configs[0] — and rejected it: 36 us against 26 us, its 16 scattered 4-byte LDS reads
+    per output and channel run into bank conflicts; tools/rejected_kernels/r06_small_map_forward_lds.patch)"""
+    rng = np.random.RandomState(31)
+    inp, rois, scale = synth.cfg1_roi_align(K=150, C=40)
+    inp = np.concatenate([inp, rng.randn(*inp.shape).astype(np.float32)], 0)
+    rois = np.concatenate([rois, _edge_rois()]).astype(np.float32)
+    rois[:, 0] = rng.randint(0, 2, rois.shape[0])
+    out = emu.roi_align_forward(inp, rois, scale, ph, pw, sr)
+    assert np.array_equal(out, oracle.roi_align_forward(inp, rois, scale, ph, pw, sr))
+
+
 @pytest.mark.parametrize("ph,pw,sr", [(7, 7, 2), (14, 14, 2), (7, 7, 0), (3, 5, 3), (20, 20, 2)])
 def test_emu_roi_align_backward_small_map(ph, pw, sr, bwd_impl):
     inp, rois, scale = synth.cfg1_roi_align(K=40, C=5)
