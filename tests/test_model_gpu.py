@@ -588,24 +588,23 @@ def test_graphed_train_step_mask_rcnn_signatures_seeds_and_fallback():
 # ------------------------------------------------------------------ mixed precision: one multi-tensor weight cast per step
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 def test_half_weights_gradients_equal_the_per_layer_autocast_gradients(dtype):
-    """layers/half_weights.py on the device: forward + backward of Mask R-CNN under autocast with every weight's half copy (and
-    every weight gradient's fp32 copy) made by one multi-tensor launch gives the losses and the fp32 gradients of autocast's
-    per-layer casts — the same cast of the same masters, the same widened gradients — to the run-to-run noise of MIOpen's
-    atomic weight-gradient kernels (measured in the same test: the per-layer path twice); attributes restored, a training
-    step through TrainStep (GradScaler under fp16) keeps fp32 parameters and finite losses."""
+    """layers/half_weights.py on the device: forward + backward under autocast with every weight's half copy (and every weight
+    gradient's fp32 copy) made by one multi-tensor launch gives the losses and the fp32 gradients of autocast's per-layer casts
+    — the same cast of the same masters, the same widened gradients.  Compared on RetinaNet, whose training forward has no
+    sampler and no NMS (a deterministic function of weights and inputs up to MIOpen's atomic split-K sums; Mask R-CNN's
+    proposal set flips with one half-precision ulp of a score and its head losses with it: measured 3 % between two identical
+    fp16 runs), against the noise of the per-layer path run twice.  Then Mask R-CNN through TrainStep (GradScaler under fp16):
+    finite losses, fp32 parameters, attributes restored.  The exact statement is the CPU test (tests/test_model_cpu.py)."""
     from maskrcnn_benchmark.engine.bench_step import build_training, load_cfg, make_device_batches
-    cfg = load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml",
-                   ["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 300, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 300,
-                    "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 64, "DTYPE", dtype, "SOLVER.BASE_LR", 0.002])
+    amp = {"bfloat16": torch.bfloat16, "float16": torch.float16}[dtype]
+    cfg = load_cfg("retinanet/retinanet_R-50-FPN_1x.yaml", ["DTYPE", dtype, "SOLVER.BASE_LR", 0.002])
     (images, targets), = make_device_batches(cfg, _dev(), images_per_gpu=1, num_batches=1, height=192, width=256)
     torch.manual_seed(0)
     model, opt, sched, step = build_training(cfg, _dev())
-    amp = {"bfloat16": torch.bfloat16, "float16": torch.float16}[dtype]
 
     def grads(enabled):
         model.half_weights.enabled = enabled
         model.zero_grad(set_to_none=True)
-        torch.manual_seed(5)                                   # the samplers draw from the device generator
         with torch.autocast("cuda", dtype=amp):
             ld = model(images, targets)
         (sum(ld.values()) * 64.0).backward()
@@ -620,20 +619,26 @@ def test_half_weights_gradients_equal_the_per_layer_autocast_gradients(dtype):
     lb, gb = grads(True)
     assert len(model.half_weights.entries) > 60
     assert ga.keys() == gb.keys()
-    # (the half-precision forward is not reproducible run to run: MIOpen's split-K kernels add with atomics, the sums are rounded
-    #  to half, and a proposal score that moves by one half-precision ulp changes the ROI set the heads are trained on — two
-    #  per-layer runs differ by 1e-3 relative on the classifier loss under fp16.  The exact statement is the CPU test
-    #  (tests/test_model_cpu.py); here the bound is that noise)
     for k in la:
-        assert abs(la[k] - lb[k]) <= 2e-2 * max(1.0, abs(la[k])) + 4 * abs(la[k] - la2[k]), (k, la[k], la2[k], lb[k])
+        assert abs(la[k] - lb[k]) <= 2e-3 * max(1.0, abs(la[k])) + 4 * abs(la[k] - la2[k]), (k, la[k], la2[k], lb[k])
     for n in ga:
         assert gb[n].dtype == torch.float32 and gb[n].shape == ga[n].shape and gb[n].stride() == ga[n].stride(), n
         ref = float(ga[n].double().norm())
         noise = float((ga[n].double() - ga2[n].double()).norm()) / max(ref, 1e-30)
         err = float((ga[n].double() - gb[n].double()).norm()) / max(ref, 1e-30)
-        assert err <= 4 * noise + 0.1, (n, err, noise)
+        assert err <= 4 * noise + 2e-2, (n, err, noise)
+    # Mask R-CNN: three training iterations with the single cast
+    cfg = load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml",
+                   ["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 300, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 300,
+                    "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 64, "DTYPE", dtype, "SOLVER.BASE_LR", 0.002])
+    (images, targets), = make_device_batches(cfg, _dev(), images_per_gpu=1, num_batches=1, height=192, width=256)
+    torch.manual_seed(0)
+    model, opt, sched, step = build_training(cfg, _dev())
+    assert model.half_weights.enabled
     for _ in range(3):
         ld = step(images, targets)
     vals = {k: float(v.detach()) for k, v in ld.items()}
     assert all(v == v and abs(v) != float("inf") for v in vals.values()), vals
-    assert all(p.dtype == torch.float32 for p in model.parameters()) and not model.half_weights.installed
+    assert len(model.half_weights.entries) > 60 and not model.half_weights.installed
+    assert all(p.dtype == torch.float32 for p in model.parameters())
+    assert all("weight" not in m.__dict__ for m in model.modules())

@@ -77,6 +77,7 @@ if has extra; then
   B="python bench.py --steps 40 --warmup 12 --no-cpu-baseline"
   timeout 300 $B --dtype bfloat16 < /dev/null > $O/bench_bf16.log 2>&1; jline $O/bench_bf16.log > $O/bench_bf16.json; brief $O/bench_bf16.log bf16; el bf16
   timeout 400 $B --config e2e_mask_rcnn_R_101_FPN_1x.yaml --dtype float16 MODEL.RESNETS.STAGE_WITH_DCN "(False, True, True, True)" < /dev/null > $O/bench_cfg5.log 2>&1; jline $O/bench_cfg5.log > $O/bench_cfg5.json; brief $O/bench_cfg5.log cfg5; el cfg5
+  timeout 400 $B --hip-graph --config e2e_mask_rcnn_R_101_FPN_1x.yaml --dtype float16 MODEL.RESNETS.STAGE_WITH_DCN "(False, True, True, True)" < /dev/null > $O/bench_cfg5_graph.log 2>&1; jline $O/bench_cfg5_graph.log > $O/bench_cfg5_graph.json; brief $O/bench_cfg5_graph.log cfg5-hip-graph; el cfg5-graph
   timeout 300 $B < /dev/null > $O/bench_plain40.log 2>&1; jline $O/bench_plain40.log > $O/bench_plain40.json; brief $O/bench_plain40.log plain-40-steps; el plain40
   timeout 300 $B --force-ddp < /dev/null > $O/bench_forceddp.log 2>&1; jline $O/bench_forceddp.log > $O/bench_forceddp.json; brief $O/bench_forceddp.log force-ddp-direct; el force-ddp
   DETOPS_DDP_COMM=pg timeout 300 $B --force-ddp < /dev/null > $O/bench_forceddp_pg.log 2>&1; jline $O/bench_forceddp_pg.log > $O/bench_forceddp_pg.json; brief $O/bench_forceddp_pg.log force-ddp-pg; el force-ddp-pg
