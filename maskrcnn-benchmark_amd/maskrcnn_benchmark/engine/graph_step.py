@@ -101,7 +101,9 @@ class GraphedTrainStep(object):
                                "are enqueued from autograd hooks); use it on a single-process model")
         os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # (must be set before the HIP runtime starts to take effect)
         self.eager = step
-        self.warmup = int(warmup)
+        # at least one eager iteration before the first capture: the optimizer creates its momentum buffers on its first step
+        # (host-side `is None` test + zeros_like) — captured, that zero-fill would be replayed, i.e. reset the momentum every iteration
+        self.warmup = max(1, int(warmup))
         self.max_graphs = int(max_graphs)
         self._graphs = collections.OrderedDict()
         self._pool = None
