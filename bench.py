@@ -395,6 +395,16 @@ def cpu_baseline_extras(ref, budget_s=6.0):
 HW_QUEUES_DEFAULT = "2"
 
 
+def mask_slots_report(model):
+    try:
+        from maskrcnn_benchmark.modeling.roi_heads.mask_head import mask_head as mh
+        m = getattr(model, "module", model)
+        head = m.roi_heads["mask"] if (m.roi_heads and "mask" in m.roi_heads) else None
+        return None if head is None else {"mode": mh.slot_mode(), "slots": head.last_slots, "quota": head.max_positives}
+    except Exception:  # noqa: BLE001 — a report field only
+        return None
+
+
 def graph_env(argv):
     """--hip-graph: ROCm's graph capture of kernel-argument packets must be off BEFORE the HIP runtime starts (the replay of a
     captured training step faults otherwise: profiles/r04a_hip_graph_flags.txt)"""
@@ -757,6 +767,9 @@ def main():
             "miopen": {"search": bool(torch.backends.cudnn.benchmark), "db": miopen_db},
             # which activations are channels-last (NHWC): "nchw" none | "backbone" ResNet + FPN | "all" the heads as well
             "layout": layout,
+            # mask head batch: "dynamic" = every image's positives rounded up to 32 slots (the reference runs its mask head on the
+            # positive boxes only), "fixed" = the quota of 128 slots per image; `slots` = the last step's slot counts per image
+            "mask_slots": mask_slots_report(model),
             # True: the timed steps were replays of captured HIP graphs (engine/graph_step.py); the kernel timers' post-pass ran eagerly
             "hip_graph": ({"replays": step.replays, "graphs": len(step._graphs), "eager_steps": step.eager_steps} if args.hip_graph else False),
             "hip": {"GPU_MAX_HW_QUEUES": hw_queues, "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},

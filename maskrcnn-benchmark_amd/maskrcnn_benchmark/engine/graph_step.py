@@ -100,6 +100,11 @@ class GraphedTrainStep(object):
             raise RuntimeError("GraphedTrainStep: the data-parallel wrapper is not capturable (RCCL calls and stream waits "
                                "are enqueued from autograd hooks); use it on a single-process model")
         os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # (must be set before the HIP runtime starts to take effect)
+        # nothing can be read back inside a capture: the mask head takes its static number of slots per image
+        from maskrcnn_benchmark.modeling.roi_heads.mask_head import mask_head as _mh
+        if _mh.SLOT_MODE == "dynamic":
+            _mh.SLOT_MODE = "fixed"
+            log.info("GraphedTrainStep: mask head slots fixed (a captured step cannot read the positive counts back)")
         self.eager = step
         # at least one eager iteration before the first capture: the optimizer creates its momentum buffers on its first step
         # (host-side `is None` test + zeros_like) — captured, that zero-fill would be replayed, i.e. reset the momentum every iteration

@@ -14,12 +14,18 @@ class ROIBoxHead(torch.nn.Module):
         self.predictor = make_roi_box_predictor(cfg, self.feature_extractor.out_channels)
         self.post_processor = make_roi_box_post_processor(cfg)
         self.loss_evaluator = make_roi_box_loss_evaluator(cfg)
+        self.mask_follows = bool(cfg.MODEL.MASK_ON)
 
     def forward(self, features, proposals, targets=None):
         """-> (x: pooled features, proposals: sampled (train) / detections (eval), losses)."""
         if self.training:
             with torch.no_grad():
                 proposals = self.loss_evaluator.subsample(proposals, targets)
+                if self.mask_follows:
+                    # the mask head runs on the positives only: their per-image counts start their (asynchronous) trip to the
+                    # host here, a whole box-head forward before the mask head asks for them (mask_head.PositiveCounts)
+                    from ..mask_head.mask_head import request_positive_counts
+                    request_positive_counts(proposals)
         x = self.feature_extractor(features, proposals)
         class_logits, box_regression = self.predictor(x)
         if not self.training:

@@ -654,3 +654,44 @@ def test_half_weights_single_cast_equals_autocast_per_layer_casts(monkeypatch):
     with cpu_shim.install():
         mb(images, list(targets))
     assert not mb.half_weights.installed
+
+
+def test_mask_head_dynamic_slots_equal_the_fixed_quota(monkeypatch):
+    """roi_heads/mask_head/mask_head.py: the mask head on the first n = ceil32(positives) slots of every image ("dynamic": the
+    reference's workload, which keeps only the positive boxes) gives the losses and gradients of the fixed quota of
+    BATCH_SIZE_PER_IMAGE * POSITIVE_FRACTION slots per image — the extra slots are masked out of the loss either way —, the
+    counts are requested by the box head right after its sampler, forced slot counts ("<n>") clamp to the quota."""
+    from maskrcnn_benchmark.data.synthetic import BatchCollator, SyntheticCOCODataset
+    from maskrcnn_benchmark.engine.bench_step import load_cfg
+    from maskrcnn_benchmark.modeling.detector import build_detection_model
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head import mask_head as MH
+    cfg = load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml",
+                   ["MODEL.DEVICE", "cpu", "MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 100, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 150,
+                    "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 256, "MODEL.RESNETS.RES2_OUT_CHANNELS", 16,
+                    "MODEL.RESNETS.WIDTH_PER_GROUP", 4, "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 16,
+                    "MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM", 32, "MODEL.ROI_MASK_HEAD.CONV_LAYERS", (16, 16)])
+    ds = SyntheticCOCODataset(length=2, height=96, width=128, with_masks=True, min_objects=2, max_objects=4)
+    images, targets, _ = BatchCollator(32)([ds[0], ds[1]])
+
+    def run(mode):
+        monkeypatch.setattr(MH, "SLOT_MODE", mode)
+        torch.manual_seed(0)
+        model = build_detection_model(cfg).train()
+        with cpu_shim.install():
+            torch.manual_seed(1)
+            losses = model(images, list(targets))
+            sum(losses.values()).backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        return {k: float(v.detach()) for k, v in losses.items()}, grads, list(model.roi_heads.mask.last_slots)
+
+    lf, gf, sf = run("fixed")
+    ld, gd, sd = run("dynamic")
+    assert sf == [64, 64]                                  # the quota: 256 x 0.25
+    assert all(s % 32 == 0 and 32 <= s <= 64 for s in sd) and sd != sf, sd
+    for k in lf:
+        assert abs(lf[k] - ld[k]) <= 1e-6 * max(1.0, abs(lf[k])), (k, lf[k], ld[k])
+    assert gf.keys() == gd.keys()
+    for n in gf:
+        assert torch.allclose(gf[n], gd[n], rtol=1e-4, atol=1e-7), n
+    _, _, forced = run("16,500")
+    assert forced == [16, 64]
