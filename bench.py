@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-miopen-search", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--export-miopen-db", default=None, metavar="DIR",
                     help="write MIOpen's find-db + kernel cache of this run to DIR (see setup_miopen_db)")
+    ap.add_argument("--no-fixed-quota-line", action="store_true",
+                    help="skip the 20 extra steps that time the step with the mask head's fixed quota of slots (mask_slots.fixed_quota_ms_per_step)")
     ap.add_argument("--hip-graph", action="store_true",
                     help="N = 1: replay the training iteration from a HIP graph (engine/graph_step.py: one capture per input "
                          "signature, learning rate / sampler seeds / loss scale on the device).  Pays where the step is "
@@ -728,6 +730,25 @@ def main():
             model.exposed_wait_events = None
             exposed_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
         progress("%d kernel-timing steps done (outside the timed region)" % post_steps)
+    # Transparency line for the mask head's dynamic batch (mask_head.py: every image's positives rounded up to 32 slots, the
+    # reference's workload): the same step with the FIXED quota of 128 slots per image, i.e. what the step costs when every
+    # image fills its quota of positives — 20 more steps outside the timed region, on every rank.
+    slots_dynamic = mask_slots_report(model)
+    fixed_quota_ms = None
+    if slots_dynamic and slots_dynamic["mode"] == "dynamic" and not args.no_fixed_quota_line and device.type == "cuda":
+        from maskrcnn_benchmark.modeling.roi_heads.mask_head import mask_head as _mh
+        _mh.SLOT_MODE = "fixed"
+        saved_rank_seconds = list(RANK_SECONDS)
+        try:
+            for i in range(4):
+                step(*batches[i % len(batches)])
+            sync()
+            q_elapsed, _, _ = timed_steps(step, batches, 20, sync, distributed, device)
+            fixed_quota_ms = round(q_elapsed / 20 * 1e3, 3)
+        finally:
+            _mh.SLOT_MODE = "dynamic"
+            RANK_SECONDS[:] = saved_rank_seconds
+        progress("20 steps with the fixed mask-head quota done (outside the timed region)")
     gpu_phase_s = time.perf_counter() - gpu_t0
     loss_vals = {k: float(v.detach()) for k, v in losses.items()} if losses else {}
     # N > 1 diagnosis (VERDICT r05 #4b): every rank's communication path and its exposed all-reduce time, gathered on rank 0
@@ -769,7 +790,7 @@ def main():
             "layout": layout,
             # mask head batch: "dynamic" = every image's positives rounded up to 32 slots (the reference runs its mask head on the
             # positive boxes only), "fixed" = the quota of 128 slots per image; `slots` = the last step's slot counts per image
-            "mask_slots": mask_slots_report(model),
+            "mask_slots": dict(slots_dynamic, fixed_quota_ms_per_step=fixed_quota_ms) if slots_dynamic else None,
             # True: the timed steps were replays of captured HIP graphs (engine/graph_step.py); the kernel timers' post-pass ran eagerly
             "hip_graph": ({"replays": step.replays, "graphs": len(step._graphs), "eager_steps": step.eager_steps} if args.hip_graph else False),
             "hip": {"GPU_MAX_HW_QUEUES": hw_queues, "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")},

@@ -642,3 +642,43 @@ def test_half_weights_gradients_equal_the_per_layer_autocast_gradients(dtype):
     assert len(model.half_weights.entries) > 60 and not model.half_weights.installed
     assert all(p.dtype == torch.float32 for p in model.parameters())
     assert all("weight" not in m.__dict__ for m in model.modules())
+
+
+# ------------------------------------------------------------------ mask head on the positives only
+def test_mask_head_dynamic_slots_equal_the_fixed_quota_on_the_device(monkeypatch):
+    """roi_heads/mask_head/mask_head.py on the MI355X (fp32): the mask head on ceil32(positives) slots per image — the counts
+    read back through the asynchronous copy the box head starts after its sampler — gives the losses and gradients of the
+    fixed quota of 128 slots per image (the extra slots are masked out of the loss either way; the convolutions run other
+    MIOpen kernels for the other batch size, hence a tolerance, not bit equality)."""
+    from maskrcnn_benchmark.engine.bench_step import build_training, load_cfg, make_device_batches
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head import mask_head as MH
+    cfg = load_cfg("e2e_mask_rcnn_R_50_FPN_1x.yaml", ["MODEL.RPN.PRE_NMS_TOP_N_TRAIN", 500, "MODEL.RPN.FPN_POST_NMS_TOP_N_TRAIN", 500])
+    (images, targets), = make_device_batches(cfg, _dev(), images_per_gpu=2, num_batches=1, height=256, width=320)
+    torch.manual_seed(0)
+    model, opt, sched, step = build_training(cfg, _dev())
+
+    def grads(mode):
+        monkeypatch.setattr(MH, "SLOT_MODE", mode)
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(7)
+        ld = model(images, targets)
+        sum(ld.values()).backward()
+        torch.cuda.synchronize()
+        return ({k: float(v.detach()) for k, v in ld.items()},
+                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
+                list(model.roi_heads.mask.last_slots))
+
+    lf, gf, sf = grads("fixed")
+    ld, gd, sd = grads("dynamic")
+    assert sf == [128, 128] and all(s % 32 == 0 and 32 <= s <= 128 for s in sd), (sf, sd)
+    for k in lf:
+        assert abs(lf[k] - ld[k]) <= 2e-5 * max(1.0, abs(lf[k])), (k, lf[k], ld[k], sd)
+    assert gf.keys() == gd.keys()
+    for n in gf:
+        ref = float(gf[n].double().norm())
+        err = float((gf[n].double() - gd[n].double()).norm()) / max(ref, 1e-30)
+        assert err <= 2e-3, (n, err)
+    # and a training iteration in the default mode
+    monkeypatch.setattr(MH, "SLOT_MODE", "dynamic")
+    vals = {k: float(v.detach()) for k, v in step(images, targets).items()}
+    assert all(v == v and abs(v) != float("inf") for v in vals.values()), vals
