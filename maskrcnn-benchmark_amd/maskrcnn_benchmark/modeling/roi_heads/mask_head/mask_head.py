@@ -29,7 +29,7 @@ from .roi_mask_predictors import make_roi_mask_predictor
 
 # "dynamic" | "fixed" | "<n>" or "<n0>,<n1>,..." (forced slot counts per image, cycled: tuning runs that must visit a batch size)
 SLOT_MODE = os.environ.get("DETOPS_MASK_SLOTS", "dynamic")
-SLOT_GRANULE = 32
+SLOT_GRANULE = max(1, int(os.environ.get("DETOPS_MASK_SLOT_GRANULE", "32")))
 
 _SLOT_INDICES = {}
 _PINNED = {}
