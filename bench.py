@@ -730,7 +730,7 @@ def main():
             model.exposed_wait_events = None
             exposed_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
         progress("%d kernel-timing steps done (outside the timed region)" % post_steps)
-    # Transparency line for the mask head's dynamic batch (mask_head.py: every image's positives rounded up to 32 slots, the
+    # Transparency line for the mask head's dynamic batch (mask_head.py: every image's positives rounded up to a granule of 16 slots, the
     # reference's workload): the same step with the FIXED quota of 128 slots per image, i.e. what the step costs when every
     # image fills its quota of positives — 20 more steps outside the timed region, on every rank.
     slots_dynamic = mask_slots_report(model)
@@ -788,7 +788,7 @@ def main():
             "miopen": {"search": bool(torch.backends.cudnn.benchmark), "db": miopen_db},
             # which activations are channels-last (NHWC): "nchw" none | "backbone" ResNet + FPN | "all" the heads as well
             "layout": layout,
-            # mask head batch: "dynamic" = every image's positives rounded up to 32 slots (the reference runs its mask head on the
+            # mask head batch: "dynamic" = every image's positives rounded up to a granule of 16 slots (the reference runs its mask head on the
             # positive boxes only), "fixed" = the quota of 128 slots per image; `slots` = the last step's slot counts per image
             "mask_slots": dict(slots_dynamic, fixed_quota_ms_per_step=fixed_quota_ms) if slots_dynamic else None,
             # True: the timed steps were replays of captured HIP graphs (engine/graph_step.py); the kernel timers' post-pass ran eagerly

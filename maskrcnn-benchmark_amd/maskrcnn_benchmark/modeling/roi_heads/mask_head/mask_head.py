@@ -9,11 +9,11 @@ positives: the padding changes no value).
 How many slots (round 6, late).  "fixed": n = P = BATCH_SIZE_PER_IMAGE * POSITIVE_FRACTION (128) for every image
 — a static shape, no read-back, and the mask head's four 3 x 3 convolutions + deconvolution always run on N x 128
 ROIs (6 ms of the 33 ms fp32 step) however few of them are positive.  "dynamic" (default in the eager step):
-n = the image's positive count rounded up to a multiple of 32 (at least 32, at most P).  The counts leave the device
+n = the image's positive count rounded up to a multiple of 16 (DETOPS_MASK_SLOT_GRANULE; at least one granule, at most P).  The counts leave the device
 by an asynchronous copy issued right after the box head's sampler — a whole box-head forward before they are
 needed — so the wait in front of the mask head is over when the host gets there and the device queue never
 drains (`PositiveCounts`).  This is the reference's workload (it runs the mask head on the positives only),
-with its shapes quantised to seven batch sizes so that MIOpen's find-db holds every key.  A captured HIP graph
+with its shapes quantised (15 batch sizes at 2 images per GPU) so that MIOpen's find-db holds every key.  A captured HIP graph
 cannot read anything back: engine/graph_step.py switches to "fixed"."""
 import os
 
@@ -29,7 +29,7 @@ from .roi_mask_predictors import make_roi_mask_predictor
 
 # "dynamic" | "fixed" | "<n>" or "<n0>,<n1>,..." (forced slot counts per image, cycled: tuning runs that must visit a batch size)
 SLOT_MODE = os.environ.get("DETOPS_MASK_SLOTS", "dynamic")
-SLOT_GRANULE = max(1, int(os.environ.get("DETOPS_MASK_SLOT_GRANULE", "32")))
+SLOT_GRANULE = max(1, int(os.environ.get("DETOPS_MASK_SLOT_GRANULE", "16")))
 
 _SLOT_INDICES = {}
 _PINNED = {}

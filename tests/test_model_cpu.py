@@ -657,7 +657,7 @@ def test_half_weights_single_cast_equals_autocast_per_layer_casts(monkeypatch):
 
 
 def test_mask_head_dynamic_slots_equal_the_fixed_quota(monkeypatch):
-    """roi_heads/mask_head/mask_head.py: the mask head on the first n = ceil32(positives) slots of every image ("dynamic": the
+    """roi_heads/mask_head/mask_head.py: the mask head on the first n = ceil_g(positives) slots (granule g = 16) of every image ("dynamic": the
     reference's workload, which keeps only the positive boxes) gives the losses and gradients of the fixed quota of
     BATCH_SIZE_PER_IMAGE * POSITIVE_FRACTION slots per image — the extra slots are masked out of the loss either way —, the
     counts are requested by the box head right after its sampler, forced slot counts ("<n>") clamp to the quota."""
@@ -687,7 +687,7 @@ def test_mask_head_dynamic_slots_equal_the_fixed_quota(monkeypatch):
     lf, gf, sf = run("fixed")
     ld, gd, sd = run("dynamic")
     assert sf == [64, 64]                                  # the quota: 256 x 0.25
-    assert all(s % 32 == 0 and 32 <= s <= 64 for s in sd) and sd != sf, sd
+    assert all(s % MH.SLOT_GRANULE == 0 and MH.SLOT_GRANULE <= s <= 64 for s in sd) and sd != sf, sd
     for k in lf:
         assert abs(lf[k] - ld[k]) <= 1e-6 * max(1.0, abs(lf[k])), (k, lf[k], ld[k])
     assert gf.keys() == gd.keys()

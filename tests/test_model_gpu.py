@@ -646,7 +646,7 @@ def test_half_weights_gradients_equal_the_per_layer_autocast_gradients(dtype):
 
 # ------------------------------------------------------------------ mask head on the positives only
 def test_mask_head_dynamic_slots_equal_the_fixed_quota_on_the_device(monkeypatch):
-    """roi_heads/mask_head/mask_head.py on the MI355X (fp32): the mask head on ceil32(positives) slots per image — the counts
+    """roi_heads/mask_head/mask_head.py on the MI355X (fp32): the mask head on ceil16(positives) slots per image — the counts
     read back through the asynchronous copy the box head starts after its sampler — gives the losses and gradients of the
     fixed quota of 128 slots per image (the extra slots are masked out of the loss either way; the convolutions run other
     MIOpen kernels for the other batch size, hence a tolerance, not bit equality)."""
@@ -670,7 +670,7 @@ def test_mask_head_dynamic_slots_equal_the_fixed_quota_on_the_device(monkeypatch
 
     lf, gf, sf = grads("fixed")
     ld, gd, sd = grads("dynamic")
-    assert sf == [128, 128] and all(s % 32 == 0 and 32 <= s <= 128 for s in sd), (sf, sd)
+    assert sf == [128, 128] and all(s % MH.SLOT_GRANULE == 0 and MH.SLOT_GRANULE <= s <= 128 for s in sd), (sf, sd)
     for k in lf:
         assert abs(lf[k] - ld[k]) <= 2e-5 * max(1.0, abs(lf[k])), (k, lf[k], ld[k], sd)
     assert gf.keys() == gd.keys()
