@@ -199,10 +199,8 @@ class BucketedDataParallel(torch.nn.Module):
                  error_on_unused=False, comm=None):
         super(BucketedDataParallel, self).__init__()
         self.module = module
-        # the single-launch half-weight cast (layers/half_weights.py) delivers every weight gradient at the END of the backward
-        # pass — the opposite of what the bucket hooks need; under the wrapper autocast keeps its per-layer casts
-        if getattr(module, "half_weights", None) is not None:
-            module.half_weights.enabled = False
+        # (mixed precision: the per-stage half-weight casts of layers/half_weights.py deliver a stage's fp32 weight gradients as
+        #  soon as the stage's backward is over — the bucket hooks below see them at the same points as autocast's per-layer casts)
         self.process_group = process_group if process_group is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.process_group)
         self.optimizer = optimizer if isinstance(optimizer, OverlappedSGD) else None

@@ -7,16 +7,20 @@ profiles/r06_mixed_precision_traces.txt), each ~4.5 us of device time for a few 
 dispatches in a step that is host-bound.  The reference has the same structure (apex O1 patches the functional ops and caches
 the casts per iteration, engine/trainer.py:66-79 + apex.amp): this is not a parity item, it is launch count.
 
-Here `HalfWeights.install(dtype)` produces the half copy of EVERY weight in one `torch._foreach_copy_` (a handful of
-multi-tensor launches) through one autograd node, and the node's backward turns all half gradients into fp32 gradients of the
-masters in one `_foreach_copy_` again.  The values are exactly autocast's (the same round-to-nearest cast of the same fp32
+Here the half copies of all weights of one STAGE of the model (ResNet stem / layer1-4, FPN, RPN head, box head, mask head: nine
+groups) come from one `torch._foreach_copy_` through one autograd node per stage, and the node's backward turns the stage's half
+gradients into fp32 gradients of the masters in one `_foreach_copy_` again.  The values are exactly autocast's (the same round-to-nearest cast of the same fp32
 master, the same half gradient widened to fp32), the optimizer / GradScaler / checkpoint code sees nothing: parameters stay the
 fp32 masters in `module._parameters`; for the duration of one forward the modules' `weight` ATTRIBUTE resolves to the half
 copy (an instance attribute shadows `nn.Module.__getattr__`'s parameter look-up), and `remove()` drops the shadows.
 
-The node's backward runs when its LAST output's gradient exists, i.e. at the very end of the backward pass — right for the
-single-process step (the optimizer runs after backward anyway), wrong for `BucketedDataParallel`, which all-reduces a bucket as
-soon as its gradients exist: the wrapper switches this off (`enabled = False`) and keeps autocast's per-layer casts."""
+WHEN a stage's node is created matters.  The autograd engine runs ready nodes in order of creation, latest first: one node for
+the whole model, created at the start of the forward, would run LAST — every weight gradient would appear in one burst at the
+end of the backward pass (measured: two ~0.6 ms host gaps around that burst in the device-bound bf16 step; and
+`BucketedDataParallel`, which all-reduces a bucket as soon as its gradients exist, would lose its overlap).  A stage's node is
+therefore created by a forward pre-hook of the stage's module, right before the stage runs: it is younger than every node of
+the earlier stages, so in the backward pass it runs as soon as the stage's last weight gradient exists — before the engine moves
+on to the earlier stages — and the stage's fp32 gradients reach the optimizer / the bucket hooks at that point."""
 import os
 
 import torch
@@ -51,24 +55,57 @@ def _weight_modules():
     return (nn.Conv2d, nn.ConvTranspose2d, nn.Linear, DeformConv, ModulatedDeformConv)
 
 
+class _StageHook(object):
+    """forward pre-hook of a stage's module (an object, not a closure: deep copies and pickles of the model keep a hook that
+    points at THEIR HalfWeights)"""
+
+    def __init__(self, owner, stage):
+        self.owner, self.stage = owner, stage
+
+    def __call__(self, module, inputs):
+        self.owner._install_stage(self.stage)
+
+
 class HalfWeights(object):
-    """The fp32 `weight` parameters of a model's convolution / linear / deformable-convolution modules and their per-forward
-    half copies.  `install(dtype)` ... forward ... `remove()`; nothing else of the model changes."""
+    """The fp32 `weight` parameters of a model's convolution / linear / deformable-convolution modules, grouped by stage, and
+    their per-forward half copies.  `install(dtype)` arms the stages' pre-hooks ... forward ... `remove()`; nothing else of the
+    model changes."""
+
+    # module-path prefixes that are split one level further (their children are the stages)
+    SPLIT = ("backbone.body",)
 
     def __init__(self, model):
         self.model = model
         self.enabled = ENABLED
         self.entries = None          # [(module, fp32 parameter)]
+        self.groups = None           # stage name -> [(module, fp32 parameter)]
         self.installed = False
+        self._dtype = None           # not None: inside a forward that uses the copies
+        self._done = set()
+        self._hooks = []
+
+    @classmethod
+    def _stage_of(cls, name):
+        parts = name.split(".")
+        depth = 3 if ".".join(parts[:2]) in cls.SPLIT else 2
+        return ".".join(parts[:depth])
 
     def _collect(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
         kinds = _weight_modules()
-        self.entries = []
-        for m in self.model.modules():
+        self.entries, self.groups = [], {}
+        for name, m in self.model.named_modules():
             if isinstance(m, kinds):
                 p = m._parameters.get("weight")
                 if p is not None and p.dtype == torch.float32 and p.dim() >= 2:
                     self.entries.append((m, p))
+                    self.groups.setdefault(self._stage_of(name), []).append((m, p))
+        lookup = dict(self.model.named_modules())
+        for stage in self.groups:
+            anchor = lookup[stage]
+            self._hooks.append(anchor.register_forward_pre_hook(_StageHook(self, stage)))
 
     def _stale(self):
         return self.entries is None or any(m._parameters.get("weight") is not p for m, p in self.entries)
@@ -80,12 +117,24 @@ class HalfWeights(object):
                 and torch.get_autocast_dtype(kind) in (torch.float16, torch.bfloat16))
 
     def install(self, dtype):
+        """arm the stages' pre-hooks for this forward: each stage casts its weights when it is about to run"""
         if self._stale():
             self._collect()
         if not self.entries:
             return False
-        live = [p for _, p in self.entries if p.requires_grad]
-        frozen = [p for _, p in self.entries if not p.requires_grad]
+        self._dtype = dtype
+        self._done = set()
+        self.installed = True
+        return True
+
+    def _install_stage(self, stage):
+        dtype = self._dtype
+        if dtype is None or stage in self._done:
+            return
+        self._done.add(stage)
+        entries = self.groups[stage]
+        live = [p for _, p in entries if p.requires_grad]
+        frozen = [p for _, p in entries if not p.requires_grad]
         halves = {}
         if live:
             for p, h in zip(live, _CastAll.apply(dtype, *live)):
@@ -96,13 +145,13 @@ class HalfWeights(object):
                 torch._foreach_copy_(outs, frozen)
             for p, h in zip(frozen, outs):
                 halves[id(p)] = h
-        for m, p in self.entries:
+        for m, p in entries:
             m.__dict__["weight"] = halves[id(p)]
-        self.installed = True
-        return True
 
     def remove(self):
         if self.installed:
             for m, _ in self.entries:
                 m.__dict__.pop("weight", None)
             self.installed = False
+        self._dtype = None
+        self._done = set()

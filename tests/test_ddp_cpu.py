@@ -254,7 +254,7 @@ def test_bucketed_data_parallel_recovers_from_a_failed_backward(tmp_path):
 
 
 # ------------------------------------------------------------------ the detector itself under the DDP hook
-def _detector_worker(rank, world, port, config, out_dir):
+def _detector_worker(rank, world, port, config, out_dir, dtype="float32", half=None, tag="det"):
     """What bench.py / train_net.py do at N > 1, on the CPU shim: build_training(distributed=True) wraps
     the detector in BucketedDataParallel with the overlapped SGD; three iterations must run and leave both ranks
     with identical weights."""
@@ -273,11 +273,13 @@ def _detector_worker(rank, world, port, config, out_dir):
                             "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 32, "MODEL.RESNETS.RES2_OUT_CHANNELS", 16,
                             "MODEL.RESNETS.WIDTH_PER_GROUP", 4, "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 16,
                             "MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM", 32, "MODEL.ROI_MASK_HEAD.CONV_LAYERS", (16, 16),
-                            "SOLVER.BASE_LR", 0.002])
+                            "SOLVER.BASE_LR", 0.002, "DTYPE", dtype])
     torch.manual_seed(7 + rank)  # different initial weights per rank: the wrapper must broadcast rank 0's
     model, opt, sched, step = build_training(cfg, torch.device("cpu"), distributed=True, local_rank=rank)
     from maskrcnn_benchmark.engine.ddp_step import BucketedDataParallel
     assert isinstance(model, BucketedDataParallel) and opt.deferred
+    if half is not None:
+        model.module.half_weights.enabled = half
     ds = SyntheticCOCODataset(length=2, height=96, width=128, with_masks=cfg.MODEL.MASK_ON, min_objects=2,
                               max_objects=4, seed=rank)
     images, targets, _ = BatchCollator(32)([ds[0], ds[1]])
@@ -286,10 +288,31 @@ def _detector_worker(rank, world, port, config, out_dir):
         for _ in range(3):
             losses = step(images, list(targets))
     vals = {k: float(v.detach()) for k, v in losses.items()}
-    torch.save({"params": [p.detach().clone() for p in model.module.parameters()], "losses": vals},
-               os.path.join(out_dir, "det_rank%d.pt" % rank))
+    used = model.module.half_weights.entries is not None
+    torch.save({"params": [p.detach().clone() for p in model.module.parameters()], "losses": vals, "half_weights_used": used},
+               os.path.join(out_dir, "%s_rank%d.pt" % (tag, rank)))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_detector_bf16_per_stage_half_weights_under_ddp_world2(tmp_path):
+    """mixed precision under the data-parallel wrapper (CPU autocast, gloo, world 2): the per-stage half-weight casts of
+    layers/half_weights.py deliver the fp32 weight gradients to the bucket hooks stage by stage — three iterations leave both ranks
+    with identical weights, equal to the run with autocast's per-layer casts"""
+    runs = {}
+    for half in (True, False):
+        tag = "half%d" % int(half)
+        mp.spawn(_detector_worker, args=(2, _free_port(), "e2e_mask_rcnn_R_50_FPN_1x.yaml", str(tmp_path), "bfloat16", half, tag),
+                 nprocs=2, join=True)
+        r0 = torch.load(os.path.join(str(tmp_path), "%s_rank0.pt" % tag))
+        r1 = torch.load(os.path.join(str(tmp_path), "%s_rank1.pt" % tag))
+        assert r0["half_weights_used"] == half
+        assert all(v == v and abs(v) != float("inf") for v in r0["losses"].values())
+        for a, b in zip(r0["params"], r1["params"]):
+            assert torch.equal(a, b)
+        runs[half] = r0
+    for a, b in zip(runs[True]["params"], runs[False]["params"]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("config", ["e2e_mask_rcnn_R_50_FPN_1x.yaml", "retinanet/retinanet_R-50-FPN_1x.yaml"])

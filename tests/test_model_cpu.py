@@ -625,6 +625,10 @@ def test_half_weights_single_cast_equals_autocast_per_layer_casts(monkeypatch):
         model = build_detection_model(cfg).train()
         model.half_weights.enabled = enabled
         keys = list(model.state_dict().keys())
+        arrival = []
+        for n, p in model.named_parameters():
+            if n in ("roi_heads.mask.feature_extractor.mask_fcn1.weight", "backbone.body.layer2.0.conv1.weight", "rpn.head.conv.weight"):
+                p.register_post_accumulate_grad_hook(lambda q, _n=n: arrival.append(_n))
         with cpu_shim.install():
             torch.manual_seed(1)
             with torch.autocast("cpu", dtype=torch.bfloat16):
@@ -634,12 +638,24 @@ def test_half_weights_single_cast_equals_autocast_per_layer_casts(monkeypatch):
         assert list(model.state_dict().keys()) == keys
         for m in model.modules():
             assert "weight" not in m.__dict__
+        model._arrival = arrival
         grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
         return {k: float(v.detach()) for k, v in losses.items()}, grads, model
 
     la, ga, ma = run(False)
     lb, gb, mb = run(True)
     assert mb.half_weights.entries and len(mb.half_weights.entries) > 40 and ma.half_weights.entries is None
+    # one cast node per STAGE, created right before the stage runs: a stage's fp32 gradients arrive when its backward is over
+    # (heads before the RPN head before the backbone) — not all at once at the end of the backward pass in parameter order
+    assert sorted(mb.half_weights.groups) == ["backbone.body.layer1", "backbone.body.layer2", "backbone.body.layer3",
+                                              "backbone.body.layer4", "backbone.body.stem", "backbone.fpn", "roi_heads.box",
+                                              "roi_heads.mask", "rpn.head"], sorted(mb.half_weights.groups)
+    assert mb._arrival == ma._arrival == ["roi_heads.mask.feature_extractor.mask_fcn1.weight", "rpn.head.conv.weight",
+                                          "backbone.body.layer2.0.conv1.weight"], (ma._arrival, mb._arrival)
+    import copy
+    mc = copy.deepcopy(mb)
+    assert mc.half_weights is not mb.half_weights and mc.half_weights.model is mc
+    assert all(h.owner is mc.half_weights for m in mc.modules() for h in m._forward_pre_hooks.values() if hasattr(h, "owner"))
     assert la.keys() == lb.keys() and ga.keys() == gb.keys()
     for k in la:
         assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(la[k])), (k, la[k], lb[k])

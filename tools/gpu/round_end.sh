@@ -21,7 +21,7 @@ if has bench; then
 fi
 if has trace; then
   P=/tmp/prof_bench; rm -rf $P
-  timeout 500 rocprofv3 --kernel-trace --output-format csv -d $P -o bench -- python bench.py --steps 6 --warmup 6 --no-cpu-baseline < /dev/null > $O/prof_bench.log 2>&1
+  timeout 500 rocprofv3 --kernel-trace --output-format csv -d $P -o bench -- python bench.py --steps 6 --warmup 6 --no-cpu-baseline --no-fixed-quota-line < /dev/null > $O/prof_bench.log 2>&1
   T=$(find $P -name "*kernel_trace.csv" | head -1)
   if [ -n "$T" ]; then
     python tools/trace_steps.py "$T" 4 60 > $O/bench_f32_step_breakdown.txt 2>&1
