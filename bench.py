@@ -407,6 +407,26 @@ def mask_slots_report(model):
         return None
 
 
+def prewarm_mask_batch_sizes(model, step, batches, images_per_gpu):
+    """one training step per possible mask-head batch size (mask_head.SLOT_MODE == "dynamic"): total slots from one granule per
+    image to the quota per image, in steps of one granule -> number of steps run"""
+    rep = mask_slots_report(model)
+    if not rep or rep["mode"] != "dynamic":
+        return 0
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head import mask_head as mh
+    g, quota, n = mh.SLOT_GRANULE, rep["quota"], int(images_per_gpu)
+    done = 0
+    try:
+        for total in range(n * g, n * quota + 1, g):
+            per, extra = divmod(total // g, n)           # granules per image, the first `extra` images take one more
+            mh.SLOT_MODE = ",".join(str(min(quota, (per + (1 if i < extra else 0)) * g)) for i in range(n))
+            step(*batches[done % len(batches)])
+            done += 1
+    finally:
+        mh.SLOT_MODE = "dynamic"
+    return done
+
+
 def graph_env(argv):
     """--hip-graph: ROCm's graph capture of kernel-argument packets must be off BEFORE the HIP runtime starts (the replay of a
     captured training step faults otherwise: profiles/r04a_hip_graph_flags.txt)"""
@@ -697,7 +717,15 @@ def main():
             losses = step(*batches[i % len(batches)])
             torch.cuda.synchronize(device)
         progress("warm-up step %d done" % (i + 1))
-    _C.KERNEL_TIMER = None
+    # The mask head's batch follows the number of positives (mask_slots): up to 15 batch sizes at 2 images per GPU, each a
+    # MIOpen problem of its own whose FIRST use loads its kernels (tens of ms).  A long run amortises that; a 20-step timed
+    # region would carry whichever sizes the warm-up steps happened not to see (measured: 31.4 instead of 29.1 ms per step).
+    # One untimed step per batch size, forced, before the timed region — on every rank (the same collective sequence).
+    _C.KERNEL_TIMER = None      # (the call counter of the last warm-up step must not see the steps below)
+    prewarmed = prewarm_mask_batch_sizes(model, step, batches, args.images_per_gpu) if (device.type == "cuda" and not args.hip_graph) else 0
+    if prewarmed:
+        torch.cuda.synchronize(device)
+        progress("%d untimed steps over the mask head's batch sizes done" % prewarmed)
     # The timed region carries NO kernel timers (round 6): an event pair around a launch drains the queue
     # (~30 us of device time per timed launch in the fp32 step, ~100 us under fp16), which used to cost the driver's
     # 20-step line ~0.4 ms per step.  `value` comes from this loop; the per-kernel figures from the post-pass below.
