@@ -102,3 +102,36 @@ def test_kernel_timer_per_name_strides_from_a_counted_step():
     sampled = {name: sum(timer.span(name, x, every=8) is not _NOSPAN for _ in range(n * steps)) for name, n in per_step.items()}
     assert all(10 <= v <= 24 for v in sampled.values()), sampled
     assert sum(sampled.values()) < sum(per_step.values()) * steps / 4      # far fewer than "every 2nd call of everything"
+
+
+def test_prewarm_visits_every_mask_head_batch_size_once():
+    """bench.py::prewarm_mask_batch_sizes: one untimed step per possible mask-head batch size (total slots from one granule per
+    image to the quota per image in steps of one granule), every image within its quota, the mode restored afterwards"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "maskrcnn-benchmark_amd"))
+    import bench
+    from maskrcnn_benchmark.modeling.roi_heads.mask_head import mask_head as mh
+
+    class Head(object):
+        max_positives, last_slots = 128, None
+
+    class Model(object):
+        roi_heads = {"mask": Head()}
+
+    seen = []
+    old = mh.SLOT_MODE
+    mh.SLOT_MODE = "dynamic"
+    try:
+        for n in (1, 2, 3):
+            seen.clear()
+            done = bench.prewarm_mask_batch_sizes(Model(), lambda *b: seen.append([int(v) for v in mh.SLOT_MODE.split(",")]),
+                                                  [("images", "targets")], n)
+            g = mh.SLOT_GRANULE
+            assert done == len(seen) == (n * 128 - n * g) // g + 1
+            assert [sum(s) for s in seen] == list(range(n * g, n * 128 + 1, g))
+            assert all(len(s) == n and all(g <= v <= 128 and v % g == 0 for v in s) for s in seen)
+            assert mh.SLOT_MODE == "dynamic"
+        mh.SLOT_MODE = "fixed"
+        assert bench.prewarm_mask_batch_sizes(Model(), lambda *b: seen.append(1), [("i", "t")], 2) == 0
+    finally:
+        mh.SLOT_MODE = old
